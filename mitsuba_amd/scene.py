@@ -1,0 +1,461 @@
+"""Flattened scene description handed to the HIP core through the C ABI (include/mtsamd.h).
+
+The reference builds this information as an object graph (Scene/TriMesh/BSDF/Emitter/Sensor/Film,
+src/librender/scene.cpp:477-556); the GPU core wants plain arrays. `SceneData` is the host-side
+container: numpy arrays for geometry plus small dict records for shapes, materials, emitters,
+camera, film and integrator parameters, named after the reference's XML properties.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+BSDF_DIFFUSE, BSDF_ROUGHCONDUCTOR, BSDF_ROUGHPLASTIC, BSDF_DIELECTRIC, BSDF_WARD = range(5)
+DISTR_BECKMANN, DISTR_GGX = 0, 1
+SHAPE_HAS_NORMALS, SHAPE_HAS_TEXCOORDS = 1, 2
+
+_DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+# lookupIOR presets used by the configs (src/bsdfs/ior.h:39-111)
+IOR = {"vacuum": 1.0, "air": 1.000277, "water": 1.3330, "bk7": 1.5046, "polypropylene": 1.49,
+       "diamond": 2.419, "acrylic glass": 1.49168, "pyrex": 1.470}
+
+
+def look_at(origin, target, up) -> np.ndarray:
+    """Camera-to-world matrix of Transform::lookAt (src/libcore/transform.cpp:191-214)."""
+    o = np.asarray(origin, np.float32)
+    t = np.asarray(target, np.float32)
+    u = np.asarray(up, np.float32)
+    d = t - o
+    d = d / np.float32(np.sqrt(np.float32(np.dot(d, d))))
+    left = np.cross(u, d).astype(np.float32)
+    left = left / np.float32(np.sqrt(np.float32(np.dot(left, left))))
+    new_up = np.cross(d, left).astype(np.float32)
+    m = np.eye(4, dtype=np.float32)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = left, new_up, d, o
+    return m
+
+
+def gaussian_filter(stddev: float = 0.5):
+    """(radius, 32 table values) of GaussianFilter + ReconstructionFilter::configure
+    (src/rfilters/gaussian.cpp:32-57, src/libcore/rfilter.cpp:37-55), in single precision."""
+    f32 = np.float32
+    stddev = f32(stddev)
+    radius = f32(4) * stddev
+    alpha = f32(-1.0) / (f32(2.0) * stddev * stddev)
+
+    def ev(x):
+        a = f32(np.exp(np.float64(alpha * x * x)))
+        b = f32(np.exp(np.float64(alpha * radius * radius)))
+        return max(f32(0.0), f32(a - b))
+
+    vals = np.zeros(32, np.float32)
+    s = f32(0)
+    for i in range(31):
+        v = ev(f32(radius * f32(i)) / f32(31))
+        vals[i] = v
+        s = f32(s + v)
+    s = f32(s * (f32(2) * radius / f32(31)))
+    norm = f32(1.0) / s
+    for i in range(31):
+        vals[i] = f32(vals[i] * norm)
+    return float(radius), vals
+
+
+def box_filter(radius: float = 0.5):
+    """BoxFilter: eval = 1 inside the radius (src/rfilters/box.cpp), same normalisation."""
+    f32 = np.float32
+    radius = f32(radius)
+    vals = np.zeros(32, np.float32)
+    s = f32(31.0)
+    s = f32(s * (f32(2) * radius / f32(31)))
+    vals[:31] = f32(1.0) / s
+    return float(radius), vals
+
+
+@dataclass
+class SceneData:
+    positions: np.ndarray
+    indices: np.ndarray
+    normals: Optional[np.ndarray] = None
+    texcoords: Optional[np.ndarray] = None
+    shapes: List[Dict] = field(default_factory=list)
+    materials: List[Dict] = field(default_factory=list)
+    emitters: List[Dict] = field(default_factory=list)
+    camera: Dict = field(default_factory=dict)
+    film: Dict = field(default_factory=dict)
+    integrator: Dict = field(default_factory=lambda: dict(max_depth=-1, rr_depth=5, strict_normals=0, hide_emitters=0))
+
+    @property
+    def n_triangles(self) -> int:
+        return int(self.indices.shape[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# Material records (defaults follow the reference constructors)
+# ------------------------------------------------------------------------------------------------
+def _mat(**kw) -> Dict:
+    m = dict(type=BSDF_DIFFUSE, distribution=DISTR_BECKMANN, sample_visible=1, variant=0,
+             alpha_u=0.1, alpha_v=0.1, int_ior=1.5046, ext_ior=1.000277,
+             diffuse_reflectance=(0.5, 0.5, 0.5), specular_reflectance=(1.0, 1.0, 1.0),
+             specular_transmittance=(1.0, 1.0, 1.0), eta=(0.0, 0.0, 0.0), k=(1.0, 1.0, 1.0),
+             ext_eta=1.000277, ensure_energy_conservation=1,
+             rtrans=None, rtrans_diffuse_ext=0.0, rtrans_diffuse_int=0.0)
+    m.update(kw)
+    return m
+
+
+def diffuse(reflectance=(0.5, 0.5, 0.5)) -> Dict:
+    """src/bsdfs/diffuse.cpp:77-84"""
+    return _mat(type=BSDF_DIFFUSE, diffuse_reflectance=tuple(reflectance))
+
+
+def roughconductor(eta, k, alpha=0.1, distribution="beckmann", specular_reflectance=(1, 1, 1),
+                   ext_eta=IOR["air"], sample_visible=True, alpha_v=None) -> Dict:
+    """src/bsdfs/roughconductor.cpp:168-201 with explicit RGB eta/k (material presets are spectral data
+    the host adapter resolves before filling this record)."""
+    return _mat(type=BSDF_ROUGHCONDUCTOR, distribution=_distr(distribution), alpha_u=alpha,
+                alpha_v=alpha if alpha_v is None else alpha_v, eta=tuple(eta), k=tuple(k), ext_eta=ext_eta,
+                specular_reflectance=tuple(specular_reflectance), sample_visible=int(sample_visible))
+
+
+def dielectric(int_ior=IOR["bk7"], ext_ior=IOR["air"], specular_reflectance=(1, 1, 1),
+               specular_transmittance=(1, 1, 1)) -> Dict:
+    """src/bsdfs/dielectric.cpp:147-165"""
+    return _mat(type=BSDF_DIELECTRIC, int_ior=int_ior, ext_ior=ext_ior,
+                specular_reflectance=tuple(specular_reflectance),
+                specular_transmittance=tuple(specular_transmittance))
+
+
+def ward(alpha=0.1, diffuse_reflectance=(0.5, 0.5, 0.5), specular_reflectance=(0.2, 0.2, 0.2),
+         variant="balanced", alpha_v=None) -> Dict:
+    """src/bsdfs/ward.cpp:97-126"""
+    v = {"ward": 0, "ward-duer": 1, "balanced": 2}[variant]
+    return _mat(type=BSDF_WARD, alpha_u=alpha, alpha_v=alpha if alpha_v is None else alpha_v, variant=v,
+                diffuse_reflectance=tuple(diffuse_reflectance), specular_reflectance=tuple(specular_reflectance))
+
+
+def roughplastic(alpha=0.1, distribution="beckmann", int_ior=IOR["polypropylene"], ext_ior=IOR["air"],
+                 diffuse_reflectance=(0.5, 0.5, 0.5), specular_reflectance=(1, 1, 1), nonlinear=False,
+                 sample_visible=True, rtrans=None) -> Dict:
+    """src/bsdfs/roughplastic.cpp:197-228. The reduced rough-transmittance table (what
+    RoughPlastic::configure derives from data/microfacet/<distr>.dat, roughplastic.cpp:281-299) is
+    looked up in the packaged slices unless given."""
+    if rtrans is None:
+        rtrans = load_rtrans_slice(distribution, int_ior / ext_ior, alpha)
+    T, d_ext, d_int = rtrans
+    return _mat(type=BSDF_ROUGHPLASTIC, distribution=_distr(distribution), alpha_u=alpha, alpha_v=alpha,
+                int_ior=int_ior, ext_ior=ext_ior, diffuse_reflectance=tuple(diffuse_reflectance),
+                specular_reflectance=tuple(specular_reflectance), variant=int(nonlinear),
+                sample_visible=int(sample_visible), rtrans=np.asarray(T, np.float32),
+                rtrans_diffuse_ext=float(d_ext), rtrans_diffuse_int=float(d_int))
+
+
+def _distr(name) -> int:
+    if isinstance(name, int):
+        return name
+    return {"beckmann": DISTR_BECKMANN, "ggx": DISTR_GGX}[name.lower()]
+
+
+_slices = None
+
+
+def rtrans_key(distribution, eta, alpha) -> str:
+    name = distribution if isinstance(distribution, str) else ("beckmann", "ggx")[distribution]
+    return "%s:%.6f:%.6f" % (name.lower(), eta, alpha)
+
+
+def load_rtrans_slice(distribution, eta, alpha):
+    """Reduced tables for the (distribution, eta, alpha) combinations the bundled scenes use, produced by
+    tools/make_rtrans_slices.py from the reference's data/microfacet/*.dat with mtsamd_rtrans_reduce."""
+    global _slices
+    if _slices is None:
+        with open(os.path.join(_DATA_DIR, "rtrans_slices.json")) as f:
+            _slices = json.load(f)
+    key = rtrans_key(distribution, eta, alpha)
+    if key not in _slices:
+        raise KeyError("no packaged rough-transmittance slice for %s; reduce it from the Mitsuba data file "
+                       "with mitsuba_amd.capi.rtrans_reduce()" % key)
+    e = _slices[key]
+    return np.asarray(e["T"], np.float32), e["diffuse_ext"], e["diffuse_int"]
+
+
+# ------------------------------------------------------------------------------------------------
+# Mesh assembly
+# ------------------------------------------------------------------------------------------------
+class SceneBuilder:
+    def __init__(self):
+        self.P, self.N, self.UV, self.I = [], [], [], []
+        self.shapes, self.materials, self.emitters = [], [], []
+        self.nv = 0
+        self.nt = 0
+        self.any_normals = False
+        self.any_uvs = False
+
+    def add_material(self, m: Dict) -> int:
+        self.materials.append(m)
+        return len(self.materials) - 1
+
+    def add_mesh(self, positions, indices, material: int, normals=None, texcoords=None, radiance=None,
+                 sampling_weight=1.0) -> int:
+        positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        indices = np.ascontiguousarray(indices, np.uint32).reshape(-1, 3)
+        flags = 0
+        n = positions.shape[0]
+        if normals is not None:
+            flags |= SHAPE_HAS_NORMALS
+            self.any_normals = True
+            self.N.append(np.ascontiguousarray(normals, np.float32).reshape(-1, 3))
+        else:
+            self.N.append(np.zeros((n, 3), np.float32))
+        if texcoords is not None:
+            flags |= SHAPE_HAS_TEXCOORDS
+            self.any_uvs = True
+            self.UV.append(np.ascontiguousarray(texcoords, np.float32).reshape(-1, 2))
+        else:
+            self.UV.append(np.zeros((n, 2), np.float32))
+        self.P.append(positions)
+        self.I.append(indices + np.uint32(self.nv))
+        sid = len(self.shapes)
+        em = -1
+        if radiance is not None:
+            em = len(self.emitters)
+            self.emitters.append(dict(shape=sid, radiance=tuple(float(x) for x in radiance),
+                                      sampling_weight=float(sampling_weight)))
+        self.shapes.append(dict(first_triangle=self.nt, n_triangles=int(indices.shape[0]), material=material,
+                                emitter=em, flags=flags))
+        self.nv += n
+        self.nt += int(indices.shape[0])
+        return sid
+
+    def add_quad(self, p0, p1, p2, p3, material, **kw) -> int:
+        return self.add_mesh(np.array([p0, p1, p2, p3], np.float32), np.array([[0, 1, 2], [0, 2, 3]]), material, **kw)
+
+    def add_box(self, lo, hi, material, to_world=None, **kw) -> int:
+        lo = np.asarray(lo, np.float32)
+        hi = np.asarray(hi, np.float32)
+        c = np.array([[lo[0], lo[1], lo[2]], [hi[0], lo[1], lo[2]], [hi[0], hi[1], lo[2]], [lo[0], hi[1], lo[2]],
+                      [lo[0], lo[1], hi[2]], [hi[0], lo[1], hi[2]], [hi[0], hi[1], hi[2]], [lo[0], hi[1], hi[2]]], np.float32)
+        if to_world is not None:
+            m = np.asarray(to_world, np.float32)
+            c = (c @ m[:3, :3].T + m[:3, 3]).astype(np.float32)
+        # outward-facing faces
+        quads = [(0, 3, 2, 1), (4, 5, 6, 7), (0, 1, 5, 4), (2, 3, 7, 6), (1, 2, 6, 5), (0, 4, 7, 3)]
+        idx = []
+        for a, b, cc, d in quads:
+            idx += [[a, b, cc], [a, cc, d]]
+        return self.add_mesh(c, np.array(idx), material, **kw)
+
+    def finish(self, camera: Dict, film: Dict, integrator: Optional[Dict] = None) -> SceneData:
+        sd = SceneData(
+            positions=np.ascontiguousarray(np.concatenate(self.P), np.float32),
+            indices=np.ascontiguousarray(np.concatenate(self.I), np.uint32),
+            normals=np.ascontiguousarray(np.concatenate(self.N), np.float32) if self.any_normals else None,
+            texcoords=np.ascontiguousarray(np.concatenate(self.UV), np.float32) if self.any_uvs else None,
+            shapes=self.shapes, materials=self.materials, emitters=self.emitters, camera=camera, film=film)
+        if integrator:
+            sd.integrator.update(integrator)
+        return sd
+
+
+def make_film(width, height, rfilter=None, crop=None) -> Dict:
+    radius, vals = rfilter if rfilter is not None else gaussian_filter()
+    cx, cy, cw, ch = crop if crop is not None else (0, 0, width, height)
+    return dict(width=width, height=height, crop_x=cx, crop_y=cy, crop_w=cw, crop_h=ch,
+                filter_radius=radius, filter_values=vals)
+
+
+def make_camera(origin, target, up, x_fov, near_clip=1e-2, far_clip=1e4) -> Dict:
+    return dict(to_world=look_at(origin, target, up), x_fov=float(x_fov), near_clip=float(near_clip),
+                far_clip=float(far_clip))
+
+
+# ------------------------------------------------------------------------------------------------
+# Procedural meshes
+# ------------------------------------------------------------------------------------------------
+def icosphere(subdiv: int):
+    t = (1.0 + 5 ** 0.5) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                  [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    f = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2],
+                  [10, 7, 6], [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5],
+                  [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]], np.int64)
+    for _ in range(subdiv):
+        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+        e.sort(axis=1)
+        ue, inv = np.unique(e, axis=0, return_inverse=True)
+        mid = v[ue[:, 0]] + v[ue[:, 1]]
+        mid /= np.linalg.norm(mid, axis=1, keepdims=True)
+        n0 = v.shape[0]
+        v = np.concatenate([v, mid])
+        nf = f.shape[0]
+        a, b, c = inv[:nf] + n0, inv[nf:2 * nf] + n0, inv[2 * nf:] + n0
+        f = np.concatenate([np.stack([f[:, 0], a, c], 1), np.stack([f[:, 1], b, a], 1),
+                            np.stack([f[:, 2], c, b], 1), np.stack([a, b, c], 1)])
+    return v, f
+
+
+def vertex_normals(p, f):
+    """Angle-weighted vertex normals (TriMesh::computeNormals, src/librender/trimesh.cpp:636-672)."""
+    p = p.astype(np.float64)
+    n = np.zeros_like(p)
+    for i in range(3):
+        v0, v1, v2 = p[f[:, i]], p[f[:, (i + 1) % 3]], p[f[:, (i + 2) % 3]]
+        a, b = v1 - v0, v2 - v0
+        fn = np.cross(p[f[:, 1]] - p[f[:, 0]], p[f[:, 2]] - p[f[:, 0]])
+        ln = np.linalg.norm(fn, axis=1, keepdims=True)
+        fn = fn / np.maximum(ln, 1e-30)
+        an = a / np.maximum(np.linalg.norm(a, axis=1, keepdims=True), 1e-30)
+        bn = b / np.maximum(np.linalg.norm(b, axis=1, keepdims=True), 1e-30)
+        ang = np.arccos(np.clip(np.sum(an * bn, axis=1), -1, 1))
+        np.add.at(n, f[:, i], fn * ang[:, None])
+    ln = np.linalg.norm(n, axis=1, keepdims=True)
+    n = np.where(ln > 0, n / np.maximum(ln, 1e-30), np.array([1.0, 0, 0]))
+    return n.astype(np.float32)
+
+
+def blob(subdiv: int, rng: np.random.Generator, radius=1.0, bump=0.12):
+    """Displaced icosphere: low-frequency sinusoidal lobes plus a small per-vertex jitter."""
+    v, f = icosphere(subdiv)
+    k = rng.uniform(1.5, 4.0, size=(3, 3))
+    ph = rng.uniform(0, 2 * math.pi, size=3)
+    disp = sum(np.sin(v @ k[i] + ph[i]) for i in range(3)) / 3.0
+    jitter = rng.uniform(-1, 1, size=v.shape[0]) * 0.004
+    r = radius * (1.0 + bump * disp + jitter)
+    p = (v * r[:, None]).astype(np.float32)
+    return p, f.astype(np.uint32), vertex_normals(p, f)
+
+
+def grid(nx: int, ny: int, lo, hi, z=0.0):
+    xs = np.linspace(lo[0], hi[0], nx + 1, dtype=np.float32)
+    ys = np.linspace(lo[1], hi[1], ny + 1, dtype=np.float32)
+    X, Y = np.meshgrid(xs, ys)
+    p = np.stack([X.ravel(), Y.ravel(), np.full(X.size, z, np.float32)], 1).astype(np.float32)
+    i = (np.arange(ny)[:, None] * (nx + 1) + np.arange(nx)[None, :]).ravel()
+    f = np.concatenate([np.stack([i, i + 1, i + nx + 2], 1), np.stack([i, i + nx + 2, i + nx + 1], 1)])
+    return p, f.astype(np.uint32)
+
+
+# ------------------------------------------------------------------------------------------------
+# Benchmark / test scenes
+# ------------------------------------------------------------------------------------------------
+def cornell_box(width=512, height=512, max_depth=-1) -> SceneData:
+    """Standard 555-unit Cornell box authored as triangle meshes with diffuse reflectances and one quad
+    area light (config 1: `path`, diffuse BSDF)."""
+    b = SceneBuilder()
+    white = b.add_material(diffuse((0.725, 0.71, 0.68)))
+    red = b.add_material(diffuse((0.63, 0.065, 0.05)))
+    green = b.add_material(diffuse((0.14, 0.45, 0.091)))
+    light = b.add_material(diffuse((0.78, 0.78, 0.78)))
+    S = 555.0
+    b.add_quad([0, 0, 0], [0, 0, S], [S, 0, S], [S, 0, 0], white)          # floor (y=0), normal +y
+    b.add_quad([0, S, 0], [S, S, 0], [S, S, S], [0, S, S], white)          # ceiling, normal -y
+    b.add_quad([0, 0, S], [0, S, S], [S, S, S], [S, 0, S], white)          # back wall (z=S), normal -z
+    b.add_quad([S, 0, 0], [S, 0, S], [S, S, S], [S, S, 0], red)            # x=S wall, normal -x
+    b.add_quad([0, 0, 0], [0, S, 0], [0, S, S], [0, 0, S], green)          # x=0 wall, normal +x
+
+    def rot_y(deg, t):
+        a = math.radians(deg)
+        m = np.eye(4, dtype=np.float32)
+        m[0, 0], m[0, 2], m[2, 0], m[2, 2] = math.cos(a), math.sin(a), -math.sin(a), math.cos(a)
+        m[:3, 3] = t
+        return m
+
+    b.add_box([-82.5, 0, -82.5], [82.5, 165, 82.5], white, to_world=rot_y(-17, [185, 0, 169]))
+    b.add_box([-82.5, 0, -82.5], [82.5, 330, 82.5], white, to_world=rot_y(20, [368, 0, 351]))
+    y = S - 0.5
+    b.add_quad([213, y, 227], [343, y, 227], [343, y, 332], [213, y, 332], light, radiance=(17.0, 12.0, 4.0))
+    cam = make_camera([278, 273, -800], [278, 273, 0], [0, 1, 0], 39.3077, near_clip=10, far_clip=2800)
+    return b.finish(cam, make_film(width, height), dict(max_depth=max_depth))
+
+
+def microfacet_field(n_objects=64, subdiv=5, ground_res=90, width=1920, height=1080, seed=42,
+                     max_depth=-1, n_lights=4, light_radiance=20.0, emitters_grid=0) -> SceneData:
+    """Configs 3-5: a field of displaced icosphere "blobs" over a tessellated ground plane.
+    Objects cycle through roughconductor (GGX), roughplastic (GGX) and dielectric; the ground is
+    diffuse; quad area lights hang above. subdiv=5 gives 20480 triangles per object."""
+    rng = np.random.default_rng(seed)
+    b = SceneBuilder()
+    m_cond = b.add_material(roughconductor(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), alpha=0.15, distribution="ggx"))
+    m_plast = b.add_material(roughplastic(alpha=0.1, distribution="ggx", int_ior=1.49, ext_ior=IOR["air"],
+                                          diffuse_reflectance=(0.5, 0.2, 0.2)))
+    m_glass = b.add_material(dielectric(1.5, 1.0))
+    m_ground = b.add_material(diffuse((0.5, 0.5, 0.5)))
+    m_light = b.add_material(diffuse((0.5, 0.5, 0.5)))
+    side = int(math.ceil(math.sqrt(n_objects)))
+    spacing = 2.6
+    ext = side * spacing * 0.5
+    k = 0
+    for gy in range(side):
+        for gx in range(side):
+            if k >= n_objects:
+                break
+            p, f, n = blob(subdiv, rng)
+            c = np.array([(gx + 0.5) * spacing - ext + rng.uniform(-0.2, 0.2),
+                          (gy + 0.5) * spacing - ext + rng.uniform(-0.2, 0.2), 1.25], np.float32)
+            b.add_mesh(p + c, f, (m_cond, m_plast, m_glass)[k % 3], normals=n)
+            k += 1
+    gp, gf = grid(ground_res, ground_res, (-ext - 4, -ext - 4), (ext + 4, ext + 4), 0.0)
+    b.add_mesh(gp, gf, m_ground)
+    H = 9.0
+    if emitters_grid:
+        g = emitters_grid
+        s = 2 * (ext + 2) / g
+        q = 0.18 * s
+        for j in range(g):
+            for i in range(g):
+                cx, cy = -ext - 2 + (i + 0.5) * s, -ext - 2 + (j + 0.5) * s
+                rad = light_radiance * (s * s) / (4 * q * q) * 0.25
+                b.add_quad([cx - q, cy - q, H], [cx - q, cy + q, H], [cx + q, cy + q, H], [cx + q, cy - q, H],
+                           m_light, radiance=(rad, rad, rad))
+    else:
+        L = 2.0
+        offs = [(-0.5, -0.5), (0.5, -0.5), (-0.5, 0.5), (0.5, 0.5)][:n_lights]
+        for ox, oy in offs:
+            cx, cy = ox * ext, oy * ext
+            b.add_quad([cx - L, cy - L, H], [cx - L, cy + L, H], [cx + L, cy + L, H], [cx + L, cy - L, H],
+                       m_light, radiance=(light_radiance,) * 3)
+    cam = make_camera([0.0, -2.3 * ext - 6, 0.9 * ext + 4], [0, 0, 0.8], [0, 0, 1], 35.0, near_clip=0.1, far_clip=1000)
+    return b.finish(cam, make_film(width, height), dict(max_depth=max_depth))
+
+
+def config3(width=1920, height=1080) -> SceneData:
+    """~1.0 M triangles: 48 objects x 20480 + 2 x 90^2 ground."""
+    return microfacet_field(n_objects=48, subdiv=5, ground_res=90, width=width, height=height)
+
+
+def config5(width=3840, height=2160) -> SceneData:
+    """~10 M triangles, 1024 quad emitters, max depth 16."""
+    return microfacet_field(n_objects=120, subdiv=6, ground_res=300, width=width, height=height,
+                            max_depth=16, emitters_grid=32)
+
+
+def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1) -> SceneData:
+    """A few hundred triangles with every BSDF type present; used by the parity tests."""
+    rng = np.random.default_rng(7)
+    b = SceneBuilder()
+    mats = [b.add_material(diffuse((0.6, 0.5, 0.4))),
+            b.add_material(roughconductor(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), alpha=0.15, distribution="ggx")),
+            b.add_material(roughplastic(alpha=0.1, distribution="ggx", int_ior=1.49, diffuse_reflectance=(0.5, 0.2, 0.2))),
+            b.add_material(dielectric(1.5, 1.0)),
+            b.add_material(ward(alpha=0.4, diffuse_reflectance=(0.1, 0.1, 0.1), specular_reflectance=(0.616, 0.4752, 0.352))),
+            b.add_material(roughconductor(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), alpha=0.3, distribution="beckmann")),
+            b.add_material(roughplastic(alpha=0.3, distribution="beckmann", int_ior=1.49, diffuse_reflectance=(0.2, 0.4, 0.6)))]
+    m_ground = b.add_material(diffuse((0.5, 0.5, 0.5)))
+    for k, m in enumerate(mats):
+        p, f, n = blob(subdiv, rng, radius=0.8)
+        c = np.array([(k % 4) * 2.2 - 3.3, (k // 4) * 2.4 - 1.2, 1.0], np.float32)
+        uv = (p[:, :2] * 0.5 + 0.5).astype(np.float32) if k == 4 else None
+        b.add_mesh(p + c, f, m, normals=n if k != 0 else None, texcoords=uv)
+    gp, gf = grid(6, 6, (-7, -6), (7, 6), 0.0)
+    b.add_mesh(gp, gf, m_ground)
+    b.add_quad([-2, -2, 6], [-2, 2, 6], [2, 2, 6], [2, -2, 6], m_ground, radiance=(15, 14, 12))
+    b.add_quad([4, -1, 3.5], [4, 1, 3.5], [5, 1, 4.5], [5, -1, 4.5], m_ground, radiance=(6, 9, 12), sampling_weight=0.5)
+    cam = make_camera([0.5, -11, 5.5], [0, 0, 0.8], [0, 0, 1], 40.0, near_clip=0.1, far_clip=100)
+    return b.finish(cam, make_film(width, height), dict(max_depth=max_depth))

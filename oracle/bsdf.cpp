@@ -1,0 +1,674 @@
+// TEST INFRASTRUCTURE ONLY -- CPU oracle: BSDF models of the `path` hot path.
+#include "bsdf.h"
+
+namespace orc {
+
+static inline void sincos_(float theta, float *s, float *c) { ::sincosf(theta, s, c); }
+
+// ---- warps (src/libcore/warp.cpp) -------------------------------------------------------------
+Vec2 squareToUniformDiskConcentric(const Vec2 &sample) {
+    float r1 = 2.0f * sample.x - 1.0f;
+    float r2 = 2.0f * sample.y - 1.0f;
+    float phi, r;
+    if (r1 == 0 && r2 == 0) {
+        r = phi = 0;
+    } else if (r1 * r1 > r2 * r2) {
+        r = r1;
+        phi = (M_PI_F / 4.0f) * (r2 / r1);
+    } else {
+        r = r2;
+        phi = (M_PI_F / 2.0f) - (r1 / r2) * (M_PI_F / 4.0f);
+    }
+    float cosPhi, sinPhi;
+    sincos_(phi, &sinPhi, &cosPhi);
+    return Vec2{ r * cosPhi, r * sinPhi };
+}
+
+Vec3 squareToCosineHemisphere(const Vec2 &sample) {
+    Vec2 p = squareToUniformDiskConcentric(sample);
+    float z = safe_sqrt(1.0f - p.x * p.x - p.y * p.y);
+    if (z == 0) z = 1e-10f;
+    return Vec3(p.x, p.y, z);
+}
+
+Vec2 squareToUniformTriangle(const Vec2 &sample) {
+    float a = safe_sqrt(1.0f - sample.x);
+    return Vec2{ 1 - a, a * sample.y };
+}
+
+// ---- src/libcore/math.cpp ----------------------------------------------------------------------
+float erfinv(float x) {
+    float w = -fastlog((1.0f - x) * (1.0f + x));
+    float p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = 3.43273939e-07f + p * w;
+        p = -3.5233877e-06f + p * w;
+        p = -4.39150654e-06f + p * w;
+        p = 0.00021858087f + p * w;
+        p = -0.00125372503f + p * w;
+        p = -0.00417768164f + p * w;
+        p = 0.246640727f + p * w;
+        p = 1.50140941f + p * w;
+    } else {
+        w = std::sqrt(w) - 3.0f;
+        p = -0.000200214257f;
+        p = 0.000100950558f + p * w;
+        p = 0.00134934322f + p * w;
+        p = -0.00367342844f + p * w;
+        p = 0.00573950773f + p * w;
+        p = -0.0076224613f + p * w;
+        p = 0.00943887047f + p * w;
+        p = 1.00167406f + p * w;
+        p = 2.83297682f + p * w;
+    }
+    return p * x;
+}
+
+float erf(float x) {
+    float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f, a5 = 1.061405429f;
+    float p = 0.3275911f;
+    float sign = signum(x);
+    x = std::abs(x);
+    float t = 1.0f / (1.0f + p * x);
+    float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * fastexp(-x * x);
+    return sign * y;
+}
+
+float hypot2(float a, float b) {
+    float r;
+    if (std::abs(a) > std::abs(b)) {
+        r = b / a;
+        r = std::abs(a) * std::sqrt(1.0f + r * r);
+    } else if (b != 0.0f) {
+        r = a / b;
+        r = std::abs(b) * std::sqrt(1.0f + r * r);
+    } else {
+        r = 0.0f;
+    }
+    return r;
+}
+
+// ---- src/libcore/util.cpp ----------------------------------------------------------------------
+float fresnelDielectricExt(float cosThetaI_, float &cosThetaT_, float eta) {
+    if (eta == 1) {
+        cosThetaT_ = -cosThetaI_;
+        return 0.0f;
+    }
+    float scale = (cosThetaI_ > 0) ? 1 / eta : eta,
+          cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
+    if (cosThetaTSqr <= 0.0f) {
+        cosThetaT_ = 0.0f;
+        return 1.0f;
+    }
+    float cosThetaI = std::abs(cosThetaI_);
+    float cosThetaT = std::sqrt(cosThetaTSqr);
+    float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    cosThetaT_ = (cosThetaI_ > 0) ? -cosThetaT : cosThetaT;
+    return 0.5f * (Rs * Rs + Rp * Rp);
+}
+
+static inline Spectrum specSafeSqrt(const Spectrum &s) { return Spectrum(safe_sqrt(s.x), safe_sqrt(s.y), safe_sqrt(s.z)); }
+
+Spectrum fresnelConductorExact(float cosThetaI, const Spectrum &eta, const Spectrum &k) {
+    float cosThetaI2 = cosThetaI * cosThetaI, sinThetaI2 = 1 - cosThetaI2, sinThetaI4 = sinThetaI2 * sinThetaI2;
+    Spectrum temp1 = eta * eta - k * k - Spectrum(sinThetaI2),
+             a2pb2 = specSafeSqrt(temp1 * temp1 + k * k * eta * eta * 4.0f),
+             a = specSafeSqrt((a2pb2 + temp1) * 0.5f);
+    Spectrum term1 = a2pb2 + Spectrum(cosThetaI2), term2 = a * (2 * cosThetaI);
+    Spectrum Rs2 = (term1 - term2) / (term1 + term2);
+    Spectrum term3 = a2pb2 * cosThetaI2 + Spectrum(sinThetaI4), term4 = term2 * sinThetaI2;
+    Spectrum Rp2 = Rs2 * (term3 - term4) / (term3 + term4);
+    return 0.5f * (Rp2 + Rs2);
+}
+
+// ---- src/libcore/spline.cpp --------------------------------------------------------------------
+float evalCubicInterp1D(float x, const float *values, size_t size, float min, float max) {
+    if (!(x >= min && x <= max)) return 0.0f;
+    float t = ((x - min) * (size - 1)) / (max - min);
+    size_t k = std::max((size_t) 0, std::min((size_t) t, size - 2));
+    float f0 = values[k], f1 = values[k + 1], d0, d1;
+    if (k > 0) d0 = 0.5f * (values[k + 1] - values[k - 1]);
+    else d0 = values[k + 1] - values[k];
+    if (k + 2 < size) d1 = 0.5f * (values[k + 2] - values[k]);
+    else d1 = values[k + 1] - values[k];
+    t = t - (float) k;
+    float t2 = t * t, t3 = t2 * t;
+    return (2 * t3 - 3 * t2 + 1) * f0 + (-2 * t3 + 3 * t2) * f1 + (t3 - 2 * t2 + t) * d0 + (t3 - t2) * d1;
+}
+
+static bool cubicWeights(float p, size_t size, float *weights, size_t &knot) {
+    // one dimension of evalCubicInterp2D/3D (spline.cpp:242-287) with min=0, max=1
+    if (!(p >= 0.0f && p <= 1.0f)) return false;
+    float t = ((p - 0.0f) * (size - 1)) / (1.0f - 0.0f);
+    knot = std::min((size_t) t, size - 2);
+    t = t - (float) knot;
+    float t2 = t * t, t3 = t2 * t;
+    weights[0] = 0.0f;
+    weights[1] = 2 * t3 - 3 * t2 + 1;
+    weights[2] = -2 * t3 + 3 * t2;
+    weights[3] = 0.0f;
+    float d0 = t3 - 2 * t2 + t, d1 = t3 - t2;
+    if (knot > 0) { weights[2] += 0.5f * d0; weights[0] -= 0.5f * d0; }
+    else { weights[2] += d0; weights[1] -= d0; }
+    if (knot + 2 < size) { weights[3] += 0.5f * d1; weights[1] -= 0.5f * d1; }
+    else { weights[2] += d1; weights[1] -= d1; }
+    return true;
+}
+
+float evalCubicInterp2D(float px, float py, const float *values, size_t sx, size_t sy) {
+    float w[2][4];
+    size_t knot[2];
+    if (!cubicWeights(px, sx, w[0], knot[0])) return 0.0f;
+    if (!cubicWeights(py, sy, w[1], knot[1])) return 0.0f;
+    float result = 0.0f;
+    for (int y = -1; y <= 2; ++y) {
+        float wy = w[1][y + 1];
+        for (int x = -1; x <= 2; ++x) {
+            float wxy = w[0][x + 1] * wy;
+            if (wxy == 0) continue;
+            size_t pos = (knot[1] + y) * sx + knot[0] + x;
+            result += values[pos] * wxy;
+        }
+    }
+    return result;
+}
+
+float evalCubicInterp3D(float px, float py, float pz, const float *values, size_t sx, size_t sy, size_t sz) {
+    float w[3][4];
+    size_t knot[3];
+    if (!cubicWeights(px, sx, w[0], knot[0])) return 0.0f;
+    if (!cubicWeights(py, sy, w[1], knot[1])) return 0.0f;
+    if (!cubicWeights(pz, sz, w[2], knot[2])) return 0.0f;
+    float result = 0.0f;
+    for (int z = -1; z <= 2; ++z) {
+        float wz = w[2][z + 1];
+        for (int y = -1; y <= 2; ++y) {
+            float wyz = w[1][y + 1] * wz;
+            for (int x = -1; x <= 2; ++x) {
+                float wxyz = w[0][x + 1] * wyz;
+                if (wxyz == 0) continue;
+                size_t pos = ((knot[2] + z) * sy + (knot[1] + y)) * sx + knot[0] + x;
+                result += values[pos] * wxyz;
+            }
+        }
+    }
+    return result;
+}
+
+// ---- src/bsdfs/microfacet.h --------------------------------------------------------------------
+float MicrofacetDistribution::eval(const Vec3 &m) const {
+    if (Frame::cosTheta(m) <= 0) return 0.0f;
+    float cosTheta2 = Frame::cosTheta2(m);
+    float beckmannExponent = ((m.x * m.x) / (alphaU * alphaU) + (m.y * m.y) / (alphaV * alphaV)) / cosTheta2;
+    float result;
+    if (type == ORC_DISTR_BECKMANN) {
+        result = fastexp(-beckmannExponent) / (M_PI_F * alphaU * alphaV * cosTheta2 * cosTheta2);
+    } else {
+        float root = (1.0f + beckmannExponent) * cosTheta2;
+        result = 1.0f / (M_PI_F * alphaU * alphaV * root * root);
+    }
+    if (result * Frame::cosTheta(m) < 1e-20f) result = 0;
+    return result;
+}
+
+Vec3 MicrofacetDistribution::sample(const Vec3 &wi, const Vec2 &s, float &pdf_) const {
+    Vec3 m;
+    if (sampleVisible) {
+        m = sampleVisible_(wi, s);
+        pdf_ = pdfVisible(wi, m);
+    } else {
+        m = sampleAll(s, pdf_);
+    }
+    return m;
+}
+
+Vec3 MicrofacetDistribution::sample(const Vec3 &wi, const Vec2 &s) const {
+    if (sampleVisible) return sampleVisible_(wi, s);
+    float pdf_;
+    return sampleAll(s, pdf_);
+}
+
+float MicrofacetDistribution::pdf(const Vec3 &wi, const Vec3 &m) const {
+    return sampleVisible ? pdfVisible(wi, m) : pdfAll(m);
+}
+
+Vec3 MicrofacetDistribution::sampleAll(const Vec2 &sample, float &pdf_) const {
+    float cosThetaM = 0.0f, sinPhiM, cosPhiM, alphaSqr;
+    if (isIsotropic()) {
+        sincos_((2.0f * M_PI_F) * sample.y, &sinPhiM, &cosPhiM);
+        alphaSqr = alphaU * alphaU;
+    } else {
+        float phiM = std::atan(alphaV / alphaU * std::tan(M_PI_F + 2 * M_PI_F * sample.y))
+                     + M_PI_F * std::floor(2 * sample.y + 0.5f);
+        sincos_(phiM, &sinPhiM, &cosPhiM);
+        float cosSc = cosPhiM / alphaU, sinSc = sinPhiM / alphaV;
+        alphaSqr = 1.0f / (cosSc * cosSc + sinSc * sinSc);
+    }
+    if (type == ORC_DISTR_BECKMANN) {
+        float tanThetaMSqr = alphaSqr * -fastlog(1.0f - sample.x);
+        cosThetaM = 1.0f / std::sqrt(1.0f + tanThetaMSqr);
+        pdf_ = (1.0f - sample.x) / (M_PI_F * alphaU * alphaV * cosThetaM * cosThetaM * cosThetaM);
+    } else {
+        float tanThetaMSqr = alphaSqr * sample.x / (1.0f - sample.x);
+        cosThetaM = 1.0f / std::sqrt(1.0f + tanThetaMSqr);
+        float temp = 1 + tanThetaMSqr / alphaSqr;
+        pdf_ = INV_PI_F / (alphaU * alphaV * cosThetaM * cosThetaM * cosThetaM * temp * temp);
+    }
+    if (pdf_ < 1e-20f) pdf_ = 0;
+    float sinThetaM = std::sqrt(std::max(0.0f, 1 - cosThetaM * cosThetaM));
+    return Vec3(sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM);
+}
+
+Vec3 MicrofacetDistribution::sampleVisible_(const Vec3 &_wi, const Vec2 &sample) const {
+    Vec3 wi = normalize(Vec3(alphaU * _wi.x, alphaV * _wi.y, _wi.z));
+    float theta = 0, phi = 0;
+    if (wi.z < 0.99999f) {
+        theta = std::acos(wi.z);
+        phi = std::atan2(wi.y, wi.x);
+    }
+    float sinPhi, cosPhi;
+    sincos_(phi, &sinPhi, &cosPhi);
+    Vec2 slope = sampleVisible11(theta, sample);
+    slope = Vec2{ cosPhi * slope.x - sinPhi * slope.y, sinPhi * slope.x + cosPhi * slope.y };
+    slope.x *= alphaU;
+    slope.y *= alphaV;
+    float normalization = 1.0f / std::sqrt(slope.x * slope.x + slope.y * slope.y + 1.0f);
+    return Vec3(-slope.x * normalization, -slope.y * normalization, normalization);
+}
+
+float MicrofacetDistribution::pdfVisible(const Vec3 &wi, const Vec3 &m) const {
+    if (Frame::cosTheta(wi) == 0) return 0.0f;
+    return smithG1(wi, m) * absDot(wi, m) * eval(m) / std::abs(Frame::cosTheta(wi));
+}
+
+float MicrofacetDistribution::projectRoughness(const Vec3 &v) const {
+    float invSinTheta2 = 1 / Frame::sinTheta2(v);
+    if (isIsotropic() || invSinTheta2 <= 0) return alphaU;
+    float cosPhi2 = v.x * v.x * invSinTheta2;
+    float sinPhi2 = v.y * v.y * invSinTheta2;
+    return std::sqrt(cosPhi2 * alphaU * alphaU + sinPhi2 * alphaV * alphaV);
+}
+
+float MicrofacetDistribution::smithG1(const Vec3 &v, const Vec3 &m) const {
+    if (dot(v, m) * Frame::cosTheta(v) <= 0) return 0.0f;
+    float tanTheta = std::abs(Frame::tanTheta(v));
+    if (tanTheta == 0.0f) return 1.0f;
+    float alpha = projectRoughness(v);
+    if (type == ORC_DISTR_BECKMANN) {
+        float a = 1.0f / (alpha * tanTheta);
+        if (a >= 1.6f) return 1.0f;
+        float aSqr = a * a;
+        return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
+    } else {
+        float root = alpha * tanTheta;
+        return 2.0f / (1.0f + hypot2(1.0f, root));
+    }
+}
+
+Vec2 MicrofacetDistribution::sampleVisible11(float thetaI, Vec2 sample) const {
+    const float SQRT_PI_INV = 1 / std::sqrt(M_PI_F);
+    Vec2 slope;
+    if (type == ORC_DISTR_BECKMANN) {
+        if (thetaI < 1e-4f) {
+            float sinPhi, cosPhi;
+            float r = std::sqrt(-fastlog(1.0f - sample.x));
+            sincos_(2 * M_PI_F * sample.y, &sinPhi, &cosPhi);
+            return Vec2{ r * cosPhi, r * sinPhi };
+        }
+        float tanThetaI = std::tan(thetaI);
+        float cotThetaI = 1 / tanThetaI;
+        float a = -1, c = erf(cotThetaI);
+        float sample_x = std::max(sample.x, 1e-6f);
+        float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
+        float b = c - (1 + c) * std::pow(1 - sample_x, fit);
+        float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * std::exp(-cotThetaI * cotThetaI));
+        int it = 0;
+        while (++it < 10) {
+            if (!(b >= a && b <= c)) b = 0.5f * (a + c);
+            float invErf = erfinv(b);
+            float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * std::exp(-invErf * invErf)) - sample_x;
+            float derivative = normalization * (1 - invErf * tanThetaI);
+            if (std::abs(value) < 1e-5f) break;
+            if (value > 0) c = b; else a = b;
+            b -= value / derivative;
+        }
+        slope.x = erfinv(b);
+        slope.y = erfinv(2.0f * std::max(sample.y, 1e-6f) - 1.0f);
+    } else {
+        if (thetaI < 1e-4f) {
+            float sinPhi, cosPhi;
+            float r = safe_sqrt(sample.x / (1 - sample.x));
+            sincos_(2 * M_PI_F * sample.y, &sinPhi, &cosPhi);
+            return Vec2{ r * cosPhi, r * sinPhi };
+        }
+        float tanThetaI = std::tan(thetaI);
+        float a = 1 / tanThetaI;
+        float G1 = 2.0f / (1.0f + safe_sqrt(1.0f + 1.0f / (a * a)));
+        float A = 2.0f * sample.x / G1 - 1.0f;
+        if (std::abs(A) == 1) A -= signum(A) * Epsilon;
+        float tmp = 1.0f / (A * A - 1.0f);
+        float B = tanThetaI;
+        float D = safe_sqrt(B * B * tmp * tmp - (A * A - B * B) * tmp);
+        float slope_x_1 = B * tmp - D;
+        float slope_x_2 = B * tmp + D;
+        slope.x = (A < 0.0f || slope_x_2 > 1.0f / tanThetaI) ? slope_x_1 : slope_x_2;
+        float S;
+        if (sample.y > 0.5f) { S = 1.0f; sample.y = 2.0f * (sample.y - 0.5f); }
+        else { S = -1.0f; sample.y = 2.0f * (0.5f - sample.y); }
+        float z = (sample.y * (sample.y * (sample.y * (-0.365728915865723f) + 0.790235037209296f) - 0.424965825137544f) + 0.000152998850436920f) /
+                  (sample.y * (sample.y * (sample.y * (sample.y * 0.169507819808272f - 0.397203533833404f) - 0.232500544458471f) + 1.0f) - 0.539825872510702f);
+        slope.y = S * z * std::sqrt(1.0f + slope.x * slope.x);
+    }
+    return slope;
+}
+
+// ---- Material configuration ----------------------------------------------------------------------
+static Spectrum toSpec(const float *v) { return Spectrum(v[0], v[1], v[2]); }
+
+// BSDF::ensureEnergyConservation (src/librender/bsdf.cpp:88-146)
+static void ensureEnergy(bool enabled, Spectrum &a) {
+    if (!enabled) return;
+    float actualMax = a.max();
+    if (actualMax > 1.0f) a *= 0.99f * (1.0f / actualMax);
+}
+static void ensureEnergy2(bool enabled, Spectrum &a, Spectrum &b) {
+    if (!enabled) return;
+    float actualMax = (a + b).max();
+    if (actualMax > 1.0f) { float scale = 0.99f * (1.0f / actualMax); a *= scale; b *= scale; }
+}
+
+void Material::configure() {
+    bool ee = m.ensure_energy_conservation != 0;
+    diffuse = toSpec(m.diffuse_reflectance);
+    specular = toSpec(m.specular_reflectance);
+    transmittance = toSpec(m.specular_transmittance);
+    unsigned aniso = (m.alpha_u != m.alpha_v) ? EAnisotropic : 0;
+    switch (m.type) {
+        case ORC_BSDF_DIFFUSE:   // src/bsdfs/diffuse.cpp:93-104
+            ensureEnergy(ee, diffuse);
+            type_flags = diffuse.max() > 0 ? (EDiffuseReflection | EFrontSide) : 0;
+            break;
+        case ORC_BSDF_ROUGHCONDUCTOR:   // src/bsdfs/roughconductor.cpp:187-190,228-250
+            ensureEnergy(ee, specular);
+            condEta = toSpec(m.eta) / m.ext_eta;
+            condK = toSpec(m.k) / m.ext_eta;
+            type_flags = EGlossyReflection | EFrontSide | aniso;
+            break;
+        case ORC_BSDF_ROUGHPLASTIC: {   // src/bsdfs/roughplastic.cpp:213,255-307
+            ensureEnergy(ee, specular);
+            ensureEnergy(ee, diffuse);
+            eta = m.int_ior / m.ext_ior;
+            invEta2 = 1.0f / (eta * eta);
+            float dAvg = luminance(diffuse), sAvg = luminance(specular);
+            specularSamplingWeight = sAvg / (dAvg + sAvg);
+            if (m.rtrans && m.rtrans_n) rtrans.assign(m.rtrans, m.rtrans + m.rtrans_n);
+            type_flags = EGlossyReflection | EDiffuseReflection | EFrontSide;
+            break;
+        }
+        case ORC_BSDF_DIELECTRIC:   // src/bsdfs/dielectric.cpp:158-159,184-202
+            ensureEnergy(ee, specular);
+            ensureEnergy(ee, transmittance);
+            eta = m.int_ior / m.ext_ior;
+            invEta = 1 / eta;
+            type_flags = EDeltaReflection | EDeltaTransmission | EFrontSide | EBackSide | ENonSymmetric;
+            break;
+        case ORC_BSDF_WARD: {   // src/bsdfs/ward.cpp:139-171
+            ensureEnergy2(ee, specular, diffuse);
+            float dAvg = luminance(diffuse), sAvg = luminance(specular);
+            specularSamplingWeight = sAvg / (dAvg + sAvg);
+            type_flags = EGlossyReflection | EDiffuseReflection | EFrontSide | aniso;
+            break;
+        }
+    }
+}
+
+// ---- RoughTransmittance::eval in the fully reduced (1-D) state (src/bsdfs/rtrans.h:183-194,233) ---
+static float rtransEval(const Material &mat, float cosTheta) {
+    float warpedCosTheta = std::pow(std::abs(cosTheta), 0.25f);
+    if (!(cosTheta >= 0)) return 0.f;
+    float result = evalCubicInterp1D(warpedCosTheta, mat.rtrans.data(), mat.rtrans.size(), 0.0f, 1.0f);
+    return std::min(1.0f, std::max(0.0f, result));
+}
+
+static inline Vec3 reflect(const Vec3 &wi, const Vec3 &m) { return 2 * dot(wi, m) * m - wi; }
+
+// src/libcore/util.cpp sphericalDirection
+static Vec3 sphericalDirection(float theta, float phi) {
+    float sinTheta, cosTheta, sinPhi, cosPhi;
+    sincos_(theta, &sinTheta, &cosTheta);
+    sincos_(phi, &sinPhi, &cosPhi);
+    return Vec3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+}
+
+// ---- eval -----------------------------------------------------------------------------------------
+Spectrum bsdfEval(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
+    const orc_material &m = mat.m;
+    switch (m.type) {
+        case ORC_BSDF_DIFFUSE: {   // diffuse.cpp:110-118
+            if (!(mat.type_flags & EDiffuseReflection)) return Spectrum(0.0f);
+            if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0) return Spectrum(0.0f);
+            return mat.diffuse * (INV_PI_F * Frame::cosTheta(wo));
+        }
+        case ORC_BSDF_ROUGHCONDUCTOR: {   // roughconductor.cpp:257-294
+            if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0) return Spectrum(0.0f);
+            Vec3 H = normalize(wo + wi);
+            MicrofacetDistribution distr(m.distribution, m.alpha_u, m.alpha_v, m.sample_visible != 0);
+            const float D = distr.eval(H);
+            if (D == 0) return Spectrum(0.0f);
+            const Spectrum F = fresnelConductorExact(dot(wi, H), mat.condEta, mat.condK) * mat.specular;
+            const float G = distr.G(wi, wo, H);
+            float model = D * G / (4.0f * Frame::cosTheta(wi));
+            return F * model;
+        }
+        case ORC_BSDF_ROUGHPLASTIC: {   // roughplastic.cpp:326-382
+            if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0) return Spectrum(0.0f);
+            MicrofacetDistribution distr(m.distribution, m.alpha_u, m.alpha_u, m.sample_visible != 0);
+            Spectrum result(0.0f);
+            {
+                const Vec3 H = normalize(wo + wi);
+                const float D = distr.eval(H);
+                const float F = fresnelDielectricExt(dot(wi, H), mat.eta);
+                const float G = distr.G(wi, wo, H);
+                float value = F * D * G / (4.0f * Frame::cosTheta(wi));
+                result += mat.specular * value;
+            }
+            {
+                Spectrum diff = mat.diffuse;
+                float T12 = rtransEval(mat, Frame::cosTheta(wi));
+                float T21 = rtransEval(mat, Frame::cosTheta(wo));
+                float Fdr = 1 - m.rtrans_diffuse_int;
+                if (m.variant) diff = diff / (Spectrum(1.0f) - diff * Fdr);
+                else diff /= 1 - Fdr;
+                result += diff * (INV_PI_F * Frame::cosTheta(wo) * T12 * T21 * mat.invEta2);
+            }
+            return result;
+        }
+        case ORC_BSDF_DIELECTRIC:   // dielectric.cpp:228-253: zero for the solid-angle measure
+            return Spectrum(0.0f);
+        case ORC_BSDF_WARD: {   // ward.cpp:178-226
+            if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0) return Spectrum(0.0f);
+            Spectrum result(0.0f);
+            Vec3 H = wi + wo;
+            float alphaU = m.alpha_u, alphaV = m.alpha_v;
+            float factor1 = 0.0f;
+            switch (m.variant) {
+                case 0: factor1 = 1.0f / (4.0f * M_PI_F * alphaU * alphaV * std::sqrt(Frame::cosTheta(wi) * Frame::cosTheta(wo))); break;
+                case 1: factor1 = 1.0f / (4.0f * M_PI_F * alphaU * alphaV * Frame::cosTheta(wi) * Frame::cosTheta(wo)); break;
+                default:   // std::pow(Float, int) promotes to double in the reference expression
+                    factor1 = (float) ((double) dot(H, H) / ((double) (M_PI_F * alphaU * alphaV) * std::pow((double) Frame::cosTheta(H), 4.0))); break;
+            }
+            float factor2 = H.x / alphaU, factor3 = H.y / alphaV;
+            float exponent = -(factor2 * factor2 + factor3 * factor3) / (H.z * H.z);
+            float specRef = factor1 * fastexp(exponent);
+            if (specRef > 1e-10f) result += mat.specular * specRef;
+            result += mat.diffuse * INV_PI_F;
+            return result * Frame::cosTheta(wo);
+        }
+    }
+    return Spectrum(0.0f);
+}
+
+// ---- pdf ------------------------------------------------------------------------------------------
+float bsdfPdf(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
+    const orc_material &m = mat.m;
+    switch (m.type) {
+        case ORC_BSDF_DIFFUSE:   // diffuse.cpp:120-127
+            if (!(mat.type_flags & EDiffuseReflection)) return 0.0f;
+            if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0) return 0.0f;
+            return squareToCosineHemispherePdf(wo);
+        case ORC_BSDF_ROUGHCONDUCTOR: {   // roughconductor.cpp:296-321
+            if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0) return 0.0f;
+            Vec3 H = normalize(wo + wi);
+            MicrofacetDistribution distr(m.distribution, m.alpha_u, m.alpha_v, m.sample_visible != 0);
+            if (distr.sampleVisible)
+                return distr.eval(H) * distr.smithG1(wi, H) / (4.0f * Frame::cosTheta(wi));
+            else
+                return distr.pdf(wi, H) / (4 * absDot(wo, H));
+        }
+        case ORC_BSDF_ROUGHPLASTIC: {   // roughplastic.cpp:384-437
+            if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0) return 0.0f;
+            MicrofacetDistribution distr(m.distribution, m.alpha_u, m.alpha_u, m.sample_visible != 0);
+            const Vec3 H = normalize(wo + wi);
+            float probSpecular = 1 - rtransEval(mat, Frame::cosTheta(wi));
+            probSpecular = (probSpecular * mat.specularSamplingWeight) /
+                (probSpecular * mat.specularSamplingWeight + (1 - probSpecular) * (1 - mat.specularSamplingWeight));
+            float probDiffuse = 1 - probSpecular;
+            const float dwh_dwo = 1.0f / (4.0f * dot(wo, H));
+            const float prob = distr.pdf(wi, H);
+            float result = prob * dwh_dwo * probSpecular;
+            result += probDiffuse * squareToCosineHemispherePdf(wo);
+            return result;
+        }
+        case ORC_BSDF_DIELECTRIC:
+            return 0.0f;
+        case ORC_BSDF_WARD: {   // ward.cpp:228-264
+            if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0) return 0.0f;
+            float alphaU = m.alpha_u, alphaV = m.alpha_v;
+            Vec3 H = normalize(wi + wo);
+            float factor1 = (float) (1.0 / ((double) (4.0f * M_PI_F * alphaU * alphaV * dot(H, wi)) * std::pow((double) Frame::cosTheta(H), 3.0)));
+            float factor2 = H.x / alphaU, factor3 = H.y / alphaV;
+            float exponent = -(factor2 * factor2 + factor3 * factor3) / (H.z * H.z);
+            float specProb = factor1 * fastexp(exponent);
+            float diffuseProb = squareToCosineHemispherePdf(wo);
+            return mat.specularSamplingWeight * specProb + (1 - mat.specularSamplingWeight) * diffuseProb;
+        }
+    }
+    return 0.0f;
+}
+
+// ---- sample (the pdf-returning overload the integrator calls, path.cpp:209) --------------------------
+Spectrum bsdfSample(const Material &mat, const Vec3 &wi, const Vec2 &_sample, BSDFSample &out, float &pdf) {
+    const orc_material &m = mat.m;
+    pdf = 0;
+    out.eta = 1.0f;
+    out.sampledType = 0;
+    switch (m.type) {
+        case ORC_BSDF_DIFFUSE: {   // diffuse.cpp:140-150
+            if (!(mat.type_flags & EDiffuseReflection) || Frame::cosTheta(wi) <= 0) return Spectrum(0.0f);
+            out.wo = squareToCosineHemisphere(_sample);
+            out.eta = 1.0f;
+            out.sampledType = EDiffuseReflection;
+            pdf = squareToCosineHemispherePdf(out.wo);
+            return mat.diffuse;
+        }
+        case ORC_BSDF_ROUGHCONDUCTOR: {   // roughconductor.cpp:369-415
+            if (Frame::cosTheta(wi) < 0) return Spectrum(0.0f);
+            MicrofacetDistribution distr(m.distribution, m.alpha_u, m.alpha_v, m.sample_visible != 0);
+            Vec3 mm = distr.sample(wi, _sample, pdf);
+            if (pdf == 0) return Spectrum(0.0f);
+            out.wo = reflect(wi, mm);
+            out.eta = 1.0f;
+            out.sampledType = EGlossyReflection;
+            if (Frame::cosTheta(out.wo) <= 0) return Spectrum(0.0f);
+            Spectrum F = fresnelConductorExact(dot(wi, mm), mat.condEta, mat.condK) * mat.specular;
+            float weight;
+            if (distr.sampleVisible) weight = distr.smithG1(out.wo, mm);
+            else weight = distr.eval(mm) * distr.G(wi, out.wo, mm) * dot(wi, mm) / (pdf * Frame::cosTheta(wi));
+            pdf /= 4.0f * dot(out.wo, mm);
+            return F * weight;
+        }
+        case ORC_BSDF_ROUGHPLASTIC: {   // roughplastic.cpp:439-501
+            if (Frame::cosTheta(wi) <= 0) return Spectrum(0.0f);
+            bool choseSpecular = true;
+            Vec2 sample = _sample;
+            MicrofacetDistribution distr(m.distribution, m.alpha_u, m.alpha_u, m.sample_visible != 0);
+            float probSpecular = 1 - rtransEval(mat, Frame::cosTheta(wi));
+            probSpecular = (probSpecular * mat.specularSamplingWeight) /
+                (probSpecular * mat.specularSamplingWeight + (1 - probSpecular) * (1 - mat.specularSamplingWeight));
+            if (sample.y < probSpecular) {
+                sample.y /= probSpecular;
+            } else {
+                sample.y = (sample.y - probSpecular) / (1 - probSpecular);
+                choseSpecular = false;
+            }
+            if (choseSpecular) {
+                Vec3 mm = distr.sample(wi, sample);
+                out.wo = reflect(wi, mm);
+                out.sampledType = EGlossyReflection;
+                if (Frame::cosTheta(out.wo) <= 0) return Spectrum(0.0f);
+            } else {
+                out.sampledType = EDiffuseReflection;
+                out.wo = squareToCosineHemisphere(sample);
+            }
+            out.eta = 1.0f;
+            pdf = bsdfPdf(mat, wi, out.wo);
+            if (pdf == 0) return Spectrum(0.0f);
+            return bsdfEval(mat, wi, out.wo) / pdf;
+        }
+        case ORC_BSDF_DIELECTRIC: {   // dielectric.cpp:277-333 (both lobes enabled, ERadiance)
+            float cosThetaT;
+            float F = fresnelDielectricExt(Frame::cosTheta(wi), cosThetaT, mat.eta);
+            if (_sample.x <= F) {
+                out.sampledType = EDeltaReflection;
+                out.wo = Vec3(-wi.x, -wi.y, wi.z);
+                out.eta = 1.0f;
+                pdf = F;
+                return mat.specular;
+            } else {
+                out.sampledType = EDeltaTransmission;
+                float scale = -(cosThetaT < 0 ? mat.invEta : mat.eta);
+                out.wo = Vec3(scale * wi.x, scale * wi.y, cosThetaT);
+                out.eta = cosThetaT < 0 ? mat.eta : mat.invEta;
+                pdf = 1 - F;
+                float factor = cosThetaT < 0 ? mat.invEta : mat.eta;
+                return mat.transmittance * (factor * factor);
+            }
+        }
+        case ORC_BSDF_WARD: {   // ward.cpp:266-326
+            Vec2 sample = _sample;
+            bool choseSpecular = true;
+            if (sample.x <= mat.specularSamplingWeight) {
+                sample.x /= mat.specularSamplingWeight;
+            } else {
+                sample.x = (sample.x - mat.specularSamplingWeight) / (1 - mat.specularSamplingWeight);
+                choseSpecular = false;
+            }
+            if (choseSpecular) {
+                float alphaU = m.alpha_u, alphaV = m.alpha_v;
+                float phiH = std::atan(alphaV / alphaU * std::tan(2.0f * M_PI_F * sample.y));
+                if (sample.y > 0.5f) phiH += M_PI_F;
+                float cosPhiH = std::cos(phiH);
+                float sinPhiH = safe_sqrt(1.0f - cosPhiH * cosPhiH);
+                float thetaH = std::atan(safe_sqrt(-fastlog(sample.x) /
+                    ((cosPhiH * cosPhiH) / (alphaU * alphaU) + (sinPhiH * sinPhiH) / (alphaV * alphaV))));
+                Vec3 H = sphericalDirection(thetaH, phiH);
+                out.wo = H * (2.0f * dot(wi, H)) - wi;
+                out.sampledType = EGlossyReflection;
+                if (Frame::cosTheta(out.wo) <= 0.0f) return Spectrum(0.0f);
+            } else {
+                out.wo = squareToCosineHemisphere(sample);
+                out.sampledType = EDiffuseReflection;
+            }
+            out.eta = 1.0f;
+            pdf = bsdfPdf(mat, wi, out.wo);
+            if (pdf == 0) return Spectrum(0.0f);
+            return bsdfEval(mat, wi, out.wo) / pdf;
+        }
+    }
+    return Spectrum(0.0f);
+}
+
+}  // namespace orc

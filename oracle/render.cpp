@@ -1,0 +1,733 @@
+// TEST INFRASTRUCTURE ONLY -- CPU oracle: scene set-up, emitter sampling, the MIPathTracer::Li
+// loop, perspective camera, film accumulation and a block-parallel renderer, restated from the
+// reference files cited per function.
+#include "bsdf.h"
+#include "rng.h"
+#include <chrono>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+namespace orc {
+
+// ---- DiscreteDistribution (include/mitsuba/core/pmf.h:101-188) ----------------------------------
+float DiscreteDistribution::normalize() {
+    sum = cdf[cdf.size() - 1];
+    if (sum > 0) {
+        normalization = 1.0f / sum;
+        for (size_t i = 1; i < cdf.size(); ++i) cdf[i] *= normalization;
+        cdf[cdf.size() - 1] = 1.0f;
+    } else {
+        normalization = 0.0f;
+    }
+    return sum;
+}
+
+size_t DiscreteDistribution::sample(float v) const {
+    std::vector<float>::const_iterator entry = std::lower_bound(cdf.begin(), cdf.end(), v);
+    size_t index = std::min(cdf.size() - 2, (size_t) std::max((ptrdiff_t) 0, entry - cdf.begin() - 1));
+    while (operator[](index) == 0 && index < cdf.size() - 1) ++index;
+    return index;
+}
+
+size_t DiscreteDistribution::sampleReuse(float &v) const {
+    size_t index = sample(v);
+    v = (v - cdf[index]) / (cdf[index + 1] - cdf[index]);
+    return index;
+}
+
+size_t DiscreteDistribution::sampleReuse(float &v, float &pdf) const {
+    size_t index = sample(v);
+    pdf = operator[](index);
+    v = (v - cdf[index]) / (cdf[index + 1] - cdf[index]);
+    return index;
+}
+
+// ---- 4x4 helpers for the camera (src/libcore/transform.cpp:99-123, perspective.cpp:126-157) -----
+static void matMul(const float *a, const float *b, float *out) {
+    float r[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float s = 0;
+            for (int k = 0; k < 4; ++k) s += a[i * 4 + k] * b[k * 4 + j];
+            r[i * 4 + j] = s;
+        }
+    memcpy(out, r, sizeof(r));
+}
+
+static bool matInvert(const float *m, float *out) {
+    // Gauss-Jordan elimination with partial pivoting (Matrix4x4::invert, src/libcore/matrix.cpp)
+    float a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { a[i][j] = m[i * 4 + j]; a[i][j + 4] = (i == j) ? 1.0f : 0.0f; }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r) if (std::abs(a[r][c]) > std::abs(a[piv][c])) piv = r;
+        if (a[piv][c] == 0) return false;
+        if (piv != c) for (int j = 0; j < 8; ++j) std::swap(a[c][j], a[piv][j]);
+        float inv = 1.0f / a[c][c];
+        for (int j = 0; j < 8; ++j) a[c][j] *= inv;
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            float f = a[r][c];
+            if (f != 0) for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+        }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[i * 4 + j] = a[i][j + 4];
+    return true;
+}
+
+static void matScale(float x, float y, float z, float *m) {
+    memset(m, 0, 64); m[0] = x; m[5] = y; m[10] = z; m[15] = 1;
+}
+static void matTranslate(float x, float y, float z, float *m) {
+    matScale(1, 1, 1, m); m[3] = x; m[7] = y; m[11] = z;
+}
+
+// ---- Scene::build ----------------------------------------------------------------------------------
+std::string Scene::build(const orc_scene_desc *d) {
+    desc = *d;
+    positions.resize(d->n_vertices);
+    for (uint32_t i = 0; i < d->n_vertices; ++i)
+        positions[i] = Vec3(d->positions[3 * i], d->positions[3 * i + 1], d->positions[3 * i + 2]);
+    if (d->normals) {
+        normals.resize(d->n_vertices);
+        for (uint32_t i = 0; i < d->n_vertices; ++i)
+            normals[i] = Vec3(d->normals[3 * i], d->normals[3 * i + 1], d->normals[3 * i + 2]);
+    }
+    if (d->texcoords) {
+        texcoords.resize(d->n_vertices);
+        for (uint32_t i = 0; i < d->n_vertices; ++i) texcoords[i] = Vec2{ d->texcoords[2 * i], d->texcoords[2 * i + 1] };
+    }
+    indices.assign(d->indices, d->indices + (size_t) d->n_triangles * 3);
+    for (size_t i = 0; i < indices.size(); ++i)
+        if (indices[i] >= d->n_vertices) return "vertex index out of range";
+    shapes.assign(d->shapes, d->shapes + d->n_shapes);
+    emitters.assign(d->emitters, d->emitters + d->n_emitters);
+    materials.resize(d->n_materials);
+    for (uint32_t i = 0; i < d->n_materials; ++i) { materials[i].m = d->materials[i]; materials[i].configure(); }
+
+    triShape.assign(d->n_triangles, 0xFFFFFFFFu);
+    uvDpdu.assign(d->n_triangles, Vec3(0.0f));
+    uvDpduValid.assign(d->n_triangles, 0);
+    for (uint32_t s = 0; s < d->n_shapes; ++s) {
+        const orc_shape &sh = shapes[s];
+        if ((uint64_t) sh.first_triangle + sh.n_triangles > d->n_triangles) return "shape triangle range out of bounds";
+        if (sh.material < 0 || (uint32_t) sh.material >= d->n_materials) return "shape material out of range";
+        if ((sh.flags & ORC_SHAPE_HAS_NORMALS) && !d->normals) return "shape claims normals but none given";
+        if ((sh.flags & ORC_SHAPE_HAS_TEXCOORDS) && !d->texcoords) return "shape claims texcoords but none given";
+        for (uint32_t j = 0; j < sh.n_triangles; ++j) {
+            uint32_t t = sh.first_triangle + j;
+            triShape[t] = s;
+            if (sh.flags & ORC_SHAPE_HAS_TEXCOORDS) {
+                // TriMesh::computeUVTangents (src/librender/trimesh.cpp:701-735)
+                uint32_t i0 = indices[3 * t], i1 = indices[3 * t + 1], i2 = indices[3 * t + 2];
+                const Vec3 &v0 = positions[i0], &v1 = positions[i1], &v2 = positions[i2];
+                const Vec2 &uv0 = texcoords[i0], &uv1 = texcoords[i1], &uv2 = texcoords[i2];
+                Vec3 dP1 = v1 - v0, dP2 = v2 - v0;
+                Vec2 dUV1{ uv1.x - uv0.x, uv1.y - uv0.y }, dUV2{ uv2.x - uv0.x, uv2.y - uv0.y };
+                Vec3 n = cross(dP1, dP2);
+                float length = n.length();
+                if (length == 0) continue;
+                float determinant = dUV1.x * dUV2.y - dUV1.y * dUV2.x;
+                if (determinant == 0) {
+                    Vec3 dpdu, dpdv;
+                    coordinateSystem(n / length, dpdu, dpdv);
+                    uvDpdu[t] = dpdu;
+                } else {
+                    float invDet = 1.0f / determinant;
+                    uvDpdu[t] = (dUV2.y * dP1 - dUV1.y * dP2) * invDet;
+                }
+                uvDpduValid[t] = 1;
+            }
+        }
+    }
+    for (uint32_t t = 0; t < d->n_triangles; ++t)
+        if (triShape[t] == 0xFFFFFFFFu) return "triangle not owned by any shape";
+
+    // Per-emitter-shape area distribution (TriMesh::prepareSamplingTable, trimesh.cpp:388-403)
+    areaDistr.assign(d->n_shapes, DiscreteDistribution());
+    invSurfaceArea.assign(d->n_shapes, 0.0f);
+    for (uint32_t e = 0; e < d->n_emitters; ++e) {
+        int s = emitters[e].shape;
+        if (s < 0 || (uint32_t) s >= d->n_shapes) return "emitter shape out of range";
+        if (shapes[s].emitter != (int32_t) e) return "shape/emitter cross reference mismatch";
+        DiscreteDistribution &ad = areaDistr[s];
+        for (uint32_t j = 0; j < shapes[s].n_triangles; ++j) {
+            uint32_t t = shapes[s].first_triangle + j;
+            const Vec3 &p0 = positions[indices[3 * t]], &p1 = positions[indices[3 * t + 1]], &p2 = positions[indices[3 * t + 2]];
+            ad.append(0.5f * cross(p1 - p0, p2 - p0).length());     // Triangle::surfaceArea, triangle.cpp:61-67
+        }
+        float area = ad.normalize();
+        invSurfaceArea[s] = 1.0f / area;
+        emitterPDF.append(emitters[e].sampling_weight);             // scene.cpp:375-380
+    }
+    if (d->n_emitters) emitterPDF.normalize();
+
+    buildKDTree();
+
+    // Camera (perspective.cpp:126-157)
+    const orc_film &f = d->film;
+    aspect = (float) f.width / (float) f.height;
+    invResolution = Vec2{ 1.0f / (float) f.crop_w, 1.0f / (float) f.crop_h };
+    float relSizeX = (float) f.crop_w / (float) f.width, relSizeY = (float) f.crop_h / (float) f.height;
+    float relOffX = (float) f.crop_x / (float) f.width, relOffY = (float) f.crop_y / (float) f.height;
+    float persp[16];
+    {
+        float nearC = d->camera.near_clip, farC = d->camera.far_clip;
+        float recip = 1.0f / (farC - nearC);
+        float cot = 1.0f / std::tan((d->camera.x_fov / 2.0f) * (M_PI_F / 180.0f));
+        memset(persp, 0, 64);
+        persp[0] = cot; persp[5] = cot; persp[10] = farC * recip; persp[11] = -nearC * farC * recip; persp[14] = 1;
+    }
+    float m[16], tmp[16];
+    matScale(1.0f / relSizeX, 1.0f / relSizeY, 1.0f, m);
+    matTranslate(-relOffX, -relOffY, 0.0f, tmp); matMul(m, tmp, m);
+    matScale(-0.5f, -0.5f * aspect, 1.0f, tmp); matMul(m, tmp, m);
+    matTranslate(-1.0f, -1.0f / aspect, 0.0f, tmp); matMul(m, tmp, m);
+    matMul(m, persp, m);
+    if (!matInvert(m, sampleToCamera)) return "singular camera matrix";
+    memcpy(camToWorld, d->camera.to_world, 64);
+    return "";
+}
+
+// ---- Emitter sampling --------------------------------------------------------------------------------
+struct DirectSample {
+    Vec3 p, n, d;
+    float dist = 0, pdf = 0;
+    int emitter = -1;
+};
+
+// Scene::sampleEmitterDirect sans visibility (scene.cpp:828-852), AreaLight::sampleDirect
+// (area.cpp:158-173), Shape::sampleDirect (shape.cpp:102-115), TriMesh::samplePosition
+// (trimesh.cpp:412-423), Triangle::sample (triangle.cpp:24-59)
+static Spectrum sampleEmitterDirect(const Scene &sc, const Vec3 &ref, const Vec3 &refN, Vec2 sample, DirectSample &dRec) {
+    if (sc.emitters.empty()) { dRec.pdf = 0; return Spectrum(0.0f); }
+    float emPdf;
+    size_t index = sc.emitterPDF.sampleReuse(sample.x, emPdf);
+    const orc_emitter &em = sc.emitters[index];
+    const orc_shape &sh = sc.shapes[em.shape];
+    size_t triIdx = sc.areaDistr[em.shape].sampleReuse(sample.y);
+    uint32_t t = sh.first_triangle + (uint32_t) triIdx;
+    uint32_t i0 = sc.indices[3 * t], i1 = sc.indices[3 * t + 1], i2 = sc.indices[3 * t + 2];
+    const Vec3 &p0 = sc.positions[i0], &p1 = sc.positions[i1], &p2 = sc.positions[i2];
+    Vec2 bary = squareToUniformTriangle(sample);
+    Vec3 sideA = p1 - p0, sideB = p2 - p0;
+    dRec.p = p0 + (sideA * bary.x) + (sideB * bary.y);
+    if (sh.flags & ORC_SHAPE_HAS_NORMALS) {
+        const Vec3 &n0 = sc.normals[i0], &n1 = sc.normals[i1], &n2 = sc.normals[i2];
+        dRec.n = normalize(n0 * (1.0f - bary.x - bary.y) + n1 * bary.x + n2 * bary.y);
+    } else {
+        dRec.n = normalize(cross(sideA, sideB));
+    }
+    dRec.pdf = sc.invSurfaceArea[em.shape];
+    dRec.d = dRec.p - ref;
+    float distSquared = dRec.d.lengthSquared();
+    dRec.dist = std::sqrt(distSquared);
+    dRec.d /= dRec.dist;
+    float dp = absDot(dRec.d, dRec.n);
+    dRec.pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
+    Spectrum value;
+    if (dot(dRec.d, refN) >= 0 && dot(dRec.d, dRec.n) < 0 && dRec.pdf != 0) {
+        value = Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]) / dRec.pdf;
+    } else {
+        dRec.pdf = 0.0f;
+        return Spectrum(0.0f);
+    }
+    dRec.emitter = (int) index;
+    dRec.pdf *= emPdf;
+    value /= emPdf;
+    return value;
+}
+
+static inline float miWeight(float pdfA, float pdfB) {
+    pdfA *= pdfA; pdfB *= pdfB;
+    return pdfA / (pdfA + pdfB);
+}
+
+struct RayCounters { uint64_t normal = 0, shadow = 0; TraversalCounters trav; };
+
+// ---- MIPathTracer::Li (src/integrators/path/path.cpp:119-294) -------------------------------------------
+static Spectrum Li(const Scene &sc, const Ray &r, Pcg32 &rng, float &alpha, RayCounters &cnt) {
+    const orc_integrator &ig = sc.desc.integrator;
+    Intersection its;
+    Ray ray(r);
+    Spectrum Li(0.0f);
+    bool scattered = false;
+    bool emittedRadiance = true;   // rRec.type & EEmittedRadiance
+    int depth = 1;
+
+    cnt.normal++;
+    sc.rayIntersect(ray, its, &cnt.trav);
+    alpha = its.isValid() ? 1.0f : 0.0f;   // records.inl:121-137
+    ray.mint = Epsilon;
+
+    Spectrum throughput(1.0f);
+    float eta = 1.0f;
+
+    while (depth <= ig.max_depth || ig.max_depth < 0) {
+        if (!its.isValid()) break;     // no environment emitter on this path
+        const orc_shape &shape = sc.shapes[its.shape];
+        const Material &bsdf = sc.materials[shape.material];
+
+        if (shape.emitter >= 0 && emittedRadiance && (!ig.hide_emitters || scattered)) {
+            // AreaLight::eval (area.cpp:104-109)
+            const orc_emitter &em = sc.emitters[shape.emitter];
+            if (dot(its.shFrame.n, -ray.d) > 0)
+                Li += throughput * Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]);
+        }
+
+        if ((depth >= ig.max_depth && ig.max_depth > 0) ||
+            (ig.strict_normals && dot(ray.d, its.geoFrame.n) * Frame::cosTheta(its.wi) >= 0))
+            break;
+
+        // DirectSamplingRecord(its) (records.inl:160-164)
+        Vec3 refN(0.0f);
+        if ((bsdf.type_flags & (ETransmission | EBackSide)) == 0) refN = its.shFrame.n;
+
+        if (bsdf.type_flags & ESmooth) {
+            DirectSample dRec;
+            Vec2 s = rng.next2D();
+            Spectrum value = sampleEmitterDirect(sc, its.p, refN, s, dRec);
+            if (dRec.pdf != 0) {
+                cnt.shadow++;
+                Ray shadowRay(its.p, dRec.d, Epsilon, dRec.dist * (1 - ShadowEpsilon));
+                if (sc.rayIntersectShadow(shadowRay, &cnt.trav)) value = Spectrum(0.0f);
+            }
+            if (!value.isZero()) {
+                Vec3 wo = its.toLocal(dRec.d);
+                const Spectrum bsdfVal = bsdfEval(bsdf, its.wi, wo);
+                if (!bsdfVal.isZero() && (!ig.strict_normals || dot(its.geoFrame.n, dRec.d) * Frame::cosTheta(wo) > 0)) {
+                    float bsdfPdf_ = bsdfPdf(bsdf, its.wi, wo);   // area lights: on surface, solid angle
+                    float weight = miWeight(dRec.pdf, bsdfPdf_);
+                    Li += throughput * value * bsdfVal * weight;
+                }
+            }
+        }
+
+        float bsdfPdf_;
+        BSDFSample bs;
+        Spectrum bsdfWeight = bsdfSample(bsdf, its.wi, rng.next2D(), bs, bsdfPdf_);
+        if (bsdfWeight.isZero()) break;
+        scattered |= bs.sampledType != ENull;
+
+        const Vec3 wo = its.toWorld(bs.wo);
+        float woDotGeoN = dot(its.geoFrame.n, wo);
+        if (ig.strict_normals && woDotGeoN * Frame::cosTheta(bs.wo) <= 0) break;
+
+        bool hitEmitter = false;
+        Spectrum value;
+        Vec3 refP = its.p;
+        ray = Ray(its.p, wo);
+        cnt.normal++;
+        if (sc.rayIntersect(ray, its, &cnt.trav)) {
+            const orc_shape &hs = sc.shapes[its.shape];
+            if (hs.emitter >= 0) {
+                const orc_emitter &em = sc.emitters[hs.emitter];
+                value = dot(its.shFrame.n, -ray.d) > 0 ? Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]) : Spectrum(0.0f);
+                hitEmitter = true;
+            }
+        } else {
+            break;
+        }
+        (void) refP;
+
+        throughput *= bsdfWeight;
+        eta *= bs.eta;
+
+        if (hitEmitter) {
+            // pdfEmitterDirect (scene.cpp:949-952) -> AreaLight::pdfDirect (area.cpp:175-183)
+            // -> Shape::pdfDirect (shape.cpp:117-121) with dRec.setQuery(ray, its)
+            float lumPdf = 0;
+            if (!(bs.sampledType & EDelta)) {
+                const orc_shape &hs = sc.shapes[its.shape];
+                if (dot(ray.d, refN) >= 0 && dot(ray.d, its.shFrame.n) < 0)
+                    lumPdf = sc.invSurfaceArea[its.shape] * (its.t * its.t) / absDot(ray.d, its.shFrame.n);
+                lumPdf *= sc.emitters[hs.emitter].sampling_weight * sc.emitterPDF.normalization;
+            }
+            Li += throughput * value * miWeight(bsdfPdf_, lumPdf);
+        }
+
+        emittedRadiance = false;   // rRec.type = ERadianceNoEmission
+        if (depth++ >= ig.rr_depth) {
+            float q = std::min(throughput.max() * eta * eta, 0.95f);
+            if (rng.next1D() >= q) break;
+            throughput /= q;
+        }
+    }
+    return Li;
+}
+
+// ---- PerspectiveCameraImpl::sampleRayDifferential (perspective.cpp:271-298), ray part ---------------------
+static Ray cameraRay(const Scene &sc, float px, float py) {
+    const float *M = sc.sampleToCamera;
+    float sx = px * sc.invResolution.x, sy = py * sc.invResolution.y;
+    // Transform::operator()(Point) with homogeneous divide (transform.h)
+    float x = M[0] * sx + M[1] * sy + M[3];
+    float y = M[4] * sx + M[5] * sy + M[7];
+    float z = M[8] * sx + M[9] * sy + M[11];
+    float w = M[12] * sx + M[13] * sy + M[15];
+    Vec3 nearP(x, y, z);
+    if (w != 1.0f) nearP = nearP / w;
+    Vec3 d = normalize(nearP);
+    float invZ = 1.0f / d.z;
+    const float *W = sc.camToWorld;
+    Vec3 o(W[3], W[7], W[11]);   // transformAffine(Point(0))
+    Vec3 dw(W[0] * d.x + W[1] * d.y + W[2] * d.z,
+            W[4] * d.x + W[5] * d.y + W[6] * d.z,
+            W[8] * d.x + W[9] * d.y + W[10] * d.z);
+    return Ray(o, dw, sc.desc.camera.near_clip * invZ, sc.desc.camera.far_clip * invZ);
+}
+
+// ---- ImageBlock::put (include/mitsuba/render/imageblock.h:144-204) onto a border-less film -----------------
+static bool filmPut(const Scene &sc, float *film, float posx, float posy, const float *value /* R,G,B,alpha */) {
+    const orc_film &f = sc.desc.film;
+    float temp[5] = { value[0], value[1], value[2], value[3], 1.0f };
+    for (int i = 0; i < 5; ++i)
+        if (!std::isfinite(temp[i]) || temp[i] < 0) return false;
+    const float filterRadius = f.filter_radius;
+    const float scaleFactor = 31.0f / filterRadius;    // rfilter.cpp:49
+    const float px = posx - 0.5f, py = posy - 0.5f;
+    const int minx = std::max((int) std::ceil(px - filterRadius), 0), miny = std::max((int) std::ceil(py - filterRadius), 0);
+    const int maxx = std::min((int) std::floor(px + filterRadius), f.crop_w - 1), maxy = std::min((int) std::floor(py + filterRadius), f.crop_h - 1);
+    float wx[16], wy[16];
+    for (int x = minx, idx = 0; x <= maxx; ++x) wx[idx++] = f.filter_values[std::min((int) std::abs((x - px) * scaleFactor), 31)];
+    for (int y = miny, idx = 0; y <= maxy; ++y) wy[idx++] = f.filter_values[std::min((int) std::abs((y - py) * scaleFactor), 31)];
+    for (int y = miny, yr = 0; y <= maxy; ++y, ++yr) {
+        const float weightY = wy[yr];
+        float *dest = film + ((size_t) y * f.crop_w + minx) * 5;
+        for (int x = minx, xr = 0; x <= maxx; ++x, ++xr) {
+            const float weight = wx[xr] * weightY;
+            for (int k = 0; k < 5; ++k) *dest++ += weight * temp[k];
+        }
+    }
+    return true;
+}
+
+}  // namespace orc
+
+using namespace orc;
+
+struct orc_scene { Scene s; };
+
+static thread_local std::string g_err;
+extern "C" const char *orc_last_error(void) { return g_err.c_str(); }
+
+extern "C" orc_scene *orc_scene_create(const orc_scene_desc *desc) {
+    orc_scene *h = new orc_scene();
+    std::string err = h->s.build(desc);
+    if (!err.empty()) { g_err = err; delete h; return nullptr; }
+    return h;
+}
+extern "C" void orc_scene_destroy(orc_scene *s) { delete s; }
+
+static void fillHit(const Intersection &its, bool hit, orc_hit &h) {
+    memset(&h, 0, sizeof(h));
+    if (!hit) { h.t = std::numeric_limits<float>::infinity(); h.shape = h.prim = 0xFFFFFFFFu; return; }
+    h.t = its.t; h.u = its.u; h.v = its.v; h.shape = its.shape; h.prim = its.prim;
+    for (int i = 0; i < 3; ++i) {
+        h.p[i] = its.p[i]; h.geo_n[i] = its.geoFrame.n[i]; h.sh_n[i] = its.shFrame.n[i];
+        h.sh_s[i] = its.shFrame.s[i]; h.sh_t[i] = its.shFrame.t[i]; h.wi[i] = its.wi[i];
+    }
+    h.uv[0] = its.uv.x; h.uv[1] = its.uv.y;
+}
+
+static Ray rayFrom(const float *r) {
+    return Ray(Vec3(r[0], r[1], r[2]), Vec3(r[4], r[5], r[6]), r[3], r[7]);
+}
+
+template <typename F> static void parallelFor(uint64_t n, int nThreads, F fn) {
+    unsigned nt = nThreads > 0 ? (unsigned) nThreads : std::max(1u, std::thread::hardware_concurrency());
+    if (n < 4096) nt = 1;
+    std::atomic<uint64_t> next(0);
+    const uint64_t chunk = 1024;
+    auto worker = [&]() {
+        for (;;) {
+            uint64_t b = next.fetch_add(chunk);
+            if (b >= n) break;
+            uint64_t e = std::min(n, b + chunk);
+            for (uint64_t i = b; i < e; ++i) fn(i);
+        }
+    };
+    if (nt == 1) { worker(); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(worker);
+    for (auto &t : th) t.join();
+}
+
+extern "C" int orc_trace(const orc_scene *s, uint64_t n, const float *rays, orc_hit *hits, int brute) {
+    parallelFor(n, 0, [&](uint64_t i) {
+        Ray ray = rayFrom(rays + 8 * i);
+        Intersection its;
+        bool hit = brute ? s->s.rayIntersectBrute(ray, its, false) : s->s.rayIntersect(ray, its);
+        fillHit(its, hit, hits[i]);
+    });
+    return 0;
+}
+
+extern "C" int orc_occluded(const orc_scene *s, uint64_t n, const float *rays, uint8_t *out, int brute) {
+    parallelFor(n, 0, [&](uint64_t i) {
+        Ray ray = rayFrom(rays + 8 * i);
+        Intersection its;
+        out[i] = brute ? s->s.rayIntersectBrute(ray, its, true) : s->s.rayIntersectShadow(ray);
+    });
+    return 0;
+}
+
+extern "C" int orc_bsdf_eval(const orc_scene *s, int material, uint64_t n, const float *wi, const float *wo, float *out) {
+    if (material < 0 || (size_t) material >= s->s.materials.size()) return -1;
+    const Material &m = s->s.materials[material];
+    for (uint64_t i = 0; i < n; ++i) {
+        Spectrum r = bsdfEval(m, Vec3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), Vec3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]));
+        out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+    }
+    return 0;
+}
+
+extern "C" int orc_bsdf_pdf(const orc_scene *s, int material, uint64_t n, const float *wi, const float *wo, float *out) {
+    if (material < 0 || (size_t) material >= s->s.materials.size()) return -1;
+    const Material &m = s->s.materials[material];
+    for (uint64_t i = 0; i < n; ++i)
+        out[i] = bsdfPdf(m, Vec3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), Vec3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]));
+    return 0;
+}
+
+extern "C" int orc_bsdf_sample(const orc_scene *s, int material, uint64_t n, const float *wi, const float *sample,
+                               float *wo, float *weight, float *pdf, float *eta, uint32_t *sampled_type) {
+    if (material < 0 || (size_t) material >= s->s.materials.size()) return -1;
+    const Material &m = s->s.materials[material];
+    for (uint64_t i = 0; i < n; ++i) {
+        BSDFSample bs;
+        float p;
+        Spectrum w = bsdfSample(m, Vec3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), Vec2{ sample[2 * i], sample[2 * i + 1] }, bs, p);
+        wo[3 * i] = bs.wo.x; wo[3 * i + 1] = bs.wo.y; wo[3 * i + 2] = bs.wo.z;
+        weight[3 * i] = w.x; weight[3 * i + 1] = w.y; weight[3 * i + 2] = w.z;
+        pdf[i] = p; eta[i] = bs.eta; sampled_type[i] = bs.sampledType;
+    }
+    return 0;
+}
+
+extern "C" int orc_sample_emitter_direct(const orc_scene *s, uint64_t n, const float *ref, const float *ref_n,
+                                         const float *sample, float *d, float *dist, float *pdf, float *value) {
+    for (uint64_t i = 0; i < n; ++i) {
+        DirectSample dRec;
+        Spectrum v = sampleEmitterDirect(s->s, Vec3(ref[3 * i], ref[3 * i + 1], ref[3 * i + 2]),
+                                         Vec3(ref_n[3 * i], ref_n[3 * i + 1], ref_n[3 * i + 2]),
+                                         Vec2{ sample[2 * i], sample[2 * i + 1] }, dRec);
+        for (int k = 0; k < 3; ++k) { d[3 * i + k] = dRec.d[k]; value[3 * i + k] = v[k]; }
+        dist[i] = dRec.dist; pdf[i] = dRec.pdf;
+    }
+    return 0;
+}
+
+extern "C" int orc_camera_rays(const orc_scene *s, uint64_t n, const float *pos, float *rays) {
+    for (uint64_t i = 0; i < n; ++i) {
+        Ray r = cameraRay(s->s, pos[2 * i], pos[2 * i + 1]);
+        float *o = rays + 8 * i;
+        o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.mint;
+        o[4] = r.d.x; o[5] = r.d.y; o[6] = r.d.z; o[7] = r.maxt;
+    }
+    return 0;
+}
+
+static bool checkOpts(const Scene &sc, const orc_render_opts *o) {
+    const orc_film &f = sc.desc.film;
+    if (o->x0 < 0 || o->y0 < 0 || o->x1 > f.crop_w || o->y1 > f.crop_h || o->x0 >= o->x1 || o->y0 >= o->y1) { g_err = "bad rectangle"; return false; }
+    if (o->spp <= 0 || o->spp_total < o->sample_offset + o->spp) { g_err = "bad sample counts"; return false; }
+    return true;
+}
+
+// One camera sample: SamplingIntegrator::renderBlock inner loop (integrator.cpp:169-186)
+static inline void renderSample(const Scene &sc, const orc_render_opts *o, int x, int y, int sIdx, float *pos, float *rgba, RayCounters &cnt) {
+    uint64_t pixelIndex = (uint64_t) y * sc.desc.film.crop_w + x;
+    Pcg32 rng(o->seed, pixelIndex * (uint64_t) o->spp_total + (uint64_t) sIdx);
+    Vec2 j = rng.next2D();
+    pos[0] = (float) x + j.x; pos[1] = (float) y + j.y;
+    Ray ray = cameraRay(sc, pos[0], pos[1]);
+    float alpha;
+    Spectrum L = Li(sc, ray, rng, alpha, cnt);
+    rgba[0] = L.x; rgba[1] = L.y; rgba[2] = L.z; rgba[3] = alpha;
+}
+
+extern "C" int orc_li(const orc_scene *s, const orc_render_opts *o, float *out, float *pos, orc_stats *stats) {
+    const Scene &sc = s->s;
+    if (!checkOpts(sc, o)) return -1;
+    int w = o->x1 - o->x0, h = o->y1 - o->y0;
+    std::mutex mtx;
+    RayCounters total;
+    auto t0 = std::chrono::steady_clock::now();
+    std::atomic<int> nextRow(0);
+    unsigned nt = o->n_threads > 0 ? (unsigned) o->n_threads : std::max(1u, std::thread::hardware_concurrency());
+    auto worker = [&]() {
+        RayCounters cnt;
+        for (;;) {
+            int row = nextRow.fetch_add(1);
+            if (row >= h) break;
+            for (int xx = 0; xx < w; ++xx)
+                for (int k = 0; k < o->spp; ++k) {
+                    size_t idx = ((size_t) row * w + xx) * o->spp + k;
+                    renderSample(sc, o, o->x0 + xx, o->y0 + row, o->sample_offset + k, pos + 2 * idx, out + 4 * idx, cnt);
+                }
+        }
+        std::lock_guard<std::mutex> g(mtx);
+        total.normal += cnt.normal; total.shadow += cnt.shadow;
+        total.trav.steps += cnt.trav.steps; total.trav.tests += cnt.trav.tests;
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(worker);
+    for (auto &t : th) t.join();
+    if (stats) {
+        stats->normal_rays = total.normal; stats->shadow_rays = total.shadow;
+        stats->paths = (uint64_t) w * h * o->spp;
+        stats->kd_traversal_steps = total.trav.steps; stats->kd_prim_tests = total.trav.tests;
+        stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        stats->threads = (int) nt;
+    }
+    return 0;
+}
+
+// Block-parallel render: 32x32 blocks (scene.cpp:24) handed to a thread pool, each rendered into a
+// private bordered block and merged into the film under a mutex (renderproc.cpp:68-86,142-149).
+extern "C" int orc_render(const orc_scene *s, const orc_render_opts *o, float *film, orc_stats *stats) {
+    const Scene &sc = s->s;
+    if (!checkOpts(sc, o)) return -1;
+    const orc_film &f = sc.desc.film;
+    const int BS = 32;
+    int bw = (o->x1 - o->x0 + BS - 1) / BS, bh = (o->y1 - o->y0 + BS - 1) / BS;
+    std::mutex mtx;
+    RayCounters total;
+    std::atomic<int> nextBlock(0);
+    unsigned nt = o->n_threads > 0 ? (unsigned) o->n_threads : std::max(1u, std::thread::hardware_concurrency());
+    auto t0 = std::chrono::steady_clock::now();
+    // The block-local accumulation followed by a merge is what the reference does; summation order
+    // therefore differs from a direct film splat only by float re-association.
+    auto worker = [&]() {
+        RayCounters cnt;
+        const int border = (int) std::ceil(f.filter_radius - 0.5f);
+        const int tw = BS + 2 * border;
+        std::vector<float> tile((size_t) tw * tw * 5);
+        for (;;) {
+            int b = nextBlock.fetch_add(1);
+            if (b >= bw * bh) break;
+            int bx0 = o->x0 + (b % bw) * BS, by0 = o->y0 + (b / bw) * BS;
+            int bx1 = std::min(bx0 + BS, o->x1), by1 = std::min(by0 + BS, o->y1);
+            std::fill(tile.begin(), tile.end(), 0.0f);
+            const float scaleFactor = 31.0f / f.filter_radius;
+            for (int y = by0; y < by1; ++y)
+                for (int x = bx0; x < bx1; ++x)
+                    for (int k = 0; k < o->spp; ++k) {
+                        float pos[2], rgba[4];
+                        renderSample(sc, o, x, y, o->sample_offset + k, pos, rgba, cnt);
+                        // ImageBlock::put into the bordered block (imageblock.h:144-189)
+                        float temp[5] = { rgba[0], rgba[1], rgba[2], rgba[3], 1.0f };
+                        bool bad = false;
+                        for (int i = 0; i < 5; ++i) if (!std::isfinite(temp[i]) || temp[i] < 0) bad = true;
+                        if (bad) continue;
+                        const float px = pos[0] - 0.5f - (float) (bx0 - border), py = pos[1] - 0.5f - (float) (by0 - border);
+                        const int minx = std::max((int) std::ceil(px - f.filter_radius), 0), miny = std::max((int) std::ceil(py - f.filter_radius), 0);
+                        const int maxx = std::min((int) std::floor(px + f.filter_radius), tw - 1), maxy = std::min((int) std::floor(py + f.filter_radius), tw - 1);
+                        float wx[16], wy[16];
+                        for (int xx = minx, idx = 0; xx <= maxx; ++xx) wx[idx++] = f.filter_values[std::min((int) std::abs((xx - px) * scaleFactor), 31)];
+                        for (int yy = miny, idx = 0; yy <= maxy; ++yy) wy[idx++] = f.filter_values[std::min((int) std::abs((yy - py) * scaleFactor), 31)];
+                        for (int yy = miny, yr = 0; yy <= maxy; ++yy, ++yr) {
+                            float *dest = tile.data() + ((size_t) yy * tw + minx) * 5;
+                            for (int xx = minx, xr = 0; xx <= maxx; ++xx, ++xr) {
+                                const float weight = wx[xr] * wy[yr];
+                                for (int c = 0; c < 5; ++c) *dest++ += weight * temp[c];
+                            }
+                        }
+                    }
+            std::lock_guard<std::mutex> g(mtx);
+            for (int ty = 0; ty < tw; ++ty) {
+                int fy = by0 - border + ty;
+                if (fy < 0 || fy >= f.crop_h) continue;
+                for (int tx = 0; tx < tw; ++tx) {
+                    int fx = bx0 - border + tx;
+                    if (fx < 0 || fx >= f.crop_w) continue;
+                    const float *src = tile.data() + ((size_t) ty * tw + tx) * 5;
+                    float *dst = film + ((size_t) fy * f.crop_w + fx) * 5;
+                    for (int c = 0; c < 5; ++c) dst[c] += src[c];
+                }
+            }
+        }
+        std::lock_guard<std::mutex> g(mtx);
+        total.normal += cnt.normal; total.shadow += cnt.shadow;
+        total.trav.steps += cnt.trav.steps; total.trav.tests += cnt.trav.tests;
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(worker);
+    for (auto &t : th) t.join();
+    if (stats) {
+        stats->normal_rays = total.normal; stats->shadow_rays = total.shadow;
+        stats->paths = (uint64_t) (o->x1 - o->x0) * (o->y1 - o->y0) * o->spp;
+        stats->kd_traversal_steps = total.trav.steps; stats->kd_prim_tests = total.trav.tests;
+        stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        stats->threads = (int) nt;
+    }
+    return 0;
+}
+
+extern "C" int orc_film_put(const orc_scene *s, uint64_t n, const float *pos, const float *value, float *film) {
+    for (uint64_t i = 0; i < n; ++i) filmPut(s->s, film, pos[2 * i], pos[2 * i + 1], value + 4 * i);
+    return 0;
+}
+
+// Bitmap::convert ESpectrumAlphaWeight -> RGBA (src/libcore/fmtconv.cpp:978-990)
+extern "C" int orc_film_develop(const orc_scene *s, const float *film, float *rgba) {
+    const orc_film &f = s->s.desc.film;
+    for (size_t i = 0; i < (size_t) f.crop_w * f.crop_h; ++i) {
+        float w = film[5 * i + 4];
+        float inv = w != 0 ? 1.0f / w : 0.0f;
+        for (int c = 0; c < 4; ++c) rgba[4 * i + c] = film[5 * i + c] * inv;
+    }
+    return 0;
+}
+
+extern "C" int orc_clipped_aabb(const float *v, const float *box, float *out) {
+    AABB b;
+    b.min = Vec3(box[0], box[1], box[2]); b.max = Vec3(box[3], box[4], box[5]);
+    AABB r = triangleClippedAABB(Vec3(v[0], v[1], v[2]), Vec3(v[3], v[4], v[5]), Vec3(v[6], v[7], v[8]), b);
+    for (int i = 0; i < 3; ++i) { out[i] = r.min[i]; out[3 + i] = r.max[i]; }
+    return 0;
+}
+
+extern "C" int orc_microfacet_eval(int distribution, float au, float av, int sv, int kind, uint64_t n,
+                                   const float *wi, const float *m, float *out) {
+    MicrofacetDistribution d(distribution, au, av, sv != 0);
+    for (uint64_t i = 0; i < n; ++i) {
+        Vec3 w(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), mm(m[3 * i], m[3 * i + 1], m[3 * i + 2]);
+        out[i] = kind == 0 ? d.eval(mm) : kind == 1 ? d.pdf(w, mm) : d.smithG1(w, mm);
+    }
+    return 0;
+}
+
+extern "C" int orc_microfacet_sample(int distribution, float au, float av, int sv, uint64_t n,
+                                     const float *wi, const float *sample, float *m, float *pdf) {
+    MicrofacetDistribution d(distribution, au, av, sv != 0);
+    for (uint64_t i = 0; i < n; ++i) {
+        float p;
+        Vec3 r = d.sample(Vec3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), Vec2{ sample[2 * i], sample[2 * i + 1] }, p);
+        m[3 * i] = r.x; m[3 * i + 1] = r.y; m[3 * i + 2] = r.z; pdf[i] = p;
+    }
+    return 0;
+}
+
+extern "C" int orc_fresnel_dielectric(uint64_t n, const float *cos_i, float eta, float *F, float *cos_t) {
+    for (uint64_t i = 0; i < n; ++i) F[i] = fresnelDielectricExt(cos_i[i], cos_t[i], eta);
+    return 0;
+}
+
+extern "C" int orc_fresnel_conductor(uint64_t n, const float *cos_i, const float *eta3, const float *k3, float *out3) {
+    Spectrum e(eta3[0], eta3[1], eta3[2]), k(k3[0], k3[1], k3[2]);
+    for (uint64_t i = 0; i < n; ++i) {
+        Spectrum r = fresnelConductorExact(cos_i[i], e, k);
+        out3[3 * i] = r.x; out3[3 * i + 1] = r.y; out3[3 * i + 2] = r.z;
+    }
+    return 0;
+}
+
+extern "C" int orc_rng_stream(uint32_t seed, uint64_t key, uint32_t n, float *out) {
+    Pcg32 rng(seed, key);
+    for (uint32_t i = 0; i < n; ++i) out[i] = rng.next1D();
+    return 0;
+}

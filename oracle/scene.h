@@ -1,0 +1,129 @@
+// TEST INFRASTRUCTURE ONLY -- internal scene representation of the CPU oracle.
+#pragma once
+#include "vec.h"
+#include "oracle.h"
+#include <vector>
+#include <atomic>
+#include <string>
+
+namespace orc {
+
+// include/mitsuba/render/triaccel.h:37-52
+struct TriAccel {
+    uint32_t k;
+    float n_u, n_v, n_d;
+    float a_u, a_v, b_nu, b_nv;
+    float c_nu, c_nv;
+    uint32_t shapeIndex, primIndex;
+    int load(const Vec3 &A, const Vec3 &B, const Vec3 &C);
+    inline bool rayIntersect(const Ray &ray, float mint, float maxt, float &u, float &v, float &t) const;
+};
+
+// 8-byte node like include/mitsuba/render/gkdtree.h:452-601: children are adjacent
+// (left = index, right = index+1); leaves hold a [start,end) range into the index list.
+struct KDNode {
+    uint32_t combined;  // inner: (leftIndex << 2) | axis ; leaf: (primStart << 2) | 3
+    union { float split; uint32_t primEnd; };
+    bool isLeaf() const { return (combined & 3) == 3; }
+    int axis() const { return combined & 3; }
+    uint32_t left() const { return combined >> 2; }
+    uint32_t primStart() const { return combined >> 2; }
+};
+
+// include/mitsuba/core/pmf.h:40-188
+struct DiscreteDistribution {
+    std::vector<float> cdf;
+    float sum = 0, normalization = 0;
+    DiscreteDistribution() { cdf.push_back(0.0f); }
+    void append(float v) { cdf.push_back(cdf.back() + v); }
+    size_t size() const { return cdf.size() - 1; }
+    float operator[](size_t i) const { return cdf[i + 1] - cdf[i]; }
+    float normalize();
+    size_t sample(float v) const;
+    size_t sampleReuse(float &v) const;
+    size_t sampleReuse(float &v, float &pdf) const;
+};
+
+struct Material {
+    orc_material m;
+    // derived at configure() time
+    Spectrum diffuse, specular, transmittance;   // after ensureEnergyConservation
+    Spectrum condEta, condK;                     // divided by extEta
+    float eta = 1, invEta = 1, invEta2 = 1;
+    float specularSamplingWeight = 0;
+    std::vector<float> rtrans;
+    unsigned type_flags = 0;                     // BSDF::EBSDFType combined
+    void configure();
+};
+
+// BSDF::EBSDFType bits (include/mitsuba/render/bsdf.h:230-284)
+enum {
+    ENull = 0x1, EDiffuseReflection = 0x2, EDiffuseTransmission = 0x4, EGlossyReflection = 0x8,
+    EGlossyTransmission = 0x10, EDeltaReflection = 0x20, EDeltaTransmission = 0x40,
+    EAnisotropic = 0x1000, ENonSymmetric = 0x4000, EFrontSide = 0x8000, EBackSide = 0x10000,
+    EReflection = EDiffuseReflection | EDeltaReflection | EGlossyReflection,
+    ETransmission = EDiffuseTransmission | EDeltaTransmission | EGlossyTransmission | ENull,
+    EDiffuse = EDiffuseReflection | EDiffuseTransmission,
+    EGlossy = EGlossyReflection | EGlossyTransmission,
+    ESmooth = EDiffuse | EGlossy,
+    EDelta = ENull | EDeltaReflection | EDeltaTransmission
+};
+
+struct Intersection {
+    float t = std::numeric_limits<float>::infinity();
+    float u = 0, v = 0;
+    uint32_t shape = 0xFFFFFFFFu, prim = 0xFFFFFFFFu;
+    Vec3 p, dpdu, dpdv, wi;
+    Vec2 uv;
+    Frame geoFrame, shFrame;
+    bool isValid() const { return t != std::numeric_limits<float>::infinity(); }
+    Vec3 toLocal(const Vec3 &v_) const { return shFrame.toLocal(v_); }
+    Vec3 toWorld(const Vec3 &v_) const { return shFrame.toWorld(v_); }
+};
+
+struct TraversalCounters { uint64_t steps = 0, tests = 0; };
+
+struct Scene {
+    orc_scene_desc desc;
+    std::vector<Vec3> positions, normals;
+    std::vector<Vec2> texcoords;
+    std::vector<uint32_t> indices;
+    std::vector<orc_shape> shapes;
+    std::vector<Material> materials;
+    std::vector<orc_emitter> emitters;
+    std::vector<uint32_t> triShape;            // triangle -> shape
+    std::vector<Vec3> uvDpdu;                  // per-triangle UV tangent (meshes with texcoords)
+    std::vector<uint8_t> uvDpduValid;
+    std::vector<DiscreteDistribution> areaDistr;   // per shape (emitters only)
+    std::vector<float> invSurfaceArea;
+    DiscreteDistribution emitterPDF;
+
+    // kd-tree
+    std::vector<TriAccel> triAccel;
+    std::vector<KDNode> nodes;
+    std::vector<uint32_t> kdIndices;
+    AABB aabb, tightAABB;
+    int kdMaxDepth = 0;
+
+    // camera (src/sensors/perspective.cpp:126-180)
+    float sampleToCamera[16];
+    float camToWorld[16];
+    float aspect = 1;
+    Vec2 invResolution;
+
+    std::string build(const orc_scene_desc *d);
+    void buildKDTree();
+
+    // src/librender/skdtree.cpp:112-142 / 207-226
+    bool rayIntersect(const Ray &ray, Intersection &its, TraversalCounters *c = nullptr) const;
+    bool rayIntersectShadow(const Ray &ray, TraversalCounters *c = nullptr) const;
+    bool rayIntersectBrute(const Ray &ray, Intersection &its, bool shadow) const;
+    void fillIntersectionRecord(const Ray &ray, Intersection &its) const;
+    template <bool shadowRay>
+    bool rayIntersectHavran(const Ray &ray, float mint, float maxt, float &t,
+                            Intersection *its, TraversalCounters *c) const;
+};
+
+AABB triangleClippedAABB(const Vec3 &p0, const Vec3 &p1, const Vec3 &p2, const AABB &box);
+
+}  // namespace orc
