@@ -1,0 +1,243 @@
+/*
+ * mtsamd -- C ABI of the MI355X path-tracing core (libmtsamd.so).
+ *
+ * The library replaces what runs below SamplingIntegrator::render for the `path` integrator of
+ * Mitsuba 0.5 (src/librender/integrator.cpp:95-188 -> src/integrators/path/path.cpp:119-294 and
+ * everything that loop calls). A host adapter (an Integrator plugin inside a Mitsuba build, or the
+ * standalone driver in this repository) flattens the scene graph into the plain arrays below, calls
+ * mtsamd_render*, and hands the resulting (R,G,B,alpha,weight) film to Film::setBitmap / develop.
+ *
+ * Conventions: every function returns 0 on success or a negative MTSAMD_E* code; the message of the
+ * last failure on the calling thread is available from mtsamd_last_error(). Nothing throws, nothing
+ * aborts. The caller owns every input array (they are copied during mtsamd_scene_create) and every
+ * output buffer. One render per scene handle at a time; mtsamd_cancel is the only call that may be
+ * made from another thread while a render is running.
+ */
+#ifndef MTSAMD_H
+#define MTSAMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    MTSAMD_OK = 0,
+    MTSAMD_EINVAL = -1,     /* malformed description / argument */
+    MTSAMD_EDEVICE = -2,    /* HIP runtime error, no device, out of memory */
+    MTSAMD_ECANCELLED = -3, /* mtsamd_cancel was called */
+    MTSAMD_EUNSUPPORTED = -4
+};
+
+/* BSDF plugins on the hot path (src/bsdfs/{diffuse,roughconductor,roughplastic,dielectric,ward}.cpp) */
+enum { MTSAMD_BSDF_DIFFUSE = 0, MTSAMD_BSDF_ROUGHCONDUCTOR = 1, MTSAMD_BSDF_ROUGHPLASTIC = 2,
+       MTSAMD_BSDF_DIELECTRIC = 3, MTSAMD_BSDF_WARD = 4 };
+/* MicrofacetDistribution::EType (src/bsdfs/microfacet.h:48-57); Phong is not supported */
+enum { MTSAMD_DISTR_BECKMANN = 0, MTSAMD_DISTR_GGX = 1 };
+enum { MTSAMD_SHAPE_HAS_NORMALS = 1, MTSAMD_SHAPE_HAS_TEXCOORDS = 2 };
+
+/* One TriMesh (include/mitsuba/render/trimesh.h). Its triangles occupy
+   [first_triangle, first_triangle + n_triangles) of the global index array; the primitive index the
+   reference reports (Intersection::primIndex) is the offset inside that range. */
+typedef struct {
+    uint32_t first_triangle;
+    uint32_t n_triangles;
+    int32_t material;       /* Shape::getBSDF() */
+    int32_t emitter;        /* Shape::getEmitter(), -1 if none */
+    uint32_t flags;         /* MTSAMD_SHAPE_* : which per-vertex arrays are valid for this mesh */
+} mtsamd_shape;
+
+/* Constructor-level BSDF parameters (what the XML properties give). Derived quantities
+   (energy-conservation scaling, sampling weights, eta ratios) are computed by the library exactly as
+   the plugins' configure() methods do. */
+typedef struct {
+    int32_t type;               /* MTSAMD_BSDF_* */
+    int32_t distribution;       /* MTSAMD_DISTR_* */
+    int32_t sample_visible;     /* microfacet.h m_sampleVisible (default true) */
+    int32_t variant;            /* ward: 0 ward, 1 ward-duer, 2 balanced; roughplastic: nonlinear flag */
+    float alpha_u, alpha_v;
+    float int_ior, ext_ior;     /* dielectric, roughplastic */
+    float diffuse_reflectance[3];   /* diffuse: reflectance; roughplastic, ward: diffuseReflectance */
+    float specular_reflectance[3];
+    float specular_transmittance[3];
+    float eta[3], k[3];         /* roughconductor, before the division by ext_eta (roughconductor.cpp:189-190) */
+    float ext_eta;
+    int32_t ensure_energy_conservation;   /* BSDF::m_ensureEnergyConservation (default true) */
+    /* roughplastic: external rough transmittance reduced to 1-D, i.e. the state RoughPlastic::configure
+       leaves m_externalRoughTransmittance in (roughplastic.cpp:281-299); see mtsamd_rtrans_reduce */
+    const float *rtrans;
+    uint32_t rtrans_n;
+    float rtrans_diffuse_ext;   /* m_externalRoughTransmittance->evalDiffuse(alpha) */
+    float rtrans_diffuse_int;   /* m_internalRoughTransmittance->evalDiffuse(alpha) */
+} mtsamd_material;
+
+/* AreaLight attached to a mesh (src/emitters/area.cpp) */
+typedef struct {
+    int32_t shape;
+    float radiance[3];
+    float sampling_weight;      /* Emitter::getSamplingWeight() */
+} mtsamd_emitter;
+
+/* PerspectiveCamera (src/sensors/perspective.cpp) */
+typedef struct {
+    float to_world[16];         /* row-major camera-to-world, no scale */
+    float x_fov;                /* degrees along x (PerspectiveCamera::getXFov) */
+    float near_clip, far_clip;
+} mtsamd_camera;
+
+/* Film size/crop (src/librender/film.cpp:25-55) and the discretised reconstruction filter
+   (ReconstructionFilter::m_values, include/mitsuba/core/rfilter.h:76-97) */
+typedef struct {
+    int32_t width, height;
+    int32_t crop_x, crop_y, crop_w, crop_h;
+    float filter_radius;
+    float filter_values[32];
+} mtsamd_film;
+
+/* MonteCarloIntegrator parameters (src/librender/integrator.cpp:190-225) */
+typedef struct {
+    int32_t max_depth, rr_depth, strict_normals, hide_emitters;
+} mtsamd_integrator;
+
+typedef struct {
+    uint32_t n_vertices, n_triangles, n_shapes, n_materials, n_emitters;
+    const float *positions;     /* n_vertices * 3 (world space) */
+    const float *normals;       /* n_vertices * 3 or NULL */
+    const float *texcoords;     /* n_vertices * 2 or NULL */
+    const uint32_t *indices;    /* n_triangles * 3, indices into the global vertex arrays */
+    const mtsamd_shape *shapes;
+    const mtsamd_material *materials;
+    const mtsamd_emitter *emitters;
+    mtsamd_camera camera;
+    mtsamd_film film;
+    mtsamd_integrator integrator;
+} mtsamd_scene_desc;
+
+typedef struct {
+    int32_t spp;            /* samples per pixel rendered by this call */
+    int32_t spp_total;      /* stride of the per-pixel sample index in the sample-stream key */
+    int32_t sample_offset;  /* index of the first sample (progressive / multi-pass rendering) */
+    uint32_t seed;
+    int32_t x0, y0, x1, y1; /* pixel rectangle [x0,x1) x [y0,y1) of the crop window rendered by this call
+                               (the unit a multi-GPU driver deals out); all zero = whole crop window */
+    int32_t spp_per_pass;   /* samples per pixel traced together in one wavefront pass; 0 = automatic */
+} mtsamd_render_opts;
+
+/* Counters matching the reference's statistics: "Normal rays traced" / "Shadow rays traced"
+   (src/librender/skdtree.cpp:46-47,123,210) */
+typedef struct {
+    uint64_t normal_rays, shadow_rays, paths;
+    uint64_t bounce_iterations;
+    double seconds;             /* wall time of the render loop, device-synchronised */
+    double extend_ms, shade_ms, shadow_ms, film_ms, raygen_ms;   /* per-kernel-class device time (HIP events) */
+    uint64_t extend_launches, shadow_launches;
+    uint64_t node_visits, tri_tests;    /* filled only when traversal counters are enabled */
+} mtsamd_stats;
+
+typedef struct {
+    uint32_t n_nodes, n_triangles, depth;
+    uint64_t node_bytes, triangle_bytes;
+    double build_seconds;
+    double sah_cost;
+} mtsamd_bvh_info;
+
+/* Closest-hit record, the fields of ShapeKDTree::IntersectionCache + t
+   (include/mitsuba/render/skdtree.h:237-241) */
+typedef struct {
+    float t, u, v;
+    uint32_t shape, prim;   /* 0xFFFFFFFF = miss */
+} mtsamd_hit;
+
+/* Intersection fields the integrator consumes (include/mitsuba/render/shape.h:36-172) */
+typedef struct {
+    float t, u, v;
+    uint32_t shape, prim;
+    float p[3], geo_n[3], sh_n[3], sh_s[3], sh_t[3], wi[3], uv[2];
+} mtsamd_intersection;
+
+typedef struct mtsamd_scene mtsamd_scene;
+
+const char *mtsamd_last_error(void);
+
+/* Select the HIP device used by subsequent calls on this thread (one process per GPU: pass LOCAL_RANK).
+   Replaces nothing in the reference (it has no device notion); mirrors Scheduler worker registration
+   in src/mitsuba/mitsuba.cpp:278-329. */
+int mtsamd_init(int device);
+
+/* Scene::initialize + ShapeKDTree::build (src/librender/scene.cpp:322-384, src/librender/skdtree.cpp:68-110):
+   validates and copies the description, configures materials, builds the wide BVH and uploads everything. */
+int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene **out);
+void mtsamd_scene_destroy(mtsamd_scene *scene);
+int mtsamd_scene_bvh_info(const mtsamd_scene *scene, mtsamd_bvh_info *info);
+
+/* SamplingIntegrator::render (src/librender/integrator.cpp:95-129) for the `path` integrator:
+   renders opts->spp samples per pixel of the rectangle and ACCUMULATES into film, a
+   crop_w*crop_h*5 float array of (R,G,B,alpha,weight) -- the ESpectrumAlphaWeight storage of
+   HDRFilm (src/films/hdrfilm.cpp:351-356). mtsamd_render takes a host film, mtsamd_render_device a
+   device pointer on the current HIP device (e.g. a torch tensor that is then reduced over RCCL). */
+int mtsamd_render(mtsamd_scene *scene, const mtsamd_render_opts *opts, float *film_host, mtsamd_stats *stats);
+int mtsamd_render_device(mtsamd_scene *scene, const mtsamd_render_opts *opts, float *film_device, mtsamd_stats *stats);
+
+/* Integrator::cancel (include/mitsuba/render/integrator.h:84): polled between wavefront iterations */
+void mtsamd_cancel(mtsamd_scene *scene);
+
+/* HDRFilm::develop weight division (src/libcore/fmtconv.cpp:978-990): film (w*h*5) -> rgba (w*h*4), host */
+int mtsamd_film_develop(const mtsamd_scene *scene, const float *film_host, float *rgba_host);
+
+/* ---- batch entry points (host arrays in, host arrays out) used by the parity harness --------------- */
+
+/* Scene::rayIntersect(ray, its) (include/mitsuba/render/scene.h:187-189): rays = n*8 floats
+   (ox,oy,oz,mint, dx,dy,dz,maxt); mint == 1e-4f triggers the adaptive epsilon of skdtree.cpp:126-129 */
+int mtsamd_trace(mtsamd_scene *scene, uint64_t n, const float *rays, mtsamd_hit *hits);
+/* Scene::rayIntersect(ray) shadow query (src/librender/skdtree.cpp:207-226) */
+int mtsamd_occluded(mtsamd_scene *scene, uint64_t n, const float *rays, uint8_t *occluded);
+/* rayIntersect + fillIntersectionRecord (include/mitsuba/render/skdtree.h:343-428) */
+int mtsamd_intersect(mtsamd_scene *scene, uint64_t n, const float *rays, mtsamd_intersection *its);
+
+/* BSDF::eval / pdf / sample(bRec, pdf, sample) in the local shading frame, ERadiance mode, all components.
+   wi, wo: n*3; sample: n*2; eval -> n*3 (value includes the cosine factor); sample -> wo n*3, weight n*3,
+   pdf n, eta n, sampled_type n (BSDF::EBSDFType bits) */
+int mtsamd_bsdf_eval(mtsamd_scene *scene, int material, uint64_t n, const float *wi, const float *wo, float *out);
+int mtsamd_bsdf_pdf(mtsamd_scene *scene, int material, uint64_t n, const float *wi, const float *wo, float *out);
+int mtsamd_bsdf_sample(mtsamd_scene *scene, int material, uint64_t n, const float *wi, const float *sample,
+                       float *wo, float *weight, float *pdf, float *eta, uint32_t *sampled_type);
+
+/* Scene::sampleEmitterDirect without the visibility test (src/librender/scene.cpp:828-852):
+   ref n*3, ref_n n*3 (DirectSamplingRecord::refN), sample n*2 -> d n*3, dist n, pdf n, value n*3 */
+int mtsamd_sample_emitter_direct(mtsamd_scene *scene, uint64_t n, const float *ref, const float *ref_n,
+                                 const float *sample, float *d, float *dist, float *pdf, float *value);
+
+/* PerspectiveCameraImpl::sampleRayDifferential (src/sensors/perspective.cpp:271-298), ray part only:
+   pos n*2 fractional pixel coordinates relative to the crop window -> rays n*8 */
+int mtsamd_camera_rays(mtsamd_scene *scene, uint64_t n, const float *pos, float *rays);
+
+/* MIPathTracer::Li per camera sample (no film): out[(pixel*spp+s)*4] = (R,G,B,alpha) for the pixels of the
+   rectangle in row-major order, pos[(pixel*spp+s)*2] = sample position */
+int mtsamd_li(mtsamd_scene *scene, const mtsamd_render_opts *opts, float *out, float *pos, mtsamd_stats *stats);
+
+/* ImageBlock::put (include/mitsuba/render/imageblock.h:124-204) for explicit samples: pos n*2,
+   value n*4 (R,G,B,alpha); film host array, accumulated */
+int mtsamd_film_put(mtsamd_scene *scene, uint64_t n, const float *pos, const float *value, float *film_host);
+
+/* The sample stream that stands in for Sampler::next1D (src/samplers/independent.cpp:95-103):
+   n consecutive floats of the stream keyed by (seed, key), generated on the device */
+int mtsamd_rng_stream(uint32_t seed, uint64_t key, uint32_t n, float *out);
+
+/* ---- host-side helpers -------------------------------------------------------------------------- */
+
+/* RoughTransmittance (src/bsdfs/rtrans.h:81-149 loader, :292-388 setEta/setAlpha): reduce the image of a
+   data/microfacet/<distribution>.dat file to what RoughPlastic::configure keeps. out_T receives
+   *theta_samples floats (capacity out_cap). */
+int mtsamd_rtrans_reduce(const void *dat, uint64_t size, float eta, float alpha, float *out_T, uint32_t out_cap,
+                         uint32_t *theta_samples, float *diffuse_ext, float *diffuse_int);
+
+/* GaussianFilter / BoxFilter tables as ReconstructionFilter::configure builds them
+   (src/rfilters/gaussian.cpp:32-57, src/libcore/rfilter.cpp:37-55) */
+int mtsamd_filter_gaussian(float stddev, float *radius, float values[32]);
+int mtsamd_filter_box(float radius_in, float *radius, float values[32]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTSAMD_H */

@@ -1,0 +1,332 @@
+"""ctypes binding of libmtsamd.so (include/mtsamd.h) -- the only compute path of this package.
+
+There is no CPU fallback: if the HIP library is missing or no device is present, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmtsamd.so")
+_f32p = C.POINTER(C.c_float)
+_u32p = C.POINTER(C.c_uint32)
+
+
+class Shape(C.Structure):
+    _fields_ = [("first_triangle", C.c_uint32), ("n_triangles", C.c_uint32), ("material", C.c_int32),
+                ("emitter", C.c_int32), ("flags", C.c_uint32)]
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_int32), ("distribution", C.c_int32), ("sample_visible", C.c_int32), ("variant", C.c_int32),
+                ("alpha_u", C.c_float), ("alpha_v", C.c_float), ("int_ior", C.c_float), ("ext_ior", C.c_float),
+                ("diffuse_reflectance", C.c_float * 3), ("specular_reflectance", C.c_float * 3),
+                ("specular_transmittance", C.c_float * 3), ("eta", C.c_float * 3), ("k", C.c_float * 3),
+                ("ext_eta", C.c_float), ("ensure_energy_conservation", C.c_int32),
+                ("rtrans", _f32p), ("rtrans_n", C.c_uint32), ("rtrans_diffuse_ext", C.c_float),
+                ("rtrans_diffuse_int", C.c_float)]
+
+
+class Emitter(C.Structure):
+    _fields_ = [("shape", C.c_int32), ("radiance", C.c_float * 3), ("sampling_weight", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("to_world", C.c_float * 16), ("x_fov", C.c_float), ("near_clip", C.c_float), ("far_clip", C.c_float)]
+
+
+class Film(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("crop_x", C.c_int32), ("crop_y", C.c_int32),
+                ("crop_w", C.c_int32), ("crop_h", C.c_int32), ("filter_radius", C.c_float),
+                ("filter_values", C.c_float * 32)]
+
+
+class Integrator(C.Structure):
+    _fields_ = [("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("strict_normals", C.c_int32),
+                ("hide_emitters", C.c_int32)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_vertices", C.c_uint32), ("n_triangles", C.c_uint32), ("n_shapes", C.c_uint32),
+                ("n_materials", C.c_uint32), ("n_emitters", C.c_uint32),
+                ("positions", _f32p), ("normals", _f32p), ("texcoords", _f32p), ("indices", _u32p),
+                ("shapes", C.POINTER(Shape)), ("materials", C.POINTER(Material)), ("emitters", C.POINTER(Emitter)),
+                ("camera", Camera), ("film", Film), ("integrator", Integrator)]
+
+
+class RenderOpts(C.Structure):
+    _fields_ = [("spp", C.c_int32), ("spp_total", C.c_int32), ("sample_offset", C.c_int32), ("seed", C.c_uint32),
+                ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32), ("spp_per_pass", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("normal_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("paths", C.c_uint64),
+                ("bounce_iterations", C.c_uint64), ("seconds", C.c_double),
+                ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("shadow_ms", C.c_double), ("film_ms", C.c_double),
+                ("raygen_ms", C.c_double), ("extend_launches", C.c_uint64), ("shadow_launches", C.c_uint64),
+                ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64)]
+
+
+class BvhInfo(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("n_triangles", C.c_uint32), ("depth", C.c_uint32),
+                ("node_bytes", C.c_uint64), ("triangle_bytes", C.c_uint64), ("build_seconds", C.c_double),
+                ("sah_cost", C.c_double)]
+
+
+HIT_DTYPE = np.dtype([("t", "f4"), ("u", "f4"), ("v", "f4"), ("shape", "u4"), ("prim", "u4")])
+ISECT_DTYPE = np.dtype([("t", "f4"), ("u", "f4"), ("v", "f4"), ("shape", "u4"), ("prim", "u4"), ("p", "f4", 3),
+                        ("geo_n", "f4", 3), ("sh_n", "f4", 3), ("sh_s", "f4", 3), ("sh_t", "f4", 3), ("wi", "f4", 3),
+                        ("uv", "f4", 2)])
+
+# every symbol include/mtsamd.h declares
+EXPORTS = ["mtsamd_last_error", "mtsamd_init", "mtsamd_scene_create", "mtsamd_scene_destroy", "mtsamd_scene_bvh_info",
+           "mtsamd_render", "mtsamd_render_device", "mtsamd_cancel", "mtsamd_film_develop", "mtsamd_trace",
+           "mtsamd_occluded", "mtsamd_intersect", "mtsamd_bsdf_eval", "mtsamd_bsdf_pdf", "mtsamd_bsdf_sample",
+           "mtsamd_sample_emitter_direct", "mtsamd_camera_rays", "mtsamd_li", "mtsamd_film_put", "mtsamd_rng_stream",
+           "mtsamd_rtrans_reduce", "mtsamd_filter_gaussian", "mtsamd_filter_box"]
+
+_lib = None
+
+
+class MtsamdError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise MtsamdError("%s is missing: build it with `make -C mitsuba_amd/csrc` (hipcc, gfx950); "
+                              "there is no CPU fallback" % _LIB_PATH)
+        L = C.CDLL(_LIB_PATH)
+        L.mtsamd_last_error.restype = C.c_char_p
+        L.mtsamd_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
+        L.mtsamd_scene_destroy.argtypes = [C.c_void_p]
+        L.mtsamd_cancel.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise MtsamdError("mtsamd error %d: %s" % (rc, lib().mtsamd_last_error().decode()))
+
+
+def _fp(a):
+    return a.ctypes.data_as(_f32p)
+
+
+def init(device: int = 0):
+    _check(lib().mtsamd_init(int(device)))
+
+
+def fill_desc(sd):
+    """SceneData -> (SceneDesc, keep-alive list)."""
+    keep = []
+    d = SceneDesc()
+    pos = np.ascontiguousarray(sd.positions, np.float32)
+    idx = np.ascontiguousarray(sd.indices, np.uint32)
+    keep += [pos, idx]
+    d.n_vertices, d.n_triangles = pos.shape[0], idx.shape[0]
+    d.positions, d.indices = _fp(pos), idx.ctypes.data_as(_u32p)
+    if sd.normals is not None:
+        nrm = np.ascontiguousarray(sd.normals, np.float32)
+        keep.append(nrm)
+        d.normals = _fp(nrm)
+    if sd.texcoords is not None:
+        uv = np.ascontiguousarray(sd.texcoords, np.float32)
+        keep.append(uv)
+        d.texcoords = _fp(uv)
+    shapes = (Shape * max(1, len(sd.shapes)))()
+    for i, s in enumerate(sd.shapes):
+        shapes[i].first_triangle, shapes[i].n_triangles = s["first_triangle"], s["n_triangles"]
+        shapes[i].material, shapes[i].emitter, shapes[i].flags = s["material"], s["emitter"], s["flags"]
+    mats = (Material * max(1, len(sd.materials)))()
+    for i, m in enumerate(sd.materials):
+        c = mats[i]
+        for k in ("type", "distribution", "sample_visible", "variant", "alpha_u", "alpha_v", "int_ior", "ext_ior",
+                  "ext_eta", "ensure_energy_conservation", "rtrans_diffuse_ext", "rtrans_diffuse_int"):
+            setattr(c, k, m[k])
+        for k in ("diffuse_reflectance", "specular_reflectance", "specular_transmittance", "eta", "k"):
+            setattr(c, k, (C.c_float * 3)(*[float(x) for x in m[k]]))
+        if m.get("rtrans") is not None:
+            t = np.ascontiguousarray(m["rtrans"], np.float32)
+            keep.append(t)
+            c.rtrans, c.rtrans_n = _fp(t), t.shape[0]
+    ems = (Emitter * max(1, len(sd.emitters)))()
+    for i, e in enumerate(sd.emitters):
+        ems[i].shape = e["shape"]
+        ems[i].radiance = (C.c_float * 3)(*e["radiance"])
+        ems[i].sampling_weight = e["sampling_weight"]
+    keep += [shapes, mats, ems]
+    d.n_shapes, d.n_materials, d.n_emitters = len(sd.shapes), len(sd.materials), len(sd.emitters)
+    d.shapes, d.materials, d.emitters = shapes, mats, ems
+    cam = sd.camera
+    d.camera.to_world = (C.c_float * 16)(*np.asarray(cam["to_world"], np.float32).reshape(-1))
+    d.camera.x_fov, d.camera.near_clip, d.camera.far_clip = cam["x_fov"], cam["near_clip"], cam["far_clip"]
+    f = sd.film
+    for k in ("width", "height", "crop_x", "crop_y", "crop_w", "crop_h", "filter_radius"):
+        setattr(d.film, k, f[k])
+    d.film.filter_values = (C.c_float * 32)(*np.asarray(f["filter_values"], np.float32))
+    for k in ("max_depth", "rr_depth", "strict_normals", "hide_emitters"):
+        setattr(d.integrator, k, sd.integrator[k])
+    return d, keep
+
+
+class Scene:
+    """An uploaded scene (mtsamd_scene handle)."""
+
+    def __init__(self, sd):
+        self.L = lib()
+        self.sd = sd
+        desc, self._keep = fill_desc(sd)
+        h = C.c_void_p()
+        _check(self.L.mtsamd_scene_create(C.byref(desc), C.byref(h)))
+        self.h = h
+        self.w, self.hgt = sd.film["crop_w"], sd.film["crop_h"]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mtsamd_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def bvh_info(self) -> BvhInfo:
+        info = BvhInfo()
+        _check(self.L.mtsamd_scene_bvh_info(self.h, C.byref(info)))
+        return info
+
+    def _opts(self, spp, spp_total=None, sample_offset=0, seed=1, rect=None, spp_per_pass=0):
+        x0, y0, x1, y1 = rect if rect is not None else (0, 0, self.w, self.hgt)
+        return RenderOpts(spp, spp_total if spp_total is not None else sample_offset + spp, sample_offset, seed,
+                          x0, y0, x1, y1, spp_per_pass)
+
+    def render(self, spp, film=None, **kw):
+        o = self._opts(spp, **kw)
+        if film is None:
+            film = np.zeros((self.hgt, self.w, 5), np.float32)
+        st = Stats()
+        _check(self.L.mtsamd_render(self.h, C.byref(o), _fp(film), C.byref(st)))
+        return film, st
+
+    def render_device(self, spp, film_ptr: int, **kw):
+        """Accumulate into a device film (crop_h*crop_w*5 floats) given by its raw pointer."""
+        o = self._opts(spp, **kw)
+        st = Stats()
+        _check(self.L.mtsamd_render_device(self.h, C.byref(o), C.cast(C.c_void_p(film_ptr), _f32p), C.byref(st)))
+        return st
+
+    def li(self, spp, **kw):
+        o = self._opts(spp, **kw)
+        npx = (o.x1 - o.x0) * (o.y1 - o.y0)
+        out = np.zeros((npx, spp, 4), np.float32)
+        pos = np.zeros((npx, spp, 2), np.float32)
+        st = Stats()
+        _check(self.L.mtsamd_li(self.h, C.byref(o), _fp(out), _fp(pos), C.byref(st)))
+        return out, pos, st
+
+    def develop(self, film):
+        film = np.ascontiguousarray(film, np.float32)
+        out = np.zeros((self.hgt, self.w, 4), np.float32)
+        _check(self.L.mtsamd_film_develop(self.h, _fp(film), _fp(out)))
+        return out
+
+    def cancel(self):
+        self.L.mtsamd_cancel(self.h)
+
+    def trace(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        hits = np.zeros(rays.shape[0], HIT_DTYPE)
+        _check(self.L.mtsamd_trace(self.h, C.c_uint64(rays.shape[0]), _fp(rays), hits.ctypes.data_as(C.c_void_p)))
+        return hits
+
+    def occluded(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros(rays.shape[0], np.uint8)
+        _check(self.L.mtsamd_occluded(self.h, C.c_uint64(rays.shape[0]), _fp(rays), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def intersect(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        its = np.zeros(rays.shape[0], ISECT_DTYPE)
+        _check(self.L.mtsamd_intersect(self.h, C.c_uint64(rays.shape[0]), _fp(rays), its.ctypes.data_as(C.c_void_p)))
+        return its
+
+    def bsdf_eval(self, mat, wi, wo):
+        wi, wo = np.ascontiguousarray(wi, np.float32), np.ascontiguousarray(wo, np.float32)
+        out = np.zeros_like(wi)
+        _check(self.L.mtsamd_bsdf_eval(self.h, int(mat), C.c_uint64(wi.shape[0]), _fp(wi), _fp(wo), _fp(out)))
+        return out
+
+    def bsdf_pdf(self, mat, wi, wo):
+        wi, wo = np.ascontiguousarray(wi, np.float32), np.ascontiguousarray(wo, np.float32)
+        out = np.zeros(wi.shape[0], np.float32)
+        _check(self.L.mtsamd_bsdf_pdf(self.h, int(mat), C.c_uint64(wi.shape[0]), _fp(wi), _fp(wo), _fp(out)))
+        return out
+
+    def bsdf_sample(self, mat, wi, sample):
+        wi, sample = np.ascontiguousarray(wi, np.float32), np.ascontiguousarray(sample, np.float32)
+        n = wi.shape[0]
+        wo, w = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+        pdf, eta, typ = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint32)
+        _check(self.L.mtsamd_bsdf_sample(self.h, int(mat), C.c_uint64(n), _fp(wi), _fp(sample), _fp(wo), _fp(w), _fp(pdf),
+                                         _fp(eta), typ.ctypes.data_as(_u32p)))
+        return wo, w, pdf, eta, typ
+
+    def sample_emitter_direct(self, ref, ref_n, sample):
+        ref, ref_n, sample = (np.ascontiguousarray(a, np.float32) for a in (ref, ref_n, sample))
+        n = ref.shape[0]
+        d, value = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+        dist, pdf = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        _check(self.L.mtsamd_sample_emitter_direct(self.h, C.c_uint64(n), _fp(ref), _fp(ref_n), _fp(sample), _fp(d),
+                                                   _fp(dist), _fp(pdf), _fp(value)))
+        return d, dist, pdf, value
+
+    def camera_rays(self, pos):
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 2)
+        rays = np.zeros((pos.shape[0], 8), np.float32)
+        _check(self.L.mtsamd_camera_rays(self.h, C.c_uint64(pos.shape[0]), _fp(pos), _fp(rays)))
+        return rays
+
+    def film_put(self, pos, value, film=None):
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 2)
+        value = np.ascontiguousarray(value, np.float32).reshape(-1, 4)
+        if film is None:
+            film = np.zeros((self.hgt, self.w, 5), np.float32)
+        _check(self.L.mtsamd_film_put(self.h, C.c_uint64(pos.shape[0]), _fp(pos), _fp(value), _fp(film)))
+        return film
+
+
+def rng_stream(seed, key, n):
+    out = np.zeros(n, np.float32)
+    _check(lib().mtsamd_rng_stream(C.c_uint32(seed), C.c_uint64(key), C.c_uint32(n), _fp(out)))
+    return out
+
+
+def rtrans_reduce(dat: bytes, eta, alpha):
+    """RoughPlastic::configure's table reduction (mtsamd_rtrans_reduce): -> (T[theta], diffuse_ext, diffuse_int)."""
+    out = np.zeros(256, np.float32)
+    n = C.c_uint32()
+    de, di = C.c_float(), C.c_float()
+    _check(lib().mtsamd_rtrans_reduce(dat, C.c_uint64(len(dat)), C.c_float(eta), C.c_float(alpha), _fp(out), 256,
+                                      C.byref(n), C.byref(de), C.byref(di)))
+    return out[:n.value].copy(), de.value, di.value
+
+
+def filter_gaussian(stddev=0.5):
+    r = C.c_float()
+    v = (C.c_float * 32)()
+    _check(lib().mtsamd_filter_gaussian(C.c_float(stddev), C.byref(r), v))
+    return r.value, np.array(v, np.float32)
+
+
+def filter_box(radius=0.5):
+    r = C.c_float()
+    v = (C.c_float * 32)()
+    _check(lib().mtsamd_filter_box(C.c_float(radius), C.byref(r), v))
+    return r.value, np.array(v, np.float32)

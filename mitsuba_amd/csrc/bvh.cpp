@@ -1,0 +1,341 @@
+// Host-side construction of the 8-wide quantised BVH: binned-SAH binary build (multi-threaded), greedy
+// surface-area collapse to 8-ary nodes, octant-ordered slot assignment and outward-rounded quantisation.
+#include "bvh.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <thread>
+
+namespace mtsamd {
+
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() {
+        for (int i = 0; i < 3; ++i) { lo[i] = std::numeric_limits<float>::infinity(); hi[i] = -lo[i]; }
+    }
+    void grow(const float *p) {
+        for (int i = 0; i < 3; ++i) { lo[i] = std::min(lo[i], p[i]); hi[i] = std::max(hi[i], p[i]); }
+    }
+    void grow(const Box &b) {
+        for (int i = 0; i < 3; ++i) { lo[i] = std::min(lo[i], b.lo[i]); hi[i] = std::max(hi[i], b.hi[i]); }
+    }
+    float area() const {
+        float d0 = hi[0] - lo[0], d1 = hi[1] - lo[1], d2 = hi[2] - lo[2];
+        if (!(d0 >= 0 && d1 >= 0 && d2 >= 0)) return 0.0f;
+        return 2.0f * (d0 * d1 + d0 * d2 + d1 * d2);
+    }
+};
+
+struct Prim { Box box; float c[3]; uint32_t tri; };
+
+struct Node2 {
+    Box box;
+    uint32_t left = 0, right = 0;   // children (internal)
+    uint32_t first = 0, count = 0;  // prim range (leaf when count > 0)
+};
+
+const float kCostNode = 1.0f, kCostTri = 0.3f;
+const int kBins = 16;
+const uint32_t kMaxLeaf = 3;
+
+struct Builder2 {
+    std::vector<Prim> prims;
+    std::vector<Node2> nodes;
+    std::atomic<uint32_t> nextNode{ 0 };
+    std::atomic<int> liveThreads{ 0 };
+    int maxThreads = 1;
+
+    uint32_t alloc2() { return nextNode.fetch_add(2); }
+
+    void build(uint32_t nodeIdx, uint32_t first, uint32_t count, int depth) {
+        Node2 &node = nodes[nodeIdx];
+        Box box, cbox;
+        box.reset(); cbox.reset();
+        for (uint32_t i = first; i < first + count; ++i) { box.grow(prims[i].box); cbox.grow(prims[i].c); }
+        node.box = box;
+        if (count == 1) { node.first = first; node.count = count; return; }
+
+        // binned SAH over the centroid bounds
+        int bestAxis = -1, bestBin = -1;
+        float bestCost = std::numeric_limits<float>::infinity();
+        for (int axis = 0; axis < 3; ++axis) {
+            float lo = cbox.lo[axis], hi = cbox.hi[axis];
+            if (!(hi > lo)) continue;
+            Box bb[kBins];
+            uint32_t bc[kBins];
+            for (int b = 0; b < kBins; ++b) { bb[b].reset(); bc[b] = 0; }
+            float scale = (float) kBins / (hi - lo);
+            for (uint32_t i = first; i < first + count; ++i) {
+                int b = std::min(kBins - 1, std::max(0, (int) ((prims[i].c[axis] - lo) * scale)));
+                bb[b].grow(prims[i].box); bc[b]++;
+            }
+            float rightArea[kBins];
+            uint32_t rightCount[kBins];
+            Box acc; acc.reset();
+            uint32_t n = 0;
+            for (int b = kBins - 1; b > 0; --b) {
+                acc.grow(bb[b]); n += bc[b];
+                rightArea[b] = acc.area(); rightCount[b] = n;
+            }
+            acc.reset(); n = 0;
+            for (int b = 0; b < kBins - 1; ++b) {
+                acc.grow(bb[b]); n += bc[b];
+                if (n == 0 || rightCount[b + 1] == 0) continue;
+                float cost = acc.area() * (float) n + rightArea[b + 1] * (float) rightCount[b + 1];
+                if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = b; }
+            }
+        }
+        float area = box.area();
+        if (count <= kMaxLeaf) {
+            float leafCost = kCostTri * (float) count;
+            float splitCost = bestAxis >= 0 && area > 0 ? kCostNode + kCostTri * bestCost / area : std::numeric_limits<float>::infinity();
+            if (leafCost <= splitCost) { node.first = first; node.count = count; return; }
+        }
+        uint32_t mid;
+        if (bestAxis >= 0) {
+            float lo = cbox.lo[bestAxis], hi = cbox.hi[bestAxis];
+            float scale = (float) kBins / (hi - lo);
+            Prim *b = prims.data() + first, *e = b + count;
+            Prim *m = std::partition(b, e, [&](const Prim &p) {
+                int bin = std::min(kBins - 1, std::max(0, (int) ((p.c[bestAxis] - lo) * scale)));
+                return bin <= bestBin;
+            });
+            mid = (uint32_t) (m - prims.data());
+        } else {
+            mid = first + count / 2;    // all centroids coincide
+        }
+        if (mid == first || mid == first + count) mid = first + count / 2;
+        uint32_t c = alloc2();
+        node.left = c; node.right = c + 1;
+        uint32_t nl = mid - first, nr = count - nl;
+        bool spawn = nl > 32768 && nr > 32768 && liveThreads.load() < maxThreads;
+        if (spawn) {
+            liveThreads.fetch_add(1);
+            std::thread t([=]() { build(c, first, nl, depth + 1); liveThreads.fetch_sub(1); });
+            build(c + 1, mid, nr, depth + 1);
+            t.join();
+        } else {
+            build(c, first, nl, depth + 1);
+            build(c + 1, mid, nr, depth + 1);
+        }
+    }
+};
+
+inline uint32_t floatBits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float bitsFloat(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+}  // namespace
+
+void loadTriRecord(const float *A, const float *B, const float *C, TriRecord &t) {
+    static const int waldModulo[4] = { 1, 2, 0, 1 };
+    float b[3] = { C[0] - A[0], C[1] - A[1], C[2] - A[2] };
+    float c[3] = { B[0] - A[0], B[1] - A[1], B[2] - A[2] };
+    float N[3] = { c[1] * b[2] - c[2] * b[1], c[2] * b[0] - c[0] * b[2], c[0] * b[1] - c[1] * b[0] };
+    uint32_t k = 0;
+    for (int j = 0; j < 3; j++)
+        if (std::abs(N[j]) > std::abs(N[k])) k = j;
+    uint32_t u = waldModulo[k], v = waldModulo[k + 1];
+    const float n_k = N[k], denom = b[u] * c[v] - b[v] * c[u];
+    memset(&t, 0, sizeof(t));
+    if (denom == 0) { t.k = 3; return; }
+    t.k = k;
+    t.n_u = N[u] / n_k;
+    t.n_v = N[v] / n_k;
+    t.n_d = (A[0] * N[0] + A[1] * N[1] + A[2] * N[2]) / n_k;
+    t.b_nu = b[u] / denom;
+    t.b_nv = -b[v] / denom;
+    t.a_u = A[u];
+    t.a_v = A[v];
+    t.c_nu = c[v] / denom;
+    t.c_nv = -c[u] / denom;
+}
+
+const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BVH &out) {
+    auto t0 = std::chrono::steady_clock::now();
+    out.nodes.clear(); out.tris.clear(); out.depth = 0;
+    for (int i = 0; i < 3; ++i) { out.aabbMin[i] = 0; out.aabbMax[i] = 0; }
+    if (nTris == 0) {
+        WideNode n;
+        memset(&n, 0, sizeof(n));
+        n.e[0] = n.e[1] = n.e[2] = 1;
+        out.nodes.push_back(n);
+        return "";
+    }
+    if (nTris >= (1u << 27)) return "too many triangles";
+
+    Builder2 b2;
+    b2.prims.resize(nTris);
+    Box sceneBox; sceneBox.reset();
+    for (uint32_t t = 0; t < nTris; ++t) {
+        Prim &p = b2.prims[t];
+        p.tri = t;
+        p.box.reset();
+        for (int j = 0; j < 3; ++j) {
+            uint32_t vi = indices[3 * t + j];
+            if (vi >= nVerts) return "vertex index out of range";
+            const float *v = positions + 3 * (size_t) vi;
+            if (!(std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]))) return "non-finite vertex position";
+            p.box.grow(v);
+        }
+        for (int i = 0; i < 3; ++i) p.c[i] = 0.5f * (p.box.lo[i] + p.box.hi[i]);
+        sceneBox.grow(p.box);
+    }
+    for (int i = 0; i < 3; ++i) { out.aabbMin[i] = sceneBox.lo[i]; out.aabbMax[i] = sceneBox.hi[i]; }
+
+    b2.nodes.resize(2 * (size_t) nTris + 2);
+    b2.nextNode = 1;
+    b2.maxThreads = (int) std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    b2.build(0, 0, nTris, 0);
+
+    // ---- collapse to 8-wide -------------------------------------------------------------------------
+    struct Work { uint32_t n2; uint32_t wide; uint32_t depth; };
+    std::vector<Work> queue;
+    out.nodes.reserve(nTris / 4 + 16);
+    out.tris.reserve(nTris);
+    out.nodes.push_back(WideNode());
+    queue.push_back({ 0, 0, 1 });
+    double sah = 0;
+    const float rootArea = std::max(sceneBox.area(), 1e-30f);
+
+    for (size_t qi = 0; qi < queue.size(); ++qi) {
+        Work w = queue[qi];
+        out.depth = std::max(out.depth, w.depth);
+        const Node2 &n2 = b2.nodes[w.n2];
+        uint32_t kids[8];
+        int nk = 0;
+        if (n2.count > 0) {
+            kids[nk++] = w.n2;      // single-leaf tree
+        } else {
+            kids[nk++] = n2.left; kids[nk++] = n2.right;
+            while (nk < 8) {
+                int best = -1; float bestArea = -1;
+                for (int i = 0; i < nk; ++i) {
+                    const Node2 &c = b2.nodes[kids[i]];
+                    if (c.count > 0) continue;
+                    float a = c.box.area();
+                    if (a > bestArea) { bestArea = a; best = i; }
+                }
+                if (best < 0) break;
+                const Node2 &c = b2.nodes[kids[best]];
+                kids[best] = c.left;
+                kids[nk++] = c.right;
+            }
+        }
+        // padded child boxes and node bounds
+        Box cb[8], nb;
+        nb.reset();
+        for (int i = 0; i < nk; ++i) {
+            cb[i] = b2.nodes[kids[i]].box;
+            for (int a = 0; a < 3; ++a) {
+                float m = std::max(std::abs(cb[i].lo[a]), std::abs(cb[i].hi[a]));
+                float pad = m * 0x1p-20f + 1e-30f;
+                cb[i].lo[a] -= pad; cb[i].hi[a] += pad;
+            }
+            nb.grow(cb[i]);
+        }
+        sah += (double) (nb.area() / rootArea) * kCostNode;
+
+        // slot assignment: slot s is the first one visited by rays whose sign octant is s, so it should
+        // hold the child lying furthest "behind" along the representative direction of that octant
+        int slotOf[8], childAt[8];
+        for (int i = 0; i < 8; ++i) { slotOf[i] = -1; childAt[i] = -1; }
+        float nc[3] = { 0.5f * (nb.lo[0] + nb.hi[0]), 0.5f * (nb.lo[1] + nb.hi[1]), 0.5f * (nb.lo[2] + nb.hi[2]) };
+        float cost[8][8];
+        for (int i = 0; i < nk; ++i)
+            for (int s = 0; s < 8; ++s) {
+                float c = 0;
+                for (int a = 0; a < 3; ++a) {
+                    float d = 0.5f * (cb[i].lo[a] + cb[i].hi[a]) - nc[a];
+                    c += ((s >> a) & 1) ? -d : d;
+                }
+                cost[i][s] = c;
+            }
+        for (int it = 0; it < nk; ++it) {
+            int bi = -1, bs = -1; float bc = std::numeric_limits<float>::infinity();
+            for (int i = 0; i < nk; ++i) {
+                if (slotOf[i] >= 0) continue;
+                for (int s = 0; s < 8; ++s) {
+                    if (childAt[s] >= 0) continue;
+                    if (cost[i][s] < bc) { bc = cost[i][s]; bi = i; bs = s; }
+                }
+            }
+            slotOf[bi] = bs; childAt[bs] = bi;
+        }
+
+        WideNode node;
+        memset(&node, 0, sizeof(node));
+        for (int a = 0; a < 3; ++a) {
+            node.p[a] = nb.lo[a];
+            float ext = nb.hi[a] - nb.lo[a];
+            int e = 1;
+            if (ext > 0) {
+                int ex;
+                std::frexp(ext / 255.0f, &ex);       // ext/255 = m * 2^ex with m in [0.5,1)  => 2^ex >= ext/255
+                e = std::min(254, std::max(1, ex + 127));
+            }
+            node.e[a] = (uint8_t) e;
+        }
+        node.childBase = (uint32_t) out.nodes.size();
+        node.triBase = (uint32_t) out.tris.size();
+        uint32_t nInternal = 0, triOfs = 0;
+        for (int s = 0; s < 8; ++s) {
+            int i = childAt[s];
+            if (i < 0) continue;
+            const Node2 &c = b2.nodes[kids[i]];
+            for (int a = 0; a < 3; ++a) {
+                double scale = (double) bitsFloat((uint32_t) node.e[a] << 23);
+                double p = node.p[a];
+                int lo = (int) std::floor(((double) cb[i].lo[a] - p) / scale);
+                int hi = (int) std::ceil(((double) cb[i].hi[a] - p) / scale);
+                lo = std::min(255, std::max(0, lo));
+                hi = std::min(255, std::max(0, hi));
+                // the decoded planes must enclose the padded child box
+                while (lo > 0 && p + lo * scale > (double) cb[i].lo[a]) --lo;
+                while (hi < 255 && p + hi * scale < (double) cb[i].hi[a]) ++hi;
+                node.qlo[a][s] = (uint8_t) lo;
+                node.qhi[a][s] = (uint8_t) hi;
+            }
+            if (c.count > 0) {
+                uint32_t unary = (1u << c.count) - 1u;     // 1 -> 001, 2 -> 011, 3 -> 111
+                node.meta[s] = (uint8_t) ((unary << 5) | triOfs);
+                for (uint32_t j = 0; j < c.count; ++j) {
+                    uint32_t tri = b2.prims[c.first + j].tri;
+                    TriRecord tr;
+                    loadTriRecord(positions + 3 * (size_t) indices[3 * tri], positions + 3 * (size_t) indices[3 * tri + 1],
+                                  positions + 3 * (size_t) indices[3 * tri + 2], tr);
+                    tr.tri = tri;
+                    out.tris.push_back(tr);
+                }
+                triOfs += c.count;
+                sah += (double) (cb[i].area() / rootArea) * kCostTri * c.count;
+            } else {
+                node.imask |= (uint8_t) (1u << s);
+                node.meta[s] = (uint8_t) (0x20 | (24 + s));
+                nInternal++;
+            }
+        }
+        out.nodes[w.wide] = node;
+        // internal children are laid out contiguously in slot order
+        for (int s = 0; s < 8; ++s) {
+            int i = childAt[s];
+            if (i < 0 || b2.nodes[kids[i]].count > 0) continue;
+            uint32_t idx = (uint32_t) out.nodes.size();
+            out.nodes.push_back(WideNode());
+            queue.push_back({ kids[i], idx, w.depth + 1 });
+        }
+        (void) nInternal;
+    }
+    if (out.nodes.size() >= (1u << 24)) return "BVH has too many nodes for the 24-bit traversal stack entries";
+    if ((int) out.depth > kMaxWideDepth) return "BVH too deep for the traversal stack";
+    out.sahCost = sah;
+    out.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return "";
+}
+
+}  // namespace mtsamd

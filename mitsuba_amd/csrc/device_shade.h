@@ -1,0 +1,630 @@
+// Device-side shading: intersection records, the five BSDF models, microfacet machinery and next-event
+// emitter sampling. Each function names the reference code it reproduces.
+#pragma once
+#include "device_math.h"
+
+namespace mtsamd {
+
+struct Isect {
+    V3 p, geoN, wi;
+    Frame3 sh;
+    float uvx, uvy;
+    uint32_t shape, prim;
+};
+
+// ShapeKDTree::fillIntersectionRecord<true> (include/mitsuba/render/skdtree.h:343-428) + computeShadingFrame
+// (src/libcore/util.cpp:603-608). tri is the global triangle index.
+MTS_DEV void fillIntersection(const DevScene &sc, uint32_t tri, float u, float v, V3 rayD, Isect &its) {
+    const uint32_t shapeIdx = sc.triShape[tri];
+    const DevShape sh = sc.shapes[shapeIdx];
+    const float bx = 1 - u - v, by = u, bz = v;
+    const uint32_t i0 = sc.indices[3 * (size_t) tri], i1 = sc.indices[3 * (size_t) tri + 1], i2 = sc.indices[3 * (size_t) tri + 2];
+    const V3 p0 = ld3(sc.positions, i0), p1 = ld3(sc.positions, i1), p2 = ld3(sc.positions, i2);
+    its.shape = shapeIdx;
+    its.prim = tri - sh.firstTri;
+    its.p = p0 * bx + p1 * by + p2 * bz;
+    const V3 side1 = p1 - p0, side2 = p2 - p0;
+    V3 faceNormal = cross(side1, side2);
+    const float len = length(faceNormal);
+    if (!isZero(faceNormal)) faceNormal = faceNormal / len;
+    V3 dpdu;
+    if (sh.flags & 2u) dpdu = ld3(sc.uvDpdu, tri);   // TriMesh::computeUVTangents result (trimesh.cpp:683-735)
+    else dpdu = side1;
+    V3 shN;
+    if (sh.flags & 1u) {
+        const V3 n0 = ld3(sc.normals, i0), n1 = ld3(sc.normals, i1), n2 = ld3(sc.normals, i2);
+        shN = normalize(n0 * bx + n1 * by + n2 * bz);
+        if (dot(faceNormal, shN) < 0) faceNormal = -faceNormal;
+    } else {
+        shN = faceNormal;
+    }
+    its.geoN = faceNormal;
+    if (sh.flags & 2u) {
+        const float *t = sc.texcoords;
+        its.uvx = t[2 * (size_t) i0] * bx + t[2 * (size_t) i1] * by + t[2 * (size_t) i2] * bz;
+        its.uvy = t[2 * (size_t) i0 + 1] * bx + t[2 * (size_t) i1 + 1] * by + t[2 * (size_t) i2 + 1] * bz;
+    } else {
+        its.uvx = by; its.uvy = bz;
+    }
+    its.sh.n = shN;
+    its.sh.s = normalize(dpdu - shN * dot(shN, dpdu));
+    its.sh.t = cross(shN, its.sh.s);
+    its.wi = toLocal(its.sh, -rayD);
+}
+
+// ---- warps (src/libcore/warp.cpp:51-60,84-110) -----------------------------------------------------------
+MTS_DEV void squareToUniformDiskConcentric(float sx, float sy, float &px, float &py) {
+    const float r1 = 2.0f * sx - 1.0f, r2 = 2.0f * sy - 1.0f;
+    float phi, r;
+    if (r1 == 0 && r2 == 0) { r = phi = 0; }
+    else if (r1 * r1 > r2 * r2) { r = r1; phi = (kPi / 4.0f) * (r2 / r1); }
+    else { r = r2; phi = (kPi / 2.0f) - (r1 / r2) * (kPi / 4.0f); }
+    float s, c;
+    sincosf(phi, &s, &c);
+    px = r * c; py = r * s;
+}
+
+MTS_DEV V3 squareToCosineHemisphere(float sx, float sy) {
+    float px, py;
+    squareToUniformDiskConcentric(sx, sy, px, py);
+    float z = safeSqrt(1.0f - px * px - py * py);
+    if (z == 0) z = 1e-10f;
+    return mk(px, py, z);
+}
+
+// ---- math::erf / erfinv / hypot2 (src/libcore/math.cpp:25-86); fastexp/fastlog are exp/log rounded to float ----
+MTS_DEV float erfinvM(float x) {
+    float w = -logf((1.0f - x) * (1.0f + x));
+    float p;
+    if (w < 5.0f) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = 3.43273939e-07f + p * w;
+        p = -3.5233877e-06f + p * w;
+        p = -4.39150654e-06f + p * w;
+        p = 0.00021858087f + p * w;
+        p = -0.00125372503f + p * w;
+        p = -0.00417768164f + p * w;
+        p = 0.246640727f + p * w;
+        p = 1.50140941f + p * w;
+    } else {
+        w = sqrtf(w) - 3.0f;
+        p = -0.000200214257f;
+        p = 0.000100950558f + p * w;
+        p = 0.00134934322f + p * w;
+        p = -0.00367342844f + p * w;
+        p = 0.00573950773f + p * w;
+        p = -0.0076224613f + p * w;
+        p = 0.00943887047f + p * w;
+        p = 1.00167406f + p * w;
+        p = 2.83297682f + p * w;
+    }
+    return p * x;
+}
+
+MTS_DEV float erfM(float x) {
+    const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f, a5 = 1.061405429f, p = 0.3275911f;
+    const float sign = copysignf(1.0f, x);
+    x = fabsf(x);
+    const float t = 1.0f / (1.0f + p * x);
+    const float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * expf(-x * x);
+    return sign * y;
+}
+
+MTS_DEV float hypot2(float a, float b) {
+    float r;
+    if (fabsf(a) > fabsf(b)) { r = b / a; r = fabsf(a) * sqrtf(1.0f + r * r); }
+    else if (b != 0.0f) { r = a / b; r = fabsf(b) * sqrtf(1.0f + r * r); }
+    else r = 0.0f;
+    return r;
+}
+
+// ---- Fresnel (src/libcore/util.cpp:651-681, 739-761) -----------------------------------------------------
+MTS_DEV float fresnelDielectricExt(float cosThetaI_, float &cosThetaT_, float eta) {
+    if (eta == 1) { cosThetaT_ = -cosThetaI_; return 0.0f; }
+    const float scale = (cosThetaI_ > 0) ? 1 / eta : eta;
+    const float cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
+    if (cosThetaTSqr <= 0.0f) { cosThetaT_ = 0.0f; return 1.0f; }
+    const float cosThetaI = fabsf(cosThetaI_);
+    const float cosThetaT = sqrtf(cosThetaTSqr);
+    const float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    const float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    cosThetaT_ = (cosThetaI_ > 0) ? -cosThetaT : cosThetaT;
+    return 0.5f * (Rs * Rs + Rp * Rp);
+}
+
+MTS_DEV float fresnelConductorExact1(float cosThetaI, float eta, float k) {
+    const float cosThetaI2 = cosThetaI * cosThetaI, sinThetaI2 = 1 - cosThetaI2, sinThetaI4 = sinThetaI2 * sinThetaI2;
+    const float temp1 = eta * eta - k * k - sinThetaI2;
+    const float a2pb2 = safeSqrt(temp1 * temp1 + k * k * eta * eta * 4.0f);
+    const float a = safeSqrt((a2pb2 + temp1) * 0.5f);
+    const float term1 = a2pb2 + cosThetaI2, term2 = a * (2 * cosThetaI);
+    const float Rs2 = (term1 - term2) / (term1 + term2);
+    const float term3 = a2pb2 * cosThetaI2 + sinThetaI4, term4 = term2 * sinThetaI2;
+    const float Rp2 = Rs2 * (term3 - term4) / (term3 + term4);
+    return 0.5f * (Rp2 + Rs2);
+}
+
+MTS_DEV V3 fresnelConductorExact(float cosThetaI, V3 eta, V3 k) {
+    return mk(fresnelConductorExact1(cosThetaI, eta.x, k.x), fresnelConductorExact1(cosThetaI, eta.y, k.y),
+              fresnelConductorExact1(cosThetaI, eta.z, k.z));
+}
+
+// ---- evalCubicInterp1D on [0,1] (src/libcore/spline.cpp:23-60) ---------------------------------------------
+MTS_DEV float evalCubicInterp1D01(float x, const float *values, uint32_t size) {
+    if (!(x >= 0.0f && x <= 1.0f)) return 0.0f;
+    float t = ((x - 0.0f) * (float) (size - 1)) / (1.0f - 0.0f);
+    uint32_t k = (uint32_t) t;
+    if (k > size - 2) k = size - 2;
+    const float f0 = values[k], f1 = values[k + 1];
+    float d0, d1;
+    if (k > 0) d0 = 0.5f * (values[k + 1] - values[k - 1]); else d0 = values[k + 1] - values[k];
+    if (k + 2 < size) d1 = 0.5f * (values[k + 2] - values[k]); else d1 = values[k + 1] - values[k];
+    t = t - (float) k;
+    const float t2 = t * t, t3 = t2 * t;
+    return (2 * t3 - 3 * t2 + 1) * f0 + (-2 * t3 + 3 * t2) * f1 + (t3 - 2 * t2 + t) * d0 + (t3 - t2) * d1;
+}
+
+// RoughTransmittance::eval in its fully reduced state (src/bsdfs/rtrans.h:183-194,233)
+MTS_DEV float rtransEval(const DevScene &sc, const DevMaterial &m, float cosTheta) {
+    const float warped = powf(fabsf(cosTheta), 0.25f);
+    if (!(cosTheta >= 0)) return 0.f;
+    const float result = evalCubicInterp1D01(warped, sc.rtrans + m.rtransOffset, m.rtransN);
+    return fminf(1.0f, fmaxf(0.0f, result));
+}
+
+// ---- MicrofacetDistribution (src/bsdfs/microfacet.h) -------------------------------------------------------
+struct Microfacet {
+    int type;
+    float alphaU, alphaV;
+    bool sampleVisible;
+
+    MTS_DEV void init(int type_, float au, float av, bool sv) {
+        type = type_; alphaU = fmaxf(au, 1e-4f); alphaV = fmaxf(av, 1e-4f); sampleVisible = sv;    // :67-74
+    }
+    MTS_DEV bool isotropic() const { return alphaU == alphaV; }
+
+    MTS_DEV float eval(V3 m) const {   // :191-234
+        if (m.z <= 0) return 0.0f;
+        const float cosTheta2 = m.z * m.z;
+        const float beckmannExponent = ((m.x * m.x) / (alphaU * alphaU) + (m.y * m.y) / (alphaV * alphaV)) / cosTheta2;
+        float result;
+        if (type == 0) {
+            result = expf(-beckmannExponent) / (kPi * alphaU * alphaV * cosTheta2 * cosTheta2);
+        } else {
+            const float root = (1.0f + beckmannExponent) * cosTheta2;
+            result = 1.0f / (kPi * alphaU * alphaV * root * root);
+        }
+        if (result * m.z < 1e-20f) result = 0;
+        return result;
+    }
+
+    MTS_DEV float projectRoughness(V3 v) const {   // :541-551
+        const float invSinTheta2 = 1 / (1.0f - v.z * v.z);
+        if (isotropic() || invSinTheta2 <= 0) return alphaU;
+        const float cosPhi2 = v.x * v.x * invSinTheta2, sinPhi2 = v.y * v.y * invSinTheta2;
+        return sqrtf(cosPhi2 * alphaU * alphaU + sinPhi2 * alphaV * alphaV);
+    }
+
+    MTS_DEV float smithG1(V3 v, V3 m) const {   // :477-514
+        if (dot(v, m) * v.z <= 0) return 0.0f;
+        const float temp = 1 - v.z * v.z;
+        const float tanTheta = temp <= 0.0f ? 0.0f : fabsf(sqrtf(temp) / v.z);   // |Frame::tanTheta|
+        if (tanTheta == 0.0f) return 1.0f;
+        const float alpha = projectRoughness(v);
+        if (type == 0) {
+            const float a = 1.0f / (alpha * tanTheta);
+            if (a >= 1.6f) return 1.0f;
+            const float aSqr = a * a;
+            return (3.535f * a + 2.181f * aSqr) / (1.0f + 2.276f * a + 2.577f * aSqr);
+        } else {
+            const float root = alpha * tanTheta;
+            return 2.0f / (1.0f + hypot2(1.0f, root));
+        }
+    }
+    MTS_DEV float G(V3 wi, V3 wo, V3 m) const { return smithG1(wi, m) * smithG1(wo, m); }
+
+    MTS_DEV float pdfVisible(V3 wi, V3 m) const {   // :462-466
+        if (wi.z == 0) return 0.0f;
+        return smithG1(wi, m) * fabsf(dot(wi, m)) * eval(m) / fabsf(wi.z);
+    }
+    MTS_DEV float pdfAll(V3 m) const { return eval(m) * m.z; }
+    MTS_DEV float pdf(V3 wi, V3 m) const { return sampleVisible ? pdfVisible(wi, m) : pdfAll(m); }
+
+    MTS_DEV V3 sampleAll(float sx, float sy, float &pdf_) const {   // :287-395
+        float cosThetaM, sinPhiM, cosPhiM, alphaSqr;
+        if (isotropic()) {
+            sincosf((2.0f * kPi) * sy, &sinPhiM, &cosPhiM);
+            alphaSqr = alphaU * alphaU;
+        } else {
+            const float phiM = atanf(alphaV / alphaU * tanf(kPi + 2 * kPi * sy)) + kPi * floorf(2 * sy + 0.5f);
+            sincosf(phiM, &sinPhiM, &cosPhiM);
+            const float cosSc = cosPhiM / alphaU, sinSc = sinPhiM / alphaV;
+            alphaSqr = 1.0f / (cosSc * cosSc + sinSc * sinSc);
+        }
+        if (type == 0) {
+            const float tanThetaMSqr = alphaSqr * -logf(1.0f - sx);
+            cosThetaM = 1.0f / sqrtf(1.0f + tanThetaMSqr);
+            pdf_ = (1.0f - sx) / (kPi * alphaU * alphaV * cosThetaM * cosThetaM * cosThetaM);
+        } else {
+            const float tanThetaMSqr = alphaSqr * sx / (1.0f - sx);
+            cosThetaM = 1.0f / sqrtf(1.0f + tanThetaMSqr);
+            const float temp = 1 + tanThetaMSqr / alphaSqr;
+            pdf_ = kInvPi / (alphaU * alphaV * cosThetaM * cosThetaM * cosThetaM * temp * temp);
+        }
+        if (pdf_ < 1e-20f) pdf_ = 0;
+        const float sinThetaM = sqrtf(fmaxf(0.0f, 1 - cosThetaM * cosThetaM));
+        return mk(sinThetaM * cosPhiM, sinThetaM * sinPhiM, cosThetaM);
+    }
+
+    MTS_DEV void sampleVisible11(float thetaI, float sx, float sy, float &slopeX, float &slopeY) const {   // :573-697
+        const float SQRT_PI_INV = 1 / sqrtf(kPi);
+        if (type == 0) {
+            if (thetaI < 1e-4f) {
+                float sinPhi, cosPhi;
+                const float r = sqrtf(-logf(1.0f - sx));
+                sincosf(2 * kPi * sy, &sinPhi, &cosPhi);
+                slopeX = r * cosPhi; slopeY = r * sinPhi;
+                return;
+            }
+            const float tanThetaI = tanf(thetaI);
+            const float cotThetaI = 1 / tanThetaI;
+            float a = -1, c = erfM(cotThetaI);
+            const float sample_x = fmaxf(sx, 1e-6f);
+            const float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
+            float b = c - (1 + c) * powf(1 - sample_x, fit);
+            const float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * expf(-cotThetaI * cotThetaI));
+            int it = 0;
+            while (++it < 10) {
+                if (!(b >= a && b <= c)) b = 0.5f * (a + c);
+                const float invErf = erfinvM(b);
+                const float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * expf(-invErf * invErf)) - sample_x;
+                const float derivative = normalization * (1 - invErf * tanThetaI);
+                if (fabsf(value) < 1e-5f) break;
+                if (value > 0) c = b; else a = b;
+                b -= value / derivative;
+            }
+            slopeX = erfinvM(b);
+            slopeY = erfinvM(2.0f * fmaxf(sy, 1e-6f) - 1.0f);
+        } else {
+            if (thetaI < 1e-4f) {
+                float sinPhi, cosPhi;
+                const float r = safeSqrt(sx / (1 - sx));
+                sincosf(2 * kPi * sy, &sinPhi, &cosPhi);
+                slopeX = r * cosPhi; slopeY = r * sinPhi;
+                return;
+            }
+            const float tanThetaI = tanf(thetaI);
+            const float a = 1 / tanThetaI;
+            const float G1 = 2.0f / (1.0f + safeSqrt(1.0f + 1.0f / (a * a)));
+            float A = 2.0f * sx / G1 - 1.0f;
+            if (fabsf(A) == 1) A -= copysignf(1.0f, A) * kEpsilon;
+            const float tmp = 1.0f / (A * A - 1.0f);
+            const float B = tanThetaI;
+            const float D = safeSqrt(B * B * tmp * tmp - (A * A - B * B) * tmp);
+            const float slope_x_1 = B * tmp - D;
+            const float slope_x_2 = B * tmp + D;
+            slopeX = (A < 0.0f || slope_x_2 > 1.0f / tanThetaI) ? slope_x_1 : slope_x_2;
+            float S;
+            if (sy > 0.5f) { S = 1.0f; sy = 2.0f * (sy - 0.5f); }
+            else { S = -1.0f; sy = 2.0f * (0.5f - sy); }
+            const float z = (sy * (sy * (sy * (-0.365728915865723f) + 0.790235037209296f) - 0.424965825137544f) + 0.000152998850436920f) /
+                            (sy * (sy * (sy * (sy * 0.169507819808272f - 0.397203533833404f) - 0.232500544458471f) + 1.0f) - 0.539825872510702f);
+            slopeY = S * z * sqrtf(1.0f + slopeX * slopeX);
+        }
+    }
+
+    MTS_DEV V3 sampleVisibleN(V3 _wi, float sx, float sy) const {   // :421-459
+        const V3 wi = normalize(mk(alphaU * _wi.x, alphaV * _wi.y, _wi.z));
+        float theta = 0, phi = 0;
+        if (wi.z < 0.99999f) { theta = acosf(wi.z); phi = atan2f(wi.y, wi.x); }
+        float sinPhi, cosPhi;
+        sincosf(phi, &sinPhi, &cosPhi);
+        float slx, sly;
+        sampleVisible11(theta, sx, sy, slx, sly);
+        float rx = cosPhi * slx - sinPhi * sly, ry = sinPhi * slx + cosPhi * sly;
+        rx *= alphaU; ry *= alphaV;
+        const float normalization = 1.0f / sqrtf(rx * rx + ry * ry + 1.0f);
+        return mk(-rx * normalization, -ry * normalization, normalization);
+    }
+
+    MTS_DEV V3 sample(V3 wi, float sx, float sy, float &pdf_) const {   // :240-249
+        if (sampleVisible) { const V3 m = sampleVisibleN(wi, sx, sy); pdf_ = pdfVisible(wi, m); return m; }
+        return sampleAll(sx, sy, pdf_);
+    }
+    MTS_DEV V3 sample(V3 wi, float sx, float sy) const {   // :255-264
+        if (sampleVisible) return sampleVisibleN(wi, sx, sy);
+        float p; return sampleAll(sx, sy, p);
+    }
+};
+
+MTS_DEV V3 reflectM(V3 wi, V3 m) { return 2 * dot(wi, m) * m - wi; }
+MTS_DEV float cosHemiPdf(V3 d) { return kInvPi * d.z; }
+
+// ---- BSDF::eval (value includes the cosine factor) -----------------------------------------------------------
+MTS_DEV V3 bsdfEval(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
+    const V3 zero = mk(0.0f);
+    if (m.type == 3) return zero;                               // dielectric.cpp:228-253: no solid-angle lobe
+    if (wi.z <= 0 || wo.z <= 0) return zero;
+    const V3 diff = ld3(m.diffuse), spec = ld3(m.specular);
+    switch (m.type) {
+        case 0:                                                 // diffuse.cpp:110-118
+            if (!(m.typeFlags & EDiffuseReflection)) return zero;
+            return diff * (kInvPi * wo.z);
+        case 1: {                                               // roughconductor.cpp:257-294
+            const V3 H = normalize(wo + wi);
+            Microfacet distr; distr.init(m.distribution, m.alphaU, m.alphaV, m.sampleVisible != 0);
+            const float D = distr.eval(H);
+            if (D == 0) return zero;
+            const V3 F = fresnelConductorExact(dot(wi, H), ld3(m.condEta), ld3(m.condK)) * spec;
+            const float G = distr.G(wi, wo, H);
+            const float model = D * G / (4.0f * wi.z);
+            return F * model;
+        }
+        case 2: {                                               // roughplastic.cpp:326-382
+            Microfacet distr; distr.init(m.distribution, m.alphaU, m.alphaU, m.sampleVisible != 0);
+            V3 result = zero;
+            {
+                const V3 H = normalize(wo + wi);
+                const float D = distr.eval(H);
+                float ct;
+                const float F = fresnelDielectricExt(dot(wi, H), ct, m.eta);
+                const float G = distr.G(wi, wo, H);
+                const float value = F * D * G / (4.0f * wi.z);
+                result = result + spec * value;
+            }
+            {
+                V3 d = diff;
+                const float T12 = rtransEval(sc, m, wi.z);
+                const float T21 = rtransEval(sc, m, wo.z);
+                const float Fdr = 1 - m.fdrInt;
+                if (m.variant) d = d / (mk(1.0f) - d * Fdr);
+                else d = d / (1 - Fdr);
+                result = result + d * (kInvPi * wo.z * T12 * T21 * m.invEta2);
+            }
+            return result;
+        }
+        default: {                                              // ward.cpp:178-226
+            V3 result = zero;
+            const V3 H = wi + wo;
+            float factor1;
+            if (m.variant == 0) factor1 = 1.0f / (4.0f * kPi * m.alphaU * m.alphaV * sqrtf(wi.z * wo.z));
+            else if (m.variant == 1) factor1 = 1.0f / (4.0f * kPi * m.alphaU * m.alphaV * wi.z * wo.z);
+            else {
+                // std::pow(Float, int) runs in double in the reference; so does this quotient
+                const double c = (double) H.z;
+                factor1 = (float) ((double) dot(H, H) / ((double) (kPi * m.alphaU * m.alphaV) * (c * c * c * c)));
+            }
+            const float factor2 = H.x / m.alphaU, factor3 = H.y / m.alphaV;
+            const float exponent = -(factor2 * factor2 + factor3 * factor3) / (H.z * H.z);
+            const float specRef = factor1 * expf(exponent);
+            if (specRef > 1e-10f) result = result + spec * specRef;
+            result = result + diff * kInvPi;
+            return result * wo.z;
+        }
+    }
+}
+
+// ---- BSDF::pdf -----------------------------------------------------------------------------------------------
+MTS_DEV float bsdfPdf(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
+    if (m.type == 3) return 0.0f;
+    if (wi.z <= 0 || wo.z <= 0) return 0.0f;
+    switch (m.type) {
+        case 0:                                                 // diffuse.cpp:120-127
+            if (!(m.typeFlags & EDiffuseReflection)) return 0.0f;
+            return cosHemiPdf(wo);
+        case 1: {                                               // roughconductor.cpp:296-321
+            const V3 H = normalize(wo + wi);
+            Microfacet distr; distr.init(m.distribution, m.alphaU, m.alphaV, m.sampleVisible != 0);
+            if (distr.sampleVisible) return distr.eval(H) * distr.smithG1(wi, H) / (4.0f * wi.z);
+            return distr.pdf(wi, H) / (4 * fabsf(dot(wo, H)));
+        }
+        case 2: {                                               // roughplastic.cpp:384-437
+            Microfacet distr; distr.init(m.distribution, m.alphaU, m.alphaU, m.sampleVisible != 0);
+            const V3 H = normalize(wo + wi);
+            float probSpecular = 1 - rtransEval(sc, m, wi.z);
+            probSpecular = (probSpecular * m.specSamplingWeight) /
+                (probSpecular * m.specSamplingWeight + (1 - probSpecular) * (1 - m.specSamplingWeight));
+            const float probDiffuse = 1 - probSpecular;
+            const float dwh_dwo = 1.0f / (4.0f * dot(wo, H));
+            const float prob = distr.pdf(wi, H);
+            float result = prob * dwh_dwo * probSpecular;
+            result += probDiffuse * cosHemiPdf(wo);
+            return result;
+        }
+        default: {                                              // ward.cpp:228-264
+            const V3 H = normalize(wi + wo);
+            const double c = (double) H.z;
+            const float factor1 = (float) (1.0 / ((double) (4.0f * kPi * m.alphaU * m.alphaV * dot(H, wi)) * (c * c * c)));
+            const float factor2 = H.x / m.alphaU, factor3 = H.y / m.alphaV;
+            const float exponent = -(factor2 * factor2 + factor3 * factor3) / (H.z * H.z);
+            const float specProb = factor1 * expf(exponent);
+            const float diffuseProb = cosHemiPdf(wo);
+            return m.specSamplingWeight * specProb + (1 - m.specSamplingWeight) * diffuseProb;
+        }
+    }
+}
+
+// ---- BSDF::sample(bRec, pdf, sample) -----------------------------------------------------------------------------
+MTS_DEV V3 bsdfSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, V3 &wo, float &pdf, float &eta,
+                      uint32_t &sampledType) {
+    const V3 zero = mk(0.0f);
+    pdf = 0; eta = 1.0f; sampledType = 0; wo = zero;
+    const V3 diff = ld3(m.diffuse), spec = ld3(m.specular);
+    switch (m.type) {
+        case 0: {                                               // diffuse.cpp:140-150
+            if (!(m.typeFlags & EDiffuseReflection) || wi.z <= 0) return zero;
+            wo = squareToCosineHemisphere(sx, sy);
+            sampledType = EDiffuseReflection;
+            pdf = cosHemiPdf(wo);
+            return diff;
+        }
+        case 1: {                                               // roughconductor.cpp:369-415
+            if (wi.z < 0) return zero;
+            Microfacet distr; distr.init(m.distribution, m.alphaU, m.alphaV, m.sampleVisible != 0);
+            const V3 mm = distr.sample(wi, sx, sy, pdf);
+            if (pdf == 0) return zero;
+            wo = reflectM(wi, mm);
+            sampledType = EGlossyReflection;
+            if (wo.z <= 0) return zero;
+            const V3 F = fresnelConductorExact(dot(wi, mm), ld3(m.condEta), ld3(m.condK)) * spec;
+            float weight;
+            if (distr.sampleVisible) weight = distr.smithG1(wo, mm);
+            else weight = distr.eval(mm) * distr.G(wi, wo, mm) * dot(wi, mm) / (pdf * wi.z);
+            pdf /= 4.0f * dot(wo, mm);
+            return F * weight;
+        }
+        case 2: {                                               // roughplastic.cpp:439-501
+            if (wi.z <= 0) return zero;
+            bool choseSpecular = true;
+            Microfacet distr; distr.init(m.distribution, m.alphaU, m.alphaU, m.sampleVisible != 0);
+            float probSpecular = 1 - rtransEval(sc, m, wi.z);
+            probSpecular = (probSpecular * m.specSamplingWeight) /
+                (probSpecular * m.specSamplingWeight + (1 - probSpecular) * (1 - m.specSamplingWeight));
+            if (sy < probSpecular) sy /= probSpecular;
+            else { sy = (sy - probSpecular) / (1 - probSpecular); choseSpecular = false; }
+            if (choseSpecular) {
+                const V3 mm = distr.sample(wi, sx, sy);
+                wo = reflectM(wi, mm);
+                sampledType = EGlossyReflection;
+                if (wo.z <= 0) return zero;
+            } else {
+                sampledType = EDiffuseReflection;
+                wo = squareToCosineHemisphere(sx, sy);
+            }
+            pdf = bsdfPdf(sc, m, wi, wo);
+            if (pdf == 0) return zero;
+            return bsdfEval(sc, m, wi, wo) / pdf;
+        }
+        case 3: {                                               // dielectric.cpp:277-308 (both lobes, ERadiance)
+            float cosThetaT;
+            const float F = fresnelDielectricExt(wi.z, cosThetaT, m.eta);
+            if (sx <= F) {
+                sampledType = EDeltaReflection;
+                wo = mk(-wi.x, -wi.y, wi.z);
+                pdf = F;
+                return spec;
+            } else {
+                sampledType = EDeltaTransmission;
+                const float scale = -(cosThetaT < 0 ? m.invEta : m.eta);
+                wo = mk(scale * wi.x, scale * wi.y, cosThetaT);
+                eta = cosThetaT < 0 ? m.eta : m.invEta;
+                pdf = 1 - F;
+                const float factor = cosThetaT < 0 ? m.invEta : m.eta;
+                return ld3(m.transmittance) * (factor * factor);
+            }
+        }
+        default: {                                              // ward.cpp:266-326
+            bool choseSpecular = true;
+            if (sx <= m.specSamplingWeight) sx /= m.specSamplingWeight;
+            else { sx = (sx - m.specSamplingWeight) / (1 - m.specSamplingWeight); choseSpecular = false; }
+            if (choseSpecular) {
+                float phiH = atanf(m.alphaV / m.alphaU * tanf(2.0f * kPi * sy));
+                if (sy > 0.5f) phiH += kPi;
+                const float cosPhiH = cosf(phiH);
+                const float sinPhiH = safeSqrt(1.0f - cosPhiH * cosPhiH);
+                const float thetaH = atanf(safeSqrt(-logf(sx) /
+                    ((cosPhiH * cosPhiH) / (m.alphaU * m.alphaU) + (sinPhiH * sinPhiH) / (m.alphaV * m.alphaV))));
+                float sinTheta, cosTheta, sinPhi, cosPhi;
+                sincosf(thetaH, &sinTheta, &cosTheta);
+                sincosf(phiH, &sinPhi, &cosPhi);
+                const V3 H = mk(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+                wo = H * (2.0f * dot(wi, H)) - wi;
+                sampledType = EGlossyReflection;
+                if (wo.z <= 0.0f) return zero;
+            } else {
+                wo = squareToCosineHemisphere(sx, sy);
+                sampledType = EDiffuseReflection;
+            }
+            pdf = bsdfPdf(sc, m, wi, wo);
+            if (pdf == 0) return zero;
+            return bsdfEval(sc, m, wi, wo) / pdf;
+        }
+    }
+}
+
+// ---- DiscreteDistribution::sampleReuse on a device CDF (include/mitsuba/core/pmf.h:124-188) ---------------------
+MTS_DEV uint32_t cdfSampleReuse(const float *cdf, uint32_t n /* entries */, float &sample, float *pdfOut) {
+    // lower_bound over cdf[0..n]
+    uint32_t lo = 0, count = n + 1;
+    while (count > 0) {
+        const uint32_t step = count / 2, mid = lo + step;
+        if (cdf[mid] < sample) { lo = mid + 1; count -= step + 1; } else count = step;
+    }
+    int idx = (int) lo - 1;
+    if (idx < 0) idx = 0;
+    uint32_t index = (uint32_t) idx < n - 1 ? (uint32_t) idx : n - 1;
+    while (cdf[index + 1] - cdf[index] == 0 && index < n) ++index;
+    if (pdfOut) *pdfOut = cdf[index + 1] - cdf[index];
+    sample = (sample - cdf[index]) / (cdf[index + 1] - cdf[index]);
+    return index;
+}
+
+struct DirectRec { V3 d; float dist, pdf; };
+
+// Scene::sampleEmitterDirect without the shadow ray (src/librender/scene.cpp:828-852) -> AreaLight::sampleDirect
+// (src/emitters/area.cpp:158-173) -> Shape::sampleDirect (src/librender/shape.cpp:102-115) -> TriMesh::samplePosition
+// (src/librender/trimesh.cpp:412-423) -> Triangle::sample (src/libcore/triangle.cpp:24-59)
+MTS_DEV V3 sampleEmitterDirect(const DevScene &sc, V3 ref, V3 refN, float sx, float sy, DirectRec &dRec) {
+    dRec.pdf = 0; dRec.dist = 0; dRec.d = mk(0.0f);
+    if (sc.nEmitters == 0) return mk(0.0f);
+    float emPdf;
+    const uint32_t index = cdfSampleReuse(sc.emitterCdf, sc.nEmitters, sx, &emPdf);
+    const DevEmitter em = sc.emitters[index];
+    const uint32_t triIdx = cdfSampleReuse(sc.areaCdf + em.cdfOffset, em.nTris, sy, nullptr);
+    const uint32_t t = em.firstTri + triIdx;
+    const uint32_t i0 = sc.indices[3 * (size_t) t], i1 = sc.indices[3 * (size_t) t + 1], i2 = sc.indices[3 * (size_t) t + 2];
+    const V3 p0 = ld3(sc.positions, i0), p1 = ld3(sc.positions, i1), p2 = ld3(sc.positions, i2);
+    const float a = safeSqrt(1.0f - sx);                  // squareToUniformTriangle (warp.cpp:84-87)
+    const float baryX = 1 - a, baryY = a * sy;
+    const V3 sideA = p1 - p0, sideB = p2 - p0;
+    const V3 p = p0 + (sideA * baryX) + (sideB * baryY);
+    V3 n;
+    if (sc.shapes[em.shape].flags & 1u) {
+        const V3 n0 = ld3(sc.normals, i0), n1 = ld3(sc.normals, i1), n2 = ld3(sc.normals, i2);
+        n = normalize(n0 * (1.0f - baryX - baryY) + n1 * baryX + n2 * baryY);
+    } else {
+        n = normalize(cross(sideA, sideB));
+    }
+    float pdf = em.invArea;
+    V3 d = p - ref;
+    const float distSquared = dot(d, d);
+    const float dist = sqrtf(distSquared);
+    d = d / dist;
+    const float dp = fabsf(dot(d, n));
+    pdf *= dp != 0 ? (distSquared / dp) : 0.0f;
+    dRec.d = d; dRec.dist = dist;
+    if (dot(d, refN) >= 0 && dot(d, n) < 0 && pdf != 0) {
+        V3 value = ld3(em.radiance) / pdf;
+        dRec.pdf = pdf * emPdf;
+        return value / emPdf;
+    }
+    dRec.pdf = 0.0f;
+    return mk(0.0f);
+}
+
+MTS_DEV float miWeight(float pdfA, float pdfB) {   // path.cpp:296-300
+    pdfA *= pdfA; pdfB *= pdfB;
+    return pdfA / (pdfA + pdfB);
+}
+
+// PerspectiveCameraImpl::sampleRayDifferential, ray part (src/sensors/perspective.cpp:271-298)
+MTS_DEV void cameraRay(const DevScene &sc, float px, float py, V3 &o, V3 &d, float &mint, float &maxt) {
+    const float *M = sc.sampleToCamera;
+    const float sx = px * sc.invResX, sy = py * sc.invResY;
+    const float x = M[0] * sx + M[1] * sy + M[3];
+    const float y = M[4] * sx + M[5] * sy + M[7];
+    const float z = M[8] * sx + M[9] * sy + M[11];
+    const float w = M[12] * sx + M[13] * sy + M[15];
+    V3 nearP = mk(x, y, z);
+    if (w != 1.0f) nearP = nearP / w;
+    const V3 dl = normalize(nearP);
+    const float invZ = 1.0f / dl.z;
+    const float *W = sc.camToWorld;
+    o = mk(W[3], W[7], W[11]);
+    d = mk(W[0] * dl.x + W[1] * dl.y + W[2] * dl.z, W[4] * dl.x + W[5] * dl.y + W[6] * dl.z, W[8] * dl.x + W[9] * dl.y + W[10] * dl.z);
+    mint = sc.nearClip * invZ;
+    maxt = sc.farClip * invZ;
+}
+
+}  // namespace mtsamd

@@ -1,0 +1,95 @@
+// Plain-data views of the uploaded scene and of the wavefront queues, shared by the host driver and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mtsamd {
+
+// BSDF::EBSDFType bits (include/mitsuba/render/bsdf.h:230-284)
+enum : unsigned {
+    ENull = 0x1, EDiffuseReflection = 0x2, EDiffuseTransmission = 0x4, EGlossyReflection = 0x8,
+    EGlossyTransmission = 0x10, EDeltaReflection = 0x20, EDeltaTransmission = 0x40,
+    EAnisotropic = 0x1000, ENonSymmetric = 0x4000, EFrontSide = 0x8000, EBackSide = 0x10000,
+    ETransmission = EDiffuseTransmission | EDeltaTransmission | EGlossyTransmission | ENull,
+    ESmooth = EDiffuseReflection | EDiffuseTransmission | EGlossyReflection | EGlossyTransmission,
+    EDelta = ENull | EDeltaReflection | EDeltaTransmission
+};
+
+struct DevMaterial {
+    int32_t type, distribution, sampleVisible, variant;
+    uint32_t typeFlags;
+    float alphaU, alphaV, eta;
+    float invEta, invEta2, specSamplingWeight, fdrInt;      // fdrInt = internal evalDiffuse(alpha)
+    float diffuse[3]; uint32_t rtransOffset;
+    float specular[3]; uint32_t rtransN;
+    float transmittance[3]; float pad0;
+    float condEta[3]; float pad1;
+    float condK[3]; float pad2;
+};
+
+struct DevShape {
+    uint32_t firstTri, nTris;
+    int32_t material, emitter;
+    uint32_t flags, pad[3];
+};
+
+struct DevEmitter {
+    float radiance[3];
+    float pdfDiscrete;      // samplingWeight * normalization (scene.h:848-850)
+    uint32_t shape, firstTri, nTris, cdfOffset;
+    float invArea, pad[3];
+};
+
+struct DevScene {
+    const float4 *nodes;        // 5 x float4 per wide node
+    const float4 *tris;         // 3 x float4 per triangle record (BVH order)
+    const float *positions;     // 3 per vertex
+    const float *normals;       // 3 per vertex or null
+    const float *texcoords;     // 2 per vertex or null
+    const uint32_t *indices;    // 3 per triangle (global order)
+    const uint32_t *triShape;   // per triangle (global order)
+    const float *uvDpdu;        // 3 per triangle or null (meshes with texcoords)
+    const DevShape *shapes;
+    const DevMaterial *materials;
+    const DevEmitter *emitters;
+    const float *emitterCdf;    // nEmitters + 1
+    const float *areaCdf;       // concatenated per-emitter triangle CDFs (nTris + 1 each)
+    const float *rtrans;        // concatenated reduced transmittance tables
+    uint32_t nEmitters, nTris, nShapes, nMaterials;
+    float aabbMin[3], aabbMax[3];       // enlarged scene bounds (gkdtree.h:1213-1220)
+    float sampleToCamera[16];
+    float camToWorld[12];
+    float nearClip, farClip, invResX, invResY;
+    int32_t cropW, cropH;
+    float filterRadius;
+    float filterValues[32];
+    int32_t maxDepth, rrDepth, strictNormals, hideEmitters;
+};
+
+// Wavefront queue of live paths (structure of arrays, one float4/uint4 stream each)
+struct PathQueue {
+    float4 *rayO;       // origin.xyz, mint
+    float4 *rayD;       // direction.xyz, maxt
+    float4 *thr;        // throughput.rgb, eta
+    uint4 *misc;        // sample slot, depth | flags << 16, rng state lo, rng state hi
+    float *bsdfPdf;     // pdf of the BSDF sample that produced this ray
+};
+
+struct ShadowQueue {
+    float4 *rayO, *rayD;
+    float4 *contrib;    // rgb, sample slot (bits)
+};
+
+enum : unsigned { PF_PREV_DELTA = 1u, PF_REFN_OK = 2u, PF_SCATTERED = 4u };
+
+struct PassParams {
+    int32_t x0, y0, w, h;       // pixel rectangle of this pass
+    int32_t spp;                // samples per pixel in this pass
+    int32_t sppTotal, sampleBase;
+    uint32_t seed;
+};
+
+// counters[] layout in device memory
+enum { CNT_NEXT = 0, CNT_SHADOW = 1, CNT_NODE_VISITS = 2, CNT_TRI_TESTS = 4, CNT_WORDS = 8 };
+
+}  // namespace mtsamd

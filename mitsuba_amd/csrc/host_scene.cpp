@@ -1,0 +1,327 @@
+#include "host_scene.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace mtsamd {
+
+namespace {
+
+// spectrum luminance (include/mitsuba/core/spectrum.h:754-756)
+float luminance(const float *s) { return s[0] * 0.212671f + s[1] * 0.715160f + s[2] * 0.072169f; }
+float max3(const float *s) { return std::max(std::max(s[0], s[1]), s[2]); }
+
+// BSDF::ensureEnergyConservation (src/librender/bsdf.cpp:88-146): a "scale" texture of 0.99 * max / actualMax
+void ensureEnergy(bool on, float *a) {
+    if (!on) return;
+    float actualMax = max3(a);
+    if (actualMax > 1.0f) { float s = 0.99f * (1.0f / actualMax); for (int i = 0; i < 3; ++i) a[i] *= s; }
+}
+void ensureEnergy2(bool on, float *a, float *b) {
+    if (!on) return;
+    float sum[3] = { a[0] + b[0], a[1] + b[1], a[2] + b[2] };
+    float actualMax = max3(sum);
+    if (actualMax > 1.0f) { float s = 0.99f * (1.0f / actualMax); for (int i = 0; i < 3; ++i) { a[i] *= s; b[i] *= s; } }
+}
+
+void mul4(const float *a, const float *b, float *out) {
+    float r[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float s = 0;
+            for (int k = 0; k < 4; ++k) s += a[i * 4 + k] * b[k * 4 + j];
+            r[i * 4 + j] = s;
+        }
+    memcpy(out, r, sizeof(r));
+}
+
+bool invert4(const float *m, float *out) {
+    float a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { a[i][j] = m[i * 4 + j]; a[i][j + 4] = i == j ? 1.0f : 0.0f; }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (a[piv][c] == 0) return false;
+        if (piv != c) for (int j = 0; j < 8; ++j) std::swap(a[c][j], a[piv][j]);
+        float inv = 1.0f / a[c][c];
+        for (int j = 0; j < 8; ++j) a[c][j] *= inv;
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            float f = a[r][c];
+            if (f != 0) for (int j = 0; j < 8; ++j) a[r][j] -= f * a[c][j];
+        }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[i * 4 + j] = a[i][j + 4];
+    return true;
+}
+
+void scale4(float x, float y, float z, float *m) { memset(m, 0, 64); m[0] = x; m[5] = y; m[10] = z; m[15] = 1; }
+void translate4(float x, float y, float z, float *m) { scale4(1, 1, 1, m); m[3] = x; m[7] = y; m[11] = z; }
+
+// DiscreteDistribution::append/normalize (include/mitsuba/core/pmf.h:56-114): running float sum, then a multiply by
+// the reciprocal of the total with the last entry forced to 1
+float normalizeCdf(float *cdf, size_t n /* entries */, float *normalization) {
+    float sum = cdf[n];
+    if (sum > 0) {
+        float norm = 1.0f / sum;
+        for (size_t i = 1; i <= n; ++i) cdf[i] *= norm;
+        cdf[n] = 1.0f;
+        if (normalization) *normalization = norm;
+    } else if (normalization) {
+        *normalization = 0.0f;
+    }
+    return sum;
+}
+
+}  // namespace
+
+std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
+    if (!d) return "null scene description";
+    if (d->n_triangles && (!d->positions || !d->indices)) return "positions/indices missing";
+    if (!d->shapes && d->n_shapes) return "shapes missing";
+    if (!d->materials || d->n_materials == 0) return "at least one material is required";
+    const mtsamd_film &f = d->film;
+    if (f.width <= 0 || f.height <= 0 || f.crop_w <= 0 || f.crop_h <= 0 || f.crop_x < 0 || f.crop_y < 0 ||
+        f.crop_x + f.crop_w > f.width || f.crop_y + f.crop_h > f.height) return "invalid film/crop size";
+    if (!(f.filter_radius > 0) || f.filter_radius > 2.5f) return "reconstruction filter radius must be in (0, 2.5]";
+    if (d->integrator.rr_depth <= 0) return "'rrDepth' must be set to a value greater than zero!";                 // integrator.cpp:220-221
+    if (d->integrator.max_depth <= 0 && d->integrator.max_depth != -1)
+        return "'maxDepth' must be set to -1 (infinite) or a value greater than zero!";                            // integrator.cpp:223-224
+    if (!(d->camera.near_clip > 0)) return "The 'nearClip' parameter must be greater than zero!";                   // sensor.cpp:164-165
+    if (!(d->camera.near_clip < d->camera.far_clip)) return "The 'nearClip' parameter must be smaller than 'farClip'.";
+
+    hs.desc = *d;
+    hs.positions.assign(d->positions, d->positions + (size_t) d->n_vertices * 3);
+    hs.indices.assign(d->indices, d->indices + (size_t) d->n_triangles * 3);
+    hs.hasNormals = d->normals != nullptr;
+    hs.hasTexcoords = d->texcoords != nullptr;
+    if (hs.hasNormals) hs.normals.assign(d->normals, d->normals + (size_t) d->n_vertices * 3);
+    if (hs.hasTexcoords) hs.texcoords.assign(d->texcoords, d->texcoords + (size_t) d->n_vertices * 2);
+    for (size_t i = 0; i < hs.indices.size(); ++i)
+        if (hs.indices[i] >= d->n_vertices) return "vertex index out of range";
+
+    // ---- materials ------------------------------------------------------------------------------------
+    hs.materials.resize(d->n_materials);
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const mtsamd_material &m = d->materials[i];
+        DevMaterial dm;
+        memset(&dm, 0, sizeof(dm));
+        dm.type = m.type; dm.distribution = m.distribution; dm.sampleVisible = m.sample_visible; dm.variant = m.variant;
+        dm.alphaU = m.alpha_u; dm.alphaV = m.alpha_v;
+        dm.eta = 1; dm.invEta = 1; dm.invEta2 = 1;
+        const bool ee = m.ensure_energy_conservation != 0;
+        float diff[3], spec[3], trans[3];
+        memcpy(diff, m.diffuse_reflectance, 12); memcpy(spec, m.specular_reflectance, 12); memcpy(trans, m.specular_transmittance, 12);
+        const unsigned aniso = m.alpha_u != m.alpha_v ? EAnisotropic : 0u;
+        if (m.type != MTSAMD_BSDF_DIFFUSE && m.type != MTSAMD_BSDF_DIELECTRIC && m.type != MTSAMD_BSDF_WARD) {
+            if (m.distribution != MTSAMD_DISTR_BECKMANN && m.distribution != MTSAMD_DISTR_GGX)
+                return "Specified an invalid distribution, must be \"beckmann\" or \"ggx\"";
+        }
+        switch (m.type) {
+            case MTSAMD_BSDF_DIFFUSE:           // diffuse.cpp:93-104
+                ensureEnergy(ee, diff);
+                dm.typeFlags = max3(diff) > 0 ? (EDiffuseReflection | EFrontSide) : 0u;
+                break;
+            case MTSAMD_BSDF_ROUGHCONDUCTOR:    // roughconductor.cpp:187-190,228-250
+                ensureEnergy(ee, spec);
+                for (int c = 0; c < 3; ++c) {
+                    float recip = 1.0f / m.ext_eta;     // Spectrum / Float multiplies by the reciprocal
+                    dm.condEta[c] = m.eta[c] * recip;
+                    dm.condK[c] = m.k[c] * recip;
+                }
+                dm.typeFlags = EGlossyReflection | EFrontSide | aniso;
+                break;
+            case MTSAMD_BSDF_ROUGHPLASTIC: {    // roughplastic.cpp:209-213,255-307
+                if (m.int_ior < 0 || m.ext_ior < 0 || m.int_ior == m.ext_ior)
+                    return "The interior and exterior indices of refraction must be positive and differ!";
+                if (m.alpha_u != m.alpha_v)
+                    return "The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!";
+                if (!m.rtrans || m.rtrans_n < 2) return "roughplastic needs the reduced rough transmittance table";
+                ensureEnergy(ee, spec);
+                ensureEnergy(ee, diff);
+                dm.eta = m.int_ior / m.ext_ior;
+                dm.invEta2 = 1.0f / (dm.eta * dm.eta);
+                float dAvg = luminance(diff), sAvg = luminance(spec);
+                dm.specSamplingWeight = sAvg / (dAvg + sAvg);
+                dm.fdrInt = m.rtrans_diffuse_int;
+                dm.rtransOffset = (uint32_t) hs.rtrans.size();
+                dm.rtransN = m.rtrans_n;
+                hs.rtrans.insert(hs.rtrans.end(), m.rtrans, m.rtrans + m.rtrans_n);
+                dm.typeFlags = EGlossyReflection | EDiffuseReflection | EFrontSide;
+                break;
+            }
+            case MTSAMD_BSDF_DIELECTRIC:        // dielectric.cpp:154-159,184-202
+                if (m.int_ior < 0 || m.ext_ior < 0) return "The interior and exterior indices of refraction must be positive!";
+                ensureEnergy(ee, spec);
+                ensureEnergy(ee, trans);
+                dm.eta = m.int_ior / m.ext_ior;
+                dm.invEta = 1 / dm.eta;
+                dm.typeFlags = EDeltaReflection | EDeltaTransmission | EFrontSide | EBackSide | ENonSymmetric;
+                break;
+            case MTSAMD_BSDF_WARD: {            // ward.cpp:139-171
+                if (m.variant < 0 || m.variant > 2) return "Specified an invalid model type, must be \"ward\", \"ward-duer\", or \"balanced\"!";
+                ensureEnergy2(ee, spec, diff);
+                float dAvg = luminance(diff), sAvg = luminance(spec);
+                dm.specSamplingWeight = sAvg / (dAvg + sAvg);
+                dm.typeFlags = EGlossyReflection | EDiffuseReflection | EFrontSide | aniso;
+                break;
+            }
+            default:
+                return "unsupported BSDF type";
+        }
+        memcpy(dm.diffuse, diff, 12); memcpy(dm.specular, spec, 12); memcpy(dm.transmittance, trans, 12);
+        hs.materials[i] = dm;
+    }
+
+    // ---- shapes ----------------------------------------------------------------------------------------
+    hs.shapes.resize(d->n_shapes);
+    hs.triShape.assign(d->n_triangles, 0xFFFFFFFFu);
+    bool anyUV = false;
+    for (uint32_t s = 0; s < d->n_shapes; ++s) {
+        const mtsamd_shape &sh = d->shapes[s];
+        if ((uint64_t) sh.first_triangle + sh.n_triangles > d->n_triangles) return "shape triangle range out of bounds";
+        if (sh.material < 0 || (uint32_t) sh.material >= d->n_materials) return "shape material out of range";
+        if (sh.emitter >= (int32_t) d->n_emitters) return "shape emitter out of range";
+        if ((sh.flags & MTSAMD_SHAPE_HAS_NORMALS) && !hs.hasNormals) return "shape claims normals but none given";
+        if ((sh.flags & MTSAMD_SHAPE_HAS_TEXCOORDS) && !hs.hasTexcoords) return "shape claims texcoords but none given";
+        DevShape ds;
+        memset(&ds, 0, sizeof(ds));
+        ds.firstTri = sh.first_triangle; ds.nTris = sh.n_triangles; ds.material = sh.material; ds.emitter = sh.emitter; ds.flags = sh.flags;
+        hs.shapes[s] = ds;
+        for (uint32_t j = 0; j < sh.n_triangles; ++j) {
+            if (hs.triShape[sh.first_triangle + j] != 0xFFFFFFFFu) return "triangle owned by two shapes";
+            hs.triShape[sh.first_triangle + j] = s;
+        }
+        if (sh.flags & MTSAMD_SHAPE_HAS_TEXCOORDS) anyUV = true;
+    }
+    for (uint32_t t = 0; t < d->n_triangles; ++t)
+        if (hs.triShape[t] == 0xFFFFFFFFu) return "triangle not owned by any shape";
+
+    // per-triangle UV tangents (TriMesh::computeUVTangents, src/librender/trimesh.cpp:683-735)
+    if (anyUV) {
+        hs.uvDpdu.assign((size_t) d->n_triangles * 3, 0.0f);
+        for (uint32_t s = 0; s < d->n_shapes; ++s) {
+            const DevShape &sh = hs.shapes[s];
+            if (!(sh.flags & MTSAMD_SHAPE_HAS_TEXCOORDS)) continue;
+            for (uint32_t j = 0; j < sh.nTris; ++j) {
+                const uint32_t t = sh.firstTri + j;
+                const uint32_t i0 = hs.indices[3 * (size_t) t], i1 = hs.indices[3 * (size_t) t + 1], i2 = hs.indices[3 * (size_t) t + 2];
+                const float *v0 = &hs.positions[3 * (size_t) i0], *v1 = &hs.positions[3 * (size_t) i1], *v2 = &hs.positions[3 * (size_t) i2];
+                const float *uv0 = &hs.texcoords[2 * (size_t) i0], *uv1 = &hs.texcoords[2 * (size_t) i1], *uv2 = &hs.texcoords[2 * (size_t) i2];
+                float dP1[3] = { v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2] }, dP2[3] = { v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2] };
+                float dUV1[2] = { uv1[0] - uv0[0], uv1[1] - uv0[1] }, dUV2[2] = { uv2[0] - uv0[0], uv2[1] - uv0[1] };
+                float n[3] = { dP1[1] * dP2[2] - dP1[2] * dP2[1], dP1[2] * dP2[0] - dP1[0] * dP2[2], dP1[0] * dP2[1] - dP1[1] * dP2[0] };
+                float length = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                if (length == 0) continue;
+                float determinant = dUV1[0] * dUV2[1] - dUV1[1] * dUV2[0];
+                float *out = &hs.uvDpdu[3 * (size_t) t];
+                if (determinant == 0) {
+                    // coordinateSystem(n/length, dpdu, dpdv) (src/libcore/util.cpp:592-601): dpdu = cross(c, a)
+                    float r = 1.0f / length;
+                    float a[3] = { n[0] * r, n[1] * r, n[2] * r }, c[3];
+                    if (std::fabs(a[0]) > std::fabs(a[1])) {
+                        float invLen = 1.0f / std::sqrt(a[0] * a[0] + a[2] * a[2]);
+                        c[0] = a[2] * invLen; c[1] = 0.0f; c[2] = -a[0] * invLen;
+                    } else {
+                        float invLen = 1.0f / std::sqrt(a[1] * a[1] + a[2] * a[2]);
+                        c[0] = 0.0f; c[1] = a[2] * invLen; c[2] = -a[1] * invLen;
+                    }
+                    out[0] = c[1] * a[2] - c[2] * a[1]; out[1] = c[2] * a[0] - c[0] * a[2]; out[2] = c[0] * a[1] - c[1] * a[0];
+                } else {
+                    float invDet = 1.0f / determinant;
+                    for (int k = 0; k < 3; ++k) out[k] = (dUV2[1] * dP1[k] - dUV1[1] * dP2[k]) * invDet;
+                }
+            }
+        }
+    }
+
+    // ---- emitters: per-mesh area CDF (TriMesh::prepareSamplingTable, trimesh.cpp:388-403) and the scene's
+    //      emitter CDF (scene.cpp:375-380) ------------------------------------------------------------------
+    hs.emitters.resize(d->n_emitters);
+    hs.emitterCdf.assign(1, 0.0f);
+    for (uint32_t e = 0; e < d->n_emitters; ++e) {
+        const mtsamd_emitter &em = d->emitters[e];
+        if (em.shape < 0 || (uint32_t) em.shape >= d->n_shapes) return "emitter shape out of range";
+        if (hs.shapes[em.shape].emitter != (int32_t) e) return "shape/emitter cross reference mismatch";
+        const DevShape &sh = hs.shapes[em.shape];
+        if (sh.nTris == 0) return "Encountered an empty triangle mesh!";
+        DevEmitter de;
+        memset(&de, 0, sizeof(de));
+        memcpy(de.radiance, em.radiance, 12);
+        de.shape = em.shape; de.firstTri = sh.firstTri; de.nTris = sh.nTris;
+        de.cdfOffset = (uint32_t) hs.areaCdf.size();
+        size_t base = hs.areaCdf.size();
+        hs.areaCdf.push_back(0.0f);
+        for (uint32_t j = 0; j < sh.nTris; ++j) {
+            const uint32_t t = sh.firstTri + j;
+            const float *p0 = &hs.positions[3 * (size_t) hs.indices[3 * (size_t) t]], *p1 = &hs.positions[3 * (size_t) hs.indices[3 * (size_t) t + 1]],
+                        *p2 = &hs.positions[3 * (size_t) hs.indices[3 * (size_t) t + 2]];
+            float a[3] = { p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2] }, b[3] = { p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2] };
+            float c[3] = { a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0] };
+            float area = 0.5f * std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);     // Triangle::surfaceArea (triangle.cpp:61-67)
+            hs.areaCdf.push_back(hs.areaCdf.back() + area);
+        }
+        float total = normalizeCdf(&hs.areaCdf[base], sh.nTris, nullptr);
+        de.invArea = 1.0f / total;
+        hs.emitters[e] = de;
+        hs.emitterCdf.push_back(hs.emitterCdf.back() + em.sampling_weight);
+    }
+    if (d->n_emitters) {
+        float norm;
+        normalizeCdf(hs.emitterCdf.data(), d->n_emitters, &norm);
+        for (uint32_t e = 0; e < d->n_emitters; ++e) hs.emitters[e].pdfDiscrete = d->emitters[e].sampling_weight * norm;   // scene.h:848-850
+    }
+
+    // ---- acceleration structure ---------------------------------------------------------------------------
+    const char *err = buildBVH(hs.positions.data(), d->n_vertices, hs.indices.data(), d->n_triangles, hs.bvh);
+    if (err && *err) return err;
+
+    // ---- scalar parameters -------------------------------------------------------------------------------------
+    DevScene &p = hs.params;
+    memset(&p, 0, sizeof(p));
+    p.nEmitters = d->n_emitters; p.nTris = d->n_triangles; p.nShapes = d->n_shapes; p.nMaterials = d->n_materials;
+    // enlarged scene bounds (gkdtree.h:1213-1220, MTS_KD_AABB_EPSILON = 1e-3f; note max grows by the already grown extent)
+    {
+        float lo[3], hi[3];
+        const float eps = 1e-3f;
+        for (int i = 0; i < 3; ++i) { lo[i] = hs.bvh.aabbMin[i]; hi[i] = hs.bvh.aabbMax[i]; }
+        if (d->n_triangles) {
+            for (int i = 0; i < 3; ++i) lo[i] = lo[i] - ((hi[i] - lo[i]) * eps + eps);
+            for (int i = 0; i < 3; ++i) hi[i] = hi[i] + ((hi[i] - lo[i]) * eps + eps);
+        }
+        for (int i = 0; i < 3; ++i) { p.aabbMin[i] = lo[i]; p.aabbMax[i] = hi[i]; }
+    }
+    // camera (perspective.cpp:126-157, transform.cpp:99-123)
+    {
+        const float aspect = (float) f.width / (float) f.height;
+        p.invResX = 1.0f / (float) f.crop_w; p.invResY = 1.0f / (float) f.crop_h;
+        const float relSizeX = (float) f.crop_w / (float) f.width, relSizeY = (float) f.crop_h / (float) f.height;
+        const float relOffX = (float) f.crop_x / (float) f.width, relOffY = (float) f.crop_y / (float) f.height;
+        float persp[16];
+        const float nearC = d->camera.near_clip, farC = d->camera.far_clip;
+        const float recip = 1.0f / (farC - nearC);
+        const float cot = 1.0f / std::tan((d->camera.x_fov / 2.0f) * (3.14159265358979323846f / 180.0f));
+        memset(persp, 0, 64);
+        persp[0] = cot; persp[5] = cot; persp[10] = farC * recip; persp[11] = -nearC * farC * recip; persp[14] = 1;
+        float m[16], tmp[16];
+        scale4(1.0f / relSizeX, 1.0f / relSizeY, 1.0f, m);
+        translate4(-relOffX, -relOffY, 0.0f, tmp); mul4(m, tmp, m);
+        scale4(-0.5f, -0.5f * aspect, 1.0f, tmp); mul4(m, tmp, m);
+        translate4(-1.0f, -1.0f / aspect, 0.0f, tmp); mul4(m, tmp, m);
+        mul4(m, persp, m);
+        if (!invert4(m, p.sampleToCamera)) return "singular camera projection";
+        memcpy(p.camToWorld, d->camera.to_world, 48);
+        p.nearClip = nearC; p.farClip = farC;
+    }
+    p.cropW = f.crop_w; p.cropH = f.crop_h;
+    p.filterRadius = f.filter_radius;
+    memcpy(p.filterValues, f.filter_values, sizeof(p.filterValues));
+    p.maxDepth = d->integrator.max_depth; p.rrDepth = d->integrator.rr_depth;
+    p.strictNormals = d->integrator.strict_normals; p.hideEmitters = d->integrator.hide_emitters;
+    return "";
+}
+
+}  // namespace mtsamd

@@ -1,0 +1,28 @@
+// CPU-side preparation of a scene description for upload: validation, material configuration
+// (what the BSDF plugins' configure() methods derive), sampling tables, camera matrices and the BVH.
+#pragma once
+#include "../../include/mtsamd.h"
+#include "bvh.h"
+#include "device_types.h"
+#include <string>
+#include <vector>
+
+namespace mtsamd {
+
+struct HostScene {
+    std::vector<float> positions, normals, texcoords, uvDpdu;
+    std::vector<uint32_t> indices, triShape;
+    std::vector<DevShape> shapes;
+    std::vector<DevMaterial> materials;
+    std::vector<DevEmitter> emitters;
+    std::vector<float> emitterCdf, areaCdf, rtrans;
+    BVH bvh;
+    DevScene params;        // scalar members filled; pointers left null until upload
+    mtsamd_scene_desc desc; // copy of the scalar parts of the description
+    bool hasNormals = false, hasTexcoords = false;
+};
+
+// Returns an empty string on success.
+std::string prepareScene(const mtsamd_scene_desc *desc, HostScene &out);
+
+}  // namespace mtsamd

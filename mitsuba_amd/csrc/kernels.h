@@ -1,0 +1,414 @@
+// GPU kernels of the wavefront path tracer (gfx950): raygen -> extend -> shade -> shadow-connect -> film.
+#pragma once
+#include "device_trace.h"
+#include "device_shade.h"
+
+namespace mtsamd {
+
+static constexpr uint32_t kMiss = 0xFFFFFFFFu;
+
+// Appends one element per active lane to a queue: one atomic per wavefront (ballot + popcount + lane prefix).
+MTS_DEV uint32_t waveAppend(uint32_t *counter, bool active) {
+    const unsigned long long mask = __ballot(active);
+    if (mask == 0) return 0;
+    const uint32_t lane = __lane_id();
+    const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
+    uint32_t base = 0;
+    const int leader = __ffsll((long long) mask) - 1;
+    if ((int) lane == leader) base = atomicAdd(counter, (uint32_t) __popcll(mask));
+    base = __shfl(base, leader);
+    return base + prefix;
+}
+
+MTS_DEV uint64_t sampleKey(const DevScene &sc, const PassParams &pp, uint32_t slot, int &px, int &py, int &s) {
+    const uint32_t pix = slot / (uint32_t) pp.spp;
+    s = (int) (slot - pix * (uint32_t) pp.spp);
+    py = pp.y0 + (int) (pix / (uint32_t) pp.w);
+    px = pp.x0 + (int) (pix % (uint32_t) pp.w);
+    const uint64_t pixelIndex = (uint64_t) py * (uint64_t) sc.cropW + (uint64_t) px;
+    return pixelIndex * (uint64_t) pp.sppTotal + (uint64_t) (pp.sampleBase + s);
+}
+
+// ---- K1 raygen: SamplingIntegrator::renderBlock sample loop + sensor->sampleRayDifferential
+//      (src/librender/integrator.cpp:162-186, src/sensors/perspective.cpp:271-298) ------------------------------------
+__global__ void __launch_bounds__(256) k_raygen(DevScene sc, PassParams pp, PathQueue q, float4 *sampleL, float2 *samplePos, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int px, py, s;
+    const uint64_t key = sampleKey(sc, pp, i, px, py, s);
+    Rng rng;
+    rng.init(pp.seed, key);
+    const float jx = rng.next1D(), jy = rng.next1D();
+    const float posx = (float) px + jx, posy = (float) py + jy;
+    V3 o, d; float mint, maxt;
+    cameraRay(sc, posx, posy, o, d, mint, maxt);
+    q.rayO[i] = make_float4(o.x, o.y, o.z, mint);
+    q.rayD[i] = make_float4(d.x, d.y, d.z, maxt);
+    q.thr[i] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    q.misc[i] = make_uint4(i, 0u, (uint32_t) rng.state, (uint32_t) (rng.state >> 32));
+    q.bsdfPdf[i] = 0.0f;
+    sampleL[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    samplePos[i] = make_float2(posx, posy);
+}
+
+// ---- K2 extend: closest hit for every live path (Scene::rayIntersect(ray, its)) ---------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(kTraceBlock) k_extend(DevScene sc, PathQueue q, float4 *hits, uint32_t n, unsigned long long *counters) {
+    __shared__ uint2 ldsStack[kLdsStack * kTraceBlock];
+    const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
+    uint32_t nv = 0, nt = 0;
+    if (i < n) {
+        const float4 ro = q.rayO[i], rd = q.rayD[i];
+        HitRec hit;
+        sceneIntersect<COUNT>(sc, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), ro.w, rd.w, hit, ldsStack + threadIdx.x, nv, nt);
+        hits[i] = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
+    }
+    if (COUNT) {
+        atomicAdd(&counters[CNT_NODE_VISITS / 2], (unsigned long long) nv);
+        atomicAdd(&counters[CNT_TRI_TESTS / 2], (unsigned long long) nt);
+    }
+}
+
+// ---- K4 shadow-connect: any-hit test for the emitter samples; unoccluded ones add their weighted contribution
+//      (the visibility test inside Scene::sampleEmitterDirect, src/librender/scene.cpp:839-843) ----------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(kTraceBlock) k_shadow(DevScene sc, ShadowQueue sq, float4 *sampleL, uint32_t n, unsigned long long *counters) {
+    __shared__ uint2 ldsStack[kLdsStack * kTraceBlock];
+    const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
+    uint32_t nv = 0, nt = 0;
+    if (i < n) {
+        const float4 ro = sq.rayO[i], rd = sq.rayD[i];
+        const bool occ = sceneOccluded<COUNT>(sc, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), ro.w, rd.w, ldsStack + threadIdx.x, nv, nt);
+        if (!occ) {
+            const float4 c = sq.contrib[i];
+            if (c.x != 0 || c.y != 0 || c.z != 0) {
+                const uint32_t slot = __float_as_uint(c.w);
+                float4 L = sampleL[slot];
+                L.x += c.x; L.y += c.y; L.z += c.z;
+                sampleL[slot] = L;
+            }
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&counters[CNT_NODE_VISITS / 2], (unsigned long long) nv);
+        atomicAdd(&counters[CNT_TRI_TESTS / 2], (unsigned long long) nt);
+    }
+}
+
+// ---- K3 shade: one vertex of MIPathTracer::Li per live path (src/integrators/path/path.cpp:135-287) --------------------
+// The loop body of the reference is cut at the extension-ray trace: everything after `scene->rayIntersect(ray, its)`
+// (:226) for vertex k runs at the start of the invocation that shades vertex k+1. Queue entries carry the depth of
+// the vertex that spawned the ray (0 for camera rays).
+__global__ void __launch_bounds__(256) k_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out,
+                                               ShadowQueue sq, float4 *sampleL, uint32_t *counters, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool alive = false, wantShadow = false;
+    float4 oRayO = make_float4(0, 0, 0, 0), oRayD = oRayO, oThr = oRayO, sRayO = oRayO, sRayD = oRayO, sContrib = oRayO;
+    uint4 oMisc = make_uint4(0, 0, 0, 0);
+    float oPdf = 0;
+
+    if (i < n) {
+        const float4 hit = hits[i];
+        const uint32_t tri = __float_as_uint(hit.w);
+        if (tri != kMiss) {     // a miss ends the path: no environment emitter on this path (path.cpp:136-143,245-247)
+            const float4 rd = in.rayD[i], th = in.thr[i];
+            const uint4 misc = in.misc[i];
+            const V3 rayD = mk(rd.x, rd.y, rd.z);
+            const uint32_t slot = misc.x;
+            const uint32_t prevDepth = misc.y & 0xffffu;
+            uint32_t flags = misc.y >> 16;
+            Rng rng;
+            {
+                int px, py, s;
+                const uint64_t key = sampleKey(sc, pp, slot, px, py, s);
+                rng.inc = (key << 1) | 1u;
+                rng.state = (uint64_t) misc.z | ((uint64_t) misc.w << 32);
+            }
+            V3 throughput = mk(th.x, th.y, th.z);
+            float eta = th.w;
+
+            Isect its;
+            fillIntersection(sc, tri, hit.y, hit.z, rayD, its);
+            const DevShape shape = sc.shapes[its.shape];
+            const DevMaterial &bsdf = sc.materials[shape.material];
+            float4 L = sampleL[slot];
+            bool Lchanged = false, terminate = false;
+            int depth;
+
+            if (prevDepth == 0) {
+                // camera vertex: alpha (records.inl:121-137) and directly visible emitters (path.cpp:148-150)
+                depth = 1;
+                L.w = 1.0f; Lchanged = true;
+                if (shape.emitter >= 0 && !sc.hideEmitters) {
+                    if (dot(its.sh.n, -rayD) > 0) {     // AreaLight::eval (area.cpp:104-109)
+                        const V3 c = throughput * ld3(sc.emitters[shape.emitter].radiance);
+                        L.x += c.x; L.y += c.y; L.z += c.z;
+                    }
+                }
+            } else {
+                // emitter reached by BSDF sampling: MIS against the emitter-sampling pdf (path.cpp:228-232,257-264)
+                if (shape.emitter >= 0) {
+                    const DevEmitter em = sc.emitters[shape.emitter];
+                    const V3 value = dot(its.sh.n, -rayD) > 0 ? ld3(em.radiance) : mk(0.0f);
+                    float lumPdf = 0;
+                    if (!(flags & PF_PREV_DELTA)) {
+                        // pdfEmitterDirect (scene.cpp:949-952) -> AreaLight::pdfDirect (area.cpp:175-183) -> Shape::pdfDirect (shape.cpp:117-121)
+                        if ((flags & PF_REFN_OK) && dot(rayD, its.sh.n) < 0)
+                            lumPdf = em.invArea * (hit.x * hit.x) / fabsf(dot(rayD, its.sh.n));
+                        lumPdf *= em.pdfDiscrete;
+                    }
+                    const V3 c = throughput * value * miWeight(in.bsdfPdf[i], lumPdf);
+                    L.x += c.x; L.y += c.y; L.z += c.z; Lchanged = true;
+                }
+                // Russian roulette (path.cpp:276-286) ...
+                if ((int) prevDepth >= sc.rrDepth) {
+                    const float q = fminf(maxComp(throughput) * eta * eta, 0.95f);
+                    if (rng.next1D() >= q) terminate = true;
+                    throughput = throughput / q;
+                }
+                depth = (int) prevDepth + 1;
+                // ... and the loop condition (path.cpp:135)
+                if (!(depth <= sc.maxDepth || sc.maxDepth < 0)) terminate = true;
+            }
+
+            // path.cpp:156-165
+            if (!terminate && ((depth >= sc.maxDepth && sc.maxDepth > 0) ||
+                               (sc.strictNormals && dot(rayD, its.geoN) * its.wi.z >= 0)))
+                terminate = true;
+
+            if (!terminate) {
+                // DirectSamplingRecord(its) (records.inl:160-164)
+                V3 refN = mk(0.0f);
+                if ((bsdf.typeFlags & (ETransmission | EBackSide)) == 0) refN = its.sh.n;
+
+                // direct illumination sampling (path.cpp:172-200)
+                if (bsdf.typeFlags & ESmooth) {
+                    const float sx = rng.next1D(), sy = rng.next1D();
+                    DirectRec dRec;
+                    const V3 value = sampleEmitterDirect(sc, its.p, refN, sx, sy, dRec);
+                    if (dRec.pdf != 0) {
+                        V3 c = mk(0.0f);
+                        const V3 wo = toLocal(its.sh, dRec.d);
+                        const V3 bsdfVal = bsdfEval(sc, bsdf, its.wi, wo);
+                        if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
+                            const float bPdf = bsdfPdf(sc, bsdf, its.wi, wo);    // area emitters: on surface, solid-angle measure
+                            c = throughput * value * bsdfVal * miWeight(dRec.pdf, bPdf);
+                        }
+                        wantShadow = true;
+                        sRayO = make_float4(its.p.x, its.p.y, its.p.z, kEpsilon);
+                        sRayD = make_float4(dRec.d.x, dRec.d.y, dRec.d.z, dRec.dist * (1 - kShadowEpsilon));   // scene.cpp:840-841
+                        sContrib = make_float4(c.x, c.y, c.z, __uint_as_float(slot));
+                    }
+                }
+
+                // BSDF sampling (path.cpp:206-226)
+                const float bx = rng.next1D(), by = rng.next1D();
+                V3 woLocal; float bPdf, bEta; uint32_t sampledType;
+                const V3 bsdfWeight = bsdfSample(sc, bsdf, its.wi, bx, by, woLocal, bPdf, bEta, sampledType);
+                if (!isZero(bsdfWeight)) {
+                    if (sampledType != ENull) flags |= PF_SCATTERED;
+                    const V3 wo = toWorld(its.sh, woLocal);
+                    const float woDotGeoN = dot(its.geoN, wo);
+                    if (!(sc.strictNormals && woDotGeoN * woLocal.z <= 0)) {
+                        alive = true;
+                        throughput = throughput * bsdfWeight;   // path.cpp:252-253
+                        eta *= bEta;
+                        uint32_t nf = flags & PF_SCATTERED;
+                        if (sampledType & EDelta) nf |= PF_PREV_DELTA;
+                        if (dot(wo, refN) >= 0) nf |= PF_REFN_OK;
+                        oRayO = make_float4(its.p.x, its.p.y, its.p.z, kEpsilon);     // Ray(its.p, wo, time): mint = Epsilon, maxt = inf
+                        oRayD = make_float4(wo.x, wo.y, wo.z, kInf);
+                        oThr = make_float4(throughput.x, throughput.y, throughput.z, eta);
+                        oMisc = make_uint4(slot, (uint32_t) depth | (nf << 16), (uint32_t) rng.state, (uint32_t) (rng.state >> 32));
+                        oPdf = bPdf;
+                    }
+                }
+            }
+            if (Lchanged) sampleL[slot] = L;
+        }
+    }
+
+    const uint32_t si = waveAppend(&counters[CNT_SHADOW], wantShadow);
+    if (wantShadow) { sq.rayO[si] = sRayO; sq.rayD[si] = sRayD; sq.contrib[si] = sContrib; }
+    const uint32_t oi = waveAppend(&counters[CNT_NEXT], alive);
+    if (alive) { out.rayO[oi] = oRayO; out.rayD[oi] = oRayD; out.thr[oi] = oThr; out.misc[oi] = oMisc; out.bsdfPdf[oi] = oPdf; }
+}
+
+// ---- K6 film: ImageBlock::put in gather form (include/mitsuba/render/imageblock.h:144-189). One thread per film
+// pixel of the pass rectangle grown by the filter border; it visits the samples of the pixels whose footprint can
+// reach it, in a fixed order, so the accumulation is deterministic and needs no atomics. A sample with a
+// non-finite or negative channel is dropped as a whole (imageblock.h:147-151).
+__global__ void __launch_bounds__(256) k_film(DevScene sc, PassParams pp, const float4 *sampleL, const float2 *samplePos, float *film) {
+    const int border = (int) ceilf(sc.filterRadius - 0.5f);     // rfilter.cpp:50
+    const int gx0 = max(pp.x0 - border, 0), gy0 = max(pp.y0 - border, 0);
+    const int gx1 = min(pp.x0 + pp.w + border, sc.cropW), gy1 = min(pp.y0 + pp.h + border, sc.cropH);
+    const int gw = gx1 - gx0, gh = gy1 - gy0;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= gw * gh) return;
+    const int x = gx0 + idx % gw, y = gy0 + idx / gw;
+    const float scaleFactor = 31.0f / sc.filterRadius;          // rfilter.cpp:49 (MTS_FILTER_RESOLUTION = 31)
+    float acc[5] = { 0, 0, 0, 0, 0 };
+    const int qx0 = max(x - border, pp.x0), qx1 = min(x + border, pp.x0 + pp.w - 1);
+    const int qy0 = max(y - border, pp.y0), qy1 = min(y + border, pp.y0 + pp.h - 1);
+    for (int qy = qy0; qy <= qy1; ++qy)
+        for (int qx = qx0; qx <= qx1; ++qx) {
+            const uint32_t base = ((uint32_t) (qy - pp.y0) * (uint32_t) pp.w + (uint32_t) (qx - pp.x0)) * (uint32_t) pp.spp;
+            for (int s = 0; s < pp.spp; ++s) {
+                const float4 L = sampleL[base + s];
+                const float2 pos = samplePos[base + s];
+                if (!(isfinite(L.x) && isfinite(L.y) && isfinite(L.z) && isfinite(L.w)) || L.x < 0 || L.y < 0 || L.z < 0 || L.w < 0) continue;
+                const float px = pos.x - 0.5f, py = pos.y - 0.5f;
+                // pixels outside [ceil(p - r), floor(p + r)] are not touched by the reference
+                if ((float) x < ceilf(px - sc.filterRadius) || (float) x > floorf(px + sc.filterRadius) ||
+                    (float) y < ceilf(py - sc.filterRadius) || (float) y > floorf(py + sc.filterRadius)) continue;
+                const float wx = sc.filterValues[min((int) fabsf(((float) x - px) * scaleFactor), 31)];
+                const float wy = sc.filterValues[min((int) fabsf(((float) y - py) * scaleFactor), 31)];
+                const float w = wx * wy;
+                acc[0] += w * L.x; acc[1] += w * L.y; acc[2] += w * L.z; acc[3] += w * L.w; acc[4] += w * 1.0f;
+            }
+        }
+    float *dst = film + ((size_t) y * sc.cropW + x) * 5;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) dst[c] += acc[c];
+}
+
+// ---- batch kernels behind the parity entry points -------------------------------------------------------------------------
+__global__ void __launch_bounds__(kTraceBlock) k_trace_batch(DevScene sc, const float *rays, uint32_t n, float4 *hits) {
+    __shared__ uint2 ldsStack[kLdsStack * kTraceBlock];
+    const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
+    if (i >= n) return;
+    const float *r = rays + 8 * (size_t) i;
+    HitRec hit; uint32_t a = 0, b = 0;
+    sceneIntersect<false>(sc, mk(r[0], r[1], r[2]), mk(r[4], r[5], r[6]), r[3], r[7], hit, ldsStack + threadIdx.x, a, b);
+    hits[i] = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
+}
+
+__global__ void __launch_bounds__(kTraceBlock) k_occluded_batch(DevScene sc, const float *rays, uint32_t n, uint8_t *out) {
+    __shared__ uint2 ldsStack[kLdsStack * kTraceBlock];
+    const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
+    if (i >= n) return;
+    const float *r = rays + 8 * (size_t) i;
+    uint32_t a = 0, b = 0;
+    out[i] = sceneOccluded<false>(sc, mk(r[0], r[1], r[2]), mk(r[4], r[5], r[6]), r[3], r[7], ldsStack + threadIdx.x, a, b) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_fill_isect(DevScene sc, const float *rays, const float4 *hits, uint32_t n, mtsamd_intersection *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 h = hits[i];
+    const uint32_t tri = __float_as_uint(h.w);
+    mtsamd_intersection r;
+    memset(&r, 0, sizeof(r));
+    if (tri == kMiss) {
+        r.t = kInf; r.shape = r.prim = kMiss;
+    } else {
+        const float *ry = rays + 8 * (size_t) i;
+        Isect its;
+        fillIntersection(sc, tri, h.y, h.z, mk(ry[4], ry[5], ry[6]), its);
+        r.t = h.x; r.u = h.y; r.v = h.z; r.shape = its.shape; r.prim = its.prim;
+        r.p[0] = its.p.x; r.p[1] = its.p.y; r.p[2] = its.p.z;
+        r.geo_n[0] = its.geoN.x; r.geo_n[1] = its.geoN.y; r.geo_n[2] = its.geoN.z;
+        r.sh_n[0] = its.sh.n.x; r.sh_n[1] = its.sh.n.y; r.sh_n[2] = its.sh.n.z;
+        r.sh_s[0] = its.sh.s.x; r.sh_s[1] = its.sh.s.y; r.sh_s[2] = its.sh.s.z;
+        r.sh_t[0] = its.sh.t.x; r.sh_t[1] = its.sh.t.y; r.sh_t[2] = its.sh.t.z;
+        r.wi[0] = its.wi.x; r.wi[1] = its.wi.y; r.wi[2] = its.wi.z;
+        r.uv[0] = its.uvx; r.uv[1] = its.uvy;
+    }
+    out[i] = r;
+}
+
+__global__ void k_hits_to_records(DevScene sc, const float4 *hits, uint32_t n, mtsamd_hit *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 h = hits[i];
+    const uint32_t tri = __float_as_uint(h.w);
+    mtsamd_hit r;
+    r.t = h.x; r.u = h.y; r.v = h.z;
+    if (tri == kMiss) { r.shape = r.prim = kMiss; }
+    else { r.shape = sc.triShape[tri]; r.prim = tri - sc.shapes[r.shape].firstTri; }
+    out[i] = r;
+}
+
+// mode 0: eval -> out[3n]; 1: pdf -> out[n]
+__global__ void k_bsdf_evalpdf(DevScene sc, int material, int mode, uint32_t n, const float *wi, const float *wo, float *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DevMaterial &m = sc.materials[material];
+    const V3 a = ld3(wi, i), b = ld3(wo, i);
+    if (mode == 0) { const V3 r = bsdfEval(sc, m, a, b); out[3 * (size_t) i] = r.x; out[3 * (size_t) i + 1] = r.y; out[3 * (size_t) i + 2] = r.z; }
+    else out[i] = bsdfPdf(sc, m, a, b);
+}
+
+__global__ void k_bsdf_sample(DevScene sc, int material, uint32_t n, const float *wi, const float *sample, float *wo, float *weight,
+                              float *pdf, float *eta, uint32_t *sampledType) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DevMaterial &m = sc.materials[material];
+    V3 o; float p, e; uint32_t t;
+    const V3 w = bsdfSample(sc, m, ld3(wi, i), sample[2 * (size_t) i], sample[2 * (size_t) i + 1], o, p, e, t);
+    wo[3 * (size_t) i] = o.x; wo[3 * (size_t) i + 1] = o.y; wo[3 * (size_t) i + 2] = o.z;
+    weight[3 * (size_t) i] = w.x; weight[3 * (size_t) i + 1] = w.y; weight[3 * (size_t) i + 2] = w.z;
+    pdf[i] = p; eta[i] = e; sampledType[i] = t;
+}
+
+__global__ void k_emitter_sample(DevScene sc, uint32_t n, const float *ref, const float *refN, const float *sample, float *d, float *dist,
+                                 float *pdf, float *value) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    DirectRec dRec;
+    const V3 v = sampleEmitterDirect(sc, ld3(ref, i), ld3(refN, i), sample[2 * (size_t) i], sample[2 * (size_t) i + 1], dRec);
+    d[3 * (size_t) i] = dRec.d.x; d[3 * (size_t) i + 1] = dRec.d.y; d[3 * (size_t) i + 2] = dRec.d.z;
+    value[3 * (size_t) i] = v.x; value[3 * (size_t) i + 1] = v.y; value[3 * (size_t) i + 2] = v.z;
+    dist[i] = dRec.dist; pdf[i] = dRec.pdf;
+}
+
+__global__ void k_camera_rays(DevScene sc, uint32_t n, const float *pos, float *rays) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 o, d; float mint, maxt;
+    cameraRay(sc, pos[2 * (size_t) i], pos[2 * (size_t) i + 1], o, d, mint, maxt);
+    float *r = rays + 8 * (size_t) i;
+    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = mint; r[4] = d.x; r[5] = d.y; r[6] = d.z; r[7] = maxt;
+}
+
+__global__ void k_rng_stream(uint32_t seed, uint64_t key, uint32_t n, float *out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Rng rng;
+    rng.init(seed, key);
+    for (uint32_t i = 0; i < n; ++i) out[i] = rng.next1D();
+}
+
+// ImageBlock::put for explicit samples, gather form: each film pixel scans all samples in order.
+__global__ void k_film_put(DevScene sc, uint32_t n, const float *pos, const float *value, float *film) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= sc.cropW * sc.cropH) return;
+    const int x = idx % sc.cropW, y = idx / sc.cropW;
+    const float scaleFactor = 31.0f / sc.filterRadius;
+    float acc[5] = { 0, 0, 0, 0, 0 };
+    for (uint32_t s = 0; s < n; ++s) {
+        const float *L = value + 4 * (size_t) s;
+        if (!(isfinite(L[0]) && isfinite(L[1]) && isfinite(L[2]) && isfinite(L[3])) || L[0] < 0 || L[1] < 0 || L[2] < 0 || L[3] < 0) continue;
+        const float px = pos[2 * (size_t) s] - 0.5f, py = pos[2 * (size_t) s + 1] - 0.5f;
+        if ((float) x < ceilf(px - sc.filterRadius) || (float) x > floorf(px + sc.filterRadius) ||
+            (float) y < ceilf(py - sc.filterRadius) || (float) y > floorf(py + sc.filterRadius)) continue;
+        const float wx = sc.filterValues[min((int) fabsf(((float) x - px) * scaleFactor), 31)];
+        const float wy = sc.filterValues[min((int) fabsf(((float) y - py) * scaleFactor), 31)];
+        const float w = wx * wy;
+        acc[0] += w * L[0]; acc[1] += w * L[1]; acc[2] += w * L[2]; acc[3] += w * L[3]; acc[4] += w * 1.0f;
+    }
+    float *dst = film + (size_t) idx * 5;
+    for (int c = 0; c < 5; ++c) dst[c] += acc[c];
+}
+
+// copies per-sample radiance and positions out in pixel-major order for mtsamd_li
+__global__ void k_copy_samples(const float4 *sampleL, const float2 *samplePos, uint32_t n, float *out, float *pos, size_t outOffset) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 L = sampleL[i];
+    const float2 p = samplePos[i];
+    float *o = out + 4 * (outOffset + i);
+    o[0] = L.x; o[1] = L.y; o[2] = L.z; o[3] = L.w;
+    pos[2 * (outOffset + i)] = p.x; pos[2 * (outOffset + i) + 1] = p.y;
+}
+
+}  // namespace mtsamd

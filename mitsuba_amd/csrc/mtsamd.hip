@@ -1,0 +1,564 @@
+// Host driver and C ABI of the MI355X path-tracing core: scene upload, the wavefront render loop
+// (raygen -> [extend -> shade -> shadow-connect]* -> film) and the batch entry points of the parity harness.
+#include "../../include/mtsamd.h"
+#include "host_scene.h"
+#include "kernels.h"
+
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace mtsamd;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return fail(MTSAMD_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    ~DeviceBuffer() { if (ptr) (void) hipFree(ptr); }
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (ptr) { (void) hipFree(ptr); ptr = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&ptr, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <typename T> T *as() const { return (T *) ptr; }
+};
+
+template <typename T> hipError_t upload(DeviceBuffer &buf, const std::vector<T> &v) {
+    size_t n = std::max<size_t>(v.size() * sizeof(T), 16);
+    hipError_t e = buf.ensure(n);
+    if (e != hipSuccess) return e;
+    if (!v.empty()) e = hipMemcpy(buf.ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+}
+
+inline unsigned blocksFor(size_t n, unsigned bs) { return (unsigned) ((n + bs - 1) / bs); }
+
+}  // namespace
+
+struct mtsamd_scene {
+    HostScene host;
+    DevScene dev;
+    int device = 0;
+    DeviceBuffer nodes, tris, positions, normals, texcoords, indices, triShape, uvDpdu, shapes, materials, emitters,
+        emitterCdf, areaCdf, rtrans;
+    // work buffers of the wavefront loop
+    DeviceBuffer qbuf[2][5], hits, sbuf[3], sampleL, samplePos, counters, scratch[8];
+    size_t capacity = 0;
+    hipStream_t stream = nullptr;
+    uint32_t *hostCounters = nullptr;     // pinned
+    std::atomic<int> cancel{ 0 };
+    bool countTraversal = false;
+
+    ~mtsamd_scene() {
+        if (stream) (void) hipStreamDestroy(stream);
+        if (hostCounters) (void) hipHostFree(hostCounters);
+    }
+
+    PathQueue queue(int i) const {
+        PathQueue q;
+        q.rayO = qbuf[i][0].as<float4>(); q.rayD = qbuf[i][1].as<float4>(); q.thr = qbuf[i][2].as<float4>();
+        q.misc = qbuf[i][3].as<uint4>(); q.bsdfPdf = qbuf[i][4].as<float>();
+        return q;
+    }
+    ShadowQueue shadowQueue() const {
+        ShadowQueue s;
+        s.rayO = sbuf[0].as<float4>(); s.rayD = sbuf[1].as<float4>(); s.contrib = sbuf[2].as<float4>();
+        return s;
+    }
+    int ensureWork(size_t n) {
+        if (n <= capacity) return MTSAMD_OK;
+        for (int i = 0; i < 2; ++i) {
+            for (int j = 0; j < 4; ++j) HIP_TRY(qbuf[i][j].ensure(n * 16));
+            HIP_TRY(qbuf[i][4].ensure(n * 4));
+        }
+        HIP_TRY(hits.ensure(n * 16));
+        for (int j = 0; j < 3; ++j) HIP_TRY(sbuf[j].ensure(n * 16));
+        HIP_TRY(sampleL.ensure(n * 16));
+        HIP_TRY(samplePos.ensure(n * 8));
+        capacity = n;
+        return MTSAMD_OK;
+    }
+};
+
+extern "C" const char *mtsamd_last_error(void) { return g_error.c_str(); }
+
+extern "C" int mtsamd_init(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) return fail(MTSAMD_EDEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(MTSAMD_EINVAL, "device %d out of range (%d devices)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    return MTSAMD_OK;
+}
+
+extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene **out) {
+    if (!out) return fail(MTSAMD_EINVAL, "null output handle");
+    *out = nullptr;
+    mtsamd_scene *s = new (std::nothrow) mtsamd_scene();
+    if (!s) return fail(MTSAMD_EDEVICE, "out of host memory");
+    std::string err;
+    try {
+        err = prepareScene(desc, s->host);
+    } catch (const std::exception &ex) {
+        err = std::string("scene preparation failed: ") + ex.what();
+    }
+    if (!err.empty()) { delete s; return fail(MTSAMD_EINVAL, "%s", err.c_str()); }
+
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { delete s; return fail(MTSAMD_EDEVICE, "no HIP device available"); }
+    (void) hipGetDevice(&s->device);
+
+    HostScene &h = s->host;
+    auto up = [&]() -> int {
+        {   // nodes and triangle records as raw float4 streams
+            HIP_TRY(s->nodes.ensure(std::max<size_t>(h.bvh.nodes.size() * sizeof(WideNode), 80)));
+            if (!h.bvh.nodes.empty()) HIP_TRY(hipMemcpy(s->nodes.ptr, h.bvh.nodes.data(), h.bvh.nodes.size() * sizeof(WideNode), hipMemcpyHostToDevice));
+            HIP_TRY(s->tris.ensure(std::max<size_t>(h.bvh.tris.size() * sizeof(TriRecord), 48)));
+            if (!h.bvh.tris.empty()) HIP_TRY(hipMemcpy(s->tris.ptr, h.bvh.tris.data(), h.bvh.tris.size() * sizeof(TriRecord), hipMemcpyHostToDevice));
+        }
+        HIP_TRY(upload(s->positions, h.positions));
+        HIP_TRY(upload(s->indices, h.indices));
+        HIP_TRY(upload(s->triShape, h.triShape));
+        HIP_TRY(upload(s->shapes, h.shapes));
+        HIP_TRY(upload(s->materials, h.materials));
+        HIP_TRY(upload(s->emitters, h.emitters));
+        HIP_TRY(upload(s->emitterCdf, h.emitterCdf));
+        HIP_TRY(upload(s->areaCdf, h.areaCdf));
+        HIP_TRY(upload(s->rtrans, h.rtrans));
+        if (h.hasNormals) HIP_TRY(upload(s->normals, h.normals));
+        if (h.hasTexcoords) HIP_TRY(upload(s->texcoords, h.texcoords));
+        if (!h.uvDpdu.empty()) HIP_TRY(upload(s->uvDpdu, h.uvDpdu));
+        HIP_TRY(s->counters.ensure(CNT_WORDS * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(s->counters.ptr, 0, CNT_WORDS * sizeof(uint32_t)));
+        HIP_TRY(hipStreamCreate(&s->stream));
+        HIP_TRY(hipHostMalloc((void **) &s->hostCounters, CNT_WORDS * sizeof(uint32_t)));
+        return MTSAMD_OK;
+    };
+    int rc = up();
+    if (rc != MTSAMD_OK) { delete s; return rc; }
+
+    DevScene d = h.params;
+    d.nodes = s->nodes.as<float4>(); d.tris = s->tris.as<float4>();
+    d.positions = s->positions.as<float>();
+    d.normals = h.hasNormals ? s->normals.as<float>() : nullptr;
+    d.texcoords = h.hasTexcoords ? s->texcoords.as<float>() : nullptr;
+    d.indices = s->indices.as<uint32_t>(); d.triShape = s->triShape.as<uint32_t>();
+    d.uvDpdu = h.uvDpdu.empty() ? nullptr : s->uvDpdu.as<float>();
+    d.shapes = s->shapes.as<DevShape>(); d.materials = s->materials.as<DevMaterial>(); d.emitters = s->emitters.as<DevEmitter>();
+    d.emitterCdf = s->emitterCdf.as<float>(); d.areaCdf = s->areaCdf.as<float>(); d.rtrans = s->rtrans.as<float>();
+    s->dev = d;
+    const char *ct = getenv("MTSAMD_COUNT_TRAVERSAL");
+    s->countTraversal = ct && *ct == '1';
+    *out = s;
+    return MTSAMD_OK;
+}
+
+extern "C" void mtsamd_scene_destroy(mtsamd_scene *scene) { delete scene; }
+
+extern "C" int mtsamd_scene_bvh_info(const mtsamd_scene *scene, mtsamd_bvh_info *info) {
+    if (!scene || !info) return fail(MTSAMD_EINVAL, "null argument");
+    const BVH &b = scene->host.bvh;
+    info->n_nodes = (uint32_t) b.nodes.size(); info->n_triangles = (uint32_t) b.tris.size(); info->depth = b.depth;
+    info->node_bytes = b.nodes.size() * sizeof(WideNode); info->triangle_bytes = b.tris.size() * sizeof(TriRecord);
+    info->build_seconds = b.buildSeconds; info->sah_cost = b.sahCost;
+    return MTSAMD_OK;
+}
+
+extern "C" void mtsamd_cancel(mtsamd_scene *scene) { if (scene) scene->cancel.store(1); }
+
+namespace {
+
+struct EventTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool[5];
+    bool enabled = false;
+    hipStream_t stream = nullptr;
+    void begin(int cls) {
+        if (!enabled) return;
+        hipEvent_t a, b;
+        (void) hipEventCreate(&a); (void) hipEventCreate(&b);
+        (void) hipEventRecord(a, stream);
+        pool[cls].push_back({ a, b });
+    }
+    void end(int cls) {
+        if (!enabled) return;
+        (void) hipEventRecord(pool[cls].back().second, stream);
+    }
+    double total(int cls) {
+        double ms = 0;
+        for (auto &p : pool[cls]) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) ms += t;
+            (void) hipEventDestroy(p.first); (void) hipEventDestroy(p.second);
+        }
+        pool[cls].clear();
+        return ms;
+    }
+};
+enum { T_RAYGEN = 0, T_EXTEND = 1, T_SHADE = 2, T_SHADOW = 3, T_FILM = 4 };
+
+int checkOpts(const mtsamd_scene *s, const mtsamd_render_opts *o, mtsamd_render_opts &r) {
+    if (!s || !o) return fail(MTSAMD_EINVAL, "null argument");
+    r = *o;
+    const int W = s->dev.cropW, H = s->dev.cropH;
+    if (r.x0 == 0 && r.y0 == 0 && r.x1 == 0 && r.y1 == 0) { r.x1 = W; r.y1 = H; }
+    if (r.x0 < 0 || r.y0 < 0 || r.x1 > W || r.y1 > H || r.x0 >= r.x1 || r.y0 >= r.y1) return fail(MTSAMD_EINVAL, "invalid pixel rectangle");
+    if (r.spp <= 0) return fail(MTSAMD_EINVAL, "spp must be positive");
+    if (r.spp_total <= 0) r.spp_total = r.sample_offset + r.spp;
+    if (r.sample_offset < 0 || r.sample_offset + r.spp > r.spp_total) return fail(MTSAMD_EINVAL, "sample_offset + spp exceeds spp_total");
+    return MTSAMD_OK;
+}
+
+// One pass: `pp.spp` samples for every pixel of the rectangle. When liOut is non-null the per-sample radiance is
+// copied out instead of being filtered into a film.
+int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liOut, float *liPos, size_t liOffset,
+               mtsamd_stats *stats, EventTimer &timer) {
+    const DevScene &sc = s->dev;
+    const size_t nPaths = (size_t) pp.w * pp.h * pp.spp;
+    if (nPaths >= (1ull << 31)) return fail(MTSAMD_EINVAL, "pass too large");
+    int rc = s->ensureWork(nPaths);
+    if (rc != MTSAMD_OK) return rc;
+    hipStream_t st = s->stream;
+    uint32_t *cnt = s->counters.as<uint32_t>();
+    unsigned long long *cnt64 = s->counters.as<unsigned long long>();
+    float4 *sampleL = s->sampleL.as<float4>();
+    float2 *samplePos = s->samplePos.as<float2>();
+    float4 *hits = s->hits.as<float4>();
+    ShadowQueue sq = s->shadowQueue();
+
+    uint32_t n = (uint32_t) nPaths;
+    int cur = 0;
+    timer.begin(T_RAYGEN);
+    hipLaunchKernelGGL(k_raygen, dim3(blocksFor(n, 256)), dim3(256), 0, st, sc, pp, s->queue(cur), sampleL, samplePos, n);
+    timer.end(T_RAYGEN);
+
+    uint64_t normalRays = 0, shadowRays = 0, iterations = 0;
+    while (n > 0) {
+        if (s->cancel.load()) { (void) hipStreamSynchronize(st); return fail(MTSAMD_ECANCELLED, "render cancelled"); }
+        PathQueue qin = s->queue(cur), qout = s->queue(cur ^ 1);
+        timer.begin(T_EXTEND);
+        if (s->countTraversal) hipLaunchKernelGGL(k_extend<true>, dim3(blocksFor(n, kTraceBlock)), dim3(kTraceBlock), 0, st, sc, qin, hits, n, cnt64);
+        else hipLaunchKernelGGL(k_extend<false>, dim3(blocksFor(n, kTraceBlock)), dim3(kTraceBlock), 0, st, sc, qin, hits, n, cnt64);
+        timer.end(T_EXTEND);
+        normalRays += n;
+        HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), st));
+        timer.begin(T_SHADE);
+        hipLaunchKernelGGL(k_shade, dim3(blocksFor(n, 256)), dim3(256), 0, st, sc, pp, qin, hits, qout, sq, sampleL, cnt, n);
+        timer.end(T_SHADE);
+        HIP_TRY(hipMemcpyAsync(s->hostCounters, cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const uint32_t nNext = s->hostCounters[CNT_NEXT], nShadow = s->hostCounters[CNT_SHADOW];
+        if (nShadow) {
+            timer.begin(T_SHADOW);
+            if (s->countTraversal) hipLaunchKernelGGL(k_shadow<true>, dim3(blocksFor(nShadow, kTraceBlock)), dim3(kTraceBlock), 0, st, sc, sq, sampleL, nShadow, cnt64);
+            else hipLaunchKernelGGL(k_shadow<false>, dim3(blocksFor(nShadow, kTraceBlock)), dim3(kTraceBlock), 0, st, sc, sq, sampleL, nShadow, cnt64);
+            timer.end(T_SHADOW);
+            shadowRays += nShadow;
+        }
+        n = nNext;
+        cur ^= 1;
+        ++iterations;
+    }
+    if (liOut) {
+        hipLaunchKernelGGL(k_copy_samples, dim3(blocksFor(nPaths, 256)), dim3(256), 0, st, sampleL, samplePos, (uint32_t) nPaths, liOut, liPos, liOffset);
+    } else {
+        const int border = (int) std::ceil(sc.filterRadius - 0.5f);
+        const int gx0 = std::max(pp.x0 - border, 0), gy0 = std::max(pp.y0 - border, 0);
+        const int gx1 = std::min(pp.x0 + pp.w + border, sc.cropW), gy1 = std::min(pp.y0 + pp.h + border, sc.cropH);
+        const size_t npx = (size_t) (gx1 - gx0) * (gy1 - gy0);
+        timer.begin(T_FILM);
+        hipLaunchKernelGGL(k_film, dim3(blocksFor(npx, 256)), dim3(256), 0, st, sc, pp, sampleL, samplePos, filmDev);
+        timer.end(T_FILM);
+    }
+    HIP_TRY(hipGetLastError());
+    if (stats) {
+        stats->normal_rays += normalRays; stats->shadow_rays += shadowRays; stats->paths += nPaths;
+        stats->bounce_iterations += iterations;
+        stats->extend_launches += iterations;
+    }
+    return MTSAMD_OK;
+}
+
+int renderCommon(mtsamd_scene *s, const mtsamd_render_opts *opts, float *filmDev, float *liOutDev, float *liPosDev, mtsamd_stats *stats) {
+    mtsamd_render_opts o;
+    int rc = checkOpts(s, opts, o);
+    if (rc != MTSAMD_OK) return rc;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    s->cancel.store(0);
+    HIP_TRY(hipSetDevice(s->device));
+    const int w = o.x1 - o.x0, h = o.y1 - o.y0;
+    int sppPass = o.spp_per_pass;
+    if (sppPass <= 0) {
+        const size_t target = 16u << 20;    // paths in flight per pass
+        sppPass = (int) std::max<size_t>(1, std::min<size_t>((size_t) o.spp, target / ((size_t) w * h)));
+    }
+    sppPass = std::min(sppPass, o.spp);
+    if (liOutDev) sppPass = o.spp;      // per-sample output keeps one pixel-major layout
+    EventTimer timer;
+    timer.stream = s->stream;
+    timer.enabled = stats != nullptr;
+    if (s->countTraversal) HIP_TRY(hipMemsetAsync(s->counters.ptr, 0, CNT_WORDS * sizeof(uint32_t), s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    auto t0 = std::chrono::steady_clock::now();
+    for (int done = 0; done < o.spp; done += sppPass) {
+        PassParams pp;
+        pp.x0 = o.x0; pp.y0 = o.y0; pp.w = w; pp.h = h;
+        pp.spp = std::min(sppPass, o.spp - done);
+        pp.sppTotal = o.spp_total; pp.sampleBase = o.sample_offset + done; pp.seed = o.seed;
+        rc = renderPass(s, pp, filmDev, liOutDev, liPosDev, 0, stats, timer);
+        if (rc != MTSAMD_OK) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (stats) {
+        stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        stats->raygen_ms = timer.total(T_RAYGEN); stats->extend_ms = timer.total(T_EXTEND); stats->shade_ms = timer.total(T_SHADE);
+        stats->shadow_ms = timer.total(T_SHADOW); stats->film_ms = timer.total(T_FILM);
+        if (s->countTraversal) {
+            unsigned long long c[CNT_WORDS / 2];
+            HIP_TRY(hipMemcpy(c, s->counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
+            stats->node_visits = c[CNT_NODE_VISITS / 2]; stats->tri_tests = c[CNT_TRI_TESTS / 2];
+        }
+    }
+    return MTSAMD_OK;
+}
+
+}  // namespace
+
+extern "C" int mtsamd_render_device(mtsamd_scene *scene, const mtsamd_render_opts *opts, float *film_device, mtsamd_stats *stats) {
+    if (!scene || !film_device) return fail(MTSAMD_EINVAL, "null argument");
+    return renderCommon(scene, opts, film_device, nullptr, nullptr, stats);
+}
+
+extern "C" int mtsamd_render(mtsamd_scene *scene, const mtsamd_render_opts *opts, float *film_host, mtsamd_stats *stats) {
+    if (!scene || !film_host) return fail(MTSAMD_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(scene->device));
+    const size_t bytes = (size_t) scene->dev.cropW * scene->dev.cropH * 5 * sizeof(float);
+    DeviceBuffer film;
+    HIP_TRY(film.ensure(bytes));
+    HIP_TRY(hipMemcpy(film.ptr, film_host, bytes, hipMemcpyHostToDevice));
+    int rc = renderCommon(scene, opts, film.as<float>(), nullptr, nullptr, stats);
+    if (rc != MTSAMD_OK) return rc;
+    HIP_TRY(hipMemcpy(film_host, film.ptr, bytes, hipMemcpyDeviceToHost));
+    return MTSAMD_OK;
+}
+
+extern "C" int mtsamd_li(mtsamd_scene *scene, const mtsamd_render_opts *opts, float *out, float *pos, mtsamd_stats *stats) {
+    if (!scene || !out || !pos) return fail(MTSAMD_EINVAL, "null argument");
+    mtsamd_render_opts o;
+    int rc = checkOpts(scene, opts, o);
+    if (rc != MTSAMD_OK) return rc;
+    HIP_TRY(hipSetDevice(scene->device));
+    const size_t n = (size_t) (o.x1 - o.x0) * (o.y1 - o.y0) * o.spp;
+    DeviceBuffer dOut, dPos;
+    HIP_TRY(dOut.ensure(n * 16)); HIP_TRY(dPos.ensure(n * 8));
+    rc = renderCommon(scene, opts, nullptr, dOut.as<float>(), dPos.as<float>(), stats);
+    if (rc != MTSAMD_OK) return rc;
+    HIP_TRY(hipMemcpy(out, dOut.ptr, n * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pos, dPos.ptr, n * 8, hipMemcpyDeviceToHost));
+    return MTSAMD_OK;
+}
+
+extern "C" int mtsamd_film_develop(const mtsamd_scene *scene, const float *film, float *rgba) {
+    if (!scene || !film || !rgba) return fail(MTSAMD_EINVAL, "null argument");
+    const size_t n = (size_t) scene->dev.cropW * scene->dev.cropH;
+    for (size_t i = 0; i < n; ++i) {
+        const float w = film[5 * i + 4];
+        const float inv = w != 0 ? 1.0f / w : 0.0f;     // fmtconv.cpp:978-990
+        for (int c = 0; c < 4; ++c) rgba[4 * i + c] = film[5 * i + c] * inv;
+    }
+    return MTSAMD_OK;
+}
+
+// ---- batch entry points ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct Staging {
+    std::vector<DeviceBuffer> bufs;
+    Staging() { bufs.reserve(16); }
+    int in(const void *src, size_t bytes, void **dev) {
+        bufs.emplace_back();
+        HIP_TRY(bufs.back().ensure(std::max<size_t>(bytes, 16)));
+        if (bytes) HIP_TRY(hipMemcpy(bufs.back().ptr, src, bytes, hipMemcpyHostToDevice));
+        *dev = bufs.back().ptr;
+        return MTSAMD_OK;
+    }
+    int out(size_t bytes, void **dev) {
+        bufs.emplace_back();
+        HIP_TRY(bufs.back().ensure(std::max<size_t>(bytes, 16)));
+        *dev = bufs.back().ptr;
+        return MTSAMD_OK;
+    }
+};
+
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != MTSAMD_OK) return rc_; } while (0)
+
+int finish(hipStream_t st) {
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    return MTSAMD_OK;
+}
+
+int checkBatch(mtsamd_scene *s, uint64_t n) {
+    if (!s) return fail(MTSAMD_EINVAL, "null scene");
+    if (n >= (1ull << 31)) return fail(MTSAMD_EINVAL, "batch too large");
+    HIP_TRY(hipSetDevice(s->device));
+    return MTSAMD_OK;
+}
+
+}  // namespace
+
+extern "C" int mtsamd_trace(mtsamd_scene *s, uint64_t n, const float *rays, mtsamd_hit *hits) {
+    TRY(checkBatch(s, n));
+    if (n == 0) return MTSAMD_OK;
+    if (!rays || !hits) return fail(MTSAMD_EINVAL, "null argument");
+    Staging sg; void *dR, *dH, *dO;
+    TRY(sg.in(rays, n * 32, &dR)); TRY(sg.out(n * 16, &dH)); TRY(sg.out(n * sizeof(mtsamd_hit), &dO));
+    hipLaunchKernelGGL(k_trace_batch, dim3(blocksFor(n, kTraceBlock)), dim3(kTraceBlock), 0, s->stream, s->dev, (const float *) dR, (uint32_t) n, (float4 *) dH);
+    hipLaunchKernelGGL(k_hits_to_records, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, (const float4 *) dH, (uint32_t) n, (mtsamd_hit *) dO);
+    TRY(finish(s->stream));
+    HIP_TRY(hipMemcpy(hits, dO, n * sizeof(mtsamd_hit), hipMemcpyDeviceToHost));
+    return MTSAMD_OK;
+}
+
+extern "C" int mtsamd_occluded(mtsamd_scene *s, uint64_t n, const float *rays, uint8_t *occluded) {
+    TRY(checkBatch(s, n));
+    if (n == 0) return MTSAMD_OK;
+    if (!rays || !occluded) return fail(MTSAMD_EINVAL, "null argument");
+    Staging sg; void *dR, *dO;
+    TRY(sg.in(rays, n * 32, &dR)); TRY(sg.out(n, &dO));
+    hipLaunchKernelGGL(k_occluded_batch, dim3(blocksFor(n, kTraceBlock)), dim3(kTraceBlock), 0, s->stream, s->dev, (const float *) dR, (uint32_t) n, (uint8_t *) dO);
+    TRY(finish(s->stream));
+    HIP_TRY(hipMemcpy(occluded, dO, n, hipMemcpyDeviceToHost));
+    return MTSAMD_OK;
+}
+
+extern "C" int mtsamd_intersect(mtsamd_scene *s, uint64_t n, const float *rays, mtsamd_intersection *its) {
+    TRY(checkBatch(s, n));
+    if (n == 0) return MTSAMD_OK;
+    if (!rays || !its) return fail(MTSAMD_EINVAL, "null argument");
+    Staging sg; void *dR, *dH, *dO;
+    TRY(sg.in(rays, n * 32, &dR)); TRY(sg.out(n * 16, &dH)); TRY(sg.out(n * sizeof(mtsamd_intersection), &dO));
+    hipLaunchKernelGGL(k_trace_batch, dim3(blocksFor(n, kTraceBlock)), dim3(kTraceBlock), 0, s->stream, s->dev, (const float *) dR, (uint32_t) n, (float4 *) dH);
+    hipLaunchKernelGGL(k_fill_isect, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, (const float *) dR, (const float4 *) dH, (uint32_t) n, (mtsamd_intersection *) dO);
+    TRY(finish(s->stream));
+    HIP_TRY(hipMemcpy(its, dO, n * sizeof(mtsamd_intersection), hipMemcpyDeviceToHost));
+    return MTSAMD_OK;
+}
+
+static int bsdfEvalPdf(mtsamd_scene *s, int material, int mode, uint64_t n, const float *wi, const float *wo, float *out) {
+    TRY(checkBatch(s, n));
+    if (material < 0 || (uint32_t) material >= s->dev.nMaterials) return fail(MTSAMD_EINVAL, "material index out of range");
+    if (n == 0) return MTSAMD_OK;
+    if (!wi || !wo || !out) return fail(MTSAMD_EINVAL, "null argument");
+    Staging sg; void *dI, *dW, *dO;
+    const size_t ob = mode == 0 ? n * 12 : n * 4;
+    TRY(sg.in(wi, n * 12, &dI)); TRY(sg.in(wo, n * 12, &dW)); TRY(sg.out(ob, &dO));
+    hipLaunchKernelGGL(k_bsdf_evalpdf, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, material, mode, (uint32_t) n, (const float *) dI, (const float *) dW, (float *) dO);
+    TRY(finish(s->stream));
+    HIP_TRY(hipMemcpy(out, dO, ob, hipMemcpyDeviceToHost));
+    return MTSAMD_OK;
+}
+
+extern "C" int mtsamd_bsdf_eval(mtsamd_scene *s, int material, uint64_t n, const float *wi, const float *wo, float *out) {
+    return bsdfEvalPdf(s, material, 0, n, wi, wo, out);
+}
+extern "C" int mtsamd_bsdf_pdf(mtsamd_scene *s, int material, uint64_t n, const float *wi, const float *wo, float *out) {
+    return bsdfEvalPdf(s, material, 1, n, wi, wo, out);
+}
+
+extern "C" int mtsamd_bsdf_sample(mtsamd_scene *s, int material, uint64_t n, const float *wi, const float *sample,
+                                  float *wo, float *weight, float *pdf, float *eta, uint32_t *sampled_type) {
+    TRY(checkBatch(s, n));
+    if (material < 0 || (uint32_t) material >= s->dev.nMaterials) return fail(MTSAMD_EINVAL, "material index out of range");
+    if (n == 0) return MTSAMD_OK;
+    if (!wi || !sample || !wo || !weight || !pdf || !eta || !sampled_type) return fail(MTSAMD_EINVAL, "null argument");
+    Staging sg; void *dI, *dS, *dWo, *dW, *dP, *dE, *dT;
+    TRY(sg.in(wi, n * 12, &dI)); TRY(sg.in(sample, n * 8, &dS));
+    TRY(sg.out(n * 12, &dWo)); TRY(sg.out(n * 12, &dW)); TRY(sg.out(n * 4, &dP)); TRY(sg.out(n * 4, &dE)); TRY(sg.out(n * 4, &dT));
+    hipLaunchKernelGGL(k_bsdf_sample, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, material, (uint32_t) n, (const float *) dI,
+                       (const float *) dS, (float *) dWo, (float *) dW, (float *) dP, (float *) dE, (uint32_t *) dT);
+    TRY(finish(s->stream));
+    HIP_TRY(hipMemcpy(wo, dWo, n * 12, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(weight, dW, n * 12, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pdf, dP, n * 4, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(eta, dE, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sampled_type, dT, n * 4, hipMemcpyDeviceToHost));
+    return MTSAMD_OK;
+}
+
+extern "C" int mtsamd_sample_emitter_direct(mtsamd_scene *s, uint64_t n, const float *ref, const float *ref_n, const float *sample,
+                                            float *d, float *dist, float *pdf, float *value) {
+    TRY(checkBatch(s, n));
+    if (n == 0) return MTSAMD_OK;
+    if (!ref || !ref_n || !sample || !d || !dist || !pdf || !value) return fail(MTSAMD_EINVAL, "null argument");
+    Staging sg; void *dR, *dN, *dS, *dD, *dDi, *dP, *dV;
+    TRY(sg.in(ref, n * 12, &dR)); TRY(sg.in(ref_n, n * 12, &dN)); TRY(sg.in(sample, n * 8, &dS));
+    TRY(sg.out(n * 12, &dD)); TRY(sg.out(n * 4, &dDi)); TRY(sg.out(n * 4, &dP)); TRY(sg.out(n * 12, &dV));
+    hipLaunchKernelGGL(k_emitter_sample, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, (uint32_t) n, (const float *) dR,
+                       (const float *) dN, (const float *) dS, (float *) dD, (float *) dDi, (float *) dP, (float *) dV);
+    TRY(finish(s->stream));
+    HIP_TRY(hipMemcpy(d, dD, n * 12, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(dist, dDi, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pdf, dP, n * 4, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(value, dV, n * 12, hipMemcpyDeviceToHost));
+    return MTSAMD_OK;
+}
+
+extern "C" int mtsamd_camera_rays(mtsamd_scene *s, uint64_t n, const float *pos, float *rays) {
+    TRY(checkBatch(s, n));
+    if (n == 0) return MTSAMD_OK;
+    if (!pos || !rays) return fail(MTSAMD_EINVAL, "null argument");
+    Staging sg; void *dP, *dR;
+    TRY(sg.in(pos, n * 8, &dP)); TRY(sg.out(n * 32, &dR));
+    hipLaunchKernelGGL(k_camera_rays, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, (uint32_t) n, (const float *) dP, (float *) dR);
+    TRY(finish(s->stream));
+    HIP_TRY(hipMemcpy(rays, dR, n * 32, hipMemcpyDeviceToHost));
+    return MTSAMD_OK;
+}
+
+extern "C" int mtsamd_film_put(mtsamd_scene *s, uint64_t n, const float *pos, const float *value, float *film_host) {
+    TRY(checkBatch(s, n));
+    if (!film_host) return fail(MTSAMD_EINVAL, "null argument");
+    if (n == 0) return MTSAMD_OK;
+    if (!pos || !value) return fail(MTSAMD_EINVAL, "null argument");
+    const size_t fb = (size_t) s->dev.cropW * s->dev.cropH * 20;
+    Staging sg; void *dP, *dV, *dF;
+    TRY(sg.in(pos, n * 8, &dP)); TRY(sg.in(value, n * 16, &dV)); TRY(sg.in(film_host, fb, &dF));
+    hipLaunchKernelGGL(k_film_put, dim3(blocksFor((size_t) s->dev.cropW * s->dev.cropH, 256)), dim3(256), 0, s->stream, s->dev, (uint32_t) n,
+                       (const float *) dP, (const float *) dV, (float *) dF);
+    TRY(finish(s->stream));
+    HIP_TRY(hipMemcpy(film_host, dF, fb, hipMemcpyDeviceToHost));
+    return MTSAMD_OK;
+}
+
+extern "C" int mtsamd_rng_stream(uint32_t seed, uint64_t key, uint32_t n, float *out) {
+    if (!out && n) return fail(MTSAMD_EINVAL, "null argument");
+    if (n == 0) return MTSAMD_OK;
+    DeviceBuffer b;
+    HIP_TRY(b.ensure((size_t) n * 4));
+    hipLaunchKernelGGL(k_rng_stream, dim3(1), dim3(64), 0, 0, seed, key, n, b.as<float>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, b.ptr, (size_t) n * 4, hipMemcpyDeviceToHost));
+    return MTSAMD_OK;
+}
