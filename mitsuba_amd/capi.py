@@ -101,6 +101,12 @@ def lib():
         if not os.path.exists(_LIB_PATH):
             raise MtsamdError("%s is missing: build it with `make -C mitsuba_amd/csrc` (hipcc, gfx950); "
                               "there is no CPU fallback" % _LIB_PATH)
+        # PyTorch-ROCm ships its own libamdhip64.so.7; importing it first lets this library bind to that same
+        # runtime instance, so device pointers (e.g. a film tensor handed to render_device) are shared.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(_LIB_PATH)
         L.mtsamd_last_error.restype = C.c_char_p
         L.mtsamd_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]

@@ -279,6 +279,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
             timer.end(T_SHADOW);
             shadowRays += nShadow;
         }
+        if (getenv("MTSAMD_TRACE_ITERS")) fprintf(stderr, "iter %llu n=%u shadow=%u next=%u\n", (unsigned long long) iterations, n, nShadow, nNext);
         n = nNext;
         cur ^= 1;
         ++iterations;

@@ -1,0 +1,369 @@
+"""Host-side scene ingest for the subset of the Mitsuba 0.5 scene format the `path` hot path needs:
+the XML scene description (src/librender/scenehandler.cpp:306-693) restricted to
+scene/integrator/sensor/sampler/film/rfilter/bsdf/shape/emitter/ref/transform and the scalar property tags,
+and the `.serialized` triangle-mesh container (src/librender/trimesh.cpp:175-294).
+
+The result is a flat `SceneData` for the C ABI. Everything unsupported raises -- nothing is silently
+substituted.
+"""
+from __future__ import annotations
+
+import math
+import os
+import struct
+import xml.etree.ElementTree as ET
+import zlib
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import scene as S
+
+_FILEFORMAT_HEADER = 0x041C
+_HAS_NORMALS, _HAS_TEXCOORDS, _HAS_COLORS, _FACE_NORMALS, _DOUBLE = 0x1, 0x2, 0x8, 0x10, 0x2000
+
+
+class SceneFormatError(ValueError):
+    pass
+
+
+# ------------------------------------------------------------------------------------------------
+# .serialized meshes
+# ------------------------------------------------------------------------------------------------
+def load_serialized(path_or_bytes, shape_index: int = 0) -> Dict:
+    """TriMesh::loadCompressed (src/librender/trimesh.cpp:175-252): header, optional offset dictionary at the
+    end of the file (readOffset, :272-294), then one zlib stream per mesh."""
+    data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
+    fmt, version = struct.unpack_from("<HH", data, 0)
+    if fmt != _FILEFORMAT_HEADER:
+        raise SceneFormatError("Encountered an invalid file format!")
+    if version not in (3, 4):
+        raise SceneFormatError("Encountered an incompatible file version!")
+    offset = 0
+    if shape_index != 0:
+        count = struct.unpack_from("<I", data, len(data) - 4)[0]
+        if shape_index < 0 or shape_index > count:
+            raise SceneFormatError("Unable to unserialize mesh, shape index is out of range!")
+        if version == 4:
+            offset = struct.unpack_from("<Q", data, len(data) - 8 * (count - shape_index) - 4)[0]
+        else:
+            offset = struct.unpack_from("<I", data, len(data) - 4 * (count - shape_index + 1))[0]
+    raw = zlib.decompressobj().decompress(data[offset + 4:])
+    p = 0
+    flags = struct.unpack_from("<I", raw, p)[0]; p += 4
+    name = ""
+    if version == 4:
+        e = raw.index(b"\0", p)
+        name = raw[p:e].decode("utf-8", "replace"); p = e + 1
+    nv, nt = struct.unpack_from("<QQ", raw, p); p += 16
+    ftype = np.dtype("<f8") if flags & _DOUBLE else np.dtype("<f4")
+
+    def take(n, comps):
+        nonlocal p
+        a = np.frombuffer(raw, ftype, n * comps, p).reshape(n, comps).astype(np.float32)
+        p += n * comps * ftype.itemsize
+        return a
+
+    out = dict(name=name, positions=take(nv, 3), normals=None, texcoords=None, face_normals=bool(flags & _FACE_NORMALS))
+    if flags & _HAS_NORMALS:
+        out["normals"] = take(nv, 3)
+    if flags & _HAS_TEXCOORDS:
+        out["texcoords"] = take(nv, 2)
+    if flags & _HAS_COLORS:
+        take(nv, 3)
+    out["indices"] = np.frombuffer(raw, "<u4", nt * 3, p).reshape(nt, 3).copy()
+    return out
+
+
+def serialized_mesh_count(data: bytes) -> int:
+    return struct.unpack_from("<I", data, len(data) - 4)[0]
+
+
+def apply_to_world(mesh: Dict, m: np.ndarray) -> Dict:
+    """SerializedMesh constructor (src/shapes/serialized.cpp:184-202): positions by the matrix, normals by the
+    inverse transpose followed by normalisation, winding swapped when the determinant is negative."""
+    m = np.asarray(m, np.float32)
+    if np.array_equal(m, np.eye(4, dtype=np.float32)):
+        return mesh
+    out = dict(mesh)
+    p = mesh["positions"]
+    out["positions"] = (p @ m[:3, :3].T + m[:3, 3]).astype(np.float32)
+    if mesh.get("normals") is not None:
+        inv_t = np.linalg.inv(m.astype(np.float64))[:3, :3].T.astype(np.float32)
+        n = (mesh["normals"] @ inv_t.T).astype(np.float32)
+        ln = np.sqrt((n * n).sum(1, keepdims=True)).astype(np.float32)
+        out["normals"] = (n / ln).astype(np.float32)
+    if np.linalg.det(m[:3, :3].astype(np.float64)) < 0:
+        idx = mesh["indices"].copy()
+        idx[:, [0, 1]] = idx[:, [1, 0]]
+        out["indices"] = idx
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# XML
+# ------------------------------------------------------------------------------------------------
+def _floats(s: str):
+    return [float(x) for x in s.replace(",", " ").split()]
+
+
+def _srgb_to_linear(c):
+    return c / 12.92 if c <= 0.04045 else ((c + 0.055) / 1.055) ** 2.4
+
+
+def _spectrum(node) -> tuple:
+    tag, v = node.tag, node.get("value")
+    if tag == "rgb":
+        f = _floats(v)
+        if len(f) == 1:
+            f = f * 3
+        return tuple(f[:3])
+    if tag == "srgb":
+        if v.startswith("#"):
+            f = [int(v[i:i + 2], 16) / 255.0 for i in (1, 3, 5)]
+        else:
+            f = _floats(v)
+        return tuple(_srgb_to_linear(c) for c in f[:3])
+    if tag == "spectrum":
+        f = _floats(v) if ":" not in v else None
+        if f is not None and len(f) == 1:
+            return (f[0],) * 3      # a constant spectrum maps to the same value in every RGB channel
+        raise SceneFormatError("wavelength-sampled <spectrum> values need the spectral-to-RGB conversion of "
+                               "src/libcore/spectrum.cpp, which this loader does not implement")
+    raise SceneFormatError("unsupported spectrum tag <%s>" % tag)
+
+
+def _transform(node) -> np.ndarray:
+    """<transform> children are applied in order, each pre-multiplied (scenehandler.cpp:574-640)."""
+    m = np.eye(4, dtype=np.float64)
+    for c in node:
+        if c.tag == "matrix":
+            f = _floats(c.get("value"))
+            t = np.array(f, np.float64).reshape(4, 4)
+        elif c.tag == "lookat":
+            t = S.look_at(_floats(c.get("origin")), _floats(c.get("target")), _floats(c.get("up", "0,0,1"))).astype(np.float64)
+        elif c.tag == "translate":
+            t = np.eye(4)
+            t[:3, 3] = [float(c.get(k, 0)) for k in "xyz"]
+        elif c.tag == "scale":
+            t = np.eye(4)
+            if c.get("value") is not None:
+                s = [float(c.get("value"))] * 3
+            else:
+                s = [float(c.get(k, 1)) for k in "xyz"]
+            t[0, 0], t[1, 1], t[2, 2] = s
+        elif c.tag == "rotate":
+            ax = np.array([float(c.get(k, 0)) for k in "xyz"], np.float64)
+            ax /= np.linalg.norm(ax)
+            a = math.radians(float(c.get("angle")))
+            x, y, z = ax
+            cs, sn = math.cos(a), math.sin(a)
+            t = np.eye(4)
+            t[:3, :3] = [[cs + x * x * (1 - cs), x * y * (1 - cs) - z * sn, x * z * (1 - cs) + y * sn],
+                         [y * x * (1 - cs) + z * sn, cs + y * y * (1 - cs), y * z * (1 - cs) - x * sn],
+                         [z * x * (1 - cs) - y * sn, z * y * (1 - cs) + x * sn, cs + z * z * (1 - cs)]]
+        else:
+            raise SceneFormatError("unsupported transform element <%s>" % c.tag)
+        m = t @ m
+    return m.astype(np.float32)
+
+
+def _props(node) -> Dict:
+    """Scalar properties of a plugin element."""
+    out = {}
+    for c in node:
+        n = c.get("name")
+        if c.tag == "float":
+            out[n] = float(c.get("value"))
+        elif c.tag == "integer":
+            out[n] = int(c.get("value"))
+        elif c.tag == "boolean":
+            out[n] = c.get("value").lower() == "true"
+        elif c.tag == "string":
+            out[n] = c.get("value")
+        elif c.tag in ("rgb", "srgb", "spectrum"):
+            out[n] = _spectrum(c)
+        elif c.tag == "transform":
+            out[n] = _transform(c)
+    return out
+
+
+def _ior(props, key, default):
+    v = props.get(key, default)
+    if isinstance(v, str):
+        if v.lower() not in S.IOR:
+            raise SceneFormatError("unknown IOR preset '%s'" % v)
+        return S.IOR[v.lower()]
+    return float(v)
+
+
+def _make_bsdf(node, data_dir: Optional[str]) -> Dict:
+    t = node.get("type")
+    p = _props(node)
+    for c in node:
+        if c.tag in ("texture", "bsdf"):
+            raise SceneFormatError("nested <%s> inside a <bsdf type=\"%s\"> is not supported" % (c.tag, t))
+    ee = p.get("ensureEnergyConservation", True)
+    distr = p.get("distribution", "beckmann").lower()
+    if "alpha" in p:
+        au = av = p["alpha"]
+    else:
+        au, av = p.get("alphaU", 0.1), p.get("alphaV", 0.1)
+    if t == "diffuse":
+        m = S.diffuse(p.get("reflectance", p.get("diffuseReflectance", (0.5, 0.5, 0.5))))
+    elif t == "dielectric":
+        m = S.dielectric(_ior(p, "intIOR", "bk7"), _ior(p, "extIOR", "air"), p.get("specularReflectance", (1, 1, 1)),
+                         p.get("specularTransmittance", (1, 1, 1)))
+    elif t == "ward":
+        a = p.get("alpha", 0.1)
+        m = S.ward(alpha=p.get("alphaU", a), alpha_v=p.get("alphaV", a),
+                   diffuse_reflectance=p.get("diffuseReflectance", (0.5, 0.5, 0.5)),
+                   specular_reflectance=p.get("specularReflectance", (0.2, 0.2, 0.2)), variant=p.get("variant", "balanced").lower())
+    elif t == "roughconductor":
+        if distr in ("phong", "as"):
+            raise SceneFormatError("the Phong/Ashikhmin-Shirley microfacet distribution is not supported")
+        material = p.get("material", "Cu")
+        if "eta" in p and "k" in p:
+            eta, k = p["eta"], p["k"]
+        elif material.lower() == "none":
+            eta, k = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
+        else:
+            raise SceneFormatError("roughconductor material preset '%s' needs data/ior/*.spd spectral data; give RGB "
+                                   "'eta' and 'k' instead" % material)
+        m = S.roughconductor(eta, k, alpha=au, alpha_v=av, distribution=distr,
+                             specular_reflectance=p.get("specularReflectance", (1, 1, 1)), ext_eta=_ior(p, "extEta", "air"),
+                             sample_visible=p.get("sampleVisible", True))
+    elif t == "roughplastic":
+        if distr in ("phong", "as"):
+            raise SceneFormatError("the Phong microfacet distribution is not supported")
+        int_ior, ext_ior = _ior(p, "intIOR", "polypropylene"), _ior(p, "extIOR", "air")
+        rt = None
+        if data_dir is not None:
+            from . import capi
+            dat = open(os.path.join(data_dir, "microfacet", distr + ".dat"), "rb").read()
+            rt = capi.rtrans_reduce(dat, int_ior / ext_ior, au)
+        m = S.roughplastic(alpha=au, distribution=distr, int_ior=int_ior, ext_ior=ext_ior,
+                           diffuse_reflectance=p.get("diffuseReflectance", (0.5, 0.5, 0.5)),
+                           specular_reflectance=p.get("specularReflectance", (1, 1, 1)), nonlinear=p.get("nonlinear", False),
+                           sample_visible=p.get("sampleVisible", True), rtrans=rt)
+    else:
+        raise SceneFormatError("BSDF type '%s' is outside the path hot path of this core" % t)
+    m["ensure_energy_conservation"] = int(bool(ee))
+    return m
+
+
+def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = None, integrator_override: Optional[Dict] = None,
+             data_dir: Optional[str] = None, mesh_provider=None) -> "tuple[S.SceneData, Dict]":
+    """Parse a scene file into SceneData. Returns (scene, info) where info carries the sampler's sampleCount
+    and the integrator type found in the file. `mesh_provider(filename, shape_index)` may supply mesh dicts
+    (positions/normals/texcoords/indices in object space) instead of reading `.serialized` files."""
+    root = ET.parse(path).getroot()
+    if root.tag != "scene":
+        raise SceneFormatError("root element must be <scene>")
+    base = os.path.dirname(os.path.abspath(path))
+    b = S.SceneBuilder()
+    named_bsdfs: Dict[str, int] = {}
+    info = dict(integrator_type=None, sample_count=4)
+    camera = film = None
+    integ = dict(max_depth=-1, rr_depth=5, strict_normals=0, hide_emitters=0)
+
+    def bsdf_index(node) -> int:
+        idx = b.add_material(_make_bsdf(node, data_dir))
+        if node.get("id"):
+            named_bsdfs[node.get("id")] = idx
+        return idx
+
+    default_bsdf = None
+    for el in root:
+        if el.tag == "bsdf":
+            bsdf_index(el)
+    for el in root:
+        if el.tag == "integrator":
+            p = _props(el)
+            info["integrator_type"] = el.get("type")
+            integ.update(max_depth=p.get("maxDepth", -1), rr_depth=p.get("rrDepth", 5),
+                         strict_normals=int(p.get("strictNormals", False)), hide_emitters=int(p.get("hideEmitters", False)))
+        elif el.tag == "sensor":
+            if el.get("type") != "perspective":
+                raise SceneFormatError("only the perspective sensor is supported")
+            p = _props(el)
+            fw, fh, rf = 768, 576, None      # Film defaults (src/librender/film.cpp:25-55)
+            for c in el:
+                if c.tag == "film":
+                    fp = _props(c)
+                    fw, fh = fp.get("width", 768), fp.get("height", 576)
+                    for r in c:
+                        if r.tag == "rfilter":
+                            rp = _props(r)
+                            if r.get("type") == "gaussian":
+                                rf = S.gaussian_filter(rp.get("stddev", 0.5))
+                            elif r.get("type") == "box":
+                                rf = S.box_filter(rp.get("radius", 0.5))
+                            else:
+                                raise SceneFormatError("reconstruction filter '%s' is not supported" % r.get("type"))
+                elif c.tag == "sampler":
+                    info["sample_count"] = _props(c).get("sampleCount", 4)
+            if width is not None:
+                fw, fh = width, height
+            aspect = fw / fh
+            fov = p.get("fov")
+            if fov is None:
+                raise SceneFormatError("sensor needs a 'fov' (focalLength is not supported)")
+            axis = p.get("fovAxis", "x").lower()
+            if axis == "smaller":
+                axis = "y" if aspect > 1 else "x"
+            elif axis == "larger":
+                axis = "x" if aspect > 1 else "y"
+            if axis == "y":     # PerspectiveCamera::setYFov (src/librender/sensor.cpp:296-299)
+                fov = math.degrees(2 * math.atan(math.tan(0.5 * math.radians(fov)) * aspect))
+            elif axis != "x":
+                raise SceneFormatError("fovAxis '%s' is not supported" % axis)
+            camera = dict(to_world=p.get("toWorld", np.eye(4, dtype=np.float32)), x_fov=float(fov),
+                          near_clip=float(p.get("nearClip", 1e-2)), far_clip=float(p.get("farClip", 1e4)))
+            film = S.make_film(fw, fh, rf)
+        elif el.tag == "shape":
+            p = _props(el)
+            mat = None
+            radiance, weight = None, 1.0
+            for c in el:
+                if c.tag == "ref":
+                    if c.get("id") not in named_bsdfs:
+                        raise SceneFormatError("reference to unknown id '%s'" % c.get("id"))
+                    mat = named_bsdfs[c.get("id")]
+                elif c.tag == "bsdf":
+                    mat = bsdf_index(c)
+                elif c.tag == "emitter":
+                    if c.get("type") != "area":
+                        raise SceneFormatError("only area emitters are supported")
+                    ep = _props(c)
+                    radiance, weight = ep.get("radiance", (1, 1, 1)), ep.get("samplingWeight", 1.0)
+                elif c.tag in ("medium", "subsurface"):
+                    raise SceneFormatError("<%s> is not handled by the path integrator" % c.tag)
+            if mat is None:
+                if default_bsdf is None:
+                    default_bsdf = b.add_material(S.diffuse())      # Shape::configure attaches a default diffuse BSDF
+                mat = default_bsdf
+            t = el.get("type")
+            if t == "serialized":
+                idx = p.get("shapeIndex", 0)
+                if mesh_provider is not None:
+                    mesh = mesh_provider(p["filename"], idx)
+                else:
+                    mesh = load_serialized(os.path.join(base, p["filename"]), idx)
+            else:
+                raise SceneFormatError("shape type '%s' is not supported (triangle meshes only)" % t)
+            if p.get("faceNormals", False) or mesh.get("face_normals"):
+                mesh = dict(mesh, normals=None)
+            if p.get("flipNormals", False):
+                raise SceneFormatError("flipNormals is not supported")
+            mesh = apply_to_world(mesh, p.get("toWorld", np.eye(4, dtype=np.float32)))
+            normals = mesh.get("normals")
+            if normals is None and not (p.get("faceNormals", False) or mesh.get("face_normals")):
+                normals = S.vertex_normals(mesh["positions"], mesh["indices"].astype(np.int64))
+            b.add_mesh(mesh["positions"], mesh["indices"], mat, normals=normals, texcoords=mesh.get("texcoords"),
+                       radiance=radiance, sampling_weight=weight)
+    if camera is None:
+        raise SceneFormatError("scene has no sensor")
+    if integrator_override:
+        integ.update(integrator_override)
+    return b.finish(camera, film, integ), info

@@ -459,3 +459,23 @@ def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1) -> SceneData:
     b.add_quad([4, -1, 3.5], [4, 1, 3.5], [5, 1, 4.5], [5, -1, 4.5], m_ground, radiance=(6, 9, 12), sampling_weight=0.5)
     cam = make_camera([0.5, -11, 5.5], [0, 0, 0.8], [0, 0, 1], 40.0, near_clip=0.1, far_clip=100)
     return b.finish(cam, make_film(width, height), dict(max_depth=max_depth))
+
+
+def veach_bidir(width=1024, height=768, max_depth=-1, golden_dir=None) -> SceneData:
+    """Config 2: the veach_bidir scene (geometry of testScene/veach_bidir/bidir.serialized, materials, emitters and
+    camera of bidir.bak) rendered with the `path` integrator. Geometry and scene description are read from the
+    fixtures extracted by tools/make_golden.py."""
+    from . import loader
+    if golden_dir is None:
+        golden_dir = os.path.join(os.path.dirname(_DATA_DIR.rstrip("/")), "..", "tests", "golden")
+    golden_dir = os.path.abspath(golden_dir)
+    z = np.load(os.path.join(golden_dir, "veach_bidir_meshes.npz"))
+
+    def provider(filename, idx):
+        return dict(positions=z["p%d" % idx], indices=z["i%d" % idx],
+                    normals=z["n%d" % idx] if "n%d" % idx in z.files else None,
+                    texcoords=z["t%d" % idx] if "t%d" % idx in z.files else None, face_normals=False)
+
+    sd, _ = loader.load_xml(os.path.join(golden_dir, "veach_bidir_path.xml"), width=width, height=height,
+                            integrator_override=dict(max_depth=max_depth), mesh_provider=provider)
+    return sd
