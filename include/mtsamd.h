@@ -132,7 +132,9 @@ typedef struct {
     double seconds;             /* wall time of the render loop, device-synchronised */
     double extend_ms, shade_ms, shadow_ms, film_ms, raygen_ms;   /* per-kernel-class device time (HIP events) */
     uint64_t extend_launches, shadow_launches;
-    uint64_t node_visits, tri_tests;    /* filled only when traversal counters are enabled */
+    /* interior-node visits and triangle tests of the closest-hit and of the shadow queries; filled only while
+       traversal counting is enabled (mtsamd_scene_set_counting) */
+    uint64_t node_visits, tri_tests, shadow_node_visits, shadow_tri_tests;
 } mtsamd_stats;
 
 typedef struct {
@@ -178,6 +180,11 @@ int mtsamd_scene_bvh_info(const mtsamd_scene *scene, mtsamd_bvh_info *info);
    device pointer on the current HIP device (e.g. a torch tensor that is then reduced over RCCL). */
 int mtsamd_render(mtsamd_scene *scene, const mtsamd_render_opts *opts, float *film_host, mtsamd_stats *stats);
 int mtsamd_render_device(mtsamd_scene *scene, const mtsamd_render_opts *opts, float *film_device, mtsamd_stats *stats);
+
+/* Per-ray traversal statistics, the counterpart of rayIntersectHavranCollectStatistics
+   (include/mitsuba/render/sahkdtree3.h:330-429): when enabled, renders run instrumented traversal kernels and
+   report node visits / triangle tests in mtsamd_stats. Slower; off by default. */
+int mtsamd_scene_set_counting(mtsamd_scene *scene, int enabled);
 
 /* Integrator::cancel (include/mitsuba/render/integrator.h:84): polled between wavefront iterations */
 void mtsamd_cancel(mtsamd_scene *scene);

@@ -67,7 +67,8 @@ class Stats(C.Structure):
                 ("bounce_iterations", C.c_uint64), ("seconds", C.c_double),
                 ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("shadow_ms", C.c_double), ("film_ms", C.c_double),
                 ("raygen_ms", C.c_double), ("extend_launches", C.c_uint64), ("shadow_launches", C.c_uint64),
-                ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64)]
+                ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
+                ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64)]
 
 
 class BvhInfo(C.Structure):
@@ -83,7 +84,7 @@ ISECT_DTYPE = np.dtype([("t", "f4"), ("u", "f4"), ("v", "f4"), ("shape", "u4"), 
 
 # every symbol include/mtsamd.h declares
 EXPORTS = ["mtsamd_last_error", "mtsamd_init", "mtsamd_scene_create", "mtsamd_scene_destroy", "mtsamd_scene_bvh_info",
-           "mtsamd_render", "mtsamd_render_device", "mtsamd_cancel", "mtsamd_film_develop", "mtsamd_trace",
+           "mtsamd_render", "mtsamd_render_device", "mtsamd_cancel", "mtsamd_scene_set_counting", "mtsamd_film_develop", "mtsamd_trace",
            "mtsamd_occluded", "mtsamd_intersect", "mtsamd_bsdf_eval", "mtsamd_bsdf_pdf", "mtsamd_bsdf_sample",
            "mtsamd_sample_emitter_direct", "mtsamd_camera_rays", "mtsamd_li", "mtsamd_film_put", "mtsamd_rng_stream",
            "mtsamd_rtrans_reduce", "mtsamd_filter_gaussian", "mtsamd_filter_box"]
@@ -244,6 +245,9 @@ class Scene:
 
     def cancel(self):
         self.L.mtsamd_cancel(self.h)
+
+    def set_counting(self, enabled: bool):
+        _check(self.L.mtsamd_scene_set_counting(self.h, int(enabled)))
 
     def trace(self, rays):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)

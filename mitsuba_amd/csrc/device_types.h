@@ -90,6 +90,8 @@ struct PassParams {
 };
 
 // counters[] layout in device memory
-enum { CNT_NEXT = 0, CNT_SHADOW = 1, CNT_NODE_VISITS = 2, CNT_TRI_TESTS = 4, CNT_WORDS = 8 };
+// words 0,1: queue counters (uint32); from word 2 on: 64-bit traversal counters (extend nodes, extend triangles,
+// shadow nodes, shadow triangles) addressed as uint64 index 1..4
+enum { CNT_NEXT = 0, CNT_SHADOW = 1, CNT64_EXT_NODES = 1, CNT64_EXT_TRIS = 2, CNT64_SHD_NODES = 3, CNT64_SHD_TRIS = 4, CNT_WORDS = 10 };
 
 }  // namespace mtsamd

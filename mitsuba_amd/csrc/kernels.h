@@ -64,8 +64,8 @@ __global__ void __launch_bounds__(kTraceBlock) k_extend(DevScene sc, PathQueue q
         hits[i] = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
     }
     if (COUNT) {
-        atomicAdd(&counters[CNT_NODE_VISITS / 2], (unsigned long long) nv);
-        atomicAdd(&counters[CNT_TRI_TESTS / 2], (unsigned long long) nt);
+        atomicAdd(&counters[CNT64_EXT_NODES], (unsigned long long) nv);
+        atomicAdd(&counters[CNT64_EXT_TRIS], (unsigned long long) nt);
     }
 }
 
@@ -90,8 +90,8 @@ __global__ void __launch_bounds__(kTraceBlock) k_shadow(DevScene sc, ShadowQueue
         }
     }
     if (COUNT) {
-        atomicAdd(&counters[CNT_NODE_VISITS / 2], (unsigned long long) nv);
-        atomicAdd(&counters[CNT_TRI_TESTS / 2], (unsigned long long) nt);
+        atomicAdd(&counters[CNT64_SHD_NODES], (unsigned long long) nv);
+        atomicAdd(&counters[CNT64_SHD_TRIS], (unsigned long long) nt);
     }
 }
 

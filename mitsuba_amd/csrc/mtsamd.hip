@@ -191,6 +191,12 @@ extern "C" int mtsamd_scene_bvh_info(const mtsamd_scene *scene, mtsamd_bvh_info 
 
 extern "C" void mtsamd_cancel(mtsamd_scene *scene) { if (scene) scene->cancel.store(1); }
 
+extern "C" int mtsamd_scene_set_counting(mtsamd_scene *scene, int enabled) {
+    if (!scene) return fail(MTSAMD_EINVAL, "null scene");
+    scene->countTraversal = enabled != 0;
+    return MTSAMD_OK;
+}
+
 namespace {
 
 struct EventTimer {
@@ -341,7 +347,8 @@ int renderCommon(mtsamd_scene *s, const mtsamd_render_opts *opts, float *filmDev
         if (s->countTraversal) {
             unsigned long long c[CNT_WORDS / 2];
             HIP_TRY(hipMemcpy(c, s->counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
-            stats->node_visits = c[CNT_NODE_VISITS / 2]; stats->tri_tests = c[CNT_TRI_TESTS / 2];
+            stats->node_visits = c[CNT64_EXT_NODES]; stats->tri_tests = c[CNT64_EXT_TRIS];
+            stats->shadow_node_visits = c[CNT64_SHD_NODES]; stats->shadow_tri_tests = c[CNT64_SHD_TRIS];
         }
     }
     return MTSAMD_OK;

@@ -1,0 +1,323 @@
+"""GPU parity tests: every call goes through the C ABI (libmtsamd.so) and is compared with the CPU oracle on
+the same seeded inputs. Bars: hit/miss and (shape, primitive) exact except equal-t ties, t/u/v bit-exact (the
+triangle test reproduces the reference's arithmetic), intersection fields 1e-5 relative, BSDF values 1e-4 relative,
+per-sample radiance 1e-3 relative for >= 99.5 % of the samples with identical ray counts, film 1e-4 relative."""
+import numpy as np
+import pytest
+
+from conftest import random_rays, surface_rays
+from mitsuba_amd import scene as S
+
+pytestmark = pytest.mark.gpu
+MISS = 0xFFFFFFFF
+
+
+def _scenes():
+    return {"small": S.small_test_scene(), "cornell": S.cornell_box(96, 96), "veach": S.veach_bidir(128, 96)}
+
+
+@pytest.fixture(scope="module")
+def pairs(gpu, oracle_mod):
+    out = {}
+    for name, sd in _scenes().items():
+        out[name] = (sd, gpu.Scene(sd), oracle_mod.OracleScene(sd))
+    return out
+
+
+def test_rng_stream_matches(gpu, oracle_mod):
+    for seed, key in ((1, 0), (5, 123456789), (0xFFFFFFFF, 2 ** 40 + 17)):
+        assert np.array_equal(gpu.rng_stream(seed, key, 64), oracle_mod.rng_stream(seed, key, 64))
+
+
+@pytest.mark.parametrize("name", ["small", "cornell", "veach"])
+def test_closest_hit_parity(pairs, name):
+    sd, g, o = pairs[name]
+    rng = np.random.default_rng(2)
+    cam = g.camera_rays(rng.uniform(0, 1, (40000, 2)) * [sd.film["crop_w"], sd.film["crop_h"]])
+    rays = np.concatenate([random_rays(sd, 60000), cam, surface_rays(sd, o, 40000)])
+    hg, ho = g.trace(rays), o.trace(rays)
+    mism = (hg["shape"] != ho["shape"]) | (hg["prim"] != ho["prim"])
+    tie = mism & (hg["t"] == ho["t"])           # documented tie rule: lowest triangle index vs last in kd-leaf order
+    hard = np.nonzero(mism & ~tie)[0]
+    if hard.size:
+        # the kd-tree itself can lose a hit to round-off at a split plane; exhaustive search adjudicates
+        hb = o.trace(rays[hard], brute=True)
+        ok = ((hg["shape"][hard] == hb["shape"]) & (hg["prim"][hard] == hb["prim"])) | (hg["t"][hard] == hb["t"])
+        assert ok.all(), "GPU disagrees with exhaustive search on %d rays" % (~ok).sum()
+        assert hard.size <= 1e-4 * rays.shape[0]
+    same = ~mism & (hg["prim"] != MISS)
+    assert same.sum() > 0.2 * rays.shape[0]
+    assert np.array_equal(hg["t"][same], ho["t"][same])
+    assert np.array_equal(hg["u"][same], ho["u"][same]) and np.array_equal(hg["v"][same], ho["v"][same])
+    assert np.array_equal(hg["t"][tie], ho["t"][tie])
+
+
+@pytest.mark.parametrize("name", ["small", "cornell", "veach"])
+def test_shadow_query_parity(pairs, name):
+    sd, g, o = pairs[name]
+    rays = np.concatenate([random_rays(sd, 50000, seed=5), surface_rays(sd, o, 50000, seed=6)])
+    og, oo = g.occluded(rays), o.occluded(rays)
+    bad = np.nonzero(og != oo)[0]
+    if bad.size:
+        ob = o.occluded(rays[bad], brute=True)
+        assert np.array_equal(og[bad], ob)
+        assert bad.size <= 1e-4 * rays.shape[0]
+
+
+@pytest.mark.parametrize("name", ["small", "veach"])
+def test_intersection_record_parity(pairs, name):
+    sd, g, o = pairs[name]
+    rays = np.concatenate([random_rays(sd, 30000, seed=8), surface_rays(sd, o, 20000, seed=9)])
+    ig, io = g.intersect(rays), o.trace(rays)
+    ok = (ig["prim"] == io["prim"]) & (ig["shape"] == io["shape"]) & (ig["prim"] != MISS)
+    assert ok.mean() > 0.3
+    for f in ("p", "geo_n", "sh_n", "sh_s", "sh_t", "wi", "uv"):
+        a, b = ig[f][ok], io[f][ok]
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-6), f
+
+
+def test_camera_rays(pairs):
+    for name in ("small", "cornell", "veach"):
+        sd, g, o = pairs[name]
+        pos = np.random.default_rng(4).uniform(0, 1, (5000, 2)) * [sd.film["crop_w"], sd.film["crop_h"]]
+        assert np.allclose(g.camera_rays(pos), o.camera_rays(pos), rtol=1e-5, atol=1e-6)
+
+
+def _wi(n, rng, lo=0.001):
+    z = rng.uniform(lo, 1.0, n)
+    z[: n // 10] = rng.uniform(lo, 0.05, n // 10)       # grazing incidence
+    phi = rng.uniform(0, 2 * np.pi, n)
+    r = np.sqrt(1 - z * z)
+    return np.stack([r * np.cos(phi), r * np.sin(phi), z], 1).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def material_pair(gpu, oracle_mod):
+    mats = [S.diffuse((0.6, 0.5, 0.4)),
+            S.roughconductor(eta=(0.2004, 0.924, 1.102), k=(3.912, 2.452, 2.142), alpha=0.3, distribution="beckmann"),
+            S.roughconductor(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), alpha=0.15, distribution="ggx"),
+            S.roughconductor(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), alpha=0.2, distribution="ggx", sample_visible=False),
+            S.roughconductor(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), alpha=0.1, alpha_v=0.3, distribution="beckmann"),
+            S.roughplastic(alpha=0.7, distribution="beckmann"),
+            S.roughplastic(alpha=0.1, distribution="ggx", diffuse_reflectance=(0.5, 0.2, 0.2)),
+            S.roughplastic(alpha=0.3, distribution="beckmann", diffuse_reflectance=(0.2, 0.4, 0.6), nonlinear=True),
+            S.dielectric(S.IOR["water"], S.IOR["air"]), S.dielectric(1.5, 1.0),
+            S.ward(alpha=0.4, diffuse_reflectance=(0.0, 0.0, 0.0), specular_reflectance=(0.616, 0.4752, 0.352)),
+            S.ward(alpha=0.2, variant="ward"), S.ward(alpha=0.15, alpha_v=0.3, variant="ward-duer"),
+            S.diffuse((1.4, 0.5, 0.2))]        # triggers ensureEnergyConservation scaling
+    b = S.SceneBuilder()
+    for m in mats:
+        b.add_material(m)
+    b.add_quad([0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], 0)
+    sd = b.finish(S.make_camera([0, 0, 5], [0, 0, 0], [0, 1, 0], 40), S.make_film(8, 8))
+    return mats, gpu.Scene(sd), oracle_mod.OracleScene(sd)
+
+
+def _close(a, b, rtol=1e-4, floor=1e-6):
+    return np.abs(a - b) <= rtol * np.maximum(np.abs(a), np.abs(b)) + floor
+
+
+def test_bsdf_eval_pdf_parity(material_pair):
+    mats, g, o = material_pair
+    rng = np.random.default_rng(21)
+    n = 200000
+    for mi in range(len(mats)):
+        wi, wo = _wi(n, rng), _wi(n, rng)
+        wo[::7, 2] *= -1
+        wi[::11, 2] *= -1
+        fg, fo = g.bsdf_eval(mi, wi, wo), o.bsdf_eval(mi, wi, wo)
+        pg, po_ = g.bsdf_pdf(mi, wi, wo), o.bsdf_pdf(mi, wi, wo)
+        assert _close(fg, fo).mean() > 0.9995, ("eval", mi, (~_close(fg, fo)).sum())
+        assert _close(pg, po_).mean() > 0.9995, ("pdf", mi)
+        assert np.array_equal(fg == 0, fo == 0) or (np.mean((fg == 0) != (fo == 0)) < 1e-5)
+
+
+def test_bsdf_sample_parity(material_pair):
+    mats, g, o = material_pair
+    rng = np.random.default_rng(22)
+    n = 200000
+    for mi in range(len(mats)):
+        wi = _wi(n, rng)
+        if mats[mi]["type"] == S.BSDF_DIELECTRIC:
+            wi[::2, 2] *= -1
+        s = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+        a, b = g.bsdf_sample(mi, wi, s), o.bsdf_sample(mi, wi, s)
+        same_type = a[4] == b[4]
+        assert same_type.mean() > 0.9999, mi          # a lobe choice can flip when a sample sits on the threshold
+        ok = same_type
+        # the Beckmann visible-normal sampler is an iterative root find: allow 1e-3 there, 1e-4 elsewhere
+        tol = 1e-3 if (mats[mi]["distribution"] == 0 and mats[mi]["type"] in (1, 2)) else 1e-4
+        assert np.mean(np.all(_close(a[0][ok], b[0][ok], tol, 1e-5), axis=1)) > 0.999, ("wo", mi)
+        assert np.mean(np.all(_close(a[1][ok], b[1][ok], 10 * tol, 1e-5), axis=1)) > 0.998, ("weight", mi)
+        assert np.mean(_close(a[2][ok], b[2][ok], 10 * tol, 1e-5)) > 0.998, ("pdf", mi)
+        assert np.array_equal(a[3][ok], b[3][ok])
+
+
+def test_emitter_sampling_parity(pairs):
+    for name in ("small", "veach"):
+        sd, g, o = pairs[name]
+        rng = np.random.default_rng(31)
+        n = 100000
+        lo, hi = sd.positions.min(0), sd.positions.max(0)
+        ref = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+        refn = rng.normal(size=(n, 3)).astype(np.float32)
+        refn /= np.linalg.norm(refn, axis=1, keepdims=True)
+        refn[::3] = 0
+        s = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+        a, b = g.sample_emitter_direct(ref, refn, s), o.sample_emitter_direct(ref, refn, s)
+        assert np.array_equal(a[2] == 0, b[2] == 0)
+        for x, y in zip(a, b):
+            assert np.allclose(x, y, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["small", "cornell", "veach"])
+def test_per_sample_radiance_parity(pairs, name):
+    """MIPathTracer::Li per camera sample with the shared sample stream: same ray counts, same radiance."""
+    sd, g, o = pairs[name]
+    rect = (0, 0, min(64, sd.film["crop_w"]), min(48, sd.film["crop_h"]))
+    Lg, pg, sg = g.li(4, rect=rect, seed=3)
+    Lo, pos, so = o.li(4, rect=rect, seed=3)
+    assert np.array_equal(pg, pos)
+    assert sg.normal_rays == so.normal_rays and sg.shadow_rays == so.shadow_rays
+    assert np.array_equal(Lg[..., 3], Lo[..., 3])
+    rel = np.abs(Lg[..., :3] - Lo[..., :3]).max(-1) / (np.abs(Lo[..., :3]).max(-1) + 1e-3)
+    assert np.mean(rel < 1e-3) > 0.995
+    assert abs(Lg[..., :3].mean() - Lo[..., :3].mean()) < 2e-3 * Lo[..., :3].mean() + 1e-6
+
+
+def test_max_depth_and_rr_variants(gpu, oracle_mod):
+    for md, rr in ((1, 5), (2, 5), (3, 1), (6, 2)):
+        sd = S.small_test_scene(max_depth=md)
+        sd.integrator["rr_depth"] = rr
+        g, o = gpu.Scene(sd), oracle_mod.OracleScene(sd)
+        Lg, _, sg = g.li(2, seed=5)
+        Lo, _, so = o.li(2, seed=5)
+        assert (sg.normal_rays, sg.shadow_rays) == (so.normal_rays, so.shadow_rays), (md, rr)
+        rel = np.abs(Lg[..., :3] - Lo[..., :3]).max(-1) / (np.abs(Lo[..., :3]).max(-1) + 1e-3)
+        assert np.mean(rel < 1e-3) > 0.995
+    sd = S.small_test_scene()
+    sd.integrator.update(strict_normals=1, hide_emitters=1)
+    g, o = gpu.Scene(sd), oracle_mod.OracleScene(sd)
+    Lg, _, sg = g.li(2, seed=6)
+    Lo, _, so = o.li(2, seed=6)
+    assert (sg.normal_rays, sg.shadow_rays) == (so.normal_rays, so.shadow_rays)
+    rel = np.abs(Lg[..., :3] - Lo[..., :3]).max(-1) / (np.abs(Lo[..., :3]).max(-1) + 1e-3)
+    assert np.mean(rel < 1e-3) > 0.995
+
+
+def test_film_put_parity(pairs):
+    sd, g, o = pairs["small"]
+    rng = np.random.default_rng(41)
+    n = 20000
+    pos = rng.uniform(-1, 1, (n, 2)) * 0 + rng.uniform(0, 1, (n, 2)) * [sd.film["crop_w"], sd.film["crop_h"]]
+    val = rng.uniform(0, 2, (n, 4)).astype(np.float32)
+    val[::97, 0] = np.nan           # invalid samples are dropped whole (imageblock.h:147-151)
+    val[::89, 1] = -1.0
+    val[::83, 2] = np.inf
+    fg, fo = g.film_put(pos, val), o.film_put(pos, val)
+    assert np.isfinite(fg).all()
+    assert np.allclose(fg, fo, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["small", "cornell"])
+def test_render_film_parity(pairs, name):
+    sd, g, o = pairs[name]
+    fg, sg = g.render(4, seed=9)
+    fo, so = o.render(4, seed=9)
+    assert (sg.normal_rays, sg.shadow_rays) == (so.normal_rays, so.shadow_rays)
+    assert np.allclose(fg[..., 4], fo[..., 4], rtol=1e-5, atol=1e-6)
+    dg, do = g.develop(fg), o.develop(fo)
+    rel_mse = np.mean((dg[..., :3] - do[..., :3]) ** 2 / (do[..., :3] ** 2 + 1e-2))
+    assert rel_mse < 1e-6, rel_mse
+
+
+def test_render_is_partition_and_pass_invariant(pairs):
+    """Tiles, sample chunks and pass sizes are bookkeeping: the film must not depend on them (beyond float
+    re-association in the accumulation), which is what makes the multi-GPU partition exact."""
+    sd, g, o = pairs["small"]
+    w, h = sd.film["crop_w"], sd.film["crop_h"]
+    full, _ = g.render(6, seed=2)
+    again, _ = g.render(6, seed=2)
+    assert np.array_equal(full, again)          # deterministic
+    parts = np.zeros_like(full)
+    from mitsuba_amd import render
+    for rank in range(3):
+        for r in render.tile_schedule(w, h, 16, 3, rank):
+            g.render(6, film=parts, seed=2, rect=r)
+    assert np.allclose(parts, full, rtol=1e-5, atol=1e-6)
+    chunks = np.zeros_like(full)
+    g.render(2, film=chunks, seed=2, spp_total=6, sample_offset=0)
+    g.render(4, film=chunks, seed=2, spp_total=6, sample_offset=2, spp_per_pass=1)
+    assert np.allclose(chunks, full, rtol=1e-5, atol=1e-6)
+
+
+def test_edge_cases_and_errors(gpu, pairs):
+    sd, g, o = pairs["small"]
+    assert g.trace(np.zeros((0, 8), np.float32)).shape[0] == 0
+    assert g.occluded(np.zeros((0, 8), np.float32)).shape[0] == 0
+    # rays that miss everything / degenerate directions
+    rays = np.zeros((4, 8), np.float32)
+    rays[:, :3] = [100, 100, 100]
+    rays[:, 4:7] = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [0.6, 0.8, 0.0]]
+    rays[:, 3], rays[:, 7] = 1e-4, np.inf
+    assert (g.trace(rays)["prim"] == MISS).all() and not g.occluded(rays).any()
+    # axis-parallel rays through the scene (zero direction components)
+    rays[:, :3] = [[-50, 0.1, 1.0], [0.2, -50, 1.0], [0.3, 0.1, 50], [0.0, 0.0, 1.0]]
+    rays[2, 4:7] = [0, 0, -1]
+    hg, ho = g.trace(rays), o.trace(rays)
+    assert np.array_equal(hg["prim"], ho["prim"]) and np.array_equal(hg["t"], ho["t"])
+    with pytest.raises(gpu.MtsamdError):
+        g.render(0)
+    with pytest.raises(gpu.MtsamdError):
+        g.render(1, rect=(0, 0, 10 ** 6, 4))
+    with pytest.raises(gpu.MtsamdError):
+        g.bsdf_eval(999, np.zeros((1, 3), np.float32), np.zeros((1, 3), np.float32))
+    bad = S.small_test_scene()
+    bad.indices = bad.indices.copy()
+    bad.indices[0, 0] = 10 ** 9
+    with pytest.raises(gpu.MtsamdError):
+        gpu.Scene(bad)
+    bad = S.small_test_scene()
+    bad.integrator["rr_depth"] = 0
+    with pytest.raises(gpu.MtsamdError):
+        gpu.Scene(bad)
+
+
+def test_empty_scene_renders_black(gpu):
+    b = S.SceneBuilder()
+    b.add_material(S.diffuse())
+    sd = S.SceneData(positions=np.zeros((0, 3), np.float32), indices=np.zeros((0, 3), np.uint32), shapes=[], materials=b.materials,
+                     emitters=[], camera=S.make_camera([0, 0, 5], [0, 0, 0], [0, 1, 0], 40), film=S.make_film(16, 16))
+    g = gpu.Scene(sd)
+    film, st = g.render(2)
+    assert st.normal_rays == 16 * 16 * 2 and st.shadow_rays == 0
+    assert np.all(film[..., :4] == 0) and film[..., 4].min() > 0
+
+
+def test_traversal_counters(pairs):
+    sd, g, o = pairs["small"]
+    g.set_counting(True)
+    _, st = g.render(2, seed=1)
+    g.set_counting(False)
+    assert st.node_visits >= st.normal_rays and st.tri_tests > 0
+    assert st.shadow_node_visits >= st.shadow_rays
+
+
+def test_full_size_properties(gpu):
+    """Config-3 geometry at full triangle count, reduced image: properties that need no oracle run --
+    weight channel = samples x filter mass, tile partition invariance, determinism, finite non-negative radiance."""
+    sd = S.config3(480, 270)
+    g = gpu.Scene(sd)
+    info = g.bvh_info()
+    assert info.n_triangles == sd.n_triangles and info.depth <= 23
+    film, st = g.render(8, seed=1)
+    assert np.isfinite(film).all() and film.min() >= 0
+    interior = film[8:-8, 8:-8, 4]
+    assert abs(interior.mean() - 8.0) < 0.05
+    parts = np.zeros_like(film)
+    from mitsuba_amd import render
+    for rank in range(2):
+        for r in render.band_schedule(480, 270, 2, rank, 2):
+            g.render(8, film=parts, seed=1, rect=r)
+    assert np.allclose(parts, film, rtol=1e-5, atol=1e-6)
+    assert st.normal_rays > st.paths and st.shadow_rays > 0
