@@ -1,0 +1,258 @@
+/*
+ * path_amd -- Mitsuba 0.5 integrator plugin that runs the `path` integrator's render job on an MI355X through
+ * libmtsamd.so. Drop this file into src/integrators/path/ of a Mitsuba 0.5 tree, add
+ *     plugins += env.SharedLibrary('path_amd', ['path/path_amd.cpp'], LIBS=env['LIBS']+['mtsamd'])
+ * to src/integrators/SConscript, and use <integrator type="path_amd"> with the parameters of `path`.
+ *
+ * It is NOT compiled in this repository (a Mitsuba build needs Boost/Xerces/OpenEXR); it documents, in compilable
+ * form against the 0.5 headers, the binding a maintainer adds. Interfaces used on the Mitsuba side:
+ *   Integrator::render / cancel                      include/mitsuba/render/integrator.h:70-84
+ *   MonteCarloIntegrator members                     src/librender/integrator.cpp:190-225
+ *   Scene::getMeshes/getShapes/getEmitters/getSensor include/mitsuba/render/scene.h
+ *   TriMesh getters                                  include/mitsuba/render/trimesh.h:120-155
+ *   ConfigurableObject::getProperties                include/mitsuba/core/cobject.h:77
+ *   Film::setBitmap                                  include/mitsuba/render/film.h:55
+ */
+#include <mitsuba/render/scene.h>
+#include <mitsuba/render/trimesh.h>
+#include <mitsuba/render/renderqueue.h>
+#include <mitsuba/core/fresolver.h>
+#include <mitsuba/core/fstream.h>
+#include <mitsuba/core/statistics.h>
+#include <mtsamd.h>
+#include <map>
+
+MTS_NAMESPACE_BEGIN
+
+static StatsCounter amdNormalRays("MI355X path tracer", "Normal rays traced");
+static StatsCounter amdShadowRays("MI355X path tracer", "Shadow rays traced");
+
+class PathTracerAMD : public MonteCarloIntegrator {
+public:
+	PathTracerAMD(const Properties &props) : MonteCarloIntegrator(props), m_handle(NULL) {
+		m_device = props.getInteger("device", 0);
+		m_seed = (uint32_t) props.getInteger("seed", 1);
+	}
+
+	PathTracerAMD(Stream *stream, InstanceManager *manager) : MonteCarloIntegrator(stream, manager), m_handle(NULL) {
+		m_device = stream->readInt();
+		m_seed = stream->readUInt();
+	}
+
+	void serialize(Stream *stream, InstanceManager *manager) const {
+		MonteCarloIntegrator::serialize(stream, manager);
+		stream->writeInt(m_device);
+		stream->writeUInt(m_seed);
+	}
+
+	virtual ~PathTracerAMD() { if (m_handle) mtsamd_scene_destroy(m_handle); }
+
+	/* The CPU path of SamplingIntegrator is not used; Li exists only to satisfy the interface. */
+	Spectrum Li(const RayDifferential &, RadianceQueryRecord &) const {
+		Log(EError, "path_amd renders whole jobs on the GPU; Li() is not available");
+		return Spectrum(0.0f);
+	}
+
+	bool render(Scene *scene, RenderQueue *queue, const RenderJob *job, int sceneResID, int sensorResID, int samplerResID) {
+		if (mtsamd_init(m_device) != MTSAMD_OK)
+			Log(EError, "%s", mtsamd_last_error());
+		if (!m_handle && !upload(scene))
+			return false;
+
+		Film *film = scene->getSensor()->getFilm();
+		const Vector2i size = film->getCropSize();
+		const size_t spp = scene->getSampler()->getSampleCount();
+		ref<Bitmap> accum = new Bitmap(Bitmap::EMultiChannel, Bitmap::EFloat32, size, 5);
+		accum->clear();
+
+		mtsamd_render_opts opts;
+		memset(&opts, 0, sizeof(opts));
+		opts.spp = opts.spp_total = (int32_t) spp;
+		opts.seed = m_seed;
+		mtsamd_stats st;
+		int rv = mtsamd_render(m_handle, &opts, accum->getFloat32Data(), &st);
+		if (rv == MTSAMD_ECANCELLED)
+			return false;
+		if (rv != MTSAMD_OK)
+			Log(EError, "%s", mtsamd_last_error());
+		amdNormalRays += st.normal_rays;
+		amdShadowRays += st.shadow_rays;
+
+		/* (R,G,B,alpha,weight) is HDRFilm's ESpectrumAlphaWeight storage when Spectrum is RGB
+		   (src/films/hdrfilm.cpp:351-356); setBitmap stores it and develop() divides by the weight. */
+		ref<Bitmap> storage = new Bitmap(Bitmap::ESpectrumAlphaWeight, Bitmap::EFloat32, size);
+		memcpy(storage->getFloat32Data(), accum->getFloat32Data(), (size_t) size.x * size.y * 5 * sizeof(float));
+		film->setBitmap(storage);
+		queue->signalRefresh(job);
+		return true;
+	}
+
+	void cancel() { if (m_handle) mtsamd_cancel(m_handle); }
+
+	MTS_DECLARE_CLASS()
+private:
+	static void rgb(const Spectrum &s, float out[3]) { Float r, g, b; s.toLinearRGB(r, g, b); out[0] = r; out[1] = g; out[2] = b; }
+
+	static int distribution(const Properties &p) {
+		std::string d = boost::to_lower_copy(p.getString("distribution", "beckmann"));
+		if (d == "beckmann") return MTSAMD_DISTR_BECKMANN;
+		if (d == "ggx") return MTSAMD_DISTR_GGX;
+		SLog(EError, "path_amd: microfacet distribution \"%s\" is not supported", d.c_str());
+		return -1;
+	}
+
+	/* Constructor-level parameters come from the Properties each plugin was created with; the derived state
+	   (energy-conservation scale, sampling weights, eta ratios) is recomputed by the library as configure() does. */
+	bool material(const BSDF *bsdf, mtsamd_material &m, std::vector<std::vector<float> > &tables) {
+		const Properties &p = bsdf->getProperties();
+		const std::string type = p.getPluginName();
+		memset(&m, 0, sizeof(m));
+		m.sample_visible = p.getBoolean("sampleVisible", true) ? 1 : 0;
+		m.ensure_energy_conservation = p.getBoolean("ensureEnergyConservation", true) ? 1 : 0;
+		if (type == "diffuse") {
+			m.type = MTSAMD_BSDF_DIFFUSE;
+			rgb(p.getSpectrum(p.hasProperty("reflectance") ? "reflectance" : "diffuseReflectance", Spectrum(.5f)), m.diffuse_reflectance);
+		} else if (type == "roughconductor") {
+			m.type = MTSAMD_BSDF_ROUGHCONDUCTOR;
+			m.distribution = distribution(p);
+			Float a = p.getFloat("alpha", 0.1f);
+			m.alpha_u = p.getFloat("alphaU", a); m.alpha_v = p.getFloat("alphaV", a);
+			rgb(p.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular_reflectance);
+			rgb(p.getSpectrum("eta", Spectrum(0.0f)), m.eta);      /* "material" presets: resolve to eta/k first */
+			rgb(p.getSpectrum("k", Spectrum(1.0f)), m.k);
+			m.ext_eta = p.getFloat("extEta", 1.000277f);
+		} else if (type == "roughplastic") {
+			m.type = MTSAMD_BSDF_ROUGHPLASTIC;
+			m.distribution = distribution(p);
+			m.alpha_u = m.alpha_v = p.getFloat("alpha", 0.1f);
+			m.int_ior = p.getFloat("intIOR", 1.49f); m.ext_ior = p.getFloat("extIOR", 1.000277f);
+			m.variant = p.getBoolean("nonlinear", false) ? 1 : 0;
+			rgb(p.getSpectrum("diffuseReflectance", Spectrum(.5f)), m.diffuse_reflectance);
+			rgb(p.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular_reflectance);
+			/* RoughPlastic::configure loads data/microfacet/<distr>.dat through the file resolver (roughplastic.cpp:281-299) */
+			fs::path path = Thread::getThread()->getFileResolver()->resolve(
+				std::string("data/microfacet/") + (m.distribution == MTSAMD_DISTR_GGX ? "ggx" : "beckmann") + ".dat");
+			ref<FileStream> fs = new FileStream(path, FileStream::EReadOnly);
+			std::vector<uint8_t> dat(fs->getSize());
+			fs->read(&dat[0], dat.size());
+			tables.push_back(std::vector<float>(256));
+			uint32_t n = 0;
+			if (mtsamd_rtrans_reduce(&dat[0], dat.size(), m.int_ior / m.ext_ior, m.alpha_u, &tables.back()[0], 256, &n,
+			                         &m.rtrans_diffuse_ext, &m.rtrans_diffuse_int) != MTSAMD_OK)
+				Log(EError, "%s", mtsamd_last_error());
+			m.rtrans = &tables.back()[0]; m.rtrans_n = n;
+		} else if (type == "dielectric") {
+			m.type = MTSAMD_BSDF_DIELECTRIC;
+			m.int_ior = p.getFloat("intIOR", 1.5046f); m.ext_ior = p.getFloat("extIOR", 1.000277f);
+			rgb(p.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular_reflectance);
+			rgb(p.getSpectrum("specularTransmittance", Spectrum(1.0f)), m.specular_transmittance);
+		} else if (type == "ward") {
+			m.type = MTSAMD_BSDF_WARD;
+			std::string v = boost::to_lower_copy(p.getString("variant", "balanced"));
+			m.variant = v == "ward" ? 0 : v == "ward-duer" ? 1 : 2;
+			m.alpha_u = p.getFloat("alphaU", .1f); m.alpha_v = p.getFloat("alphaV", .1f);
+			rgb(p.getSpectrum("diffuseReflectance", Spectrum(.5f)), m.diffuse_reflectance);
+			rgb(p.getSpectrum("specularReflectance", Spectrum(.2f)), m.specular_reflectance);
+		} else {
+			Log(EWarn, "path_amd: BSDF plugin \"%s\" is not on the GPU path", type.c_str());
+			return false;
+		}
+		return true;
+	}
+
+	bool upload(Scene *scene) {
+		const std::vector<TriMesh *> &meshes = scene->getMeshes();
+		if (meshes.size() != scene->getShapes().size()) {
+			Log(EWarn, "path_amd: only triangle meshes are supported"); return false;
+		}
+		std::vector<float> pos, nrm, uv;
+		std::vector<uint32_t> idx;
+		std::vector<mtsamd_shape> shapes;
+		std::vector<mtsamd_material> materials;
+		std::vector<mtsamd_emitter> emitters;
+		std::vector<std::vector<float> > tables;
+		tables.reserve(meshes.size());
+		std::map<const BSDF *, int> bsdfIds;
+		bool anyN = false, anyUV = false;
+		for (size_t i = 0; i < meshes.size(); ++i) { anyN |= meshes[i]->hasVertexNormals(); anyUV |= meshes[i]->hasVertexTexcoords(); }
+
+		for (size_t i = 0; i < meshes.size(); ++i) {
+			const TriMesh *mesh = meshes[i];
+			const uint32_t base = (uint32_t) (pos.size() / 3);
+			mtsamd_shape s;
+			s.first_triangle = (uint32_t) (idx.size() / 3);
+			s.n_triangles = (uint32_t) mesh->getTriangleCount();
+			s.flags = (mesh->hasVertexNormals() ? MTSAMD_SHAPE_HAS_NORMALS : 0) | (mesh->hasVertexTexcoords() ? MTSAMD_SHAPE_HAS_TEXCOORDS : 0);
+			for (size_t v = 0; v < mesh->getVertexCount(); ++v) {
+				const Point &p = mesh->getVertexPositions()[v];
+				pos.push_back(p.x); pos.push_back(p.y); pos.push_back(p.z);
+				if (anyN) { Normal n = mesh->hasVertexNormals() ? mesh->getVertexNormals()[v] : Normal(0.0f); nrm.push_back(n.x); nrm.push_back(n.y); nrm.push_back(n.z); }
+				if (anyUV) { Point2 t = mesh->hasVertexTexcoords() ? mesh->getVertexTexcoords()[v] : Point2(0.0f); uv.push_back(t.x); uv.push_back(t.y); }
+			}
+			for (size_t t = 0; t < mesh->getTriangleCount(); ++t)
+				for (int k = 0; k < 3; ++k)
+					idx.push_back(base + mesh->getTriangles()[t].idx[k]);
+
+			const BSDF *bsdf = mesh->getBSDF();
+			if (!bsdfIds.count(bsdf)) {
+				mtsamd_material m;
+				if (!material(bsdf, m, tables)) return false;
+				bsdfIds[bsdf] = (int) materials.size();
+				materials.push_back(m);
+			}
+			s.material = bsdfIds[bsdf];
+			s.emitter = -1;
+			if (mesh->isEmitter()) {
+				const Emitter *e = mesh->getEmitter();
+				if (e->getProperties().getPluginName() != "area") { Log(EWarn, "path_amd: only area emitters are supported"); return false; }
+				mtsamd_emitter me;
+				me.shape = (int32_t) i;
+				rgb(e->getProperties().getSpectrum("radiance", Spectrum::getD65()), me.radiance);
+				me.sampling_weight = e->getSamplingWeight();
+				s.emitter = (int32_t) emitters.size();
+				emitters.push_back(me);
+			}
+			shapes.push_back(s);
+		}
+		if (emitters.size() != scene->getEmitters().size()) {
+			Log(EWarn, "path_amd: environment / delta emitters are not supported"); return false;
+		}
+
+		mtsamd_scene_desc d;
+		memset(&d, 0, sizeof(d));
+		d.n_vertices = (uint32_t) (pos.size() / 3); d.n_triangles = (uint32_t) (idx.size() / 3);
+		d.n_shapes = (uint32_t) shapes.size(); d.n_materials = (uint32_t) materials.size(); d.n_emitters = (uint32_t) emitters.size();
+		d.positions = &pos[0]; d.normals = anyN ? &nrm[0] : NULL; d.texcoords = anyUV ? &uv[0] : NULL; d.indices = &idx[0];
+		d.shapes = &shapes[0]; d.materials = &materials[0]; d.emitters = emitters.empty() ? NULL : &emitters[0];
+
+		const PerspectiveCamera *cam = dynamic_cast<const PerspectiveCamera *>(scene->getSensor());
+		if (!cam) { Log(EWarn, "path_amd: only the perspective sensor is supported"); return false; }
+		const Matrix4x4 &m = cam->getWorldTransform()->eval(0).getMatrix();
+		for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) d.camera.to_world[4 * r + c] = m(r, c);
+		d.camera.x_fov = cam->getXFov(); d.camera.near_clip = cam->getNearClip(); d.camera.far_clip = cam->getFarClip();
+
+		const Film *film = cam->getFilm();
+		d.film.width = film->getSize().x; d.film.height = film->getSize().y;
+		d.film.crop_x = film->getCropOffset().x; d.film.crop_y = film->getCropOffset().y;
+		d.film.crop_w = film->getCropSize().x; d.film.crop_h = film->getCropSize().y;
+		const ReconstructionFilter *rf = film->getReconstructionFilter();
+		d.film.filter_radius = rf->getRadius();
+		for (int i = 0; i < 32; ++i)   /* same discretisation as ReconstructionFilter::configure (rfilter.cpp:37-55) */
+			d.film.filter_values[i] = i < 31 ? rf->evalDiscretized(rf->getRadius() * i / 31.0f) : 0.0f;
+
+		d.integrator.max_depth = m_maxDepth; d.integrator.rr_depth = m_rrDepth;
+		d.integrator.strict_normals = m_strictNormals; d.integrator.hide_emitters = m_hideEmitters;
+
+		if (mtsamd_scene_create(&d, &m_handle) != MTSAMD_OK)
+			Log(EError, "%s", mtsamd_last_error());
+		return true;
+	}
+
+	mtsamd_scene *m_handle;
+	int m_device;
+	uint32_t m_seed;
+};
+
+MTS_IMPLEMENT_CLASS_S(PathTracerAMD, false, MonteCarloIntegrator)
+MTS_EXPORT_PLUGIN(PathTracerAMD, "MI355X path tracer");
+MTS_NAMESPACE_END
