@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--workload", default="config3")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp-step", type=int, default=8, help="samples per pixel per step and GPU")
+    ap.add_argument("--spp-step", type=int, default=32, help="samples per pixel per step and GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()

@@ -36,8 +36,9 @@ struct Prim { Box box; float c[3]; uint32_t tri; };
 
 struct Node2 {
     Box box;
-    uint32_t left = 0, right = 0;   // children (internal)
-    uint32_t first = 0, count = 0;  // prim range (leaf when count > 0)
+    uint32_t left = 0, right = 0;   // children; left == 0 marks a single-triangle leaf of the binary tree
+    uint32_t first = 0, count = 0;  // primitive range of the whole subtree
+    bool isLeaf() const { return left == 0; }
 };
 
 const float kCostNode = 1.0f, kCostTri = 0.3f;
@@ -59,7 +60,8 @@ struct Builder2 {
         box.reset(); cbox.reset();
         for (uint32_t i = first; i < first + count; ++i) { box.grow(prims[i].box); cbox.grow(prims[i].c); }
         node.box = box;
-        if (count == 1) { node.first = first; node.count = count; return; }
+        node.first = first; node.count = count;     // primitive range of the subtree (kept for internal nodes too)
+        if (count == 1) return;
 
         // binned SAH over the centroid bounds
         int bestAxis = -1, bestBin = -1;
@@ -90,12 +92,6 @@ struct Builder2 {
                 float cost = acc.area() * (float) n + rightArea[b + 1] * (float) rightCount[b + 1];
                 if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = b; }
             }
-        }
-        float area = box.area();
-        if (count <= kMaxLeaf) {
-            float leafCost = kCostTri * (float) count;
-            float splitCost = bestAxis >= 0 && area > 0 ? kCostNode + kCostTri * bestCost / area : std::numeric_limits<float>::infinity();
-            if (leafCost <= splitCost) { node.first = first; node.count = count; return; }
         }
         uint32_t mid;
         if (bestAxis >= 0) {
@@ -193,7 +189,61 @@ const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *in
     b2.maxThreads = (int) std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     b2.build(0, 0, nTris, 0);
 
-    // ---- collapse to 8-wide -------------------------------------------------------------------------
+    // ---- collapse to 8-wide: dynamic programme over the binary tree -----------------------------------
+    // C(n,i) = least SAH cost of representing the subtree of n by at most i roots of the wide tree
+    // (a root is a leaf of <= kMaxLeaf triangles or a wide node with up to 8 roots below it):
+    //   C(n,1) = min(leaf(n), A(n) * kCostNode + D(n,8)),  D(n,j) = min_k C(left,k) + C(right,j-k),
+    //   C(n,i) = min(D(n,i), C(n,i-1)).
+    // Children carry larger indices than their parents, so a descending sweep is bottom-up.
+    const uint32_t nNodes2 = b2.nextNode.load();
+    struct Dp { float c[8]; uint8_t k[9]; uint8_t take; uint8_t leaf; };    // c[1..7], k[2..8] = left share, take bit j: D(n,j) < C(n,j-1)
+    std::vector<Dp> dp(nNodes2);
+    const float kInfCost = std::numeric_limits<float>::infinity();
+    for (uint32_t n = nNodes2; n-- > 0;) {
+        const Node2 &nd = b2.nodes[n];
+        Dp &d = dp[n];
+        const float area = nd.box.area();
+        if (nd.isLeaf()) {
+            for (int i = 1; i < 8; ++i) d.c[i] = area * kCostTri;
+            d.leaf = 1; d.take = 0;
+            continue;
+        }
+        const Dp &L = dp[nd.left], &R = dp[nd.right];
+        float dist[9];
+        for (int j = 2; j <= 8; ++j) {
+            float best = kInfCost; int bk = 1;
+            for (int k = 1; k < j; ++k) {
+                if (k > 7 || j - k > 7) continue;
+                const float c = L.c[k] + R.c[j - k];
+                if (c < best) { best = c; bk = k; }
+            }
+            dist[j] = best; d.k[j] = (uint8_t) bk;
+        }
+        const float leafCost = nd.count <= kMaxLeaf ? area * kCostTri * (float) nd.count : kInfCost;
+        const float nodeCost = area * kCostNode + dist[8];
+        d.leaf = leafCost <= nodeCost;
+        d.c[1] = std::min(leafCost, nodeCost);
+        d.take = 0;
+        for (int j = 2; j <= 7; ++j) {
+            if (dist[j] < d.c[j - 1]) { d.c[j] = dist[j]; d.take |= (uint8_t) (1u << j); }
+            else d.c[j] = d.c[j - 1];
+        }
+    }
+    // roots of the cheapest representation of subtree n by at most j roots
+    struct Collector {
+        const std::vector<Node2> &nodes; const std::vector<Dp> &dp;
+        void roots(uint32_t n, int j, uint32_t *kids, int &nk) const {
+            while (true) {
+                const Node2 &nd = nodes[n];
+                if (nd.isLeaf() || j == 1) { kids[nk++] = n; return; }
+                if (j <= 7 && !((dp[n].take >> j) & 1)) { --j; continue; }
+                const int k = dp[n].k[j];
+                roots(nd.left, k, kids, nk);
+                n = nd.right; j -= k;
+            }
+        }
+    } collector{ b2.nodes, dp };
+
     struct Work { uint32_t n2; uint32_t wide; uint32_t depth; };
     std::vector<Work> queue;
     out.nodes.reserve(nTris / 4 + 16);
@@ -209,23 +259,12 @@ const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *in
         const Node2 &n2 = b2.nodes[w.n2];
         uint32_t kids[8];
         int nk = 0;
-        if (n2.count > 0) {
-            kids[nk++] = w.n2;      // single-leaf tree
+        if (n2.isLeaf() || (w.n2 == 0 && dp[0].leaf)) {
+            kids[nk++] = w.n2;      // the whole scene fits one leaf
         } else {
-            kids[nk++] = n2.left; kids[nk++] = n2.right;
-            while (nk < 8) {
-                int best = -1; float bestArea = -1;
-                for (int i = 0; i < nk; ++i) {
-                    const Node2 &c = b2.nodes[kids[i]];
-                    if (c.count > 0) continue;
-                    float a = c.box.area();
-                    if (a > bestArea) { bestArea = a; best = i; }
-                }
-                if (best < 0) break;
-                const Node2 &c = b2.nodes[kids[best]];
-                kids[best] = c.left;
-                kids[nk++] = c.right;
-            }
+            const int k = dp[w.n2].k[8];
+            collector.roots(n2.left, k, kids, nk);
+            collector.roots(n2.right, 8 - k, kids, nk);
         }
         // padded child boxes and node bounds
         Box cb[8], nb;
@@ -301,7 +340,7 @@ const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *in
                 node.qlo[a][s] = (uint8_t) lo;
                 node.qhi[a][s] = (uint8_t) hi;
             }
-            if (c.count > 0) {
+            if (dp[kids[i]].leaf) {
                 uint32_t unary = (1u << c.count) - 1u;     // 1 -> 001, 2 -> 011, 3 -> 111
                 node.meta[s] = (uint8_t) ((unary << 5) | triOfs);
                 for (uint32_t j = 0; j < c.count; ++j) {
@@ -324,7 +363,7 @@ const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *in
         // internal children are laid out contiguously in slot order
         for (int s = 0; s < 8; ++s) {
             int i = childAt[s];
-            if (i < 0 || b2.nodes[kids[i]].count > 0) continue;
+            if (i < 0 || dp[kids[i]].leaf) continue;
             uint32_t idx = (uint32_t) out.nodes.size();
             out.nodes.push_back(WideNode());
             queue.push_back({ kids[i], idx, w.depth + 1 });

@@ -1,5 +1,8 @@
-// Ray traversal of the 8-wide quantised BVH: one lane per ray, wave64, a short per-lane stack in LDS that
-// spills to scratch. Replaces ShapeKDTree::rayIntersect + rayIntersectHavran + TriAccel::rayIntersect
+// Ray traversal of the 8-wide quantised BVH on wave64: persistent wavefronts that pull rays from a global counter
+// (idle lanes are refilled as soon as enough of them have finished), one lane per ray, node and triangle work done
+// in separate wave-uniform phases so that lanes with triangles to test wait for each other instead of stalling the
+// box tests, and a short per-lane stack in LDS that spills to scratch.
+// Replaces ShapeKDTree::rayIntersect + rayIntersectHavran + TriAccel::rayIntersect
 // (src/librender/skdtree.cpp:112-142,207-226; include/mitsuba/render/sahkdtree3.h:178-308;
 //  include/mitsuba/render/triaccel.h:96-158).
 #pragma once
@@ -9,9 +12,14 @@ namespace mtsamd {
 
 struct HitRec { float t, u, v; uint32_t tri; };     // tri = global triangle index, 0xFFFFFFFF = miss
 
-static constexpr int kLdsStack = 12;        // entries per lane kept in LDS
+static constexpr int kLdsStack = 8;         // entries per lane kept in LDS
 static constexpr int kSpillStack = 16;      // further entries in scratch
-static constexpr int kTraceBlock = 256;     // threads per workgroup of the traversal kernels
+static constexpr int kNodeFloat4 = 5;       // a wide node is 5 x float4
+// LDS of a traversal workgroup: a copy of the first `topNodes` nodes of the BVH (nodes are stored breadth first, so
+// these are the top levels every ray walks through), then kLdsStack stack entries per lane.
+inline size_t traceLdsBytes(uint32_t topNodes, uint32_t blockThreads) {
+    return (size_t) topNodes * kNodeFloat4 * 16 + (size_t) kLdsStack * blockThreads * 8;
+}
 
 // Ray interval exactly as the reference prepares it before walking the tree: clip against the enlarged
 // scene bounds (AABB::rayIntersect, include/mitsuba/core/aabb.h:308-338), apply the adaptive epsilon when
@@ -46,12 +54,13 @@ MTS_DEV bool rayInterval(const DevScene &sc, V3 o, V3 d, float rayMint, float ra
     return maxt > mint;
 }
 
-// The reference's projection test on a precomputed triangle record, same operation order, no contraction.
+// The reference's projection test on a precomputed triangle record, same operation order, no contraction. Written
+// without early exits so that the three loads of the record are issued together and the wave takes no branches;
+// a degenerate record (k == 3) computes garbage that the final predicate rejects.
 MTS_DEV bool triTest(const float4 r0, const float4 r1, const float4 r2, V3 o, V3 d, float mint, float maxt,
                      float &t, float &u, float &v) {
 #pragma clang fp contract(off)
     const uint32_t k = __float_as_uint(r0.x);
-    if (k > 2u) return false;
     const float n_u = r0.y, n_v = r0.z, n_d = r0.w;
     const float a_u = r1.x, a_v = r1.y, b_nu = r1.z, b_nv = r1.w;
     const float c_nu = r2.x, c_nv = r2.y;
@@ -62,161 +71,282 @@ MTS_DEV bool triTest(const float4 r0, const float4 r1, const float4 r2, V3 o, V3
     const float d_v = k == 0 ? d.z : (k == 1 ? d.x : d.y);
     const float d_k = k == 0 ? d.x : (k == 1 ? d.y : d.z);
     t = (n_d - o_u * n_u - o_v * n_v - o_k) / (d_u * n_u + d_v * n_v + d_k);
-    if (t < mint || t > maxt) return false;
     const float hu = o_u + t * d_u - a_u;
     const float hv = o_v + t * d_v - a_v;
     u = hv * b_nu + hu * b_nv;
     v = hu * c_nu + hv * c_nv;
-    return u >= 0 && v >= 0 && u + v <= 1.0f;
+    return (k <= 2u) & !(t < mint) & !(t > maxt) & (u >= 0) & (v >= 0) & (u + v <= 1.0f);
 }
 
-// Per-lane traversal stack: first kLdsStack entries in LDS (lane-strided, conflict free), the rest in scratch.
-struct TravStack {
-    uint2 *lds;                 // &ldsStack[0][threadIdx.x]
-    uint2 spill[kSpillStack];
-    int sp;
-    MTS_DEV void push(uint2 e) {
-        if (sp < kLdsStack) lds[sp * kTraceBlock] = e;
-        else if (sp - kLdsStack < kSpillStack) spill[sp - kLdsStack] = e;
-        ++sp;
-    }
-    MTS_DEV uint2 pop() {
-        --sp;
-        if (sp < kLdsStack) return lds[sp * kTraceBlock];
-        return spill[sp - kLdsStack < kSpillStack ? sp - kLdsStack : kSpillStack - 1];
-    }
+typedef __attribute__((address_space(3))) uint2 LdsUint2;
+typedef float __attribute__((ext_vector_type(4))) RawFloat4;
+typedef __attribute__((address_space(3))) RawFloat4 LdsFloat4;
+MTS_DEV float4 toFloat4(RawFloat4 v) { return make_float4(v.x, v.y, v.z, v.w); }
+
+// Per-lane traversal stack: first kLdsStack entries in LDS (lane-strided, conflict free), the rest in scratch. The
+// pieces are separate variables on purpose: kept in one struct, the dynamically indexed spill array drags the stack
+// pointer and the LDS base into scratch memory with it.
+// Index of this lane's column in the LDS stack, recomputed where it is used (two VALU instructions) instead of being
+// carried in a register across the traversal loop.
+MTS_DEV uint32_t stackLane() {
+    return (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x & ~63u)) + __lane_id();
+}
+
+#define MTS_STACK_PUSH(e)                                                                                        \
+    do {                                                                                                         \
+        if (sp < kLdsStack) { ldsStack[sp * blockDim.x + stackLane()].x = (e).x; ldsStack[sp * blockDim.x + stackLane()].y = (e).y; }      \
+        else if (sp - kLdsStack < kSpillStack) spill[sp - kLdsStack] = (e);                                      \
+        ++sp;                                                                                                    \
+    } while (0)
+#define MTS_STACK_POP(e)                                                                                         \
+    do {                                                                                                         \
+        --sp;                                                                                                    \
+        if (sp < kLdsStack) (e) = make_uint2(ldsStack[sp * blockDim.x + stackLane()].x, ldsStack[sp * blockDim.x + stackLane()].y);        \
+        else (e) = spill[sp - kLdsStack < kSpillStack ? sp - kLdsStack : kSpillStack - 1];                       \
+    } while (0)
+
+// State of the ray a lane is working on.
+struct LaneRay {
+    V3 o, d;
+    float idx, idy, idz;        // clamped reciprocal direction (slab tests only)
+    float mint, maxt;           // maxt shrinks to the closest hit found so far
+    uint32_t oct;               // sign octant of the direction
+    HitRec hit;
+    bool found;
+    uint2 ng;                   // node group: x = index of the first internal child, y = imask | pending (priority order) << 8
+    uint2 tg;                   // triangle group: x = first triangle record of the node, y = mask of records still to test
 };
+
+MTS_DEV void laneStart(LaneRay &r, V3 o, V3 d, float mint, float maxt) {
+    r.o = o; r.d = d; r.mint = mint; r.maxt = maxt;
+    // zero components stay finite; signs are taken from the reciprocals so that -0 picks consistent near/far planes
+    const float big = 1e30f;
+    r.idx = fabsf(d.x) > 1e-30f ? 1.0f / d.x : copysignf(big, d.x);
+    r.idy = fabsf(d.y) > 1e-30f ? 1.0f / d.y : copysignf(big, d.y);
+    r.idz = fabsf(d.z) > 1e-30f ? 1.0f / d.z : copysignf(big, d.z);
+    r.oct = (r.idx < 0 ? 1u : 0u) | (r.idy < 0 ? 2u : 0u) | (r.idz < 0 ? 4u : 0u);
+    r.hit.t = kInf; r.hit.u = 0; r.hit.v = 0; r.hit.tri = 0xFFFFFFFFu;
+    r.found = false;
+    // Priority bit k of a node group stands for slot k ^ oct; the root is a pseudo group whose only member sits in slot 0.
+    r.ng = make_uint2(0u, 1u | ((1u << r.oct) << 8));
+    r.tg = make_uint2(0u, 0u);
+}
 
 #define MTS_UBYTE(w, i) ((float) (((w) >> (8 * (i))) & 0xffu))
 
-// Walks the BVH for one ray. ANY_HIT: stop at the first accepted triangle. COUNT: accumulate node visits and
-// triangle tests (profiling builds). Equal-t ties are resolved towards the lowest global triangle index, so the
-// result does not depend on traversal order (the reference keeps the last equal-t triangle in kd-leaf order,
-// sahkdtree3.h:286-291, which depends on its tree).
-template <bool ANY_HIT, bool COUNT>
-MTS_DEV bool traverse(const DevScene &sc, V3 o, V3 d, float mint, float maxt, HitRec &hit, uint2 *ldsStack,
-                      uint32_t &nodeVisits, uint32_t &triTests) {
-    hit.t = kInf; hit.u = 0; hit.v = 0; hit.tri = 0xFFFFFFFFu;
-    bool found = false;
+// Visits the next pending internal child of the lane's node group: box tests of its 8 children, branch free.
+// Children that are hit contribute `meta >> 5` shifted to bit `meta & 31` of a 32-bit mask: leaf children put one bit
+// per triangle record into bits 0..23, internal children one bit into 24 + (slot ^ oct), i.e. already in the
+// visiting order of this ray. Empty slots have meta == 0 and contribute nothing.
+MTS_DEV void visitNode(const DevScene &sc, LaneRay &r, const LdsFloat4 *topTree, uint32_t topNodes, LdsUint2 *ldsStack,
+                       uint2 (&spill)[kSpillStack], int &sp) {
+    const uint32_t pending = r.ng.y >> 8;
+    const uint32_t kbit = __ffs((int) pending) - 1;
+    r.ng.y &= ~(0x100u << kbit);
+    const uint32_t slot = kbit ^ r.oct;
+    const uint32_t nodeIdx = r.ng.x + __popc(r.ng.y & 0xffu & ((1u << slot) - 1u));
 
-    // reciprocal direction for the slab tests only (clamped so that zero components stay finite)
-    const float big = 1e30f;
-    const float idx = fabsf(d.x) > 1e-30f ? 1.0f / d.x : copysignf(big, d.x);
-    const float idy = fabsf(d.y) > 1e-30f ? 1.0f / d.y : copysignf(big, d.y);
-    const float idz = fabsf(d.z) > 1e-30f ? 1.0f / d.z : copysignf(big, d.z);
-    // signs are taken from the reciprocals so that -0 components pick consistent near/far planes
-    const bool nx = idx < 0, ny = idy < 0, nz = idz < 0;
-    const uint32_t oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+    float4 n0, n1, n2, n3, n4;
+    if (nodeIdx < topNodes) {       // the top of the tree is read from the workgroup's LDS copy
+        const LdsFloat4 *lp = topTree + kNodeFloat4 * nodeIdx;
+        n0 = toFloat4(lp[0]); n1 = toFloat4(lp[1]); n2 = toFloat4(lp[2]); n3 = toFloat4(lp[3]); n4 = toFloat4(lp[4]);
+    } else {
+        const float4 *np = sc.nodes + kNodeFloat4 * (size_t) nodeIdx;
+        n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
+    }
+    const uint32_t ebits = __float_as_uint(n0.w);
+    const float sx = __uint_as_float((ebits & 0xffu) << 23), sy = __uint_as_float(((ebits >> 8) & 0xffu) << 23),
+                sz = __uint_as_float(((ebits >> 16) & 0xffu) << 23);
+    const uint32_t imask = ebits >> 24;
+    // t = q * as + ap per plane. The far side is scaled up by a few ulps so that rounding in the slab arithmetic can
+    // never cull a box the exact arithmetic would enter (the boxes themselves are padded at build time).
+    const float kFar = 1.0f + 12.0f * 0x1p-23f;
+    const float apx = (n0.x - r.o.x) * r.idx, apy = (n0.y - r.o.y) * r.idy, apz = (n0.z - r.o.z) * r.idz;
+    const float asx = sx * r.idx, asy = sy * r.idy, asz = sz * r.idz;
+    const float fpx = apx * kFar, fpy = apy * kFar, fpz = apz * kFar;
+    const float fsx = asx * kFar, fsy = asy * kFar, fsz = asz * kFar;
+    const float maxtPad = r.maxt * kFar;
+    const bool nx = r.idx < 0, ny = r.idy < 0, nz = r.idz < 0;
+    // near/far plane bytes per axis, two dwords (children 0-3, 4-7) each
+    const uint32_t lox0 = __float_as_uint(n2.x), lox1 = __float_as_uint(n2.y), loy0 = __float_as_uint(n2.z), loy1 = __float_as_uint(n2.w);
+    const uint32_t loz0 = __float_as_uint(n3.x), loz1 = __float_as_uint(n3.y), hix0 = __float_as_uint(n3.z), hix1 = __float_as_uint(n3.w);
+    const uint32_t hiy0 = __float_as_uint(n4.x), hiy1 = __float_as_uint(n4.y), hiz0 = __float_as_uint(n4.z), hiz1 = __float_as_uint(n4.w);
+    const uint32_t nearx[2] = { nx ? hix0 : lox0, nx ? hix1 : lox1 }, farx[2] = { nx ? lox0 : hix0, nx ? lox1 : hix1 };
+    const uint32_t neary[2] = { ny ? hiy0 : loy0, ny ? hiy1 : loy1 }, fary[2] = { ny ? loy0 : hiy0, ny ? loy1 : hiy1 };
+    const uint32_t nearz[2] = { nz ? hiz0 : loz0, nz ? hiz1 : loz1 }, farz[2] = { nz ? loz0 : hiz0, nz ? loz1 : hiz1 };
+    const uint32_t metaw[2] = { __float_as_uint(n1.z), __float_as_uint(n1.w) };
 
-    TravStack st;
-    st.lds = ldsStack;
-    st.sp = 0;
-
-    // current node group: x = index of the first internal child, y = imask | pending (priority space) << 8.
-    // Priority bit k stands for slot k ^ oct; the root is a pseudo group whose only member sits in slot 0.
-    uint2 group = make_uint2(0u, 1u | ((1u << oct) << 8));
-    const float kSlabPad = 4.0f * 0x1p-23f;
-
-    while (true) {
-        uint32_t pending = group.y >> 8;
-        if (pending == 0) {
-            if (st.sp == 0) break;
-            group = st.pop();
-            continue;
-        }
-        // next internal child in priority order
-        const uint32_t kbit = __ffs((int) pending) - 1;
-        pending &= pending - 1;
-        group.y = (group.y & 0xffu) | (pending << 8);
-        const uint32_t slot = kbit ^ oct;
-        const uint32_t nodeIdx = group.x + __popc(group.y & 0xffu & ((1u << slot) - 1u));
-
-        const float4 *np = sc.nodes + 5 * (size_t) nodeIdx;
-        const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-        if (COUNT) nodeVisits++;
-        const uint32_t ebits = __float_as_uint(n0.w);
-        const float sx = __uint_as_float((ebits & 0xffu) << 23), sy = __uint_as_float(((ebits >> 8) & 0xffu) << 23),
-                    sz = __uint_as_float(((ebits >> 16) & 0xffu) << 23);
-        const uint32_t imask = ebits >> 24;
-        const float apx = (n0.x - o.x) * idx, apy = (n0.y - o.y) * idy, apz = (n0.z - o.z) * idz;
-        const float asx = sx * idx, asy = sy * idy, asz = sz * idz;
-        const uint32_t meta0 = __float_as_uint(n1.z), meta1 = __float_as_uint(n1.w);
-        // near/far plane bytes per axis, two dwords (children 0-3, 4-7) each
-        const uint32_t lox0 = __float_as_uint(n2.x), lox1 = __float_as_uint(n2.y), loy0 = __float_as_uint(n2.z), loy1 = __float_as_uint(n2.w);
-        const uint32_t loz0 = __float_as_uint(n3.x), loz1 = __float_as_uint(n3.y), hix0 = __float_as_uint(n3.z), hix1 = __float_as_uint(n3.w);
-        const uint32_t hiy0 = __float_as_uint(n4.x), hiy1 = __float_as_uint(n4.y), hiz0 = __float_as_uint(n4.z), hiz1 = __float_as_uint(n4.w);
-        const uint32_t nearx[2] = { nx ? hix0 : lox0, nx ? hix1 : lox1 }, farx[2] = { nx ? lox0 : hix0, nx ? lox1 : hix1 };
-        const uint32_t neary[2] = { ny ? hiy0 : loy0, ny ? hiy1 : loy1 }, fary[2] = { ny ? loy0 : hiy0, ny ? loy1 : hiy1 };
-        const uint32_t nearz[2] = { nz ? hiz0 : loz0, nz ? hiz1 : loz1 }, farz[2] = { nz ? loz0 : hiz0, nz ? loz1 : hiz1 };
-        const uint32_t metaw[2] = { meta0, meta1 };
-
-        uint32_t childPending = 0, triMask = 0;
+    uint32_t hitmask = 0;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t meta4 = metaw[h];
+        const uint32_t inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;      // internal children have bits 3 and 4 of the index set
+        const uint32_t index4 = (meta4 ^ ((inner4 >> 4) * r.oct)) & 0x1f1f1f1fu;
+        const uint32_t bits4 = (meta4 >> 5) & 0x07070707u;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t meta = (metaw[h] >> (8 * i)) & 0xffu;
-                const float tx0 = __builtin_fmaf(MTS_UBYTE(nearx[h], i), asx, apx), tx1 = __builtin_fmaf(MTS_UBYTE(farx[h], i), asx, apx);
-                const float ty0 = __builtin_fmaf(MTS_UBYTE(neary[h], i), asy, apy), ty1 = __builtin_fmaf(MTS_UBYTE(fary[h], i), asy, apy);
-                const float tz0 = __builtin_fmaf(MTS_UBYTE(nearz[h], i), asz, apz), tz1 = __builtin_fmaf(MTS_UBYTE(farz[h], i), asz, apz);
-                float tn = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, mint));
-                float tf = fminf(fminf(tx1, ty1), fminf(tz1, maxt));
-                // widen by a few ulps so that rounding in the slab arithmetic can never cull a true hit
-                tn = tn - fabsf(tn) * kSlabPad;
-                tf = tf + fabsf(tf) * kSlabPad;
-                if (meta != 0 && tn <= tf) {
-                    const int s = 4 * h + i;
-                    if ((imask >> s) & 1u) childPending |= 1u << ((uint32_t) s ^ oct);
-                    else triMask |= (meta >> 5) << (meta & 31u);
-                }
-            }
-        }
-
-        // triangles of the leaf children that were hit
-        const uint32_t triBase = __float_as_uint(n1.y);
-        while (triMask) {
-            const uint32_t b = __ffs((int) triMask) - 1;
-            triMask &= triMask - 1;
-            const float4 *tp = sc.tris + 3 * (size_t) (triBase + b);
-            const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
-            if (COUNT) triTests++;
-            float t, u, v;
-            if (triTest(r0, r1, r2, o, d, mint, maxt, t, u, v)) {
-                if (ANY_HIT) { hit.t = t; return true; }
-                const uint32_t tri = __float_as_uint(r2.z);
-                if (!(found && t == hit.t && tri >= hit.tri)) {
-                    hit.t = t; hit.u = u; hit.v = v; hit.tri = tri;
-                    maxt = t;
-                    found = true;
-                }
-            }
-        }
-
-        if (childPending) {
-            // descend; siblings still pending in the current group wait on the stack
-            if (group.y >> 8) st.push(group);
-            group = make_uint2(__float_as_uint(n1.x), imask | (childPending << 8));
+        for (int i = 0; i < 4; ++i) {
+            const float tx0 = __builtin_fmaf(MTS_UBYTE(nearx[h], i), asx, apx), tx1 = __builtin_fmaf(MTS_UBYTE(farx[h], i), fsx, fpx);
+            const float ty0 = __builtin_fmaf(MTS_UBYTE(neary[h], i), asy, apy), ty1 = __builtin_fmaf(MTS_UBYTE(fary[h], i), fsy, fpy);
+            const float tz0 = __builtin_fmaf(MTS_UBYTE(nearz[h], i), asz, apz), tz1 = __builtin_fmaf(MTS_UBYTE(farz[h], i), fsz, fpz);
+            const float tn = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, r.mint));
+            const float tf = fminf(fminf(tx1, ty1), fminf(tz1, maxtPad));
+            const uint32_t bits = ((bits4 >> (8 * i)) & 0xffu) << ((index4 >> (8 * i)) & 0xffu);
+            hitmask |= tn <= tf ? bits : 0u;
         }
     }
-    return found;
+
+    const uint32_t triMask = hitmask & 0xffffffu, childPending = hitmask >> 24;
+    r.tg = make_uint2(__float_as_uint(n1.y), triMask);     // the lane's triangle group is empty whenever it visits a node
+    if (childPending) {
+        // descend; siblings still pending in the current group wait on the stack
+        if (r.ng.y >> 8) MTS_STACK_PUSH(r.ng);
+        r.ng = make_uint2(__float_as_uint(n1.x), imask | (childPending << 8));
+    }
 }
 
-// Closest-hit query with the reference's interval preparation.
-template <bool COUNT>
-MTS_DEV bool sceneIntersect(const DevScene &sc, V3 o, V3 d, float rayMint, float rayMaxt, HitRec &hit, uint2 *ldsStack,
-                            uint32_t &nv, uint32_t &nt) {
-    float mint, maxt;
-    hit.t = kInf; hit.u = 0; hit.v = 0; hit.tri = 0xFFFFFFFFu;
-    if (!rayInterval(sc, o, d, rayMint, rayMaxt, false, mint, maxt)) return false;
-    return traverse<false, COUNT>(sc, o, d, mint, maxt, hit, ldsStack, nv, nt);
+// Tests the next triangle record of the lane's triangle group. Equal-t ties are resolved towards the lowest global
+// triangle index, so the result does not depend on traversal order (the reference keeps the last equal-t triangle
+// in kd-leaf order, sahkdtree3.h:286-291, which depends on its tree). Returns true when a hit was accepted.
+MTS_DEV bool testNextTriangle(const DevScene &sc, LaneRay &r) {
+    const uint32_t b = __ffs((int) r.tg.y) - 1;
+    r.tg.y &= r.tg.y - 1;
+    const float4 *tp = sc.tris + 3 * (size_t) (r.tg.x + b);
+    const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
+    float t, u, v;
+    const uint32_t tri = __float_as_uint(r2.z);
+    const bool inside = triTest(r0, r1, r2, r.o, r.d, r.mint, r.maxt, t, u, v);
+    const bool accept = inside & !(r.found & (t == r.hit.t) & (tri >= r.hit.tri));
+    r.hit.t = accept ? t : r.hit.t; r.hit.u = accept ? u : r.hit.u; r.hit.v = accept ? v : r.hit.v;
+    r.hit.tri = accept ? tri : r.hit.tri;
+    r.maxt = accept ? t : r.maxt;
+    r.found |= accept;
+    return accept;
 }
 
-template <bool COUNT>
-MTS_DEV bool sceneOccluded(const DevScene &sc, V3 o, V3 d, float rayMint, float rayMaxt, uint2 *ldsStack, uint32_t &nv, uint32_t &nt) {
-    float mint, maxt;
-    if (!rayInterval(sc, o, d, rayMint, rayMaxt, true, mint, maxt)) return false;
-    HitRec hit;
-    return traverse<true, COUNT>(sc, o, d, mint, maxt, hit, ldsStack, nv, nt);
+// What a traversal kernel does with a finished ray
+enum TraceMode { TRACE_CLOSEST = 0, TRACE_SHADOW_ACCUM = 1, TRACE_OCCLUDED = 2 };
+
+struct TraceArgs {
+    const float4 *rayO, *rayD;      // origin.xyz + mint, direction.xyz + maxt of ray i at [i * stride]
+    uint32_t stride, n;
+    uint32_t topNodes;              // number of leading BVH nodes staged in LDS (<= node count)
+    uint32_t *fetchCounter;         // zero at launch; waves take chunks of `chunk` consecutive rays from it
+    uint32_t chunk;
+    float4 *hits;                   // TRACE_CLOSEST: (t, u, v, triangle) per ray
+    const float4 *contrib;          // TRACE_SHADOW_ACCUM: rgb + sample slot per ray ...
+    float4 *sampleL;                // ... added to sampleL[slot] when the ray is unoccluded
+    uint8_t *occluded;              // TRACE_OCCLUDED: one byte per ray
+    unsigned long long *stats;      // COUNT: [0] node visits, [1] triangle tests
+    uint32_t refillBelow;           // refill idle lanes when fewer than this many lanes hold a ray
+    uint32_t triShare;              // run the triangle phase once this many 64ths of the busy lanes wait for it
+};
+
+template <int MODE>
+MTS_DEV void laneFinish(const TraceArgs &a, uint32_t ray, const LaneRay &r, bool occluded) {
+    if (MODE == TRACE_CLOSEST) {
+        a.hits[ray] = make_float4(r.hit.t, r.hit.u, r.hit.v, __uint_as_float(r.hit.tri));
+    } else if (MODE == TRACE_SHADOW_ACCUM) {
+        if (!occluded) {
+            const float4 c = a.contrib[ray];
+            if (c.x != 0 || c.y != 0 || c.z != 0) {
+                const uint32_t slot = __float_as_uint(c.w);
+                float4 L = a.sampleL[slot];
+                L.x += c.x; L.y += c.y; L.z += c.z;
+                a.sampleL[slot] = L;
+            }
+        }
+    } else {
+        a.occluded[ray] = occluded ? 1 : 0;
+    }
+}
+
+// The traversal loop shared by the closest-hit and the any-hit kernels. Every wavefront runs until the ray counter
+// is exhausted and its own lanes have drained, so the grid may be any size >= 1.
+template <int MODE, bool COUNT>
+MTS_DEV void traceLoop(const DevScene &sc, const TraceArgs &a, LdsFloat4 *topTree, LdsUint2 *ldsStack) {
+    constexpr bool ANY_HIT = MODE != TRACE_CLOSEST;
+    for (uint32_t i = threadIdx.x; i < a.topNodes * kNodeFloat4; i += blockDim.x) { const float4 v = sc.nodes[i]; RawFloat4 w = { v.x, v.y, v.z, v.w }; topTree[i] = w; }
+    __syncthreads();
+    const uint32_t lane = __lane_id();
+    const unsigned long long laneBelow = (1ull << lane) - 1ull;
+    LaneRay r;
+    uint2 spill[kSpillStack];
+    int sp = 0;
+    int ray = -1;               // index of the ray this lane holds, -1 = idle
+    bool exhausted = false;     // wave-uniform: the counter has run past the last ray
+    uint32_t chunkNext = 0, chunkEnd = 0;   // wave-uniform: the part of the wave's current chunk not handed to lanes yet
+    uint32_t nv = 0, nt = 0;
+
+    while (true) {
+        // ---- refill idle lanes from the wave's private chunk of ray indices; a new chunk costs one atomic
+        const bool idle = ray < 0;
+        const unsigned long long idleMask = __ballot(idle);
+        if (!exhausted && idleMask) {
+            if (chunkNext >= chunkEnd) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.fetchCounter, a.chunk);
+                base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+                chunkNext = base < a.n ? base : a.n;
+                chunkEnd = base + a.chunk < a.n ? base + a.chunk : a.n;
+            }
+            if (chunkNext >= chunkEnd) {
+                exhausted = true;
+            } else {
+                const uint32_t i = chunkNext + (uint32_t) __popcll(idleMask & laneBelow);
+                chunkNext += (uint32_t) __popcll(idleMask);
+                if (idle && i < chunkEnd) {
+                    const float4 ro = a.rayO[(size_t) i * a.stride], rd = a.rayD[(size_t) i * a.stride];
+                    const V3 o = mk(ro.x, ro.y, ro.z), d = mk(rd.x, rd.y, rd.z);
+                    float mint, maxt;
+                    laneStart(r, o, d, 0.0f, 0.0f);
+                    if (rayInterval(sc, o, d, ro.w, rd.w, ANY_HIT, mint, maxt)) {
+                        r.mint = mint; r.maxt = maxt;
+                        sp = 0;
+                        ray = (int) i;
+                    } else {
+                        laneFinish<MODE>(a, i, r, false);
+                    }
+                }
+            }
+        }
+        if (__ballot(ray >= 0) == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        const uint32_t keepAbove = exhausted ? 1u : a.refillBelow;
+
+        // ---- traverse until too few lanes hold a ray
+        while (true) {
+            const bool busy = ray >= 0;
+            const bool hasTri = busy && r.tg.y != 0;
+            const uint32_t nTri = (uint32_t) __popcll(__ballot(hasTri));
+            const uint32_t nBusy = (uint32_t) __popcll(__ballot(busy));
+            if (nBusy < keepAbove) break;
+            if (nTri == nBusy || nTri * 64u >= a.triShare * nBusy) {
+                // triangle phase: one record for every lane that has some
+                if (hasTri) {
+                    if (COUNT) nt++;
+                    const bool accepted = testNextTriangle(sc, r);
+                    if (ANY_HIT && accepted) { laneFinish<MODE>(a, (uint32_t) ray, r, true); ray = -1; r.tg.y = 0; }
+                }
+            } else if (busy && !hasTri) {
+                // node phase: lanes without triangles waiting pop if needed and visit one node
+                bool go = true;
+                if (!(r.ng.y >> 8)) {
+                    if (sp == 0) { laneFinish<MODE>(a, (uint32_t) ray, r, false); ray = -1; go = false; }
+                    else MTS_STACK_POP(r.ng);
+                }
+                if (go) {
+                    if (COUNT) nv++;
+                    visitNode(sc, r, topTree, a.topNodes, ldsStack, spill, sp);
+                }
+            }
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&a.stats[0], (unsigned long long) nv);
+        atomicAdd(&a.stats[1], (unsigned long long) nt);
+    }
 }
 
 }  // namespace mtsamd

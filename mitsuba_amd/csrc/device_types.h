@@ -89,9 +89,10 @@ struct PassParams {
     uint32_t seed;
 };
 
-// counters[] layout in device memory
-// words 0,1: queue counters (uint32); from word 2 on: 64-bit traversal counters (extend nodes, extend triangles,
-// shadow nodes, shadow triangles) addressed as uint64 index 1..4
-enum { CNT_NEXT = 0, CNT_SHADOW = 1, CNT64_EXT_NODES = 1, CNT64_EXT_TRIS = 2, CNT64_SHD_NODES = 3, CNT64_SHD_TRIS = 4, CNT_WORDS = 10 };
+// counters[] layout in device memory: four 32-bit queue counters (next-queue length, shadow-queue length, and the
+// ray hand-out counters of the closest-hit and the any-hit traversal launches), then 64-bit traversal statistics
+// (extend nodes, extend triangles, shadow nodes, shadow triangles) addressed as uint64 index 2..5
+enum { CNT_NEXT = 0, CNT_SHADOW = 1, CNT_EXT_FETCH = 2, CNT_SHD_FETCH = 3, CNT_QUEUE_WORDS = 4,
+       CNT64_EXT_NODES = 2, CNT64_EXT_TRIS = 3, CNT64_SHD_NODES = 4, CNT64_SHD_TRIS = 5, CNT_WORDS = 12 };
 
 }  // namespace mtsamd

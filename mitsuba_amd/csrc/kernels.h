@@ -51,48 +51,16 @@ __global__ void __launch_bounds__(256) k_raygen(DevScene sc, PassParams pp, Path
     samplePos[i] = make_float2(posx, posy);
 }
 
-// ---- K2 extend: closest hit for every live path (Scene::rayIntersect(ray, its)) ---------------------------------------
-template <bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock) k_extend(DevScene sc, PathQueue q, float4 *hits, uint32_t n, unsigned long long *counters) {
-    __shared__ uint2 ldsStack[kLdsStack * kTraceBlock];
-    const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
-    uint32_t nv = 0, nt = 0;
-    if (i < n) {
-        const float4 ro = q.rayO[i], rd = q.rayD[i];
-        HitRec hit;
-        sceneIntersect<COUNT>(sc, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), ro.w, rd.w, hit, ldsStack + threadIdx.x, nv, nt);
-        hits[i] = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
-    }
-    if (COUNT) {
-        atomicAdd(&counters[CNT64_EXT_NODES], (unsigned long long) nv);
-        atomicAdd(&counters[CNT64_EXT_TRIS], (unsigned long long) nt);
-    }
-}
-
-// ---- K4 shadow-connect: any-hit test for the emitter samples; unoccluded ones add their weighted contribution
-//      (the visibility test inside Scene::sampleEmitterDirect, src/librender/scene.cpp:839-843) ----------------------------
-template <bool COUNT>
-__global__ void __launch_bounds__(kTraceBlock) k_shadow(DevScene sc, ShadowQueue sq, float4 *sampleL, uint32_t n, unsigned long long *counters) {
-    __shared__ uint2 ldsStack[kLdsStack * kTraceBlock];
-    const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
-    uint32_t nv = 0, nt = 0;
-    if (i < n) {
-        const float4 ro = sq.rayO[i], rd = sq.rayD[i];
-        const bool occ = sceneOccluded<COUNT>(sc, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), ro.w, rd.w, ldsStack + threadIdx.x, nv, nt);
-        if (!occ) {
-            const float4 c = sq.contrib[i];
-            if (c.x != 0 || c.y != 0 || c.z != 0) {
-                const uint32_t slot = __float_as_uint(c.w);
-                float4 L = sampleL[slot];
-                L.x += c.x; L.y += c.y; L.z += c.z;
-                sampleL[slot] = L;
-            }
-        }
-    }
-    if (COUNT) {
-        atomicAdd(&counters[CNT64_SHD_NODES], (unsigned long long) nv);
-        atomicAdd(&counters[CNT64_SHD_TRIS], (unsigned long long) nt);
-    }
+// ---- K2 extend / K4 shadow-connect / batch queries: one persistent traversal kernel, three ways of finishing a ray.
+//   TRACE_CLOSEST       closest hit for every live path (Scene::rayIntersect(ray, its))
+//   TRACE_SHADOW_ACCUM  any-hit test for the emitter samples; unoccluded ones add their weighted contribution
+//                       (the visibility test inside Scene::sampleEmitterDirect, src/librender/scene.cpp:839-843)
+//   TRACE_OCCLUDED      any-hit test, one byte per ray
+template <int MODE, bool COUNT>
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, 1024), amdgpu_waves_per_eu(6))) k_trace(DevScene sc, TraceArgs a) {
+    extern __shared__ float4 traceLds[];
+    LdsFloat4 *topTree = (LdsFloat4 *) &traceLds[0];
+    traceLoop<MODE, COUNT>(sc, a, topTree, (LdsUint2 *) (topTree + a.topNodes * kNodeFloat4));
 }
 
 // ---- K3 shade: one vertex of MIPathTracer::Li per live path (src/integrators/path/path.cpp:135-287) --------------------
@@ -272,26 +240,75 @@ __global__ void __launch_bounds__(256) k_film(DevScene sc, PassParams pp, const 
     for (int c = 0; c < 5; ++c) dst[c] += acc[c];
 }
 
+// LDS-tiled form of the same gather: a workgroup owns a 16x16 tile of film pixels, stages the samples of the
+// (16+2*border)^2 source pixels around it in LDS (a few samples per pixel at a time, sample-major so that lanes with
+// consecutive x read consecutive LDS words), and every thread walks its neighbourhood from LDS. Each sample is read
+// from memory once per tile that can see it instead of once per film pixel. Dropped samples and source pixels outside
+// the pass rectangle are staged with position +inf, which fails the footprint test.
+static constexpr int kFilmTile = 16;
+static constexpr int kFilmLdsEntries = 2048;
+
+__global__ void __launch_bounds__(256) k_film_tiled(DevScene sc, PassParams pp, const float4 *sampleL, const float2 *samplePos, float *film,
+                                                    int border, int gx0, int gy0, int gw, int gh, int tilesX, int chunk) {
+    __shared__ float4 sL[kFilmLdsEntries];
+    __shared__ float2 sP[kFilmLdsEntries];
+    __shared__ float sFilter[32];
+    const int tid = threadIdx.x;
+    if (tid < 32) sFilter[tid] = sc.filterValues[tid];
+    const int tx = blockIdx.x % tilesX, ty = blockIdx.x / tilesX;
+    const int ox = gx0 + tx * kFilmTile, oy = gy0 + ty * kFilmTile;       // first film pixel of the tile
+    const int rw = kFilmTile + 2 * border, rs = rw * rw;                  // staged region (side, pixels)
+    const int sx0 = ox - border, sy0 = oy - border;
+    const int lx = tid % kFilmTile, ly = tid / kFilmTile;
+    const int x = ox + lx, y = oy + ly;
+    const bool inside = x < gx0 + gw && y < gy0 + gh;
+    const float scaleFactor = 31.0f / sc.filterRadius;
+    const float fx = (float) x, fy = (float) y, r = sc.filterRadius;
+    float acc[5] = { 0, 0, 0, 0, 0 };
+    const float kInfPos = __builtin_inff();
+
+    for (int s0 = 0; s0 < pp.spp; s0 += chunk) {
+        const int cs = min(chunk, pp.spp - s0);
+        __syncthreads();
+        for (int e = tid; e < rs * cs; e += 256) {
+            const int s = e / rs, p = e - s * rs;
+            const int qx = sx0 + p % rw, qy = sy0 + p / rw;
+            float4 L = make_float4(0, 0, 0, 0);
+            float2 pos = make_float2(kInfPos, kInfPos);
+            if (qx >= pp.x0 && qx < pp.x0 + pp.w && qy >= pp.y0 && qy < pp.y0 + pp.h) {
+                const uint32_t slot = ((uint32_t) (qy - pp.y0) * (uint32_t) pp.w + (uint32_t) (qx - pp.x0)) * (uint32_t) pp.spp + (uint32_t) (s0 + s);
+                L = sampleL[slot];
+                const bool ok = isfinite(L.x) && isfinite(L.y) && isfinite(L.z) && isfinite(L.w) && L.x >= 0 && L.y >= 0 && L.z >= 0 && L.w >= 0;
+                if (ok) { const float2 q = samplePos[slot]; pos = make_float2(q.x - 0.5f, q.y - 0.5f); }
+            }
+            sL[e] = L; sP[e] = pos;
+        }
+        __syncthreads();
+        if (inside) {
+            for (int dy = 0; dy <= 2 * border; ++dy)
+                for (int dx = 0; dx <= 2 * border; ++dx) {
+                    const int p = (ly + dy) * rw + (lx + dx);
+                    for (int s = 0; s < cs; ++s) {
+                        const float2 pos = sP[s * rs + p];
+                        // x in [ceil(p - r), floor(p + r)] for an integer x is p - r <= x <= p + r
+                        if (fx < pos.x - r || fx > pos.x + r || fy < pos.y - r || fy > pos.y + r) continue;
+                        const float4 L = sL[s * rs + p];
+                        const float wx = sFilter[min((int) fabsf((fx - pos.x) * scaleFactor), 31)];
+                        const float wy = sFilter[min((int) fabsf((fy - pos.y) * scaleFactor), 31)];
+                        const float w = wx * wy;
+                        acc[0] += w * L.x; acc[1] += w * L.y; acc[2] += w * L.z; acc[3] += w * L.w; acc[4] += w * 1.0f;
+                    }
+                }
+        }
+    }
+    if (inside) {
+        float *dst = film + ((size_t) y * sc.cropW + x) * 5;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) dst[c] += acc[c];
+    }
+}
+
 // ---- batch kernels behind the parity entry points -------------------------------------------------------------------------
-__global__ void __launch_bounds__(kTraceBlock) k_trace_batch(DevScene sc, const float *rays, uint32_t n, float4 *hits) {
-    __shared__ uint2 ldsStack[kLdsStack * kTraceBlock];
-    const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
-    if (i >= n) return;
-    const float *r = rays + 8 * (size_t) i;
-    HitRec hit; uint32_t a = 0, b = 0;
-    sceneIntersect<false>(sc, mk(r[0], r[1], r[2]), mk(r[4], r[5], r[6]), r[3], r[7], hit, ldsStack + threadIdx.x, a, b);
-    hits[i] = make_float4(hit.t, hit.u, hit.v, __uint_as_float(hit.tri));
-}
-
-__global__ void __launch_bounds__(kTraceBlock) k_occluded_batch(DevScene sc, const float *rays, uint32_t n, uint8_t *out) {
-    __shared__ uint2 ldsStack[kLdsStack * kTraceBlock];
-    const uint32_t i = blockIdx.x * kTraceBlock + threadIdx.x;
-    if (i >= n) return;
-    const float *r = rays + 8 * (size_t) i;
-    uint32_t a = 0, b = 0;
-    out[i] = sceneOccluded<false>(sc, mk(r[0], r[1], r[2]), mk(r[4], r[5], r[6]), r[3], r[7], ldsStack + threadIdx.x, a, b) ? 1 : 0;
-}
-
 __global__ void __launch_bounds__(256) k_fill_isect(DevScene sc, const float *rays, const float4 *hits, uint32_t n, mtsamd_intersection *out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

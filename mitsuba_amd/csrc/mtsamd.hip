@@ -73,6 +73,10 @@ struct mtsamd_scene {
     uint32_t *hostCounters = nullptr;     // pinned
     std::atomic<int> cancel{ 0 };
     bool countTraversal = false;
+    // traversal launch shape: persistent workgroups (as many as fit on the device) and the lane-refill / triangle-phase
+    // thresholds of the traversal loop
+    unsigned traceGrid = 0, traceBlock = 256;
+    uint32_t refillBelow = 32, triShare = 24, topNodes = 73, chunkMax = 512;
 
     ~mtsamd_scene() {
         if (stream) (void) hipStreamDestroy(stream);
@@ -174,6 +178,27 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
     s->dev = d;
     const char *ct = getenv("MTSAMD_COUNT_TRAVERSAL");
     s->countTraversal = ct && *ct == '1';
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+        if (const char *e = getenv("MTSAMD_REFILL_BELOW")) s->refillBelow = (uint32_t) std::min(64, std::max(1, atoi(e)));
+        if (const char *e = getenv("MTSAMD_TRI_SHARE")) s->triShare = (uint32_t) std::min(64, std::max(1, atoi(e)));
+        if (const char *e = getenv("MTSAMD_CHUNK_MAX")) s->chunkMax = (uint32_t) std::min(65536, std::max(64, atoi(e)));
+        if (const char *e = getenv("MTSAMD_TOP_NODES")) s->topNodes = (uint32_t) std::min(1800, std::max(0, atoi(e)));
+        if (const char *e = getenv("MTSAMD_TRACE_BLOCK")) s->traceBlock = (unsigned) std::min(1024, std::max(64, atoi(e) / 64 * 64));
+        s->topNodes = std::min<uint32_t>(s->topNodes, (uint32_t) h.bvh.nodes.size());
+        const size_t lds = traceLdsBytes(s->topNodes, s->traceBlock);
+        if (lds > (size_t) prop.sharedMemPerBlock) {
+            const void *fns[] = { (const void *) k_trace<TRACE_CLOSEST, false>, (const void *) k_trace<TRACE_CLOSEST, true>,
+                                  (const void *) k_trace<TRACE_SHADOW_ACCUM, false>, (const void *) k_trace<TRACE_SHADOW_ACCUM, true>,
+                                  (const void *) k_trace<TRACE_OCCLUDED, false>, (const void *) k_trace<TRACE_OCCLUDED, true> };
+            for (const void *f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        }
+        int perCu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_trace<TRACE_CLOSEST, false>, (int) s->traceBlock, lds));
+        s->traceGrid = (unsigned) std::max(1, perCu) * (unsigned) std::max(1, prop.multiProcessorCount);
+        if (getenv("MTSAMD_VERBOSE")) fprintf(stderr, "mtsamd: trace block %u, %d blocks/CU, %zu B LDS, top %u nodes\n", s->traceBlock, perCu, lds, s->topNodes);
+    }
     *out = s;
     return MTSAMD_OK;
 }
@@ -239,6 +264,19 @@ int checkOpts(const mtsamd_scene *s, const mtsamd_render_opts *o, mtsamd_render_
     return MTSAMD_OK;
 }
 
+// Launches the persistent traversal kernel over n rays. The hand-out counter must be zero when the kernel starts.
+template <int MODE>
+void launchTrace(mtsamd_scene *s, TraceArgs a, hipStream_t st) {
+    a.refillBelow = s->refillBelow; a.triShare = s->triShare; a.topNodes = s->topNodes;
+    const unsigned grid = std::min(s->traceGrid, blocksFor(a.n, s->traceBlock));
+    // chunk of rays a wave takes per atomic: large enough to make the counter cheap, small enough to balance the tail
+    const uint64_t waves = (uint64_t) grid * (s->traceBlock / 64);
+    a.chunk = (uint32_t) std::min<uint64_t>(s->chunkMax, std::max<uint64_t>(64, (a.n / (waves * 8)) / 64 * 64));
+    const size_t lds = traceLdsBytes(s->topNodes, s->traceBlock);
+    if (s->countTraversal) hipLaunchKernelGGL((k_trace<MODE, true>), dim3(grid), dim3(s->traceBlock), lds, st, s->dev, a);
+    else hipLaunchKernelGGL((k_trace<MODE, false>), dim3(grid), dim3(s->traceBlock), lds, st, s->dev, a);
+}
+
 // One pass: `pp.spp` samples for every pixel of the rectangle. When liOut is non-null the per-sample radiance is
 // copied out instead of being filtered into a film.
 int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liOut, float *liPos, size_t liOffset,
@@ -258,20 +296,26 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
 
     uint32_t n = (uint32_t) nPaths;
     int cur = 0;
+    HIP_TRY(hipMemsetAsync(cnt, 0, CNT_QUEUE_WORDS * sizeof(uint32_t), st));
     timer.begin(T_RAYGEN);
     hipLaunchKernelGGL(k_raygen, dim3(blocksFor(n, 256)), dim3(256), 0, st, sc, pp, s->queue(cur), sampleL, samplePos, n);
     timer.end(T_RAYGEN);
 
     uint64_t normalRays = 0, shadowRays = 0, iterations = 0;
+    const bool traceIters = getenv("MTSAMD_TRACE_ITERS") != nullptr;
     while (n > 0) {
         if (s->cancel.load()) { (void) hipStreamSynchronize(st); return fail(MTSAMD_ECANCELLED, "render cancelled"); }
         PathQueue qin = s->queue(cur), qout = s->queue(cur ^ 1);
+        TraceArgs ta;
+        memset(&ta, 0, sizeof(ta));
+        ta.rayO = qin.rayO; ta.rayD = qin.rayD; ta.stride = 1; ta.n = n;
+        ta.fetchCounter = cnt + CNT_EXT_FETCH; ta.hits = hits; ta.stats = cnt64 + CNT64_EXT_NODES;
         timer.begin(T_EXTEND);
-        if (s->countTraversal) hipLaunchKernelGGL(k_extend<true>, dim3(blocksFor(n, kTraceBlock)), dim3(kTraceBlock), 0, st, sc, qin, hits, n, cnt64);
-        else hipLaunchKernelGGL(k_extend<false>, dim3(blocksFor(n, kTraceBlock)), dim3(kTraceBlock), 0, st, sc, qin, hits, n, cnt64);
+        launchTrace<TRACE_CLOSEST>(s, ta, st);
         timer.end(T_EXTEND);
         normalRays += n;
-        HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), st));
+        // queue lengths and both ray hand-out counters start from zero for the rest of this bounce and the next extend
+        HIP_TRY(hipMemsetAsync(cnt, 0, CNT_QUEUE_WORDS * sizeof(uint32_t), st));
         timer.begin(T_SHADE);
         hipLaunchKernelGGL(k_shade, dim3(blocksFor(n, 256)), dim3(256), 0, st, sc, pp, qin, hits, qout, sq, sampleL, cnt, n);
         timer.end(T_SHADE);
@@ -279,13 +323,16 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         HIP_TRY(hipStreamSynchronize(st));
         const uint32_t nNext = s->hostCounters[CNT_NEXT], nShadow = s->hostCounters[CNT_SHADOW];
         if (nShadow) {
+            TraceArgs sa;
+            memset(&sa, 0, sizeof(sa));
+            sa.rayO = sq.rayO; sa.rayD = sq.rayD; sa.stride = 1; sa.n = nShadow;
+            sa.fetchCounter = cnt + CNT_SHD_FETCH; sa.contrib = sq.contrib; sa.sampleL = sampleL; sa.stats = cnt64 + CNT64_SHD_NODES;
             timer.begin(T_SHADOW);
-            if (s->countTraversal) hipLaunchKernelGGL(k_shadow<true>, dim3(blocksFor(nShadow, kTraceBlock)), dim3(kTraceBlock), 0, st, sc, sq, sampleL, nShadow, cnt64);
-            else hipLaunchKernelGGL(k_shadow<false>, dim3(blocksFor(nShadow, kTraceBlock)), dim3(kTraceBlock), 0, st, sc, sq, sampleL, nShadow, cnt64);
+            launchTrace<TRACE_SHADOW_ACCUM>(s, sa, st);
             timer.end(T_SHADOW);
             shadowRays += nShadow;
         }
-        if (getenv("MTSAMD_TRACE_ITERS")) fprintf(stderr, "iter %llu n=%u shadow=%u next=%u\n", (unsigned long long) iterations, n, nShadow, nNext);
+        if (traceIters) fprintf(stderr, "iter %llu n=%u shadow=%u next=%u\n", (unsigned long long) iterations, n, nShadow, nNext);
         n = nNext;
         cur ^= 1;
         ++iterations;
@@ -297,8 +344,16 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         const int gx0 = std::max(pp.x0 - border, 0), gy0 = std::max(pp.y0 - border, 0);
         const int gx1 = std::min(pp.x0 + pp.w + border, sc.cropW), gy1 = std::min(pp.y0 + pp.h + border, sc.cropH);
         const size_t npx = (size_t) (gx1 - gx0) * (gy1 - gy0);
+        const int rw = kFilmTile + 2 * border;
         timer.begin(T_FILM);
-        hipLaunchKernelGGL(k_film, dim3(blocksFor(npx, 256)), dim3(256), 0, st, sc, pp, sampleL, samplePos, filmDev);
+        if (rw * rw <= kFilmLdsEntries) {
+            const int chunk = std::max(1, std::min(pp.spp, kFilmLdsEntries / (rw * rw)));
+            const int tilesX = (gx1 - gx0 + kFilmTile - 1) / kFilmTile, tilesY = (gy1 - gy0 + kFilmTile - 1) / kFilmTile;
+            hipLaunchKernelGGL(k_film_tiled, dim3((unsigned) (tilesX * tilesY)), dim3(256), 0, st, sc, pp, sampleL, samplePos, filmDev,
+                               border, gx0, gy0, gx1 - gx0, gy1 - gy0, tilesX, chunk);
+        } else {    // very wide filters: the staged region would not fit in LDS
+            hipLaunchKernelGGL(k_film, dim3(blocksFor(npx, 256)), dim3(256), 0, st, sc, pp, sampleL, samplePos, filmDev);
+        }
         timer.end(T_FILM);
     }
     HIP_TRY(hipGetLastError());
@@ -320,7 +375,7 @@ int renderCommon(mtsamd_scene *s, const mtsamd_render_opts *opts, float *filmDev
     const int w = o.x1 - o.x0, h = o.y1 - o.y0;
     int sppPass = o.spp_per_pass;
     if (sppPass <= 0) {
-        const size_t target = 16u << 20;    // paths in flight per pass
+        const size_t target = 64u << 20;    // paths in flight per pass
         sppPass = (int) std::max<size_t>(1, std::min<size_t>((size_t) o.spp, target / ((size_t) w * h)));
     }
     sppPass = std::min(sppPass, o.spp);
@@ -430,6 +485,20 @@ int finish(hipStream_t st) {
     return MTSAMD_OK;
 }
 
+// Batch query over host-layout rays (8 floats each: origin, mint, direction, maxt) already on the device.
+template <int MODE>
+int traceBatch(mtsamd_scene *s, const void *raysDev, uint64_t n, float4 *hitsDev, uint8_t *occludedDev) {
+    uint32_t *cnt = s->counters.as<uint32_t>();
+    HIP_TRY(hipMemsetAsync(cnt + CNT_EXT_FETCH, 0, sizeof(uint32_t), s->stream));
+    TraceArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rayO = (const float4 *) raysDev; a.rayD = a.rayO + 1; a.stride = 2; a.n = (uint32_t) n;
+    a.fetchCounter = cnt + CNT_EXT_FETCH; a.hits = hitsDev; a.occluded = occludedDev;
+    a.stats = s->counters.as<unsigned long long>() + CNT64_EXT_NODES;
+    launchTrace<MODE>(s, a, s->stream);
+    return MTSAMD_OK;
+}
+
 int checkBatch(mtsamd_scene *s, uint64_t n) {
     if (!s) return fail(MTSAMD_EINVAL, "null scene");
     if (n >= (1ull << 31)) return fail(MTSAMD_EINVAL, "batch too large");
@@ -445,7 +514,7 @@ extern "C" int mtsamd_trace(mtsamd_scene *s, uint64_t n, const float *rays, mtsa
     if (!rays || !hits) return fail(MTSAMD_EINVAL, "null argument");
     Staging sg; void *dR, *dH, *dO;
     TRY(sg.in(rays, n * 32, &dR)); TRY(sg.out(n * 16, &dH)); TRY(sg.out(n * sizeof(mtsamd_hit), &dO));
-    hipLaunchKernelGGL(k_trace_batch, dim3(blocksFor(n, kTraceBlock)), dim3(kTraceBlock), 0, s->stream, s->dev, (const float *) dR, (uint32_t) n, (float4 *) dH);
+    TRY(traceBatch<TRACE_CLOSEST>(s, dR, n, (float4 *) dH, nullptr));
     hipLaunchKernelGGL(k_hits_to_records, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, (const float4 *) dH, (uint32_t) n, (mtsamd_hit *) dO);
     TRY(finish(s->stream));
     HIP_TRY(hipMemcpy(hits, dO, n * sizeof(mtsamd_hit), hipMemcpyDeviceToHost));
@@ -458,7 +527,7 @@ extern "C" int mtsamd_occluded(mtsamd_scene *s, uint64_t n, const float *rays, u
     if (!rays || !occluded) return fail(MTSAMD_EINVAL, "null argument");
     Staging sg; void *dR, *dO;
     TRY(sg.in(rays, n * 32, &dR)); TRY(sg.out(n, &dO));
-    hipLaunchKernelGGL(k_occluded_batch, dim3(blocksFor(n, kTraceBlock)), dim3(kTraceBlock), 0, s->stream, s->dev, (const float *) dR, (uint32_t) n, (uint8_t *) dO);
+    TRY(traceBatch<TRACE_OCCLUDED>(s, dR, n, nullptr, (uint8_t *) dO));
     TRY(finish(s->stream));
     HIP_TRY(hipMemcpy(occluded, dO, n, hipMemcpyDeviceToHost));
     return MTSAMD_OK;
@@ -470,7 +539,7 @@ extern "C" int mtsamd_intersect(mtsamd_scene *s, uint64_t n, const float *rays, 
     if (!rays || !its) return fail(MTSAMD_EINVAL, "null argument");
     Staging sg; void *dR, *dH, *dO;
     TRY(sg.in(rays, n * 32, &dR)); TRY(sg.out(n * 16, &dH)); TRY(sg.out(n * sizeof(mtsamd_intersection), &dO));
-    hipLaunchKernelGGL(k_trace_batch, dim3(blocksFor(n, kTraceBlock)), dim3(kTraceBlock), 0, s->stream, s->dev, (const float *) dR, (uint32_t) n, (float4 *) dH);
+    TRY(traceBatch<TRACE_CLOSEST>(s, dR, n, (float4 *) dH, nullptr));
     hipLaunchKernelGGL(k_fill_isect, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, (const float *) dR, (const float4 *) dH, (uint32_t) n, (mtsamd_intersection *) dO);
     TRY(finish(s->stream));
     HIP_TRY(hipMemcpy(its, dO, n * sizeof(mtsamd_intersection), hipMemcpyDeviceToHost));
