@@ -9,43 +9,45 @@ struct Isect {
     V3 p, geoN, wi;
     Frame3 sh;
     float uvx, uvy;
-    uint32_t shape, prim;
+    uint32_t shape, material, flags;
+    int32_t emitter;
 };
 
 // ShapeKDTree::fillIntersectionRecord<true> (include/mitsuba/render/skdtree.h:343-428) + computeShadingFrame
-// (src/libcore/util.cpp:603-608). tri is the global triangle index.
+// (src/libcore/util.cpp:603-608). tri is the global triangle index; everything comes from the triangle's packed
+// shading record, so the six loads go out together.
 MTS_DEV void fillIntersection(const DevScene &sc, uint32_t tri, float u, float v, V3 rayD, Isect &its) {
-    const uint32_t shapeIdx = sc.triShape[tri];
-    const DevShape sh = sc.shapes[shapeIdx];
+    const float4 *g = sc.shadeTris + 6 * (size_t) tri;
+    const float4 g0 = g[0], g1 = g[1], g2 = g[2], h0 = g[3], h1 = g[4], h2 = g[5];
     const float bx = 1 - u - v, by = u, bz = v;
-    const uint32_t i0 = sc.indices[3 * (size_t) tri], i1 = sc.indices[3 * (size_t) tri + 1], i2 = sc.indices[3 * (size_t) tri + 2];
-    const V3 p0 = ld3(sc.positions, i0), p1 = ld3(sc.positions, i1), p2 = ld3(sc.positions, i2);
-    its.shape = shapeIdx;
-    its.prim = tri - sh.firstTri;
+    const V3 p0 = mk(g0.x, g0.y, g0.z), p1 = mk(g1.x, g1.y, g1.z), p2 = mk(g2.x, g2.y, g2.z);
+    its.material = __float_as_uint(g0.w) & 0xffffffu;
+    its.flags = __float_as_uint(g0.w) >> 24;
+    its.emitter = (int32_t) __float_as_uint(g1.w);
+    its.shape = __float_as_uint(g2.w);
     its.p = p0 * bx + p1 * by + p2 * bz;
     const V3 side1 = p1 - p0, side2 = p2 - p0;
     V3 faceNormal = cross(side1, side2);
     const float len = length(faceNormal);
     if (!isZero(faceNormal)) faceNormal = faceNormal / len;
-    V3 dpdu;
-    if (sh.flags & 2u) dpdu = ld3(sc.uvDpdu, tri);   // TriMesh::computeUVTangents result (trimesh.cpp:683-735)
-    else dpdu = side1;
+    V3 dpdu = side1;
+    its.uvx = by; its.uvy = bz;
+    if (its.flags & 2u) {       // TriMesh::computeUVTangents result (trimesh.cpp:683-735) and interpolated texture coordinates
+        const float4 *q = sc.shadeUV + 3 * (size_t) tri;
+        const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+        dpdu = mk(q1.z, q1.w, q2.x);
+        its.uvx = q0.x * bx + q0.z * by + q1.x * bz;
+        its.uvy = q0.y * bx + q0.w * by + q1.y * bz;
+    }
     V3 shN;
-    if (sh.flags & 1u) {
-        const V3 n0 = ld3(sc.normals, i0), n1 = ld3(sc.normals, i1), n2 = ld3(sc.normals, i2);
+    if (its.flags & 1u) {
+        const V3 n0 = mk(h0.x, h0.y, h0.z), n1 = mk(h1.x, h1.y, h1.z), n2 = mk(h2.x, h2.y, h2.z);
         shN = normalize(n0 * bx + n1 * by + n2 * bz);
         if (dot(faceNormal, shN) < 0) faceNormal = -faceNormal;
     } else {
         shN = faceNormal;
     }
     its.geoN = faceNormal;
-    if (sh.flags & 2u) {
-        const float *t = sc.texcoords;
-        its.uvx = t[2 * (size_t) i0] * bx + t[2 * (size_t) i1] * by + t[2 * (size_t) i2] * bz;
-        its.uvy = t[2 * (size_t) i0 + 1] * bx + t[2 * (size_t) i1 + 1] * by + t[2 * (size_t) i2 + 1] * bz;
-    } else {
-        its.uvx = by; its.uvy = bz;
-    }
     its.sh.n = shN;
     its.sh.s = normalize(dpdu - shN * dot(shN, dpdu));
     its.sh.t = cross(shN, its.sh.s);
@@ -573,15 +575,16 @@ MTS_DEV V3 sampleEmitterDirect(const DevScene &sc, V3 ref, V3 refN, float sx, fl
     const DevEmitter em = sc.emitters[index];
     const uint32_t triIdx = cdfSampleReuse(sc.areaCdf + em.cdfOffset, em.nTris, sy, nullptr);
     const uint32_t t = em.firstTri + triIdx;
-    const uint32_t i0 = sc.indices[3 * (size_t) t], i1 = sc.indices[3 * (size_t) t + 1], i2 = sc.indices[3 * (size_t) t + 2];
-    const V3 p0 = ld3(sc.positions, i0), p1 = ld3(sc.positions, i1), p2 = ld3(sc.positions, i2);
+    const float4 *g = sc.shadeTris + 6 * (size_t) t;
+    const float4 g0 = g[0], g1 = g[1], g2 = g[2], h0 = g[3], h1 = g[4], h2 = g[5];
+    const V3 p0 = mk(g0.x, g0.y, g0.z), p1 = mk(g1.x, g1.y, g1.z), p2 = mk(g2.x, g2.y, g2.z);
     const float a = safeSqrt(1.0f - sx);                  // squareToUniformTriangle (warp.cpp:84-87)
     const float baryX = 1 - a, baryY = a * sy;
     const V3 sideA = p1 - p0, sideB = p2 - p0;
     const V3 p = p0 + (sideA * baryX) + (sideB * baryY);
     V3 n;
-    if (sc.shapes[em.shape].flags & 1u) {
-        const V3 n0 = ld3(sc.normals, i0), n1 = ld3(sc.normals, i1), n2 = ld3(sc.normals, i2);
+    if ((__float_as_uint(g0.w) >> 24) & 1u) {
+        const V3 n0 = mk(h0.x, h0.y, h0.z), n1 = mk(h1.x, h1.y, h1.z), n2 = mk(h2.x, h2.y, h2.z);
         n = normalize(n0 * (1.0f - baryX - baryY) + n1 * baryX + n2 * baryY);
     } else {
         n = normalize(cross(sideA, sideB));

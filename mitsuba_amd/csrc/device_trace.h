@@ -10,7 +10,8 @@
 
 namespace mtsamd {
 
-struct HitRec { float t, u, v; uint32_t tri; };     // tri = global triangle index, 0xFFFFFFFF = miss
+struct HitRec { float t, u, v; uint32_t tri; };     // tri = global triangle index | BSDF type << 28, 0xFFFFFFFF = miss
+static constexpr uint32_t kTriIndexMask = 0x0fffffffu;
 
 static constexpr int kLdsStack = 8;         // entries per lane kept in LDS
 static constexpr int kSpillStack = 16;      // further entries in scratch
@@ -213,9 +214,10 @@ MTS_DEV bool testNextTriangle(const DevScene &sc, LaneRay &r) {
     const float4 *tp = sc.tris + 3 * (size_t) (r.tg.x + b);
     const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
     float t, u, v;
-    const uint32_t tri = __float_as_uint(r2.z);
+    // global triangle index in bits 0..27, BSDF type of its material in bits 28..30 (carried along for the shading kernel)
+    const uint32_t tri = __float_as_uint(r2.z) | __float_as_uint(r2.w);
     const bool inside = triTest(r0, r1, r2, r.o, r.d, r.mint, r.maxt, t, u, v);
-    const bool accept = inside & !(r.found & (t == r.hit.t) & (tri >= r.hit.tri));
+    const bool accept = inside & !(r.found & (t == r.hit.t) & ((tri & kTriIndexMask) >= (r.hit.tri & kTriIndexMask)));
     r.hit.t = accept ? t : r.hit.t; r.hit.u = accept ? u : r.hit.u; r.hit.v = accept ? v : r.hit.v;
     r.hit.tri = accept ? tri : r.hit.tri;
     r.maxt = accept ? t : r.maxt;

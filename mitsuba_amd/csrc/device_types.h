@@ -43,12 +43,11 @@ struct DevEmitter {
 struct DevScene {
     const float4 *nodes;        // 5 x float4 per wide node
     const float4 *tris;         // 3 x float4 per triangle record (BVH order)
-    const float *positions;     // 3 per vertex
-    const float *normals;       // 3 per vertex or null
-    const float *texcoords;     // 2 per vertex or null
-    const uint32_t *indices;    // 3 per triangle (global order)
-    const uint32_t *triShape;   // per triangle (global order)
-    const float *uvDpdu;        // 3 per triangle or null (meshes with texcoords)
+    // Shading record of a triangle, global order, 6 x float4: three vertex positions whose w components carry
+    // material | flags << 24, emitter (int, -1 = none) and shape; then three vertex normals (zero without normals).
+    const float4 *shadeTris;
+    // Only when some mesh has texture coordinates, 3 x float4 per triangle: (uv0, uv1), (uv2, dpdu.xy), (dpdu.z, 0, 0, 0)
+    const float4 *shadeUV;
     const DevShape *shapes;
     const DevMaterial *materials;
     const DevEmitter *emitters;

@@ -279,6 +279,30 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
     const char *err = buildBVH(hs.positions.data(), d->n_vertices, hs.indices.data(), d->n_triangles, hs.bvh);
     if (err && *err) return err;
 
+    // ---- packed per-triangle shading records; the BVH's triangle records get the BSDF type in their spare word so
+    //      that a hit carries it (bits 28..30 of the triangle word of a hit) -----------------------------------------
+    if (d->n_triangles >= (1u << 27)) return "too many triangles";
+    hs.shadeTris.assign((size_t) d->n_triangles * 24, 0.0f);
+    if (anyUV) hs.shadeUV.assign((size_t) d->n_triangles * 12, 0.0f);
+    for (uint32_t t = 0; t < d->n_triangles; ++t) {
+        const DevShape &sh = hs.shapes[hs.triShape[t]];
+        float *g = &hs.shadeTris[(size_t) t * 24];
+        const uint32_t w[3] = { (uint32_t) sh.material | (sh.flags << 24), (uint32_t) sh.emitter, hs.triShape[t] };
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t vi = hs.indices[3 * (size_t) t + k];
+            memcpy(g + 4 * k, &hs.positions[3 * (size_t) vi], 12);
+            memcpy(g + 4 * k + 3, &w[k], 4);
+            if (sh.flags & MTSAMD_SHAPE_HAS_NORMALS) memcpy(g + 12 + 4 * k, &hs.normals[3 * (size_t) vi], 12);
+        }
+        if (sh.flags & MTSAMD_SHAPE_HAS_TEXCOORDS) {
+            float *u = &hs.shadeUV[(size_t) t * 12];
+            for (int k = 0; k < 3; ++k) memcpy(u + 2 * k, &hs.texcoords[2 * (size_t) hs.indices[3 * (size_t) t + k]], 8);
+            memcpy(u + 6, &hs.uvDpdu[3 * (size_t) t], 12);
+        }
+    }
+    if (d->n_materials >= (1u << 24)) return "too many materials";
+    for (TriRecord &r : hs.bvh.tris) r.pad = (uint32_t) hs.materials[hs.shapes[hs.triShape[r.tri]].material].type << 28;
+
     // ---- scalar parameters -------------------------------------------------------------------------------------
     DevScene &p = hs.params;
     memset(&p, 0, sizeof(p));

@@ -67,9 +67,44 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 1024), amdgpu_wav
 // The loop body of the reference is cut at the extension-ray trace: everything after `scene->rayIntersect(ray, its)`
 // (:226) for vertex k runs at the start of the invocation that shades vertex k+1. Queue entries carry the depth of
 // the vertex that spawned the ray (0 for camera rays).
-__global__ void __launch_bounds__(256) k_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out,
-                                               ShadowQueue sq, float4 *sampleL, uint32_t *counters, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// A workgroup first sorts its paths by the BSDF type the hit carries (misses last), so that a wavefront mostly
+// evaluates one BSDF model instead of stepping through all of them; whole wavefronts of misses leave at once.
+static constexpr int kShadeBlock = 512;
+
+__global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out,
+                                                       ShadowQueue sq, float4 *sampleL, uint32_t *counters, uint32_t n) {
+    constexpr int kWaves = kShadeBlock / 64, kKeys = 8;
+    __shared__ uint32_t sCount[kKeys][kWaves];
+    __shared__ uint32_t sOrder[kShadeBlock];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t first = blockIdx.x * kShadeBlock;
+    {
+        const uint32_t i = first + tid;
+        uint32_t key = kKeys - 1;
+        if (i < n) {
+            const uint32_t w = __float_as_uint(hits[i].w);
+            if (w != kMiss) key = w >> 28;
+        }
+        uint32_t rank = 0;
+        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t) kKeys; ++k) {
+            const unsigned long long m = __ballot(key == k);
+            if (key == k) rank = (uint32_t) __popcll(m & below);
+            if (lane == 0) sCount[k][wave] = (uint32_t) __popcll(m);
+        }
+        __syncthreads();
+        // exclusive prefix over (key, wave) pairs in key-major order
+        uint32_t start = 0;
+        for (uint32_t k = 0; k < (uint32_t) kKeys; ++k)
+            for (uint32_t w = 0; w < (uint32_t) kWaves; ++w) {
+                const uint32_t c = sCount[k][w];
+                if (k < key || (k == key && w < wave)) start += c;
+            }
+        sOrder[start + rank] = tid;
+        __syncthreads();
+    }
+    const uint32_t i = first + sOrder[tid];
     bool alive = false, wantShadow = false;
     float4 oRayO = make_float4(0, 0, 0, 0), oRayD = oRayO, oThr = oRayO, sRayO = oRayO, sRayD = oRayO, sContrib = oRayO;
     uint4 oMisc = make_uint4(0, 0, 0, 0);
@@ -77,8 +112,9 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PassParams pp, PathQ
 
     if (i < n) {
         const float4 hit = hits[i];
-        const uint32_t tri = __float_as_uint(hit.w);
-        if (tri != kMiss) {     // a miss ends the path: no environment emitter on this path (path.cpp:136-143,245-247)
+        const uint32_t triWord = __float_as_uint(hit.w);
+        if (triWord != kMiss) {     // a miss ends the path: no environment emitter on this path (path.cpp:136-143,245-247)
+            const uint32_t tri = triWord & kTriIndexMask;
             const float4 rd = in.rayD[i], th = in.thr[i];
             const uint4 misc = in.misc[i];
             const V3 rayD = mk(rd.x, rd.y, rd.z);
@@ -97,8 +133,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PassParams pp, PathQ
 
             Isect its;
             fillIntersection(sc, tri, hit.y, hit.z, rayD, its);
-            const DevShape shape = sc.shapes[its.shape];
-            const DevMaterial &bsdf = sc.materials[shape.material];
+            const DevMaterial &bsdf = sc.materials[its.material];
             float4 L = sampleL[slot];
             bool Lchanged = false, terminate = false;
             int depth;
@@ -107,16 +142,16 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PassParams pp, PathQ
                 // camera vertex: alpha (records.inl:121-137) and directly visible emitters (path.cpp:148-150)
                 depth = 1;
                 L.w = 1.0f; Lchanged = true;
-                if (shape.emitter >= 0 && !sc.hideEmitters) {
+                if (its.emitter >= 0 && !sc.hideEmitters) {
                     if (dot(its.sh.n, -rayD) > 0) {     // AreaLight::eval (area.cpp:104-109)
-                        const V3 c = throughput * ld3(sc.emitters[shape.emitter].radiance);
+                        const V3 c = throughput * ld3(sc.emitters[its.emitter].radiance);
                         L.x += c.x; L.y += c.y; L.z += c.z;
                     }
                 }
             } else {
                 // emitter reached by BSDF sampling: MIS against the emitter-sampling pdf (path.cpp:228-232,257-264)
-                if (shape.emitter >= 0) {
-                    const DevEmitter em = sc.emitters[shape.emitter];
+                if (its.emitter >= 0) {
+                    const DevEmitter em = sc.emitters[its.emitter];
                     const V3 value = dot(its.sh.n, -rayD) > 0 ? ld3(em.radiance) : mk(0.0f);
                     float lumPdf = 0;
                     if (!(flags & PF_PREV_DELTA)) {
@@ -313,7 +348,7 @@ __global__ void __launch_bounds__(256) k_fill_isect(DevScene sc, const float *ra
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 h = hits[i];
-    const uint32_t tri = __float_as_uint(h.w);
+    const uint32_t tri = __float_as_uint(h.w) == kMiss ? kMiss : (__float_as_uint(h.w) & kTriIndexMask);
     mtsamd_intersection r;
     memset(&r, 0, sizeof(r));
     if (tri == kMiss) {
@@ -322,7 +357,7 @@ __global__ void __launch_bounds__(256) k_fill_isect(DevScene sc, const float *ra
         const float *ry = rays + 8 * (size_t) i;
         Isect its;
         fillIntersection(sc, tri, h.y, h.z, mk(ry[4], ry[5], ry[6]), its);
-        r.t = h.x; r.u = h.y; r.v = h.z; r.shape = its.shape; r.prim = its.prim;
+        r.t = h.x; r.u = h.y; r.v = h.z; r.shape = its.shape; r.prim = tri - sc.shapes[its.shape].firstTri;
         r.p[0] = its.p.x; r.p[1] = its.p.y; r.p[2] = its.p.z;
         r.geo_n[0] = its.geoN.x; r.geo_n[1] = its.geoN.y; r.geo_n[2] = its.geoN.z;
         r.sh_n[0] = its.sh.n.x; r.sh_n[1] = its.sh.n.y; r.sh_n[2] = its.sh.n.z;
@@ -338,11 +373,11 @@ __global__ void k_hits_to_records(DevScene sc, const float4 *hits, uint32_t n, m
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 h = hits[i];
-    const uint32_t tri = __float_as_uint(h.w);
+    const uint32_t tri = __float_as_uint(h.w) == kMiss ? kMiss : (__float_as_uint(h.w) & kTriIndexMask);
     mtsamd_hit r;
     r.t = h.x; r.u = h.y; r.v = h.z;
     if (tri == kMiss) { r.shape = r.prim = kMiss; }
-    else { r.shape = sc.triShape[tri]; r.prim = tri - sc.shapes[r.shape].firstTri; }
+    else { r.shape = __float_as_uint(sc.shadeTris[6 * (size_t) tri + 2].w); r.prim = tri - sc.shapes[r.shape].firstTri; }
     out[i] = r;
 }
 

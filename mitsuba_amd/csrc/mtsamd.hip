@@ -64,7 +64,7 @@ struct mtsamd_scene {
     HostScene host;
     DevScene dev;
     int device = 0;
-    DeviceBuffer nodes, tris, positions, normals, texcoords, indices, triShape, uvDpdu, shapes, materials, emitters,
+    DeviceBuffer nodes, tris, shadeTris, shadeUV, shapes, materials, emitters,
         emitterCdf, areaCdf, rtrans;
     // work buffers of the wavefront loop
     DeviceBuffer qbuf[2][5], hits, sbuf[3], sampleL, samplePos, counters, scratch[8];
@@ -145,18 +145,14 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
             HIP_TRY(s->tris.ensure(std::max<size_t>(h.bvh.tris.size() * sizeof(TriRecord), 48)));
             if (!h.bvh.tris.empty()) HIP_TRY(hipMemcpy(s->tris.ptr, h.bvh.tris.data(), h.bvh.tris.size() * sizeof(TriRecord), hipMemcpyHostToDevice));
         }
-        HIP_TRY(upload(s->positions, h.positions));
-        HIP_TRY(upload(s->indices, h.indices));
-        HIP_TRY(upload(s->triShape, h.triShape));
+        HIP_TRY(upload(s->shadeTris, h.shadeTris));
+        if (!h.shadeUV.empty()) HIP_TRY(upload(s->shadeUV, h.shadeUV));
         HIP_TRY(upload(s->shapes, h.shapes));
         HIP_TRY(upload(s->materials, h.materials));
         HIP_TRY(upload(s->emitters, h.emitters));
         HIP_TRY(upload(s->emitterCdf, h.emitterCdf));
         HIP_TRY(upload(s->areaCdf, h.areaCdf));
         HIP_TRY(upload(s->rtrans, h.rtrans));
-        if (h.hasNormals) HIP_TRY(upload(s->normals, h.normals));
-        if (h.hasTexcoords) HIP_TRY(upload(s->texcoords, h.texcoords));
-        if (!h.uvDpdu.empty()) HIP_TRY(upload(s->uvDpdu, h.uvDpdu));
         HIP_TRY(s->counters.ensure(CNT_WORDS * sizeof(uint32_t)));
         HIP_TRY(hipMemset(s->counters.ptr, 0, CNT_WORDS * sizeof(uint32_t)));
         HIP_TRY(hipStreamCreate(&s->stream));
@@ -168,11 +164,8 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
 
     DevScene d = h.params;
     d.nodes = s->nodes.as<float4>(); d.tris = s->tris.as<float4>();
-    d.positions = s->positions.as<float>();
-    d.normals = h.hasNormals ? s->normals.as<float>() : nullptr;
-    d.texcoords = h.hasTexcoords ? s->texcoords.as<float>() : nullptr;
-    d.indices = s->indices.as<uint32_t>(); d.triShape = s->triShape.as<uint32_t>();
-    d.uvDpdu = h.uvDpdu.empty() ? nullptr : s->uvDpdu.as<float>();
+    d.shadeTris = s->shadeTris.as<float4>();
+    d.shadeUV = h.shadeUV.empty() ? nullptr : s->shadeUV.as<float4>();
     d.shapes = s->shapes.as<DevShape>(); d.materials = s->materials.as<DevMaterial>(); d.emitters = s->emitters.as<DevEmitter>();
     d.emitterCdf = s->emitterCdf.as<float>(); d.areaCdf = s->areaCdf.as<float>(); d.rtrans = s->rtrans.as<float>();
     s->dev = d;
@@ -317,7 +310,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         // queue lengths and both ray hand-out counters start from zero for the rest of this bounce and the next extend
         HIP_TRY(hipMemsetAsync(cnt, 0, CNT_QUEUE_WORDS * sizeof(uint32_t), st));
         timer.begin(T_SHADE);
-        hipLaunchKernelGGL(k_shade, dim3(blocksFor(n, 256)), dim3(256), 0, st, sc, pp, qin, hits, qout, sq, sampleL, cnt, n);
+        hipLaunchKernelGGL(k_shade, dim3(blocksFor(n, kShadeBlock)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, cnt, n);
         timer.end(T_SHADE);
         HIP_TRY(hipMemcpyAsync(s->hostCounters, cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
