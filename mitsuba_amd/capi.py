@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libmtsamd.so")
+# MTSAMD_LIB selects another build of the same library (kernel tuning experiments); the default is the in-tree build
+_LIB_PATH = os.environ.get("MTSAMD_LIB") or os.path.join(_HERE, "libmtsamd.so")
 _f32p = C.POINTER(C.c_float)
 _u32p = C.POINTER(C.c_uint32)
 

@@ -13,7 +13,10 @@ namespace mtsamd {
 struct HitRec { float t, u, v; uint32_t tri; };     // tri = global triangle index | BSDF type << 28, 0xFFFFFFFF = miss
 static constexpr uint32_t kTriIndexMask = 0x0fffffffu;
 
-static constexpr int kLdsStack = 8;         // entries per lane kept in LDS
+#ifndef MTS_LDS_STACK
+#define MTS_LDS_STACK 8
+#endif
+static constexpr int kLdsStack = MTS_LDS_STACK;         // entries per lane kept in LDS
 static constexpr int kSpillStack = 16;      // further entries in scratch
 static constexpr int kNodeFloat4 = 5;       // a wide node is 5 x float4
 // LDS of a traversal workgroup: a copy of the first `topNodes` nodes of the BVH (nodes are stored breadth first, so
@@ -139,9 +142,9 @@ MTS_DEV void laneStart(LaneRay &r, V3 o, V3 d, float mint, float maxt) {
 // Children that are hit contribute `meta >> 5` shifted to bit `meta & 31` of a 32-bit mask: leaf children put one bit
 // per triangle record into bits 0..23, internal children one bit into 24 + (slot ^ oct), i.e. already in the
 // visiting order of this ray. Empty slots have meta == 0 and contribute nothing.
-MTS_DEV void visitNode(const DevScene &sc, LaneRay &r, const LdsFloat4 *topTree, uint32_t topNodes, LdsUint2 *ldsStack,
+MTS_DEV uint32_t visitNode(const DevScene &sc, LaneRay &r, const LdsFloat4 *topTree, uint32_t topNodes, LdsUint2 *ldsStack,
                        uint2 (&spill)[kSpillStack], int &sp) {
-    const uint32_t pending = r.ng.y >> 8;
+    const uint32_t pending = (r.ng.y >> 8) & 0xffu;
     const uint32_t kbit = __ffs((int) pending) - 1;
     r.ng.y &= ~(0x100u << kbit);
     const uint32_t slot = kbit ^ r.oct;
@@ -152,7 +155,7 @@ MTS_DEV void visitNode(const DevScene &sc, LaneRay &r, const LdsFloat4 *topTree,
         const LdsFloat4 *lp = topTree + kNodeFloat4 * nodeIdx;
         n0 = toFloat4(lp[0]); n1 = toFloat4(lp[1]); n2 = toFloat4(lp[2]); n3 = toFloat4(lp[3]); n4 = toFloat4(lp[4]);
     } else {
-        const float4 *np = sc.nodes + kNodeFloat4 * (size_t) nodeIdx;
+        const float4 *np = sc.nodes + sc.nodeStride * (size_t) nodeIdx;
         n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
     }
     const uint32_t ebits = __float_as_uint(n0.w);
@@ -200,9 +203,10 @@ MTS_DEV void visitNode(const DevScene &sc, LaneRay &r, const LdsFloat4 *topTree,
     r.tg = make_uint2(__float_as_uint(n1.y), triMask);     // the lane's triangle group is empty whenever it visits a node
     if (childPending) {
         // descend; siblings still pending in the current group wait on the stack
-        if (r.ng.y >> 8) MTS_STACK_PUSH(r.ng);
+        if ((r.ng.y >> 8) & 0xffu) MTS_STACK_PUSH(r.ng);
         r.ng = make_uint2(__float_as_uint(n1.x), imask | (childPending << 8));
     }
+    return hitmask;
 }
 
 // Tests the next triangle record of the lane's triangle group. Equal-t ties are resolved towards the lowest global
@@ -211,7 +215,7 @@ MTS_DEV void visitNode(const DevScene &sc, LaneRay &r, const LdsFloat4 *topTree,
 MTS_DEV bool testNextTriangle(const DevScene &sc, LaneRay &r) {
     const uint32_t b = __ffs((int) r.tg.y) - 1;
     r.tg.y &= r.tg.y - 1;
-    const float4 *tp = sc.tris + 3 * (size_t) (r.tg.x + b);
+    const float4 *tp = sc.tris + sc.triStride * (size_t) (r.tg.x + b);
     const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
     float t, u, v;
     // global triangle index in bits 0..27, BSDF type of its material in bits 28..30 (carried along for the shading kernel)
@@ -267,7 +271,7 @@ MTS_DEV void laneFinish(const TraceArgs &a, uint32_t ray, const LaneRay &r, bool
 template <int MODE, bool COUNT>
 MTS_DEV void traceLoop(const DevScene &sc, const TraceArgs &a, LdsFloat4 *topTree, LdsUint2 *ldsStack) {
     constexpr bool ANY_HIT = MODE != TRACE_CLOSEST;
-    for (uint32_t i = threadIdx.x; i < a.topNodes * kNodeFloat4; i += blockDim.x) { const float4 v = sc.nodes[i]; RawFloat4 w = { v.x, v.y, v.z, v.w }; topTree[i] = w; }
+    for (uint32_t i = threadIdx.x; i < a.topNodes * kNodeFloat4; i += blockDim.x) { const float4 v = sc.nodes[(i / kNodeFloat4) * sc.nodeStride + i % kNodeFloat4]; RawFloat4 w = { v.x, v.y, v.z, v.w }; topTree[i] = w; }
     __syncthreads();
     const uint32_t lane = __lane_id();
     const unsigned long long laneBelow = (1ull << lane) - 1ull;
@@ -277,7 +281,7 @@ MTS_DEV void traceLoop(const DevScene &sc, const TraceArgs &a, LdsFloat4 *topTre
     int ray = -1;               // index of the ray this lane holds, -1 = idle
     bool exhausted = false;     // wave-uniform: the counter has run past the last ray
     uint32_t chunkNext = 0, chunkEnd = 0;   // wave-uniform: the part of the wave's current chunk not handed to lanes yet
-    uint32_t nv = 0, nt = 0;
+    uint32_t nv = 0, nt = 0, ne = 0, ns = 0;
 
     while (true) {
         // ---- refill idle lanes from the wave's private chunk of ray indices; a new chunk costs one atomic
@@ -334,13 +338,14 @@ MTS_DEV void traceLoop(const DevScene &sc, const TraceArgs &a, LdsFloat4 *topTre
             } else if (busy && !hasTri) {
                 // node phase: lanes without triangles waiting pop if needed and visit one node
                 bool go = true;
-                if (!(r.ng.y >> 8)) {
+                if (!((r.ng.y >> 8) & 0xffu)) {
                     if (sp == 0) { laneFinish<MODE>(a, (uint32_t) ray, r, false); ray = -1; go = false; }
                     else MTS_STACK_POP(r.ng);
                 }
                 if (go) {
                     if (COUNT) nv++;
-                    visitNode(sc, r, topTree, a.topNodes, ldsStack, spill, sp);
+                    const uint32_t hm = visitNode(sc, r, topTree, a.topNodes, ldsStack, spill, sp);
+                    if (COUNT && hm == 0) { ne++; if (r.found) ns++; }
                 }
             }
         }
@@ -348,6 +353,7 @@ MTS_DEV void traceLoop(const DevScene &sc, const TraceArgs &a, LdsFloat4 *topTre
     if (COUNT) {
         atomicAdd(&a.stats[0], (unsigned long long) nv);
         atomicAdd(&a.stats[1], (unsigned long long) nt);
+        if (MODE == TRACE_CLOSEST) { atomicAdd(&a.stats[4], (unsigned long long) ne); atomicAdd(&a.stats[5], (unsigned long long) ns); }
     }
 }
 

@@ -41,8 +41,9 @@ struct DevEmitter {
 };
 
 struct DevScene {
-    const float4 *nodes;        // 5 x float4 per wide node
-    const float4 *tris;         // 3 x float4 per triangle record (BVH order)
+    const float4 *nodes;        // 5 x float4 per wide node, nodeStride float4 apart
+    const float4 *tris;         // 3 x float4 per triangle record (BVH order), triStride float4 apart
+    uint32_t nodeStride, triStride;
     // Shading record of a triangle, global order, 6 x float4: three vertex positions whose w components carry
     // material | flags << 24, emitter (int, -1 = none) and shape; then three vertex normals (zero without normals).
     const float4 *shadeTris;
@@ -92,6 +93,6 @@ struct PassParams {
 // ray hand-out counters of the closest-hit and the any-hit traversal launches), then 64-bit traversal statistics
 // (extend nodes, extend triangles, shadow nodes, shadow triangles) addressed as uint64 index 2..5
 enum { CNT_NEXT = 0, CNT_SHADOW = 1, CNT_EXT_FETCH = 2, CNT_SHD_FETCH = 3, CNT_QUEUE_WORDS = 4,
-       CNT64_EXT_NODES = 2, CNT64_EXT_TRIS = 3, CNT64_SHD_NODES = 4, CNT64_SHD_TRIS = 5, CNT_WORDS = 12 };
+       CNT64_EXT_NODES = 2, CNT64_EXT_TRIS = 3, CNT64_SHD_NODES = 4, CNT64_SHD_TRIS = 5, CNT64_EXT_EMPTY = 6, CNT64_EXT_STALE = 7, CNT_WORDS = 16 };
 
 }  // namespace mtsamd

@@ -69,9 +69,15 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 1024), amdgpu_wav
 // the vertex that spawned the ray (0 for camera rays).
 // A workgroup first sorts its paths by the BSDF type the hit carries (misses last), so that a wavefront mostly
 // evaluates one BSDF model instead of stepping through all of them; whole wavefronts of misses leave at once.
-static constexpr int kShadeBlock = 512;
+#ifndef MTS_SHADE_WAVES
+#define MTS_SHADE_WAVES 4
+#endif
+#ifndef MTS_SHADE_BLOCK
+#define MTS_SHADE_BLOCK 512
+#endif
+static constexpr int kShadeBlock = MTS_SHADE_BLOCK;
 
-__global__ void __launch_bounds__(kShadeBlock) k_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out,
+__global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out,
                                                        ShadowQueue sq, float4 *sampleL, uint32_t *counters, uint32_t n) {
     constexpr int kWaves = kShadeBlock / 64, kKeys = 8;
     __shared__ uint32_t sCount[kKeys][kWaves];

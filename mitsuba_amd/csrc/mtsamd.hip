@@ -76,6 +76,7 @@ struct mtsamd_scene {
     // traversal launch shape: persistent workgroups (as many as fit on the device) and the lane-refill / triangle-phase
     // thresholds of the traversal loop
     unsigned traceGrid = 0, traceBlock = 256;
+    uint32_t nodeStride = 5, triStride = 3;     // record strides in float4 units (padding buys line alignment)
     uint32_t refillBelow = 32, triShare = 24, topNodes = 73, chunkMax = 512;
 
     ~mtsamd_scene() {
@@ -138,12 +139,21 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
     (void) hipGetDevice(&s->device);
 
     HostScene &h = s->host;
+    if (const char *e = getenv("MTSAMD_NODE_STRIDE")) s->nodeStride = (uint32_t) std::min(16, std::max(5, atoi(e)));
+    if (const char *e = getenv("MTSAMD_TRI_STRIDE")) s->triStride = (uint32_t) std::min(16, std::max(3, atoi(e)));
     auto up = [&]() -> int {
-        {   // nodes and triangle records as raw float4 streams
-            HIP_TRY(s->nodes.ensure(std::max<size_t>(h.bvh.nodes.size() * sizeof(WideNode), 80)));
-            if (!h.bvh.nodes.empty()) HIP_TRY(hipMemcpy(s->nodes.ptr, h.bvh.nodes.data(), h.bvh.nodes.size() * sizeof(WideNode), hipMemcpyHostToDevice));
-            HIP_TRY(s->tris.ensure(std::max<size_t>(h.bvh.tris.size() * sizeof(TriRecord), 48)));
-            if (!h.bvh.tris.empty()) HIP_TRY(hipMemcpy(s->tris.ptr, h.bvh.tris.data(), h.bvh.tris.size() * sizeof(TriRecord), hipMemcpyHostToDevice));
+        {   // nodes and triangle records as raw float4 streams, each record padded to its stride
+            auto padded = [&](DeviceBuffer &buf, const void *src, size_t count, size_t recBytes, size_t strideBytes) -> int {
+                std::vector<char> tmp(std::max<size_t>(count, 1) * strideBytes, 0);
+                for (size_t i = 0; i < count; ++i) memcpy(&tmp[i * strideBytes], (const char *) src + i * recBytes, recBytes);
+                HIP_TRY(buf.ensure(tmp.size()));
+                HIP_TRY(hipMemcpy(buf.ptr, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+                return MTSAMD_OK;
+            };
+            int rc2 = padded(s->nodes, h.bvh.nodes.data(), h.bvh.nodes.size(), sizeof(WideNode), (size_t) s->nodeStride * 16);
+            if (rc2 != MTSAMD_OK) return rc2;
+            rc2 = padded(s->tris, h.bvh.tris.data(), h.bvh.tris.size(), sizeof(TriRecord), (size_t) s->triStride * 16);
+            if (rc2 != MTSAMD_OK) return rc2;
         }
         HIP_TRY(upload(s->shadeTris, h.shadeTris));
         if (!h.shadeUV.empty()) HIP_TRY(upload(s->shadeUV, h.shadeUV));
@@ -164,6 +174,7 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
 
     DevScene d = h.params;
     d.nodes = s->nodes.as<float4>(); d.tris = s->tris.as<float4>();
+    d.nodeStride = s->nodeStride; d.triStride = s->triStride;
     d.shadeTris = s->shadeTris.as<float4>();
     d.shadeUV = h.shadeUV.empty() ? nullptr : s->shadeUV.as<float4>();
     d.shapes = s->shapes.as<DevShape>(); d.materials = s->materials.as<DevMaterial>(); d.emitters = s->emitters.as<DevEmitter>();
@@ -397,6 +408,8 @@ int renderCommon(mtsamd_scene *s, const mtsamd_render_opts *opts, float *filmDev
             HIP_TRY(hipMemcpy(c, s->counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
             stats->node_visits = c[CNT64_EXT_NODES]; stats->tri_tests = c[CNT64_EXT_TRIS];
             stats->shadow_node_visits = c[CNT64_SHD_NODES]; stats->shadow_tri_tests = c[CNT64_SHD_TRIS];
+            if (getenv("MTSAMD_VERBOSE"))
+                fprintf(stderr, "mtsamd: extend node visits %llu, of which no child hit %llu (after a hit was found: %llu)\n", c[CNT64_EXT_NODES], c[CNT64_EXT_EMPTY], c[CNT64_EXT_STALE]);
         }
     }
     return MTSAMD_OK;
