@@ -15,7 +15,7 @@ enum : unsigned {
     EDelta = ENull | EDeltaReflection | EDeltaTransmission
 };
 
-struct DevMaterial {
+struct alignas(16) DevMaterial {
     int32_t type, distribution, sampleVisible, variant;
     uint32_t typeFlags;
     float alphaU, alphaV, eta;
@@ -33,7 +33,7 @@ struct DevShape {
     uint32_t flags, pad[3];
 };
 
-struct DevEmitter {
+struct alignas(16) DevEmitter {
     float radiance[3];
     float pdfDiscrete;      // samplingWeight * normalization (scene.h:848-850)
     uint32_t shape, firstTri, nTris, cdfOffset;

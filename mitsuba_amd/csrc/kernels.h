@@ -139,7 +139,15 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
 
             Isect its;
             fillIntersection(sc, tri, hit.y, hit.z, rayD, its);
-            const DevMaterial &bsdf = sc.materials[its.material];
+            // the material record comes in as seven 16-byte loads issued together, not field by field
+            DevMaterial bsdf;
+            {
+                const float4 *mp = reinterpret_cast<const float4 *>(sc.materials + its.material);
+                float4 mv[sizeof(DevMaterial) / 16];
+#pragma unroll
+                for (int k = 0; k < (int) (sizeof(DevMaterial) / 16); ++k) mv[k] = mp[k];
+                memcpy(&bsdf, mv, sizeof(DevMaterial));
+            }
             float4 L = sampleL[slot];
             bool Lchanged = false, terminate = false;
             int depth;
@@ -237,9 +245,24 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
         }
     }
 
-    const uint32_t si = waveAppend(&counters[CNT_SHADOW], wantShadow);
+    // Queue slots are reserved once per workgroup (two atomics per workgroup, not per wavefront: thousands of
+    // wavefronts hammering the same two counters serialise at the L2): wave totals go through LDS, thread 0 reserves
+    // the workgroup's ranges, every wave adds the totals of the waves before it.
+    __shared__ uint32_t sWaveShadow[kWaves], sWaveNext[kWaves], sBase[2];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long mShadow = __ballot(wantShadow), mNext = __ballot(alive);
+    if (lane == 0) { sWaveShadow[wave] = (uint32_t) __popcll(mShadow); sWaveNext[wave] = (uint32_t) __popcll(mNext); }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t ts = 0, tn = 0;
+        for (int w = 0; w < kWaves; ++w) { ts += sWaveShadow[w]; tn += sWaveNext[w]; }
+        sBase[0] = ts ? atomicAdd(&counters[CNT_SHADOW], ts) : 0u;
+        sBase[1] = tn ? atomicAdd(&counters[CNT_NEXT], tn) : 0u;
+    }
+    __syncthreads();
+    uint32_t si = sBase[0] + (uint32_t) __popcll(mShadow & below), oi = sBase[1] + (uint32_t) __popcll(mNext & below);
+    for (uint32_t w = 0; w < wave; ++w) { si += sWaveShadow[w]; oi += sWaveNext[w]; }
     if (wantShadow) { sq.rayO[si] = sRayO; sq.rayD[si] = sRayD; sq.contrib[si] = sContrib; }
-    const uint32_t oi = waveAppend(&counters[CNT_NEXT], alive);
     if (alive) { out.rayO[oi] = oRayO; out.rayD[oi] = oRayD; out.thr[oi] = oThr; out.misc[oi] = oMisc; out.bsdfPdf[oi] = oPdf; }
 }
 
