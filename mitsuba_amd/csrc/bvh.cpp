@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <thread>
@@ -41,7 +42,7 @@ struct Node2 {
     bool isLeaf() const { return left == 0; }
 };
 
-const float kCostNode = 1.0f, kCostTri = 0.3f;
+float kCostNode = 1.0f, kCostTri = 0.5f;   // relative cost of visiting a wide node / testing a triangle
 const int kBins = 16;
 const uint32_t kMaxLeaf = 3;
 
@@ -165,6 +166,7 @@ const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *in
     }
     if (nTris >= (1u << 27)) return "too many triangles";
 
+    if (const char *e = getenv("MTSAMD_COST_TRI")) kCostTri = (float) atof(e);
     Builder2 b2;
     b2.prims.resize(nTris);
     Box sceneBox; sceneBox.reset();

@@ -73,7 +73,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 1024), amdgpu_wav
 #define MTS_SHADE_WAVES 4
 #endif
 #ifndef MTS_SHADE_BLOCK
-#define MTS_SHADE_BLOCK 512
+#define MTS_SHADE_BLOCK 256
 #endif
 static constexpr int kShadeBlock = MTS_SHADE_BLOCK;
 
