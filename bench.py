@@ -63,6 +63,21 @@ def cpu_baseline(sd, seconds_budget=20.0):
                 sample="%d full-width rows x 1 spp of the same scene (%d rays), kd-tree build %.1f s excluded" % (done_rows, total_rays, build_s))
 
 
+def measured_traffic(args):
+    """HBM-side bytes per closest-hit traversal launch from the hardware counters. The counters need their own
+    rocprofv3 passes (tools/profile_round.sh), so the figure is read from the newest committed summary of those
+    passes and only reported for the workload they were taken on; otherwise null."""
+    import glob
+    if args.workload != "config3" or (args.width, args.height, args.spp_step) != (1920, 1080, 32):
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return d["traffic_bytes_per_launch"], "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)" % os.path.basename(files[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,12 +178,14 @@ def main():
         alg_bytes_per_launch = bytes_per_ray * st.normal_rays / launches
         avg_ms = st.extend_ms / launches
         achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        out["roofline"] = {"kernel": "k_extend", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        traffic, traffic_src = measured_traffic(args)
+        out["roofline"] = {"kernel": "k_trace<TRACE_CLOSEST> (extend)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "per_ray": {"node_visits": nodes_per_ray, "tri_tests": tris_per_ray, "algorithmic_bytes": bytes_per_ray,
                                        "shadow_node_visits": stc.shadow_node_visits / max(1, stc.shadow_rays),
                                        "shadow_tri_tests": stc.shadow_tri_tests / max(1, stc.shadow_rays)},
                            "launches": int(launches), "avg_launch_ms": avg_ms, "rays_per_launch": st.normal_rays / launches,
+                           "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                            "note": "working set (BVH %.1f MB + triangles %.1f MB) is Infinity-Cache resident; HBM peak is the stated roofline, L2/IC gather latency the practical bound"
                                    % (info.node_bytes / 1e6, info.triangle_bytes / 1e6)}
         del scratch
