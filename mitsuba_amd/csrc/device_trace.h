@@ -14,15 +14,17 @@ struct HitRec { float t, u, v; uint32_t tri; };     // tri = global triangle ind
 static constexpr uint32_t kTriIndexMask = 0x0fffffffu;
 
 #ifndef MTS_LDS_STACK
-#define MTS_LDS_STACK 8
+#define MTS_LDS_STACK 4
 #endif
 static constexpr int kLdsStack = MTS_LDS_STACK;         // entries per lane kept in LDS
 static constexpr int kSpillStack = 16;      // further entries in scratch
 static constexpr int kNodeFloat4 = 5;       // a wide node is 5 x float4
 // LDS of a traversal workgroup: a copy of the first `topNodes` nodes of the BVH (nodes are stored breadth first, so
-// these are the top levels every ray walks through), then kLdsStack stack entries per lane.
+// these are the top levels every ray walks through), then kLdsStack stack entries per lane,
+// and a buffer of one prepared ray (two float4 and its index) per lane from which idle lanes are refilled.
+static constexpr int kRayBufBytes = 36;     // per lane
 inline size_t traceLdsBytes(uint32_t topNodes, uint32_t blockThreads) {
-    return (size_t) topNodes * kNodeFloat4 * 16 + (size_t) kLdsStack * blockThreads * 8;
+    return (size_t) topNodes * kNodeFloat4 * 16 + (size_t) kLdsStack * blockThreads * 8 + (size_t) kRayBufBytes * blockThreads;
 }
 
 // Ray interval exactly as the reference prepares it before walking the tree: clip against the enlarged
@@ -125,9 +127,10 @@ MTS_DEV void laneStart(LaneRay &r, V3 o, V3 d, float mint, float maxt) {
     r.o = o; r.d = d; r.mint = mint; r.maxt = maxt;
     // zero components stay finite; signs are taken from the reciprocals so that -0 picks consistent near/far planes
     const float big = 1e30f;
-    r.idx = fabsf(d.x) > 1e-30f ? 1.0f / d.x : copysignf(big, d.x);
-    r.idy = fabsf(d.y) > 1e-30f ? 1.0f / d.y : copysignf(big, d.y);
-    r.idz = fabsf(d.z) > 1e-30f ? 1.0f / d.z : copysignf(big, d.z);
+    // v_rcp_f32 (1 ulp) is enough here: the reciprocals only feed the padded slab tests
+    r.idx = fabsf(d.x) > 1e-30f ? __builtin_amdgcn_rcpf(d.x) : copysignf(big, d.x);
+    r.idy = fabsf(d.y) > 1e-30f ? __builtin_amdgcn_rcpf(d.y) : copysignf(big, d.y);
+    r.idz = fabsf(d.z) > 1e-30f ? __builtin_amdgcn_rcpf(d.z) : copysignf(big, d.z);
     r.oct = (r.idx < 0 ? 1u : 0u) | (r.idy < 0 ? 2u : 0u) | (r.idz < 0 ? 4u : 0u);
     r.hit.t = kInf; r.hit.u = 0; r.hit.v = 0; r.hit.tri = 0xFFFFFFFFu;
     r.found = false;
@@ -266,28 +269,39 @@ MTS_DEV void laneFinish(const TraceArgs &a, uint32_t ray, const LaneRay &r, bool
     }
 }
 
+typedef __attribute__((address_space(3))) uint32_t LdsUint;
+
 // The traversal loop shared by the closest-hit and the any-hit kernels. Every wavefront runs until the ray counter
 // is exhausted and its own lanes have drained, so the grid may be any size >= 1.
+// Rays reach the lanes in two steps. A producer step, run by all 64 lanes together, takes the next 64 rays of the
+// wave's chunk, clips them against the scene bounds (rays that miss them are finished on the spot) and parks the
+// survivors in the wave's LDS buffer. Lanes that run out of work pick their next ray from that buffer, which costs a
+// couple of LDS reads, so they can be refilled while most of the wave is still busy.
 template <int MODE, bool COUNT>
-MTS_DEV void traceLoop(const DevScene &sc, const TraceArgs &a, LdsFloat4 *topTree, LdsUint2 *ldsStack) {
+MTS_DEV void traceLoop(const DevScene &sc, const TraceArgs &a, LdsFloat4 *topTree, LdsUint2 *ldsStack, LdsFloat4 *rayBuf, LdsUint *rayBufIdx) {
     constexpr bool ANY_HIT = MODE != TRACE_CLOSEST;
     for (uint32_t i = threadIdx.x; i < a.topNodes * kNodeFloat4; i += blockDim.x) { const float4 v = sc.nodes[(i / kNodeFloat4) * sc.nodeStride + i % kNodeFloat4]; RawFloat4 w = { v.x, v.y, v.z, v.w }; topTree[i] = w; }
     __syncthreads();
     const uint32_t lane = __lane_id();
     const unsigned long long laneBelow = (1ull << lane) - 1ull;
+    // this wave's part of the ray buffer: 64 x (origin+mint, direction+maxt) and 64 ray indices
+    const uint32_t waveFirst = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x & ~63u));
+    LdsFloat4 *bufRay = rayBuf + 2 * waveFirst;
+    LdsUint *bufIdx = rayBufIdx + waveFirst;
     LaneRay r;
+    r.tg = make_uint2(0u, 0u); r.ng = make_uint2(0u, 0u);
     uint2 spill[kSpillStack];
     int sp = 0;
     int ray = -1;               // index of the ray this lane holds, -1 = idle
     bool exhausted = false;     // wave-uniform: the counter has run past the last ray
-    uint32_t chunkNext = 0, chunkEnd = 0;   // wave-uniform: the part of the wave's current chunk not handed to lanes yet
+    uint32_t chunkNext = 0, chunkEnd = 0;   // wave-uniform: the part of the wave's current chunk not prepared yet
+    uint32_t bufHead = 0, bufCount = 0;     // wave-uniform: prepared rays waiting in LDS
     uint32_t nv = 0, nt = 0, ne = 0, ns = 0;
 
     while (true) {
-        // ---- refill idle lanes from the wave's private chunk of ray indices; a new chunk costs one atomic
-        const bool idle = ray < 0;
-        const unsigned long long idleMask = __ballot(idle);
-        if (!exhausted && idleMask) {
+        const unsigned long long idleMask = __ballot(ray < 0);
+        // ---- producer: prepare the next 64 rays of the chunk when the buffer has run dry
+        if (idleMask && bufCount == 0 && !exhausted) {
             if (chunkNext >= chunkEnd) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(a.fetchCounter, a.chunk);
@@ -298,28 +312,54 @@ MTS_DEV void traceLoop(const DevScene &sc, const TraceArgs &a, LdsFloat4 *topTre
             if (chunkNext >= chunkEnd) {
                 exhausted = true;
             } else {
-                const uint32_t i = chunkNext + (uint32_t) __popcll(idleMask & laneBelow);
-                chunkNext += (uint32_t) __popcll(idleMask);
-                if (idle && i < chunkEnd) {
-                    const float4 ro = a.rayO[(size_t) i * a.stride], rd = a.rayD[(size_t) i * a.stride];
-                    const V3 o = mk(ro.x, ro.y, ro.z), d = mk(rd.x, rd.y, rd.z);
+                const uint32_t i = chunkNext + lane;
+                chunkNext = chunkNext + 64u < chunkEnd ? chunkNext + 64u : chunkEnd;
+                bool ok = false;
+                float4 ro = make_float4(0, 0, 0, 0), rd = ro;
+                if (i < chunkEnd) {
+                    ro = a.rayO[(size_t) i * a.stride]; rd = a.rayD[(size_t) i * a.stride];
                     float mint, maxt;
-                    laneStart(r, o, d, 0.0f, 0.0f);
-                    if (rayInterval(sc, o, d, ro.w, rd.w, ANY_HIT, mint, maxt)) {
-                        r.mint = mint; r.maxt = maxt;
-                        sp = 0;
-                        ray = (int) i;
-                    } else {
-                        laneFinish<MODE>(a, i, r, false);
+                    ok = rayInterval(sc, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), ro.w, rd.w, ANY_HIT, mint, maxt);
+                    ro.w = mint; rd.w = maxt;
+                    if (!ok) {      // misses the scene bounds: finished without a traversal
+                        LaneRay miss;
+                        miss.hit.t = kInf; miss.hit.u = 0; miss.hit.v = 0; miss.hit.tri = 0xFFFFFFFFu;
+                        laneFinish<MODE>(a, i, miss, false);
                     }
                 }
+                const unsigned long long okMask = __ballot(ok);
+                if (ok) {
+                    const uint32_t pos = (uint32_t) __popcll(okMask & laneBelow);
+                    const RawFloat4 wo = { ro.x, ro.y, ro.z, ro.w }, wd = { rd.x, rd.y, rd.z, rd.w };
+                    bufRay[2 * pos] = wo; bufRay[2 * pos + 1] = wd; bufIdx[pos] = i;
+                }
+                bufHead = 0; bufCount = (uint32_t) __popcll(okMask);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
         }
-        if (__ballot(ray >= 0) == 0) {
-            if (exhausted) break;
+        // ---- consumer: idle lanes take prepared rays
+        if (idleMask && bufCount) {
+            const uint32_t k = (uint32_t) __popcll(idleMask & laneBelow);
+            if (ray < 0 && k < bufCount) {
+                const RawFloat4 wo = bufRay[2 * (bufHead + k)], wd = bufRay[2 * (bufHead + k) + 1];
+                laneStart(r, mk(wo.x, wo.y, wo.z), mk(wd.x, wd.y, wd.z), wo.w, wd.w);
+                sp = 0;
+                ray = (int) bufIdx[bufHead + k];
+            }
+            const uint32_t taken = min((uint32_t) __popcll(idleMask), bufCount);
+            bufHead += taken; bufCount -= taken;
+            __builtin_amdgcn_wave_barrier();
+        }
+        const uint32_t nHeld = (uint32_t) __popcll(__ballot(ray >= 0));
+        const bool moreRays = bufCount != 0 || !exhausted;
+        if (nHeld == 0) {
+            if (!moreRays) break;
             continue;
         }
-        const uint32_t keepAbove = exhausted ? 1u : a.refillBelow;
+        // leave the traversal loop to refill as soon as this many lanes are idle, as long as there is something to refill with
+        const uint32_t keepAbove = moreRays ? a.refillBelow : 1u;
+        if (moreRays && nHeld < keepAbove && nHeld < 64u && bufCount == 0) continue;    // buffer ran dry mid-refill: produce first
 
         // ---- traverse until too few lanes hold a ray
         while (true) {

@@ -56,11 +56,16 @@ __global__ void __launch_bounds__(256) k_raygen(DevScene sc, PassParams pp, Path
 //   TRACE_SHADOW_ACCUM  any-hit test for the emitter samples; unoccluded ones add their weighted contribution
 //                       (the visibility test inside Scene::sampleEmitterDirect, src/librender/scene.cpp:839-843)
 //   TRACE_OCCLUDED      any-hit test, one byte per ray
+#ifndef MTS_TRACE_WAVES
+#define MTS_TRACE_WAVES 5
+#endif
 template <int MODE, bool COUNT>
-__global__ void __attribute__((amdgpu_flat_work_group_size(64, 1024), amdgpu_waves_per_eu(6))) k_trace(DevScene sc, TraceArgs a) {
+__global__ void __attribute__((amdgpu_flat_work_group_size(64, 1024), amdgpu_waves_per_eu(MTS_TRACE_WAVES))) k_trace(DevScene sc, TraceArgs a) {
     extern __shared__ float4 traceLds[];
     LdsFloat4 *topTree = (LdsFloat4 *) &traceLds[0];
-    traceLoop<MODE, COUNT>(sc, a, topTree, (LdsUint2 *) (topTree + a.topNodes * kNodeFloat4));
+    LdsUint2 *stacks = (LdsUint2 *) (topTree + a.topNodes * kNodeFloat4);
+    LdsFloat4 *rayBuf = (LdsFloat4 *) (stacks + kLdsStack * blockDim.x);
+    traceLoop<MODE, COUNT>(sc, a, topTree, stacks, rayBuf, (LdsUint *) (rayBuf + 2 * blockDim.x));
 }
 
 // ---- K3 shade: one vertex of MIPathTracer::Li per live path (src/integrators/path/path.cpp:135-287) --------------------

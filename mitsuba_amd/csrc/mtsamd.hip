@@ -77,7 +77,7 @@ struct mtsamd_scene {
     // thresholds of the traversal loop
     unsigned traceGrid = 0, traceBlock = 256;
     uint32_t nodeStride = 5, triStride = 3;     // record strides in float4 units (padding buys line alignment)
-    uint32_t refillBelow = 32, triShare = 24, topNodes = 73, chunkMax = 512;
+    uint32_t refillBelow = 56, triShare = 16, topNodes = 73, chunkMax = 512;
 
     ~mtsamd_scene() {
         if (stream) (void) hipStreamDestroy(stream);
