@@ -1,0 +1,751 @@
+#include "scene_loader.h"
+#include "xml_lite.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <tuple>
+
+namespace mtsamd_host {
+
+namespace {
+
+typedef xml_lite::Element Element;
+
+struct Fail : std::runtime_error { using std::runtime_error::runtime_error; };
+
+std::string lower(std::string s) { for (char &c : s) c = (char) std::tolower((unsigned char) c); return s; }
+
+std::string dirOf(const std::string &path) {
+    size_t p = path.find_last_of('/');
+    return p == std::string::npos ? std::string(".") : path.substr(0, p);
+}
+
+std::string joinPath(const std::string &dir, const std::string &file) {
+    if (!file.empty() && file[0] == '/') return file;
+    return dir + "/" + file;
+}
+
+bool readFile(const std::string &path, std::vector<uint8_t> &out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    f.seekg(0, std::ios::end);
+    std::streamoff n = f.tellg();
+    f.seekg(0);
+    out.resize((size_t) n);
+    if (n) f.read((char *) out.data(), n);
+    return (bool) f;
+}
+
+std::vector<double> numbers(const std::string &s) {
+    std::vector<double> out;
+    std::string t = s;
+    for (char &c : t) if (c == ',') c = ' ';
+    std::istringstream is(t);
+    double v;
+    while (is >> v) out.push_back(v);
+    return out;
+}
+
+// ---- 4x4 matrices in double, row-major ------------------------------------------------------------------------------
+struct Mat4 {
+    double m[16];
+    static Mat4 identity() { Mat4 r; for (int i = 0; i < 16; ++i) r.m[i] = (i % 5 == 0) ? 1.0 : 0.0; return r; }
+    Mat4 operator*(const Mat4 &b) const {
+        Mat4 r;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double s = 0;
+                for (int k = 0; k < 4; ++k) s += m[4 * i + k] * b.m[4 * k + j];
+                r.m[4 * i + j] = s;
+            }
+        return r;
+    }
+    bool isIdentity() const { Mat4 i = identity(); return memcmp(m, i.m, sizeof(m)) == 0; }
+};
+
+bool invert(const Mat4 &a, Mat4 &out) {
+    double w[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { w[i][j] = a.m[4 * i + j]; w[i][j + 4] = i == j ? 1.0 : 0.0; }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r) if (std::fabs(w[r][c]) > std::fabs(w[piv][c])) piv = r;
+        if (w[piv][c] == 0) return false;
+        if (piv != c) for (int j = 0; j < 8; ++j) std::swap(w[c][j], w[piv][j]);
+        const double inv = 1.0 / w[c][c];
+        for (int j = 0; j < 8; ++j) w[c][j] *= inv;
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            const double f = w[r][c];
+            if (f != 0) for (int j = 0; j < 8; ++j) w[r][j] -= f * w[c][j];
+        }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out.m[4 * i + j] = w[i][j + 4];
+    return true;
+}
+
+// Transform::lookAt (src/libcore/transform.cpp:191-214), single precision like the reference
+Mat4 lookAt(const std::vector<double> &o, const std::vector<double> &t, const std::vector<double> &up) {
+    float d[3] = { (float) t[0] - (float) o[0], (float) t[1] - (float) o[1], (float) t[2] - (float) o[2] };
+    float len = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (len == 0) throw Fail("lookAt(): 'origin' and 'target' coincide!");
+    for (float &c : d) c /= len;
+    const float u[3] = { (float) up[0], (float) up[1], (float) up[2] };
+    float left[3] = { u[1] * d[2] - u[2] * d[1], u[2] * d[0] - u[0] * d[2], u[0] * d[1] - u[1] * d[0] };
+    len = std::sqrt(left[0] * left[0] + left[1] * left[1] + left[2] * left[2]);
+    if (len == 0) throw Fail("lookAt(): the forward and upward direction must be linearly independent!");
+    for (float &c : left) c /= len;
+    const float nu[3] = { d[1] * left[2] - d[2] * left[1], d[2] * left[0] - d[0] * left[2], d[0] * left[1] - d[1] * left[0] };
+    Mat4 r = Mat4::identity();
+    for (int i = 0; i < 3; ++i) { r.m[4 * i + 0] = left[i]; r.m[4 * i + 1] = nu[i]; r.m[4 * i + 2] = d[i]; r.m[4 * i + 3] = (float) o[i]; }
+    return r;
+}
+
+// <transform> children are applied in order, each one multiplied from the left (scenehandler.cpp:574-640)
+Mat4 parseTransform(const Element &node) {
+    Mat4 m = Mat4::identity();
+    for (const auto &cp : node.children) {
+        const Element &c = *cp;
+        Mat4 t = Mat4::identity();
+        auto xyz = [&](double def, double out[3]) {
+            const char *k[3] = { "x", "y", "z" };
+            for (int i = 0; i < 3; ++i) out[i] = c.has(k[i]) ? std::stod(c.get(k[i])) : def;
+        };
+        if (c.tag == "matrix") {
+            std::vector<double> f = numbers(c.get("value"));
+            if (f.size() != 16) throw Fail("<matrix> needs 16 values");
+            for (int i = 0; i < 16; ++i) t.m[i] = f[i];
+        } else if (c.tag == "lookat") {
+            std::vector<double> o = numbers(c.get("origin")), tg = numbers(c.get("target")), up = numbers(c.get("up", "0,0,1"));
+            if (o.size() != 3 || tg.size() != 3 || up.size() != 3) throw Fail("<lookat> needs origin, target (and up) with three values each");
+            t = lookAt(o, tg, up);
+        } else if (c.tag == "translate") {
+            double v[3]; xyz(0.0, v);
+            t.m[3] = v[0]; t.m[7] = v[1]; t.m[11] = v[2];
+        } else if (c.tag == "scale") {
+            double v[3];
+            if (c.has("value")) v[0] = v[1] = v[2] = std::stod(c.get("value")); else xyz(1.0, v);
+            t.m[0] = v[0]; t.m[5] = v[1]; t.m[10] = v[2];
+        } else if (c.tag == "rotate") {     // Transform::rotate (transform.cpp:65-98)
+            double ax[3]; xyz(0.0, ax);
+            const double n = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+            if (n == 0 || !c.has("angle")) throw Fail("<rotate> needs an axis and an angle");
+            const double x = ax[0] / n, y = ax[1] / n, z = ax[2] / n;
+            const double a = std::stod(c.get("angle")) * 3.14159265358979323846 / 180.0, cs = std::cos(a), sn = std::sin(a);
+            t.m[0] = cs + x * x * (1 - cs); t.m[1] = x * y * (1 - cs) - z * sn; t.m[2] = x * z * (1 - cs) + y * sn;
+            t.m[4] = y * x * (1 - cs) + z * sn; t.m[5] = cs + y * y * (1 - cs); t.m[6] = y * z * (1 - cs) - x * sn;
+            t.m[8] = z * x * (1 - cs) - y * sn; t.m[9] = z * y * (1 - cs) + x * sn; t.m[10] = cs + z * z * (1 - cs);
+        } else {
+            throw Fail("unsupported transform element <" + c.tag + ">");
+        }
+        m = t * m;
+    }
+    return m;
+}
+
+// ---- properties ---------------------------------------------------------------------------------------------------------
+struct Value {
+    enum Kind { Float, Int, Bool, String, Rgb, Transform } kind = Float;
+    double f = 0; long i = 0; bool b = false; std::string s; float rgb[3] = { 0, 0, 0 }; Mat4 t;
+};
+typedef std::map<std::string, Value> Props;
+
+float srgbToLinear(float c) { return c <= 0.04045f ? c / 12.92f : std::pow((c + 0.055f) / 1.055f, 2.4f); }
+
+void parseSpectrum(const Element &n, float out[3]) {
+    const std::string v = n.get("value");
+    if (n.tag == "rgb") {
+        std::vector<double> f = numbers(v);
+        if (f.size() == 1) f = { f[0], f[0], f[0] };
+        if (f.size() < 3) throw Fail("<rgb> needs one or three values");
+        for (int i = 0; i < 3; ++i) out[i] = (float) f[i];
+    } else if (n.tag == "srgb") {
+        float f[3];
+        if (!v.empty() && v[0] == '#') {
+            if (v.size() != 7) throw Fail("<srgb> hex value must look like #rrggbb");
+            for (int i = 0; i < 3; ++i) f[i] = (float) std::stoi(v.substr(1 + 2 * i, 2), nullptr, 16) / 255.0f;
+        } else {
+            std::vector<double> g = numbers(v);
+            if (g.size() == 1) g = { g[0], g[0], g[0] };
+            if (g.size() < 3) throw Fail("<srgb> needs one or three values");
+            for (int i = 0; i < 3; ++i) f[i] = (float) g[i];
+        }
+        for (int i = 0; i < 3; ++i) out[i] = srgbToLinear(f[i]);
+    } else if (n.tag == "spectrum") {
+        std::vector<double> f = numbers(v);
+        if (v.find(':') != std::string::npos || f.size() != 1)
+            throw Fail("wavelength-sampled <spectrum> values need the spectral-to-RGB conversion of src/libcore/spectrum.cpp, "
+                       "which this loader does not implement");
+        out[0] = out[1] = out[2] = (float) f[0];     // a constant spectrum has the same value in every RGB channel
+    } else {
+        throw Fail("unsupported spectrum tag <" + n.tag + ">");
+    }
+}
+
+Props parseProps(const Element &node) {
+    Props out;
+    for (const auto &cp : node.children) {
+        const Element &c = *cp;
+        Value v;
+        const std::string name = c.get("name");
+        if (c.tag == "float") { v.kind = Value::Float; v.f = std::stod(c.get("value")); }
+        else if (c.tag == "integer") { v.kind = Value::Int; v.i = std::stol(c.get("value")); v.f = (double) v.i; }
+        else if (c.tag == "boolean") { v.kind = Value::Bool; v.b = lower(c.get("value")) == "true"; }
+        else if (c.tag == "string") { v.kind = Value::String; v.s = c.get("value"); }
+        else if (c.tag == "rgb" || c.tag == "srgb" || c.tag == "spectrum") { v.kind = Value::Rgb; parseSpectrum(c, v.rgb); }
+        else if (c.tag == "transform") { v.kind = Value::Transform; v.t = parseTransform(c); }
+        else continue;
+        out[name] = v;
+    }
+    return out;
+}
+
+double getF(const Props &p, const char *k, double def) { auto it = p.find(k); return it == p.end() ? def : it->second.f; }
+bool getB(const Props &p, const char *k, bool def) { auto it = p.find(k); return it == p.end() ? def : it->second.b; }
+std::string getS(const Props &p, const char *k, const std::string &def) { auto it = p.find(k); return it == p.end() ? def : it->second.s; }
+void getRgb(const Props &p, const char *k, float d0, float d1, float d2, float out[3]) {
+    auto it = p.find(k);
+    if (it == p.end()) { out[0] = d0; out[1] = d1; out[2] = d2; }
+    else if (it->second.kind == Value::Rgb) memcpy(out, it->second.rgb, 12);
+    else out[0] = out[1] = out[2] = (float) it->second.f;
+}
+
+// lookupIOR (src/bsdfs/ior.h:39-111)
+float lookupIor(const Props &p, const char *key, const char *defName) {
+    static const std::pair<const char *, float> table[] = {
+        { "vacuum", 1.0f }, { "helium", 1.000036f }, { "hydrogen", 1.000132f }, { "air", 1.000277f }, { "carbon dioxide", 1.00045f },
+        { "water", 1.3330f }, { "acetone", 1.36f }, { "ethanol", 1.361f }, { "carbon tetrachloride", 1.461f }, { "glycerol", 1.4729f },
+        { "benzene", 1.501f }, { "silicone oil", 1.52045f }, { "bromine", 1.661f }, { "water ice", 1.31f }, { "fused quartz", 1.458f },
+        { "pyrex", 1.470f }, { "acrylic glass", 1.49f }, { "polypropylene", 1.49f }, { "bk7", 1.5046f }, { "sodium chloride", 1.544f },
+        { "amber", 1.55f }, { "pet", 1.5750f }, { "diamond", 2.419f } };
+    auto it = p.find(key);
+    if (it != p.end() && it->second.kind != Value::String) return (float) it->second.f;
+    const std::string name = lower(it == p.end() ? std::string(defName) : it->second.s);
+    for (const auto &e : table) if (name == e.first) return e.second;
+    throw Fail("Unable to find an IOR value for \"" + name + "\"!");
+}
+
+// ---- BSDFs -------------------------------------------------------------------------------------------------------------------
+mtsamd_material makeBsdf(const Element &node, const LoadOptions &opts, LoadedScene &out) {
+    const std::string type = node.get("type");
+    for (const auto &c : node.children)
+        if (c->tag == "texture" || c->tag == "bsdf")
+            throw Fail("nested <" + c->tag + "> inside <bsdf type=\"" + type + "\"> is not supported");
+    const Props p = parseProps(node);
+    mtsamd_material m;
+    memset(&m, 0, sizeof(m));
+    m.sample_visible = getB(p, "sampleVisible", true) ? 1 : 0;
+    m.ensure_energy_conservation = getB(p, "ensureEnergyConservation", true) ? 1 : 0;
+    const std::string distr = lower(getS(p, "distribution", "beckmann"));
+    auto distribution = [&]() {
+        if (distr == "beckmann") return (int) MTSAMD_DISTR_BECKMANN;
+        if (distr == "ggx") return (int) MTSAMD_DISTR_GGX;
+        if (distr == "phong" || distr == "as") throw Fail("the Phong/Ashikhmin-Shirley microfacet distribution is not supported");
+        throw Fail("Specified an invalid distribution \"" + distr + "\", must be \"beckmann\" or \"ggx\"");
+    };
+    const double alpha = getF(p, "alpha", 0.1);
+    const double alphaU = p.count("alpha") ? alpha : getF(p, "alphaU", 0.1), alphaV = p.count("alpha") ? alpha : getF(p, "alphaV", 0.1);
+    m.eta[0] = m.eta[1] = m.eta[2] = 0; m.k[0] = m.k[1] = m.k[2] = 1; m.ext_eta = 1.000277f;
+    m.int_ior = 1.5046f; m.ext_ior = 1.000277f;
+    for (int i = 0; i < 3; ++i) { m.diffuse_reflectance[i] = 0.5f; m.specular_reflectance[i] = 1.0f; m.specular_transmittance[i] = 1.0f; }
+
+    if (type == "diffuse") {                    // src/bsdfs/diffuse.cpp:84-91
+        m.type = MTSAMD_BSDF_DIFFUSE;
+        getRgb(p, p.count("reflectance") ? "reflectance" : "diffuseReflectance", 0.5f, 0.5f, 0.5f, m.diffuse_reflectance);
+    } else if (type == "dielectric") {          // src/bsdfs/dielectric.cpp:147-165
+        m.type = MTSAMD_BSDF_DIELECTRIC;
+        m.int_ior = lookupIor(p, "intIOR", "bk7"); m.ext_ior = lookupIor(p, "extIOR", "air");
+        getRgb(p, "specularReflectance", 1, 1, 1, m.specular_reflectance);
+        getRgb(p, "specularTransmittance", 1, 1, 1, m.specular_transmittance);
+    } else if (type == "ward") {                // src/bsdfs/ward.cpp:97-126
+        m.type = MTSAMD_BSDF_WARD;
+        const std::string v = lower(getS(p, "variant", "balanced"));
+        if (v == "ward") m.variant = 0; else if (v == "ward-duer") m.variant = 1; else if (v == "balanced") m.variant = 2;
+        else throw Fail("Specified an invalid model type \"" + v + "\", must be \"ward\", \"ward-duer\", or \"balanced\"!");
+        m.alpha_u = (float) getF(p, "alphaU", alpha); m.alpha_v = (float) getF(p, "alphaV", alpha);
+        getRgb(p, "diffuseReflectance", 0.5f, 0.5f, 0.5f, m.diffuse_reflectance);
+        getRgb(p, "specularReflectance", 0.2f, 0.2f, 0.2f, m.specular_reflectance);
+    } else if (type == "roughconductor") {      // src/bsdfs/roughconductor.cpp:168-201
+        m.type = MTSAMD_BSDF_ROUGHCONDUCTOR;
+        m.distribution = distribution();
+        m.alpha_u = (float) alphaU; m.alpha_v = (float) alphaV;
+        const std::string material = getS(p, "material", "Cu");
+        if (p.count("eta") && p.count("k")) { getRgb(p, "eta", 0, 0, 0, m.eta); getRgb(p, "k", 1, 1, 1, m.k); }
+        else if (lower(material) != "none")
+            throw Fail("roughconductor material preset '" + material + "' needs data/ior/*.spd spectral data; give RGB 'eta' and 'k' instead");
+        m.ext_eta = lookupIor(p, "extEta", "air");
+        getRgb(p, "specularReflectance", 1, 1, 1, m.specular_reflectance);
+    } else if (type == "roughplastic") {        // src/bsdfs/roughplastic.cpp:197-228,281-299
+        m.type = MTSAMD_BSDF_ROUGHPLASTIC;
+        m.distribution = distribution();
+        m.alpha_u = m.alpha_v = (float) alphaU;
+        m.int_ior = lookupIor(p, "intIOR", "polypropylene"); m.ext_ior = lookupIor(p, "extIOR", "air");
+        m.variant = getB(p, "nonlinear", false) ? 1 : 0;
+        getRgb(p, "diffuseReflectance", 0.5f, 0.5f, 0.5f, m.diffuse_reflectance);
+        getRgb(p, "specularReflectance", 1, 1, 1, m.specular_reflectance);
+        if (opts.dataDir.empty()) throw Fail("roughplastic needs the rough transmittance tables: pass the directory that holds microfacet/" + distr + ".dat");
+        std::vector<uint8_t> dat;
+        const std::string path = opts.dataDir + "/microfacet/" + distr + ".dat";
+        if (!readFile(path, dat)) throw Fail("cannot read " + path);
+        out.rtransTables.emplace_back(512);
+        uint32_t n = 0;
+        if (mtsamd_rtrans_reduce(dat.data(), dat.size(), m.int_ior / m.ext_ior, m.alpha_u, out.rtransTables.back().data(), 512, &n,
+                                 &m.rtrans_diffuse_ext, &m.rtrans_diffuse_int) != MTSAMD_OK)
+            throw Fail(mtsamd_last_error());
+        m.rtrans_n = n;     // the pointer is set in desc(), once the table storage no longer moves
+    } else {
+        throw Fail("BSDF type '" + type + "' is outside the path hot path of this core");
+    }
+    return m;
+}
+
+// ---- meshes -----------------------------------------------------------------------------------------------------------------
+// Point / Normal transforms as Transform::operator() applies them (include/mitsuba/core/transform.h), single precision.
+void applyToWorld(Mesh &mesh, const Mat4 &md) {
+    if (md.isIdentity()) return;
+    float m[16];
+    for (int i = 0; i < 16; ++i) m[i] = (float) md.m[i];
+    const size_t nv = mesh.positions.size() / 3;
+    for (size_t v = 0; v < nv; ++v) {
+        float *p = &mesh.positions[3 * v];
+        const float x = m[0] * p[0] + m[1] * p[1] + m[2] * p[2] + m[3];
+        const float y = m[4] * p[0] + m[5] * p[1] + m[6] * p[2] + m[7];
+        const float z = m[8] * p[0] + m[9] * p[1] + m[10] * p[2] + m[11];
+        const float w = m[12] * p[0] + m[13] * p[1] + m[14] * p[2] + m[15];
+        if (w == 1.0f) { p[0] = x; p[1] = y; p[2] = z; } else { p[0] = x / w; p[1] = y / w; p[2] = z / w; }
+    }
+    if (!mesh.normals.empty()) {
+        Mat4 invd;
+        if (!invert(md, invd)) throw Fail("singular toWorld transform");
+        float inv[16];
+        for (int i = 0; i < 16; ++i) inv[i] = (float) invd.m[i];
+        for (size_t v = 0; v < nv; ++v) {       // inverse transpose, then normalize (src/shapes/serialized.cpp:184-202)
+            float *n = &mesh.normals[3 * v];
+            const float x = inv[0] * n[0] + inv[4] * n[1] + inv[8] * n[2];
+            const float y = inv[1] * n[0] + inv[5] * n[1] + inv[9] * n[2];
+            const float z = inv[2] * n[0] + inv[6] * n[1] + inv[10] * n[2];
+            const float len = std::sqrt(x * x + y * y + z * z);
+            n[0] = x / len; n[1] = y / len; n[2] = z / len;
+        }
+    }
+    const double *a = md.m;
+    const double det = a[0] * (a[5] * a[10] - a[6] * a[9]) - a[1] * (a[4] * a[10] - a[6] * a[8]) + a[2] * (a[4] * a[9] - a[5] * a[8]);
+    if (det < 0)
+        for (size_t t = 0; t + 2 < mesh.indices.size(); t += 3) std::swap(mesh.indices[t], mesh.indices[t + 1]);
+}
+
+// TriMesh::computeNormals (src/librender/trimesh.cpp:636-672): angle-weighted face normals
+void computeNormals(Mesh &mesh) {
+    const size_t nv = mesh.positions.size() / 3, nt = mesh.indices.size() / 3;
+    mesh.normals.assign(nv * 3, 0.0f);
+    const float *P = mesh.positions.data();
+    for (size_t t = 0; t < nt; ++t) {
+        const uint32_t *idx = &mesh.indices[3 * t];
+        float n[3] = { 0, 0, 0 };
+        for (int i = 0; i < 3; ++i) {
+            const float *v0 = P + 3 * (size_t) idx[i], *v1 = P + 3 * (size_t) idx[(i + 1) % 3], *v2 = P + 3 * (size_t) idx[(i + 2) % 3];
+            float a[3] = { v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2] }, b[3] = { v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2] };
+            if (i == 0) {
+                n[0] = a[1] * b[2] - a[2] * b[1]; n[1] = a[2] * b[0] - a[0] * b[2]; n[2] = a[0] * b[1] - a[1] * b[0];
+                const float len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                if (len == 0) break;
+                for (float &c : n) c /= len;
+            }
+            const float la = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), lb = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+            for (int k = 0; k < 3; ++k) { a[k] /= la; b[k] /= lb; }
+            // unitAngle (include/mitsuba/core/util.h:305-310)
+            const float d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+            float angle;
+            if (d < 0) {
+                const float s[3] = { b[0] + a[0], b[1] + a[1], b[2] + a[2] };
+                angle = 3.14159265358979323846f - 2 * std::asin(0.5f * std::sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]));
+            } else {
+                const float s[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] };
+                angle = 2 * std::asin(0.5f * std::sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]));
+            }
+            for (int k = 0; k < 3; ++k) mesh.normals[3 * (size_t) idx[i] + k] += n[k] * angle;
+        }
+    }
+    for (size_t v = 0; v < nv; ++v) {
+        float *n = &mesh.normals[3 * v];
+        const float len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        if (len != 0) { n[0] /= len; n[1] /= len; n[2] /= len; } else { n[0] = 1; n[1] = 0; n[2] = 0; }
+    }
+}
+
+uint32_t addMaterial(LoadedScene &out, const mtsamd_material &m) { out.materials.push_back(m); return (uint32_t) out.materials.size() - 1; }
+
+void addMesh(LoadedScene &out, const Mesh &mesh, uint32_t material, const float *radiance, float samplingWeight) {
+    const uint32_t base = (uint32_t) (out.positions.size() / 3);
+    const size_t nv = mesh.positions.size() / 3;
+    mtsamd_shape s;
+    memset(&s, 0, sizeof(s));
+    s.first_triangle = (uint32_t) (out.indices.size() / 3);
+    s.n_triangles = (uint32_t) (mesh.indices.size() / 3);
+    s.material = (int32_t) material;
+    s.emitter = -1;
+    s.flags = (mesh.normals.empty() ? 0u : (uint32_t) MTSAMD_SHAPE_HAS_NORMALS) | (mesh.texcoords.empty() ? 0u : (uint32_t) MTSAMD_SHAPE_HAS_TEXCOORDS);
+    for (uint32_t i : mesh.indices) {
+        if (i >= nv) throw Fail("mesh '" + mesh.name + "' has a vertex index out of range");
+        out.indices.push_back(base + i);
+    }
+    out.positions.insert(out.positions.end(), mesh.positions.begin(), mesh.positions.end());
+    // per-vertex arrays are global: pad them for meshes that lack the attribute
+    out.normals.resize(3 * (size_t) base, 0.0f);
+    out.texcoords.resize(2 * (size_t) base, 0.0f);
+    if (!mesh.normals.empty()) { out.normals.insert(out.normals.end(), mesh.normals.begin(), mesh.normals.end()); out.anyNormals = true; }
+    if (!mesh.texcoords.empty()) { out.texcoords.insert(out.texcoords.end(), mesh.texcoords.begin(), mesh.texcoords.end()); out.anyTexcoords = true; }
+    if (radiance) {
+        mtsamd_emitter e;
+        e.shape = (int32_t) out.shapes.size();
+        memcpy(e.radiance, radiance, 12);
+        e.sampling_weight = samplingWeight;
+        s.emitter = (int32_t) out.emitters.size();
+        out.emitters.push_back(e);
+    }
+    out.shapes.push_back(s);
+}
+
+// GaussianFilter / BoxFilter tables come from the library so that both hosts use the same values
+void makeFilter(const Element *rf, mtsamd_film &film) {
+    int rc;
+    if (!rf || rf->get("type") == "gaussian") {
+        rc = mtsamd_filter_gaussian(rf ? (float) getF(parseProps(*rf), "stddev", 0.5) : 0.5f, &film.filter_radius, film.filter_values);
+    } else if (rf->get("type") == "box") {
+        rc = mtsamd_filter_box((float) getF(parseProps(*rf), "radius", 0.5), &film.filter_radius, film.filter_values);
+    } else {
+        throw Fail("reconstruction filter '" + rf->get("type") + "' is not supported");
+    }
+    if (rc != MTSAMD_OK) throw Fail(mtsamd_last_error());
+}
+
+}  // namespace
+
+// ---- public pieces -----------------------------------------------------------------------------------------------------------
+mtsamd_scene_desc LoadedScene::desc() const {
+    mtsamd_scene_desc d;
+    memset(&d, 0, sizeof(d));
+    d.n_vertices = (uint32_t) (positions.size() / 3); d.n_triangles = (uint32_t) (indices.size() / 3);
+    d.n_shapes = (uint32_t) shapes.size(); d.n_materials = (uint32_t) materials.size(); d.n_emitters = (uint32_t) emitters.size();
+    d.positions = positions.data(); d.indices = indices.data();
+    // pad the per-vertex attribute arrays up to the vertex count (meshes added last may lack them)
+    LoadedScene *self = const_cast<LoadedScene *>(this);
+    if (anyNormals) { self->normals.resize(positions.size(), 0.0f); d.normals = normals.data(); }
+    if (anyTexcoords) { self->texcoords.resize(positions.size() / 3 * 2, 0.0f); d.texcoords = texcoords.data(); }
+    size_t table = 0;
+    for (mtsamd_material &m : self->materials)
+        if (m.type == MTSAMD_BSDF_ROUGHPLASTIC) m.rtrans = rtransTables[table++].data();
+    d.shapes = shapes.data(); d.materials = materials.data(); d.emitters = emitters.empty() ? nullptr : emitters.data();
+    d.camera = camera; d.film = film; d.integrator = integrator;
+    return d;
+}
+
+// TriMesh::loadCompressed (src/librender/trimesh.cpp:175-252) with the offset dictionary of :272-294
+std::string loadSerialized(const std::string &path, int shapeIndex, Mesh &out) {
+    std::vector<uint8_t> data;
+    if (!readFile(path, data)) return "cannot read " + path;
+    if (data.size() < 8) return "Encountered an invalid file format!";
+    uint16_t fmt, version;
+    memcpy(&fmt, &data[0], 2); memcpy(&version, &data[2], 2);
+    if (fmt != 0x041C) return "Encountered an invalid file format!";
+    if (version != 3 && version != 4) return "Encountered an incompatible file version!";
+    size_t offset = 0;
+    if (shapeIndex != 0) {
+        uint32_t count;
+        memcpy(&count, &data[data.size() - 4], 4);
+        if (shapeIndex < 0 || (uint32_t) shapeIndex > count) return "Unable to unserialize mesh, shape index is out of range!";
+        if (version == 4) {
+            uint64_t o; const size_t at = data.size() - 8 * (size_t) (count - shapeIndex) - 4;
+            if (at + 8 > data.size()) return "corrupt offset dictionary";
+            memcpy(&o, &data[at], 8); offset = (size_t) o;
+        } else {
+            uint32_t o; const size_t at = data.size() - 4 * (size_t) (count - shapeIndex + 1);
+            if (at + 4 > data.size()) return "corrupt offset dictionary";
+            memcpy(&o, &data[at], 4); offset = o;
+        }
+        if (offset + 4 > data.size()) return "corrupt offset dictionary";
+    }
+    // inflate one zlib stream that starts after the 4-byte header of the chosen mesh
+    std::vector<uint8_t> raw;
+    {
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit(&zs) != Z_OK) return "zlib initialisation failed";
+        zs.next_in = data.data() + offset + 4;
+        zs.avail_in = (uInt) std::min<size_t>(data.size() - offset - 4, 0xFFFFFFFFu);
+        uint8_t buf[1 << 16];
+        int rc;
+        do {
+            zs.next_out = buf; zs.avail_out = sizeof(buf);
+            rc = inflate(&zs, Z_NO_FLUSH);
+            if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&zs); return "inflate(): stream error"; }
+            raw.insert(raw.end(), buf, buf + (sizeof(buf) - zs.avail_out));
+        } while (rc != Z_STREAM_END);
+        inflateEnd(&zs);
+    }
+    size_t p = 0;
+    auto need = [&](size_t n) { if (p + n > raw.size()) throw Fail("truncated mesh stream"); };
+    try {
+        need(4);
+        uint32_t flags; memcpy(&flags, &raw[p], 4); p += 4;
+        if (version == 4) {
+            size_t e = p;
+            while (e < raw.size() && raw[e] != 0) ++e;
+            out.name.assign((const char *) &raw[p], e - p);
+            p = e + 1;
+        }
+        need(16);
+        uint64_t nv, nt;
+        memcpy(&nv, &raw[p], 8); memcpy(&nt, &raw[p + 8], 8); p += 16;
+        const bool dbl = (flags & 0x2000u) != 0;
+        auto take = [&](size_t n, int comps, std::vector<float> *dst) {
+            const size_t count = n * comps, bytes = count * (dbl ? 8 : 4);
+            need(bytes);
+            if (dst) {
+                dst->resize(count);
+                if (dbl) for (size_t i = 0; i < count; ++i) { double v; memcpy(&v, &raw[p + 8 * i], 8); (*dst)[i] = (float) v; }
+                else memcpy(dst->data(), &raw[p], bytes);
+            }
+            p += bytes;
+        };
+        take(nv, 3, &out.positions);
+        if (flags & 0x1u) take(nv, 3, &out.normals);
+        if (flags & 0x2u) take(nv, 2, &out.texcoords);
+        if (flags & 0x8u) take(nv, 3, nullptr);
+        out.faceNormals = (flags & 0x10u) != 0;
+        need(nt * 12);
+        out.indices.resize(nt * 3);
+        memcpy(out.indices.data(), &raw[p], nt * 12);
+    } catch (const Fail &f) {
+        return f.what();
+    }
+    return "";
+}
+
+// Wavefront OBJ (src/shapes/obj.cpp:244-335,371-391): v / vn / vt / f, polygons as fans, negative indices not used by the
+// reference either; vertices are made unique per (position, texcoord, normal) index triple. Groups and materials are
+// ignored: the file becomes one mesh.
+std::string loadObj(const std::string &path, bool flipTexCoords, Mesh &out) {
+    std::ifstream f(path);
+    if (!f) return "cannot read " + path;
+    std::vector<float> vp, vn, vt;
+    std::map<std::tuple<int, int, int>, uint32_t> unique;
+    bool anyN = false, anyT = false, allN = true, allT = true;
+    struct Corner { int p, t, n; };
+    std::vector<Corner> corners;
+    std::string line;
+    while (std::getline(f, line)) {
+        while (!line.empty() && line.back() == '\\') { std::string next; if (!std::getline(f, next)) break; line.pop_back(); line += next; }
+        std::istringstream is(line);
+        std::string tag;
+        if (!(is >> tag)) continue;
+        if (tag == "v") { float x, y, z; is >> x >> y >> z; vp.insert(vp.end(), { x, y, z }); }
+        else if (tag == "vn") { float x, y, z; is >> x >> y >> z; vn.insert(vn.end(), { x, y, z }); }
+        else if (tag == "vt") { float u, v; is >> u >> v; if (flipTexCoords) v = 1 - v; vt.insert(vt.end(), { u, v }); }
+        else if (tag == "f") {
+            std::vector<Corner> poly;
+            std::string tok;
+            while (is >> tok) {
+                Corner c = { 0, 0, 0 };
+                const size_t s1 = tok.find('/');
+                c.p = std::atoi(tok.substr(0, s1).c_str());
+                if (s1 != std::string::npos) {
+                    const size_t s2 = tok.find('/', s1 + 1);
+                    if (s2 == std::string::npos) c.t = std::atoi(tok.substr(s1 + 1).c_str());
+                    else { if (s2 > s1 + 1) c.t = std::atoi(tok.substr(s1 + 1, s2 - s1 - 1).c_str()); c.n = std::atoi(tok.substr(s2 + 1).c_str()); }
+                }
+                poly.push_back(c);
+            }
+            if (poly.size() < 3) return "Invalid OBJ face format!";
+            for (size_t i = 2; i < poly.size(); ++i) { corners.push_back(poly[0]); corners.push_back(poly[i - 1]); corners.push_back(poly[i]); }
+        }
+    }
+    for (const Corner &c : corners) {
+        if (c.p <= 0 || (size_t) c.p > vp.size() / 3) return "OBJ face references a vertex that does not exist";
+        if (c.n) { anyN = true; if ((size_t) c.n > vn.size() / 3 || c.n < 0) return "OBJ face references a normal that does not exist"; } else allN = false;
+        if (c.t) { anyT = true; if ((size_t) c.t > vt.size() / 2 || c.t < 0) return "OBJ face references a texture coordinate that does not exist"; } else allT = false;
+    }
+    const bool useN = anyN && allN, useT = anyT && allT;
+    for (const Corner &c : corners) {
+        const auto key = std::make_tuple(c.p, useT ? c.t : 0, useN ? c.n : 0);
+        auto it = unique.find(key);
+        if (it == unique.end()) {
+            const uint32_t idx = (uint32_t) (out.positions.size() / 3);
+            it = unique.emplace(key, idx).first;
+            out.positions.insert(out.positions.end(), &vp[3 * (c.p - 1)], &vp[3 * (c.p - 1)] + 3);
+            if (useN) out.normals.insert(out.normals.end(), &vn[3 * (c.n - 1)], &vn[3 * (c.n - 1)] + 3);
+            if (useT) out.texcoords.insert(out.texcoords.end(), &vt[2 * (c.t - 1)], &vt[2 * (c.t - 1)] + 2);
+        }
+        out.indices.push_back(it->second);
+    }
+    if (out.indices.empty()) return "OBJ file has no faces";
+    return "";
+}
+
+// The 24-vertex, 12-triangle unit cube of the `cube` plugin (src/shapes/cube.cpp:24-31): every face has its own four
+// vertices with the face normal and the (0,1) (1,1) (1,0) (0,0) texture coordinates.
+void makeCube(Mesh &out) {
+    static const signed char P[24][3] = {
+        { 1, -1, -1 }, { 1, -1, 1 }, { -1, -1, 1 }, { -1, -1, -1 }, { 1, 1, -1 }, { -1, 1, -1 }, { -1, 1, 1 }, { 1, 1, 1 },
+        { 1, -1, -1 }, { 1, 1, -1 }, { 1, 1, 1 }, { 1, -1, 1 }, { 1, -1, 1 }, { 1, 1, 1 }, { -1, 1, 1 }, { -1, -1, 1 },
+        { -1, -1, 1 }, { -1, 1, 1 }, { -1, 1, -1 }, { -1, -1, -1 }, { 1, 1, -1 }, { 1, -1, -1 }, { -1, -1, -1 }, { -1, 1, -1 } };
+    static const signed char N[6][3] = { { 0, -1, 0 }, { 0, 1, 0 }, { 1, 0, 0 }, { 0, 0, 1 }, { -1, 0, 0 }, { 0, 0, -1 } };
+    static const float UV[4][2] = { { 0, 1 }, { 1, 1 }, { 1, 0 }, { 0, 0 } };
+    out.name = "cube";
+    for (int v = 0; v < 24; ++v) {
+        for (int k = 0; k < 3; ++k) { out.positions.push_back(P[v][k]); out.normals.push_back(N[v / 4][k]); }
+        out.texcoords.push_back(UV[v % 4][0]); out.texcoords.push_back(UV[v % 4][1]);
+    }
+    for (uint32_t f = 0; f < 6; ++f) {
+        const uint32_t b = 4 * f;
+        const uint32_t tri[6] = { b, b + 1, b + 2, b + 3, b, b + 2 };
+        out.indices.insert(out.indices.end(), tri, tri + 6);
+    }
+}
+
+std::string writePfm(const std::string &path, const float *rgba, int width, int height) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return "cannot write " + path;
+    fprintf(f, "PF\n%d %d\n-1\n", width, height);
+    std::vector<float> row((size_t) width * 3);
+    for (int y = height - 1; y >= 0; --y) {
+        for (int x = 0; x < width; ++x)
+            for (int c = 0; c < 3; ++c) row[3 * (size_t) x + c] = rgba[4 * ((size_t) y * width + x) + c];
+        fwrite(row.data(), sizeof(float), row.size(), f);
+    }
+    fclose(f);
+    return "";
+}
+
+std::string loadSceneXml(const std::string &path, const LoadOptions &opts, LoadedScene &out) {
+    try {
+        std::vector<uint8_t> bytes;
+        if (!readFile(path, bytes)) return "cannot read " + path;
+        const std::string text((const char *) bytes.data(), bytes.size());
+        std::unique_ptr<Element> root = xml_lite::Parser(text).parse();
+        if (root->tag != "scene") return "root element must be <scene>";
+        const std::string base = dirOf(path);
+        std::map<std::string, uint32_t> namedBsdfs;
+        int defaultBsdf = -1;
+        bool haveSensor = false;
+        out.integrator.max_depth = -1; out.integrator.rr_depth = 5; out.integrator.strict_normals = 0; out.integrator.hide_emitters = 0;
+
+        auto bsdfIndex = [&](const Element &el) {
+            const uint32_t idx = addMaterial(out, makeBsdf(el, opts, out));
+            if (el.has("id")) namedBsdfs[el.get("id")] = idx;
+            return idx;
+        };
+        for (const auto &el : root->children)
+            if (el->tag == "bsdf") bsdfIndex(*el);
+
+        for (const auto &elp : root->children) {
+            const Element &el = *elp;
+            if (el.tag == "integrator") {
+                const Props p = parseProps(el);
+                out.integratorType = el.get("type");
+                out.integrator.max_depth = (int32_t) getF(p, "maxDepth", -1);
+                out.integrator.rr_depth = (int32_t) getF(p, "rrDepth", 5);
+                out.integrator.strict_normals = getB(p, "strictNormals", false) ? 1 : 0;
+                out.integrator.hide_emitters = getB(p, "hideEmitters", false) ? 1 : 0;
+            } else if (el.tag == "sensor") {
+                if (el.get("type") != "perspective") return "only the perspective sensor is supported";
+                const Props p = parseProps(el);
+                int fw = 768, fh = 576;         // Film defaults (src/librender/film.cpp:25-55)
+                const Element *rf = nullptr;
+                for (const auto &c : el.children) {
+                    if (c->tag == "film") {
+                        const Props fp = parseProps(*c);
+                        fw = (int) getF(fp, "width", 768); fh = (int) getF(fp, "height", 576);
+                        if (fp.count("cropOffsetX") || fp.count("cropWidth")) return "film crop windows are set through the C ABI, not the scene file";
+                        for (const auto &r : c->children) if (r->tag == "rfilter") rf = r.get();
+                    } else if (c->tag == "sampler") {
+                        out.sampleCount = (int) getF(parseProps(*c), "sampleCount", 4);
+                    }
+                }
+                if (opts.width > 0 && opts.height > 0) { fw = opts.width; fh = opts.height; }
+                const double aspect = (double) fw / fh;
+                if (!p.count("fov")) return "sensor needs a 'fov' (focalLength is not supported)";
+                double fov = getF(p, "fov", 0);
+                std::string axis = lower(getS(p, "fovAxis", "x"));
+                if (axis == "smaller") axis = aspect > 1 ? "y" : "x";
+                else if (axis == "larger") axis = aspect > 1 ? "x" : "y";
+                if (axis == "y")            // PerspectiveCamera::setYFov (src/librender/sensor.cpp:296-299)
+                    fov = 2 * std::atan(std::tan(0.5 * fov * 3.14159265358979323846 / 180.0) * aspect) * 180.0 / 3.14159265358979323846;
+                else if (axis != "x") return "fovAxis '" + axis + "' is not supported";
+                memset(&out.camera, 0, sizeof(out.camera));
+                Mat4 tw = p.count("toWorld") ? p.at("toWorld").t : Mat4::identity();
+                for (int i = 0; i < 16; ++i) out.camera.to_world[i] = (float) tw.m[i];
+                out.camera.x_fov = (float) fov;
+                out.camera.near_clip = (float) getF(p, "nearClip", 1e-2); out.camera.far_clip = (float) getF(p, "farClip", 1e4);
+                memset(&out.film, 0, sizeof(out.film));
+                out.film.width = fw; out.film.height = fh; out.film.crop_w = fw; out.film.crop_h = fh;
+                makeFilter(rf, out.film);
+                haveSensor = true;
+            } else if (el.tag == "shape") {
+                const Props p = parseProps(el);
+                int mat = -1;
+                bool emitter = false;
+                float radiance[3] = { 1, 1, 1 }, weight = 1.0f;
+                for (const auto &c : el.children) {
+                    if (c->tag == "ref") {
+                        auto it = namedBsdfs.find(c->get("id"));
+                        if (it == namedBsdfs.end()) return "reference to unknown id '" + c->get("id") + "'";
+                        mat = (int) it->second;
+                    } else if (c->tag == "bsdf") {
+                        mat = (int) bsdfIndex(*c);
+                    } else if (c->tag == "emitter") {
+                        if (c->get("type") != "area") return "only area emitters are supported";
+                        const Props ep = parseProps(*c);
+                        getRgb(ep, "radiance", 1, 1, 1, radiance);
+                        weight = (float) getF(ep, "samplingWeight", 1.0);
+                        emitter = true;
+                    } else if (c->tag == "medium" || c->tag == "subsurface") {
+                        return "<" + c->tag + "> is not handled by the path integrator";
+                    }
+                }
+                if (mat < 0) {      // Shape::configure attaches a default diffuse BSDF (src/librender/shape.cpp:48-53)
+                    if (defaultBsdf < 0) {
+                        Element e; e.tag = "bsdf"; e.attrs["type"] = "diffuse";
+                        defaultBsdf = (int) addMaterial(out, makeBsdf(e, opts, out));
+                    }
+                    mat = defaultBsdf;
+                }
+                Mesh mesh;
+                const std::string type = el.get("type");
+                std::string err;
+                if (type == "serialized") err = loadSerialized(joinPath(base, getS(p, "filename", "")), (int) getF(p, "shapeIndex", 0), mesh);
+                else if (type == "obj") err = loadObj(joinPath(base, getS(p, "filename", "")), getB(p, "flipTexCoords", true), mesh);
+                else if (type == "cube") makeCube(mesh);
+                else return "shape type '" + type + "' is not supported (triangle meshes only)";
+                if (!err.empty()) return err;
+                if (getB(p, "flipNormals", false)) return "flipNormals is not supported";
+                const bool faceNormals = getB(p, "faceNormals", false) || mesh.faceNormals;
+                if (faceNormals) mesh.normals.clear();
+                applyToWorld(mesh, p.count("toWorld") ? p.at("toWorld").t : Mat4::identity());
+                if (mesh.normals.empty() && !faceNormals) computeNormals(mesh);
+                addMesh(out, mesh, (uint32_t) mat, emitter ? radiance : nullptr, weight);
+            } else if (el.tag == "bsdf") {
+                // handled above
+            } else if (el.tag == "emitter") {
+                return "only area emitters attached to shapes are supported (found a scene-level <emitter type=\"" + el.get("type") + "\">)";
+            } else if (el.tag == "medium" || el.tag == "texture" || el.tag == "include" || el.tag == "default" || el.tag == "alias") {
+                if (el.tag == "medium") continue;   // a medium no shape refers to is inert
+                return "<" + el.tag + "> is not supported";
+            }
+        }
+        if (!haveSensor) return "scene has no sensor";
+        if (opts.maxDepth != 0) out.integrator.max_depth = opts.maxDepth;
+        return "";
+    } catch (const std::exception &e) {
+        return e.what();
+    }
+}
+
+}  // namespace mtsamd_host

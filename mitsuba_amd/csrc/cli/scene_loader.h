@@ -1,0 +1,55 @@
+// Host-side scene ingest in C++ for the subset of the Mitsuba 0.5 scene format that the `path` hot path needs:
+// the XML description (src/librender/scenehandler.cpp:306-693) restricted to scene / integrator / sensor / sampler /
+// film / rfilter / bsdf / shape / emitter / ref / transform and the scalar property tags; triangle meshes from
+// `.serialized` containers (src/librender/trimesh.cpp:175-294), Wavefront OBJ files (src/shapes/obj.cpp, whole file as
+// one mesh) and the `cube` plugin (src/shapes/cube.cpp). Everything else is rejected with a message -- nothing is
+// silently substituted. The result owns flat arrays and hands out a mtsamd_scene_desc for the C ABI.
+#pragma once
+#include "../../../include/mtsamd.h"
+
+#include <string>
+#include <vector>
+
+namespace mtsamd_host {
+
+struct LoadOptions {
+    int width = 0, height = 0;          // override the film size when both are positive
+    std::string dataDir;                // directory that holds microfacet/<distribution>.dat (roughplastic)
+    int maxDepth = 0;                   // non-zero: override the integrator's maxDepth
+};
+
+struct LoadedScene {
+    std::vector<float> positions, normals, texcoords;
+    std::vector<uint32_t> indices;
+    std::vector<mtsamd_shape> shapes;
+    std::vector<mtsamd_material> materials;
+    std::vector<std::vector<float>> rtransTables;   // storage behind mtsamd_material::rtrans
+    std::vector<mtsamd_emitter> emitters;
+    mtsamd_camera camera;
+    mtsamd_film film;
+    mtsamd_integrator integrator;
+    bool anyNormals = false, anyTexcoords = false;
+    int sampleCount = 4;
+    std::string integratorType;
+
+    // The returned description points into this object; keep it alive until mtsamd_scene_create has returned.
+    mtsamd_scene_desc desc() const;
+};
+
+struct Mesh {
+    std::string name;
+    std::vector<float> positions, normals, texcoords;   // normals / texcoords may be empty
+    std::vector<uint32_t> indices;
+    bool faceNormals = false;
+};
+
+// Each loader returns an empty string on success or an error message.
+std::string loadSerialized(const std::string &path, int shapeIndex, Mesh &out);
+std::string loadObj(const std::string &path, bool flipTexCoords, Mesh &out);
+void makeCube(Mesh &out);
+std::string loadSceneXml(const std::string &path, const LoadOptions &opts, LoadedScene &out);
+
+// Portable float map, the format HDRFilm writes for ".pfm" (src/films/hdrfilm.cpp:226-227): RGB, bottom row first.
+std::string writePfm(const std::string &path, const float *rgba, int width, int height);
+
+}  // namespace mtsamd_host

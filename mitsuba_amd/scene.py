@@ -23,7 +23,7 @@ _DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
 # lookupIOR presets used by the configs (src/bsdfs/ior.h:39-111)
 IOR = {"vacuum": 1.0, "air": 1.000277, "water": 1.3330, "bk7": 1.5046, "polypropylene": 1.49,
-       "diamond": 2.419, "acrylic glass": 1.49168, "pyrex": 1.470}
+       "diamond": 2.419, "acrylic glass": 1.49, "pyrex": 1.470}
 
 
 def look_at(origin, target, up) -> np.ndarray:

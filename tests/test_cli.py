@@ -1,0 +1,154 @@
+"""The C++ host (mtsamd-render): scene-file ingest checked against the Python loader and against known geometry on CPU,
+and one end-to-end render on the GPU compared with the same scene rendered through the ctypes binding."""
+import json
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from mitsuba_amd import loader
+
+CLI = os.path.join(ROOT, "mitsuba_amd", "mtsamd-render")
+
+SCENE = """<?xml version="1.0" encoding="utf-8"?>
+<!-- test scene -->
+<scene version="0.5.0">
+  <integrator type="path"><integer name="maxDepth" value="5"/><integer name="rrDepth" value="3"/></integrator>
+  <sensor type="perspective">
+    <float name="fov" value="45"/>
+    <transform name="toWorld"><lookat origin="0, -6, 2" target="0, 0, 0.5" up="0, 0, 1"/></transform>
+    <sampler type="independent"><integer name="sampleCount" value="8"/></sampler>
+    <film type="hdrfilm"><integer name="width" value="64"/><integer name="height" value="48"/>
+      <rfilter type="gaussian"/></film>
+  </sensor>
+  <bsdf type="diffuse" id="grey"><rgb name="reflectance" value="0.6, 0.6, 0.6"/></bsdf>
+  <bsdf type="roughconductor" id="metal"><string name="distribution" value="ggx"/><float name="alpha" value="0.2"/>
+    <rgb name="eta" value="0.2, 0.92, 1.1"/><rgb name="k" value="3.9, 2.45, 2.14"/></bsdf>
+  <shape type="serialized"><string name="filename" value="meshes.serialized"/><integer name="shapeIndex" value="0"/><ref id="grey"/></shape>
+  <shape type="serialized"><string name="filename" value="meshes.serialized"/><integer name="shapeIndex" value="1"/><ref id="metal"/></shape>
+  <shape type="serialized"><string name="filename" value="meshes.serialized"/><integer name="shapeIndex" value="2"/>
+    <emitter type="area"><rgb name="radiance" value="30, 28, 25"/></emitter></shape>
+  %s
+</scene>
+"""
+
+
+def _quad(z, size, flip=False):
+    p = np.array([[-size, -size, z], [size, -size, z], [size, size, z], [-size, size, z]], np.float32)
+    idx = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    if flip:
+        idx = idx[:, ::-1].copy()
+    return p, idx
+
+
+def _write_serialized(path):
+    """Three meshes in a v4 container laid out as TriMesh::serialize writes it (src/librender/trimesh.cpp:1138-1200)."""
+    meshes = []
+    p, idx = _quad(0.0, 4.0)                                    # floor, no normals -> computed
+    meshes.append((p, None, idx))
+    rng = np.random.default_rng(3)                              # a bumpy blob with its own normals
+    from mitsuba_amd import scene as S
+    bp, bf, bn = S.blob(2, rng, radius=1.0)
+    meshes.append(((bp + np.float32([0, 0, 1.2])).astype(np.float32), bn, bf.astype(np.uint32)))
+    p, idx = _quad(4.0, 1.0, flip=True)                         # light facing down
+    meshes.append((p, None, idx))
+    blob, offsets = b"", []
+    for k, (p, n, idx) in enumerate(meshes):
+        flags = 0x1000 | (0x1 if n is not None else 0)
+        body = struct.pack("<I", flags) + b"mesh%d\0" % k + struct.pack("<QQ", len(p), len(idx)) + p.tobytes()
+        if n is not None:
+            body += n.astype(np.float32).tobytes()
+        body += idx.tobytes()
+        offsets.append(len(blob))
+        blob += struct.pack("<HH", 0x041C, 4) + zlib.compress(body)
+    blob += b"".join(struct.pack("<Q", o) for o in offsets) + struct.pack("<I", len(meshes))
+    open(path, "wb").write(blob)
+
+
+@pytest.fixture(scope="module")
+def scene_dir(tmp_path_factory):
+    if not os.path.exists(CLI):
+        pytest.skip("mtsamd-render has not been built")
+    d = tmp_path_factory.mktemp("cli")
+    _write_serialized(str(d / "meshes.serialized"))
+    (d / "scene.xml").write_text(SCENE % "")
+    (d / "tri.obj").write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nf 1/1 2/2 3/3 4/4\n")
+    extra = ('<shape type="obj"><string name="filename" value="tri.obj"/><ref id="grey"/></shape>'
+             '<shape type="cube"><transform name="toWorld"><scale value="0.5"/><translate x="2" z="0.5"/></transform><ref id="metal"/></shape>')
+    (d / "scene_extra.xml").write_text(SCENE % extra)
+    return d
+
+
+def _describe(path, *args):
+    out = subprocess.run([CLI, str(path), "--describe", *args], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    return json.loads(out.stdout)
+
+
+def test_cli_loader_matches_python_loader(scene_dir):
+    d = _describe(scene_dir / "scene.xml")
+    sd, info = loader.load_xml(str(scene_dir / "scene.xml"))
+    assert d["triangles"] == sd.n_triangles and d["vertices"] == sd.positions.shape[0]
+    assert d["shapes"] == len(sd.shapes) and d["emitters"] == len(sd.emitters) == 1
+    assert d["material_types"] == [m["type"] for m in sd.materials]
+    assert d["sum_indices"] == int(sd.indices.astype(np.uint64).sum())
+    assert abs(d["sum_positions"] - float(sd.positions.astype(np.float64).sum())) < 1e-4
+    assert abs(d["sum_normals"] - float(sd.normals.astype(np.float64).sum())) < 1e-3     # computed normals: float32 vs float64 accumulation
+    assert np.allclose(d["to_world"], sd.camera["to_world"].ravel(), atol=1e-6)
+    assert (d["width"], d["height"], d["max_depth"], d["rr_depth"], d["sample_count"]) == (64, 48, 5, 3, info["sample_count"])
+    assert _describe(scene_dir / "scene.xml", "--size", "32", "16")["width"] == 32
+
+
+def test_cli_obj_and_cube(scene_dir):
+    base = _describe(scene_dir / "scene.xml")
+    d = _describe(scene_dir / "scene_extra.xml")
+    # the OBJ quad becomes a fan of two triangles on four vertices; the cube has 24 vertices and 12 triangles
+    assert d["shape_triangles"][-2:] == [2, 12]
+    assert d["vertices"] - base["vertices"] == 4 + 24
+    assert d["has_texcoords"] is True
+    # cube scaled by 0.5 and moved to (2, 0, 0.5): its 24 positions sum to 24 * (2, 0, 0.5); the quad's sum to (2, 2, 0)
+    assert abs(d["sum_positions"] - base["sum_positions"] - (24 * 2.5 + 4.0)) < 1e-4
+    # v is flipped by default (obj.cpp flipTexCoords): quad uv sum 4 stays 4, cube uv sum is 6 faces * 4 = 24
+    assert abs(d["sum_texcoords"] - (4.0 + 24.0)) < 1e-5
+
+
+def test_cli_rejects_unsupported_content(scene_dir, tmp_path):
+    for body, needle in (('<shape type="sphere"/>', "not supported"),
+                         ('<shape type="cube"><bsdf type="plastic"/></shape>', "outside the path hot path"),
+                         ('<emitter type="constant"/>', "only area emitters"),
+                         ('<shape type="cube"><bsdf type="roughconductor"><string name="material" value="Au"/></bsdf></shape>', "spectral data")):
+        f = tmp_path / "bad.xml"
+        f.write_text(SCENE % body)
+        (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+        out = subprocess.run([CLI, str(f), "--describe"], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 1 and needle in out.stderr, out.stderr
+    f = tmp_path / "broken.xml"
+    f.write_text("<scene><sensor></scene>")
+    out = subprocess.run([CLI, str(f), "--describe"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "XML parse error" in out.stderr
+
+
+@pytest.mark.gpu
+def test_cli_render_matches_binding(scene_dir, tmp_path):
+    from mitsuba_amd import capi
+    pfm, raw = tmp_path / "out.pfm", tmp_path / "film.raw"
+    out = subprocess.run([CLI, str(scene_dir / "scene.xml"), "-o", str(pfm), "--film", str(raw), "--spp", "8", "--seed", "3"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    stats = json.loads(out.stdout)
+    film_cli = np.fromfile(str(raw), np.float32).reshape(48, 64, 5)
+    sd, _ = loader.load_xml(str(scene_dir / "scene.xml"))
+    film_py, st = capi.Scene(sd).render(8, seed=3)
+    assert stats["normal_rays"] == st.normal_rays and stats["shadow_rays"] == st.shadow_rays
+    assert np.allclose(film_cli, film_py, rtol=1e-4, atol=1e-5)
+    # the PFM holds the developed image bottom row first
+    with open(pfm, "rb") as f:
+        assert f.readline() == b"PF\n" and f.readline() == b"64 48\n" and f.readline() == b"-1\n"
+        img = np.frombuffer(f.read(), np.float32).reshape(48, 64, 3)[::-1]
+    w = film_cli[..., 4:5]
+    assert np.allclose(img, np.where(w != 0, film_cli[..., :3] / np.where(w != 0, w, 1), 0), rtol=1e-5, atol=1e-6)
+    assert img.mean() > 0.01
