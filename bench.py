@@ -6,10 +6,12 @@ counts "Normal rays traced" + "Shadow rays traced", src/librender/skdtree.cpp:46
 
 Workload: the synthetic ~1M-triangle microfacet scene (roughconductor GGX + roughplastic GGX + dielectric over a
 diffuse ground, four quad area lights), 1920x1080, `path` integrator with default parameters. A step is one wavefront
-pass of `--spp-step` samples per pixel over the whole frame (per GPU: over the bands that GPU owns, at
-`--spp-step * N` samples per pixel, so per-GPU work is fixed as N grows: weak scaling). All inputs (scene, BVH,
-film) are resident in HBM before the timed region. After the K timed steps the per-rank films are summed with one
-reduction (RCCL) inside the timed region.
+pass of `--spp-step` samples per pixel over the whole frame. With N GPUs the scene is replicated and the samples are
+partitioned: every rank renders the whole frame with its own `--spp-step` sample indices per step (disjoint sample
+streams), so per-GPU work is fixed as N grows (weak scaling) and identical on every rank (no tile imbalance). All
+inputs (scene, BVH, film) are resident in HBM before the timed region. After the K timed steps the per-rank films
+are summed with one reduction (RCCL) inside the timed region. `--partition bands` deals out interleaved full-width
+bands instead (fewer pixels, `--spp-step * N` samples each).
 """
 import argparse
 import json
@@ -89,6 +91,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp-step", type=int, default=32, help="samples per pixel per step and GPU")
+    ap.add_argument("--partition", choices=("samples", "bands"), default="samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -106,14 +109,22 @@ def main():
     info = g.bvh_info()
     W, H = sd.film["crop_w"], sd.film["crop_h"]
     film = torch.zeros(H, W, 5, device="cuda", dtype=torch.float32)
-    rects = render.band_schedule(W, H, world, rank, bands_per_rank=1 if world == 1 else 2)
-    spp_rank = args.spp_step * world        # per-GPU work stays fixed: fewer pixels, more samples
-    spp_total = spp_rank * (args.steps + args.warmup + 2)
+    n_steps_total = args.steps + args.warmup + 2
+    if args.partition == "bands" and world > 1:
+        rects = render.band_schedule(W, H, world, rank, bands_per_rank=2)
+        spp_rank = args.spp_step * world        # per-GPU work stays fixed: fewer pixels, more samples
+        spp_total, rank_offset = spp_rank * n_steps_total, 0
+        partition = "%d interleaved full-width bands per GPU, scene replicated, one film reduction" % len(rects)
+    else:
+        rects = [(0, 0, W, H)]
+        spp_rank = args.spp_step                # whole frame on every GPU, disjoint sample indices per rank
+        spp_total, rank_offset = spp_rank * n_steps_total * world, rank * spp_rank * n_steps_total
+        partition = "samples partitioned over %d GPU(s): whole frame per GPU, disjoint sample streams, scene replicated, one film reduction" % world
 
     def step(i):
         st_sum = dict(normal=0, shadow=0, ext_ms=0.0, shd_ms=0.0, shade_ms=0.0, film_ms=0.0, iters=0, paths=0)
         for r in rects:
-            st = g.render_device(spp_rank, film.data_ptr(), spp_total=spp_total, sample_offset=i * spp_rank, seed=1, rect=r,
+            st = g.render_device(spp_rank, film.data_ptr(), spp_total=spp_total, sample_offset=rank_offset + i * spp_rank, seed=1, rect=r,
                                  spp_per_pass=spp_rank)
             st_sum["normal"] += st.normal_rays; st_sum["shadow"] += st.shadow_rays
             st_sum["ext_ms"] += st.extend_ms; st_sum["shd_ms"] += st.shadow_ms; st_sum["shade_ms"] += st.shade_ms
@@ -156,7 +167,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "mpix_spp_per_s": paths / elapsed / 1e6,
             "config": {"workload": workload, "triangles": sd.n_triangles, "spp_per_step_per_gpu": spp_rank,
-                       "paths_per_step": int(paths / args.steps), "partition": "%d interleaved full-width bands per GPU, scene replicated, one film reduction" % len(rects),
+                       "paths_per_step": int(paths / args.steps), "partition": partition,
                        "bvh": {"nodes": info.n_nodes, "depth": info.depth, "node_bytes": NODE_BYTES, "tri_bytes": TRI_BYTES,
                                "build_s": round(info.build_seconds, 3)}},
             "kernel_ms_rank0": {"extend": acc["ext_ms"], "shade": acc["shade_ms"], "shadow": acc["shd_ms"], "film": acc["film_ms"],
@@ -168,10 +179,10 @@ def main():
         g.set_counting(True)
         scratch = torch.zeros_like(film)
         r0 = rects[0]
-        stc = g.render_device(spp_rank, scratch.data_ptr(), spp_total=spp_total, sample_offset=args.warmup * spp_rank, seed=1, rect=r0,
+        stc = g.render_device(spp_rank, scratch.data_ptr(), spp_total=spp_total, sample_offset=rank_offset + args.warmup * spp_rank, seed=1, rect=r0,
                               spp_per_pass=spp_rank)
         g.set_counting(False)
-        st = g.render_device(spp_rank, scratch.data_ptr(), spp_total=spp_total, sample_offset=args.warmup * spp_rank, seed=1, rect=r0,
+        st = g.render_device(spp_rank, scratch.data_ptr(), spp_total=spp_total, sample_offset=rank_offset + args.warmup * spp_rank, seed=1, rect=r0,
                              spp_per_pass=spp_rank)
         nodes_per_ray = stc.node_visits / max(1, stc.normal_rays)
         tris_per_ray = stc.tri_tests / max(1, stc.normal_rays)

@@ -2,6 +2,7 @@
 the same seeded inputs. Bars: hit/miss and (shape, primitive) exact except equal-t ties, t/u/v bit-exact (the
 triangle test reproduces the reference's arithmetic), intersection fields 1e-5 relative, BSDF values 1e-4 relative,
 per-sample radiance 1e-3 relative for >= 99.5 % of the samples with identical ray counts, film 1e-4 relative."""
+import os
 import numpy as np
 import pytest
 
@@ -349,3 +350,48 @@ def test_full_size_traversal_and_radiance_parity(gpu, oracle_mod):
     assert abs(sg.normal_rays - so.normal_rays) <= 0.005 * so.normal_rays and abs(sg.shadow_rays - so.shadow_rays) <= 0.005 * so.shadow_rays
     rel = np.abs(Lg[..., :3] - Lo[..., :3]).max(-1) / (np.abs(Lo[..., :3]).max(-1) + 1e-3)
     assert np.mean(rel < 1e-3) > 0.99
+
+
+_DIST_WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from mitsuba_amd import capi, render, scene as S
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+capi.init(0)                        # rehearsal on one card: both ranks share device 0, films meet on the CPU
+sd = S.small_test_scene()
+g = capi.Scene(sd)
+h, w = sd.film["crop_h"], sd.film["crop_w"]
+spp = 3
+# sample partition: whole frame per rank, disjoint sample indices
+film = np.zeros((h, w, 5), np.float32)
+g.render(spp, film=film, seed=4, spp_total=spp * world, sample_offset=rank * spp)
+t = torch.from_numpy(film)
+render.reduce_film(t, world)
+# tile partition: interleaved tiles, all samples
+film2 = np.zeros((h, w, 5), np.float32)
+for r in render.tile_schedule(w, h, 16, world, rank):
+    g.render(spp * world, film=film2, seed=4, rect=r)
+t2 = torch.from_numpy(film2)
+render.reduce_film(t2, world)
+if rank == 0:
+    full, _ = g.render(spp * world, seed=4)
+    assert np.allclose(t.numpy(), full, rtol=1e-5, atol=1e-6), np.abs(t.numpy() - full).max()
+    assert np.allclose(t2.numpy(), full, rtol=1e-5, atol=1e-6), np.abs(t2.numpy() - full).max()
+    print("DIST_GPU_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_sample_and_tile_partition(tmp_path):
+    """Two processes (gloo rendezvous, one card) render disjoint sample sets / disjoint tiles through the library; the
+    summed films equal the single-process render of all samples -- the arithmetic the multi-GPU benchmark relies on."""
+    import subprocess, sys
+    from conftest import ROOT
+    script = tmp_path / "worker.py"
+    script.write_text(_DIST_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29631", str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert "DIST_GPU_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
