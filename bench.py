@@ -169,7 +169,8 @@ def main():
             "config": {"workload": workload, "triangles": sd.n_triangles, "spp_per_step_per_gpu": spp_rank,
                        "paths_per_step": int(paths / args.steps), "partition": partition,
                        "bvh": {"nodes": info.n_nodes, "depth": info.depth, "node_bytes": NODE_BYTES, "tri_bytes": TRI_BYTES,
-                               "build_s": round(info.build_seconds, 3)}},
+                               "build_s": round(info.build_seconds, 3), "binary_tree_s": round(info.binary_seconds, 3),
+                               "builder": "device" if info.builder else "host"}},
             "kernel_ms_rank0": {"extend": acc["ext_ms"], "shade": acc["shade_ms"], "shadow": acc["shd_ms"], "film": acc["film_ms"],
                                 "bounce_iterations": acc["iters"]},
         }

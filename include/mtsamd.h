@@ -36,6 +36,11 @@ enum { MTSAMD_BSDF_DIFFUSE = 0, MTSAMD_BSDF_ROUGHCONDUCTOR = 1, MTSAMD_BSDF_ROUG
 /* MicrofacetDistribution::EType (src/bsdfs/microfacet.h:48-57); Phong is not supported */
 enum { MTSAMD_DISTR_BECKMANN = 0, MTSAMD_DISTR_GGX = 1 };
 enum { MTSAMD_SHAPE_HAS_NORMALS = 1, MTSAMD_SHAPE_HAS_TEXCOORDS = 2 };
+/* Who builds the binary tree that is collapsed into the 8-wide BVH (ShapeKDTree::build in the reference,
+   src/librender/skdtree.cpp:68-110): a binned-SAH sweep on the host cores (best traversal speed, default) or Morton
+   sort + locally-ordered clustering on the GPU (faster build, a few percent more node visits per ray).
+   Selected with the environment variable MTSAMD_BVH_BUILDER=host|device when the scene is created. */
+enum { MTSAMD_BVH_HOST = 0, MTSAMD_BVH_DEVICE = 1 };
 
 /* One TriMesh (include/mitsuba/render/trimesh.h). Its triangles occupy
    [first_triangle, first_triangle + n_triangles) of the global index array; the primitive index the
@@ -140,8 +145,11 @@ typedef struct {
 typedef struct {
     uint32_t n_nodes, n_triangles, depth;
     uint64_t node_bytes, triangle_bytes;
-    double build_seconds;
+    double build_seconds;       /* whole acceleration-structure build */
     double sah_cost;
+    double binary_seconds;      /* of which: the binary tree under the wide BVH (host SAH sweep or device clustering) */
+    int32_t builder;            /* MTSAMD_BVH_HOST or MTSAMD_BVH_DEVICE */
+    int32_t reserved;
 } mtsamd_bvh_info;
 
 /* Closest-hit record, the fields of ShapeKDTree::IntersectionCache + t

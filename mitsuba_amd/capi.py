@@ -75,7 +75,7 @@ class Stats(C.Structure):
 class BvhInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_triangles", C.c_uint32), ("depth", C.c_uint32),
                 ("node_bytes", C.c_uint64), ("triangle_bytes", C.c_uint64), ("build_seconds", C.c_double),
-                ("sah_cost", C.c_double)]
+                ("sah_cost", C.c_double), ("binary_seconds", C.c_double), ("builder", C.c_int32), ("reserved", C.c_int32)]
 
 
 HIT_DTYPE = np.dtype([("t", "f4"), ("u", "f4"), ("v", "f4"), ("shape", "u4"), ("prim", "u4")])

@@ -1,6 +1,7 @@
 // Host-side construction of the 8-wide quantised BVH: binned-SAH binary build (multi-threaded), greedy
 // surface-area collapse to 8-ary nodes, octant-ordered slot assignment and outward-rounded quantisation.
 #include "bvh.h"
+#include "bvh_internal.h"
 
 #include <algorithm>
 #include <atomic>
@@ -15,32 +16,7 @@ namespace mtsamd {
 
 namespace {
 
-struct Box {
-    float lo[3], hi[3];
-    void reset() {
-        for (int i = 0; i < 3; ++i) { lo[i] = std::numeric_limits<float>::infinity(); hi[i] = -lo[i]; }
-    }
-    void grow(const float *p) {
-        for (int i = 0; i < 3; ++i) { lo[i] = std::min(lo[i], p[i]); hi[i] = std::max(hi[i], p[i]); }
-    }
-    void grow(const Box &b) {
-        for (int i = 0; i < 3; ++i) { lo[i] = std::min(lo[i], b.lo[i]); hi[i] = std::max(hi[i], b.hi[i]); }
-    }
-    float area() const {
-        float d0 = hi[0] - lo[0], d1 = hi[1] - lo[1], d2 = hi[2] - lo[2];
-        if (!(d0 >= 0 && d1 >= 0 && d2 >= 0)) return 0.0f;
-        return 2.0f * (d0 * d1 + d0 * d2 + d1 * d2);
-    }
-};
-
 struct Prim { Box box; float c[3]; uint32_t tri; };
-
-struct Node2 {
-    Box box;
-    uint32_t left = 0, right = 0;   // children; left == 0 marks a single-triangle leaf of the binary tree
-    uint32_t first = 0, count = 0;  // primitive range of the whole subtree
-    bool isLeaf() const { return left == 0; }
-};
 
 float kCostNode = 1.0f, kCostTri = 0.5f;   // relative cost of visiting a wide node / testing a triangle
 const int kBins = 16;
@@ -153,20 +129,7 @@ void loadTriRecord(const float *A, const float *B, const float *C, TriRecord &t)
     t.c_nv = -c[u] / denom;
 }
 
-const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BVH &out) {
-    auto t0 = std::chrono::steady_clock::now();
-    out.nodes.clear(); out.tris.clear(); out.depth = 0;
-    for (int i = 0; i < 3; ++i) { out.aabbMin[i] = 0; out.aabbMax[i] = 0; }
-    if (nTris == 0) {
-        WideNode n;
-        memset(&n, 0, sizeof(n));
-        n.e[0] = n.e[1] = n.e[2] = 1;
-        out.nodes.push_back(n);
-        return "";
-    }
-    if (nTris >= (1u << 27)) return "too many triangles";
-
-    if (const char *e = getenv("MTSAMD_COST_TRI")) kCostTri = (float) atof(e);
+const char *buildBinaryTreeHost(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BinaryTree &out) {
     Builder2 b2;
     b2.prims.resize(nTris);
     Box sceneBox; sceneBox.reset();
@@ -184,12 +147,47 @@ const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *in
         for (int i = 0; i < 3; ++i) p.c[i] = 0.5f * (p.box.lo[i] + p.box.hi[i]);
         sceneBox.grow(p.box);
     }
-    for (int i = 0; i < 3; ++i) { out.aabbMin[i] = sceneBox.lo[i]; out.aabbMax[i] = sceneBox.hi[i]; }
-
     b2.nodes.resize(2 * (size_t) nTris + 2);
     b2.nextNode = 1;
     b2.maxThreads = (int) std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     b2.build(0, 0, nTris, 0);
+    out.nNodes = b2.nextNode.load();
+    out.nodes.swap(b2.nodes);
+    out.primTri.resize(nTris);
+    for (uint32_t i = 0; i < nTris; ++i) out.primTri[i] = b2.prims[i].tri;
+    out.sceneBox = sceneBox;
+    return "";
+}
+
+const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BVH &out, int builder) {
+    auto t0 = std::chrono::steady_clock::now();
+    out.nodes.clear(); out.tris.clear(); out.depth = 0;
+    for (int i = 0; i < 3; ++i) { out.aabbMin[i] = 0; out.aabbMax[i] = 0; }
+    if (nTris == 0) {
+        WideNode n;
+        memset(&n, 0, sizeof(n));
+        n.e[0] = n.e[1] = n.e[2] = 1;
+        out.nodes.push_back(n);
+        return "";
+    }
+    if (nTris >= (1u << 27)) return "too many triangles";
+    if (const char *e = getenv("MTSAMD_COST_TRI")) kCostTri = (float) atof(e);
+    BinaryTree tree;
+    out.builder = builder;
+    const char *err = builder == BVH_BUILDER_DEVICE ? buildBinaryTreeDevice(positions, nVerts, indices, nTris, tree)
+                                                    : buildBinaryTreeHost(positions, nVerts, indices, nTris, tree);
+    if (err && *err) return err;
+    out.binarySeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    err = collapseToWide(tree, positions, indices, out);
+    out.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return err;
+}
+
+const char *collapseToWide(const BinaryTree &tree, const float *positions, const uint32_t *indices, BVH &out) {
+    const std::vector<Node2> &nodes2 = tree.nodes;
+    const Box sceneBox = tree.sceneBox;
+    const uint32_t nTris = (uint32_t) tree.primTri.size();
+    for (int i = 0; i < 3; ++i) { out.aabbMin[i] = sceneBox.lo[i]; out.aabbMax[i] = sceneBox.hi[i]; }
 
     // ---- collapse to 8-wide: dynamic programme over the binary tree -----------------------------------
     // C(n,i) = least SAH cost of representing the subtree of n by at most i roots of the wide tree
@@ -197,12 +195,12 @@ const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *in
     //   C(n,1) = min(leaf(n), A(n) * kCostNode + D(n,8)),  D(n,j) = min_k C(left,k) + C(right,j-k),
     //   C(n,i) = min(D(n,i), C(n,i-1)).
     // Children carry larger indices than their parents, so a descending sweep is bottom-up.
-    const uint32_t nNodes2 = b2.nextNode.load();
+    const uint32_t nNodes2 = tree.nNodes;
     struct Dp { float c[8]; uint8_t k[9]; uint8_t take; uint8_t leaf; };    // c[1..7], k[2..8] = left share, take bit j: D(n,j) < C(n,j-1)
     std::vector<Dp> dp(nNodes2);
     const float kInfCost = std::numeric_limits<float>::infinity();
     for (uint32_t n = nNodes2; n-- > 0;) {
-        const Node2 &nd = b2.nodes[n];
+        const Node2 &nd = nodes2[n];
         Dp &d = dp[n];
         const float area = nd.box.area();
         if (nd.isLeaf()) {
@@ -244,7 +242,7 @@ const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *in
                 n = nd.right; j -= k;
             }
         }
-    } collector{ b2.nodes, dp };
+    } collector{ nodes2, dp };
 
     struct Work { uint32_t n2; uint32_t wide; uint32_t depth; };
     std::vector<Work> queue;
@@ -258,7 +256,7 @@ const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *in
     for (size_t qi = 0; qi < queue.size(); ++qi) {
         Work w = queue[qi];
         out.depth = std::max(out.depth, w.depth);
-        const Node2 &n2 = b2.nodes[w.n2];
+        const Node2 &n2 = nodes2[w.n2];
         uint32_t kids[8];
         int nk = 0;
         if (n2.isLeaf() || (w.n2 == 0 && dp[0].leaf)) {
@@ -272,7 +270,7 @@ const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *in
         Box cb[8], nb;
         nb.reset();
         for (int i = 0; i < nk; ++i) {
-            cb[i] = b2.nodes[kids[i]].box;
+            cb[i] = nodes2[kids[i]].box;
             for (int a = 0; a < 3; ++a) {
                 float m = std::max(std::abs(cb[i].lo[a]), std::abs(cb[i].hi[a]));
                 float pad = m * 0x1p-20f + 1e-30f;
@@ -328,7 +326,7 @@ const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *in
         for (int s = 0; s < 8; ++s) {
             int i = childAt[s];
             if (i < 0) continue;
-            const Node2 &c = b2.nodes[kids[i]];
+            const Node2 &c = nodes2[kids[i]];
             for (int a = 0; a < 3; ++a) {
                 double scale = (double) bitsFloat((uint32_t) node.e[a] << 23);
                 double p = node.p[a];
@@ -346,7 +344,7 @@ const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *in
                 uint32_t unary = (1u << c.count) - 1u;     // 1 -> 001, 2 -> 011, 3 -> 111
                 node.meta[s] = (uint8_t) ((unary << 5) | triOfs);
                 for (uint32_t j = 0; j < c.count; ++j) {
-                    uint32_t tri = b2.prims[c.first + j].tri;
+                    uint32_t tri = tree.primTri[c.first + j];
                     TriRecord tr;
                     loadTriRecord(positions + 3 * (size_t) indices[3 * tri], positions + 3 * (size_t) indices[3 * tri + 1],
                                   positions + 3 * (size_t) indices[3 * tri + 2], tr);
@@ -375,7 +373,6 @@ const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *in
     if (out.nodes.size() >= (1u << 24)) return "BVH has too many nodes for the 24-bit traversal stack entries";
     if ((int) out.depth > kMaxWideDepth) return "BVH too deep for the traversal stack";
     out.sahCost = sah;
-    out.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return "";
 }
 

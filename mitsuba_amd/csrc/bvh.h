@@ -45,11 +45,17 @@ struct BVH {
     float aabbMin[3], aabbMax[3];       // tight bounds
     uint32_t depth = 0;
     double sahCost = 0;
-    double buildSeconds = 0;
+    double buildSeconds = 0;        // whole build
+    int builder = 0;
+    double binarySeconds = 0;       // of which: the binary tree (host SAH sweep or device clustering)
 };
 
+// Which builder makes the binary tree that is then collapsed to 8-wide nodes: a binned-SAH sweep on the host cores, or
+// Morton sort + parallel locally-ordered clustering on the current HIP device.
+enum { BVH_BUILDER_HOST = 0, BVH_BUILDER_DEVICE = 1 };
+
 // positions: nVerts*3 floats, indices: nTris*3. Returns an empty string or an error message.
-const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BVH &out);
+const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BVH &out, int builder = BVH_BUILDER_HOST);
 
 // TriAccel::load restated (triaccel.h:61-94); returns k = 3 for degenerate triangles.
 void loadTriRecord(const float *A, const float *B, const float *C, TriRecord &t);

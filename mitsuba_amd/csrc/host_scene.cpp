@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -276,7 +277,10 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
     }
 
     // ---- acceleration structure ---------------------------------------------------------------------------
-    const char *err = buildBVH(hs.positions.data(), d->n_vertices, hs.indices.data(), d->n_triangles, hs.bvh);
+    // the binary tree under the wide BVH comes from the host SAH sweep unless the device builder is asked for
+    int builder = BVH_BUILDER_HOST;
+    if (const char *e = getenv("MTSAMD_BVH_BUILDER")) builder = strcmp(e, "device") == 0 ? BVH_BUILDER_DEVICE : BVH_BUILDER_HOST;
+    const char *err = buildBVH(hs.positions.data(), d->n_vertices, hs.indices.data(), d->n_triangles, hs.bvh, builder);
     if (err && *err) return err;
 
     // ---- packed per-triangle shading records; the BVH's triangle records get the BSDF type in their spare word so

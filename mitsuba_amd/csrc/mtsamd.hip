@@ -215,6 +215,7 @@ extern "C" int mtsamd_scene_bvh_info(const mtsamd_scene *scene, mtsamd_bvh_info 
     info->n_nodes = (uint32_t) b.nodes.size(); info->n_triangles = (uint32_t) b.tris.size(); info->depth = b.depth;
     info->node_bytes = b.nodes.size() * sizeof(WideNode); info->triangle_bytes = b.tris.size() * sizeof(TriRecord);
     info->build_seconds = b.buildSeconds; info->sah_cost = b.sahCost;
+    info->binary_seconds = b.binarySeconds; info->builder = b.builder; info->reserved = 0;
     return MTSAMD_OK;
 }
 
