@@ -105,29 +105,7 @@ inline float bitsFloat(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 }  // namespace
 
-void loadTriRecord(const float *A, const float *B, const float *C, TriRecord &t) {
-    static const int waldModulo[4] = { 1, 2, 0, 1 };
-    float b[3] = { C[0] - A[0], C[1] - A[1], C[2] - A[2] };
-    float c[3] = { B[0] - A[0], B[1] - A[1], B[2] - A[2] };
-    float N[3] = { c[1] * b[2] - c[2] * b[1], c[2] * b[0] - c[0] * b[2], c[0] * b[1] - c[1] * b[0] };
-    uint32_t k = 0;
-    for (int j = 0; j < 3; j++)
-        if (std::abs(N[j]) > std::abs(N[k])) k = j;
-    uint32_t u = waldModulo[k], v = waldModulo[k + 1];
-    const float n_k = N[k], denom = b[u] * c[v] - b[v] * c[u];
-    memset(&t, 0, sizeof(t));
-    if (denom == 0) { t.k = 3; return; }
-    t.k = k;
-    t.n_u = N[u] / n_k;
-    t.n_v = N[v] / n_k;
-    t.n_d = (A[0] * N[0] + A[1] * N[1] + A[2] * N[2]) / n_k;
-    t.b_nu = b[u] / denom;
-    t.b_nv = -b[v] / denom;
-    t.a_u = A[u];
-    t.a_v = A[v];
-    t.c_nu = c[v] / denom;
-    t.c_nv = -c[u] / denom;
-}
+void loadTriRecord(const float *A, const float *B, const float *C, TriRecord &t) { loadTriRecordHD(A, B, C, t); }
 
 const char *buildBinaryTreeHost(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BinaryTree &out) {
     Builder2 b2;
@@ -168,13 +146,15 @@ const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *in
         memset(&n, 0, sizeof(n));
         n.e[0] = n.e[1] = n.e[2] = 1;
         out.nodes.push_back(n);
+        out.nodeCount = 1; out.triCount = 0;
         return "";
     }
     if (nTris >= (1u << 27)) return "too many triangles";
     if (const char *e = getenv("MTSAMD_COST_TRI")) kCostTri = (float) atof(e);
+    setDeviceBuilderCosts(kCostNode, kCostTri);
     BinaryTree tree;
     out.builder = builder;
-    const char *err = builder == BVH_BUILDER_DEVICE ? buildBinaryTreeDevice(positions, nVerts, indices, nTris, tree)
+    const char *err = builder == BVH_BUILDER_DEVICE_BINARY ? buildBinaryTreeDevice(positions, nVerts, indices, nTris, tree)
                                                     : buildBinaryTreeHost(positions, nVerts, indices, nTris, tree);
     if (err && *err) return err;
     out.binarySeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -373,6 +353,7 @@ const char *collapseToWide(const BinaryTree &tree, const float *positions, const
     if (out.nodes.size() >= (1u << 24)) return "BVH has too many nodes for the 24-bit traversal stack entries";
     if ((int) out.depth > kMaxWideDepth) return "BVH too deep for the traversal stack";
     out.sahCost = sah;
+    out.nodeCount = (uint32_t) out.nodes.size(); out.triCount = (uint32_t) out.tris.size();
     return "";
 }
 

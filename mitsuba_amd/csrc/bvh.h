@@ -3,6 +3,7 @@
 // (include/mitsuba/render/gkdtree.h:958-1263, built by ShapeKDTree::build, src/librender/skdtree.cpp:68-110);
 // only query results are contractual, not the topology.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <vector>
 
@@ -40,8 +41,9 @@ struct alignas(16) TriRecord {
 static_assert(sizeof(TriRecord) == 48, "TriRecord must be 48 bytes");
 
 struct BVH {
-    std::vector<WideNode> nodes;
+    std::vector<WideNode> nodes;        // empty when the tree was emitted straight into device memory
     std::vector<TriRecord> tris;
+    uint32_t nodeCount = 0, triCount = 0;
     float aabbMin[3], aabbMax[3];       // tight bounds
     uint32_t depth = 0;
     double sahCost = 0;
@@ -52,12 +54,42 @@ struct BVH {
 
 // Which builder makes the binary tree that is then collapsed to 8-wide nodes: a binned-SAH sweep on the host cores, or
 // Morton sort + parallel locally-ordered clustering on the current HIP device.
-enum { BVH_BUILDER_HOST = 0, BVH_BUILDER_DEVICE = 1 };
+// BVH_BUILDER_DEVICE_BINARY builds only the binary tree on the device and collapses it on the host (for comparisons).
+enum { BVH_BUILDER_HOST = 0, BVH_BUILDER_DEVICE = 1, BVH_BUILDER_DEVICE_BINARY = 2 };
 
 // positions: nVerts*3 floats, indices: nTris*3. Returns an empty string or an error message.
 const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BVH &out, int builder = BVH_BUILDER_HOST);
 
-// TriAccel::load restated (triaccel.h:61-94); returns k = 3 for degenerate triangles.
+// TriAccel::load restated (triaccel.h:61-94); k = 3 marks degenerate triangles. One source for the host and the device
+// builder: both are compiled without contraction and with IEEE division, so the records are bit-identical.
+#if defined(__HIPCC__)
+#define MTS_HD __host__ __device__
+#else
+#define MTS_HD
+#endif
+MTS_HD inline void loadTriRecordHD(const float *A, const float *B, const float *C, TriRecord &t) {
+    const int waldModulo[4] = { 1, 2, 0, 1 };
+    const float b[3] = { C[0] - A[0], C[1] - A[1], C[2] - A[2] };
+    const float c[3] = { B[0] - A[0], B[1] - A[1], B[2] - A[2] };
+    const float N[3] = { c[1] * b[2] - c[2] * b[1], c[2] * b[0] - c[0] * b[2], c[0] * b[1] - c[1] * b[0] };
+    uint32_t k = 0;
+    for (int j = 0; j < 3; j++)
+        if (fabsf(N[j]) > fabsf(N[k])) k = j;
+    const uint32_t u = waldModulo[k], v = waldModulo[k + 1];
+    const float n_k = N[k], denom = b[u] * c[v] - b[v] * c[u];
+    t.k = 3; t.n_u = t.n_v = t.n_d = t.a_u = t.a_v = t.b_nu = t.b_nv = t.c_nu = t.c_nv = 0.0f; t.tri = 0; t.pad = 0;
+    if (denom == 0) return;
+    t.k = k;
+    t.n_u = N[u] / n_k;
+    t.n_v = N[v] / n_k;
+    t.n_d = (A[0] * N[0] + A[1] * N[1] + A[2] * N[2]) / n_k;
+    t.b_nu = b[u] / denom;
+    t.b_nv = -b[v] / denom;
+    t.a_u = A[u];
+    t.a_v = A[v];
+    t.c_nu = c[v] / denom;
+    t.c_nv = -c[u] / denom;
+}
 void loadTriRecord(const float *A, const float *B, const float *C, TriRecord &t);
 
 static const int kMaxWideDepth = 23;    // the traversal stack holds one entry per level

@@ -99,18 +99,65 @@ __global__ void k_morton(const float4 *lo, const float4 *hi, uint32_t n, const f
     vals[t] = t;
 }
 
-// device node: children (leaf: left = kNone, right = triangle) and box
-struct DNode { uint32_t left, right; float lo[3], hi[3]; };
+// device node: children (leaf: left = kNone, right = triangle), box and number of triangles below
+struct DNode { uint32_t left, right; float lo[3], hi[3]; uint32_t count, pad; };
 
-__global__ void k_init_clusters(const uint32_t *sortedTri, const float4 *lo, const float4 *hi, uint32_t n, DNode *nodes, uint32_t *cnode, float4 *clo, float4 *chi) {
+// Collapse table of a binary node, filled when the node is created (its children are final by then):
+// c[i] = least SAH cost of representing the subtree by at most i roots of the wide tree, k[j] = share of the left child
+// in the best split into j roots, take bit j = splitting into j beats j-1, leaf = the node becomes a leaf of the wide tree.
+struct DDp { float c[8]; uint8_t k[9]; uint8_t take; uint8_t leaf; uint8_t pad; };
+
+constexpr uint32_t kMaxLeafTris = 3;
+
+__device__ inline float boxArea(const float *lo, const float *hi) {
+    const float d0 = hi[0] - lo[0], d1 = hi[1] - lo[1], d2 = hi[2] - lo[2];
+    if (!(d0 >= 0 && d1 >= 0 && d2 >= 0)) return 0.0f;
+    return 2.0f * (d0 * d1 + d0 * d2 + d1 * d2);
+}
+
+__device__ inline void dpLeaf(const DNode &nd, float costTri, DDp &d) {
+    const float area = boxArea(nd.lo, nd.hi);
+    for (int i = 1; i < 8; ++i) d.c[i] = area * costTri;
+    d.c[0] = 0; d.take = 0; d.leaf = 1; d.pad = 0;
+    for (int j = 0; j < 9; ++j) d.k[j] = 0;
+}
+
+__device__ inline void dpInner(const DNode &nd, const DDp &L, const DDp &R, float costNode, float costTri, DDp &d) {
+    const float area = boxArea(nd.lo, nd.hi);
+    float dist[9];
+    d.k[0] = d.k[1] = 0; d.c[0] = 0; d.pad = 0;
+    for (int j = 2; j <= 8; ++j) {
+        float best = INFINITY; int bk = 1;
+        for (int k = 1; k < j; ++k) {
+            if (k > 7 || j - k > 7) continue;
+            const float c = L.c[k] + R.c[j - k];
+            if (c < best) { best = c; bk = k; }
+        }
+        dist[j] = best; d.k[j] = (uint8_t) bk;
+    }
+    const float leafCost = nd.count <= kMaxLeafTris ? area * costTri * (float) nd.count : INFINITY;
+    const float nodeCost = area * costNode + dist[8];
+    d.leaf = leafCost <= nodeCost;
+    d.c[1] = fminf(leafCost, nodeCost);
+    d.take = 0;
+    for (int j = 2; j <= 7; ++j) {
+        if (dist[j] < d.c[j - 1]) { d.c[j] = dist[j]; d.take |= (uint8_t) (1u << j); }
+        else d.c[j] = d.c[j - 1];
+    }
+}
+
+__global__ void k_init_clusters(const uint32_t *sortedTri, const float4 *lo, const float4 *hi, uint32_t n, DNode *nodes, DDp *dp, float costTri, uint32_t *cnode, float4 *clo, float4 *chi) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t t = sortedTri[i];
     const float4 a = lo[t], b = hi[t];
     DNode nd;
-    nd.left = kNone; nd.right = t;
+    nd.left = kNone; nd.right = t; nd.count = 1; nd.pad = 0;
     nd.lo[0] = a.x; nd.lo[1] = a.y; nd.lo[2] = a.z; nd.hi[0] = b.x; nd.hi[1] = b.y; nd.hi[2] = b.z;
     nodes[i] = nd;
+    DDp d;
+    dpLeaf(nd, costTri, d);
+    dp[i] = d;
     cnode[i] = i; clo[i] = a; chi[i] = b;
 }
 
@@ -133,7 +180,8 @@ __global__ void k_nearest(const float4 *clo, const float4 *chi, uint32_t n, uint
     nn[i] = bj;
 }
 
-__global__ void k_merge(const uint32_t *nn, uint32_t n, uint32_t nLeaves, uint32_t *nodeCounter, DNode *nodes, uint32_t *cnode, float4 *clo, float4 *chi, uint32_t *keep) {
+__global__ void k_merge(const uint32_t *nn, uint32_t n, uint32_t nLeaves, uint32_t *nodeCounter, DNode *nodes, DDp *dp, float costNode, float costTri,
+                        uint32_t *cnode, float4 *clo, float4 *chi, uint32_t *keep) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t j = nn[i];
@@ -146,7 +194,11 @@ __global__ void k_merge(const uint32_t *nn, uint32_t n, uint32_t nLeaves, uint32
             nd.left = cnode[i]; nd.right = cnode[j];
             nd.lo[0] = fminf(a0.x, b0.x); nd.lo[1] = fminf(a0.y, b0.y); nd.lo[2] = fminf(a0.z, b0.z);
             nd.hi[0] = fmaxf(a1.x, b1.x); nd.hi[1] = fmaxf(a1.y, b1.y); nd.hi[2] = fmaxf(a1.z, b1.z);
+            nd.count = nodes[nd.left].count + nodes[nd.right].count; nd.pad = 0;
             nodes[id] = nd;
+            DDp d;
+            dpInner(nd, dp[nd.left], dp[nd.right], costNode, costTri, d);   // the children were finished by earlier launches
+            dp[id] = d;
             // the merged cluster takes the place of its first member; written after every lane has read (separate arrays below)
             cnode[i] = id;
             clo[i] = make_float4(nd.lo[0], nd.lo[1], nd.lo[2], 0); chi[i] = make_float4(nd.hi[0], nd.hi[1], nd.hi[2], 0);
@@ -167,65 +219,75 @@ __global__ void k_compact(const uint32_t *keep, const uint32_t *pos, uint32_t n,
 
 inline unsigned blocks(size_t n) { return (unsigned) ((n + 255) / 256); }
 
-}  // namespace
 
-const char *buildBinaryTreeDevice(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BinaryTree &out) {
+// Everything the clustering stage leaves on the device
+struct ClusterTree {
+    DevBuf pos, idx, nodes, dp;
+    uint32_t root = 0, nTris = 0, nVerts = 0;
+    float box[6] = { 0, 0, 0, 0, 0, 0 };
+    int rounds = 0;
+};
+
+static bool gVerbose = false;
+static std::chrono::steady_clock::time_point gLap;
+static void lap(const char *what) {
+    if (!gVerbose) return;
+    (void) hipDeviceSynchronize();
+    auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "mtsamd: device BVH %-28s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - gLap).count());
+    gLap = now;
+}
+
+static const char *clusterOnDevice(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, float costNode, float costTri, ClusterTree &ct) {
     const size_t N = nTris;
-    const bool verbose = getenv("MTSAMD_VERBOSE") != nullptr;
-    auto tStart = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!verbose) return;
-        (void) hipDeviceSynchronize();
-        auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "mtsamd: device BVH %-28s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tStart).count());
-        tStart = now;
-    };
+    gVerbose = getenv("MTSAMD_VERBOSE") != nullptr;
+    gLap = std::chrono::steady_clock::now();
     if (const char *e = getenv("MTSAMD_PLOC_RADIUS")) gRadius = std::min(256, std::max(1, atoi(e)));
-    DevBuf dPos, dIdx, dLo, dHi, dBox, dBad, dKeys, dKeys2, dVals, dVals2, dTemp, dNodes, dCnode[2], dClo[2], dChi[2], dNn, dKeep, dScan, dCounter;
-    DEV_TRY(dPos.alloc((size_t) nVerts * 12)); DEV_TRY(dIdx.alloc(N * 12));
-    DEV_TRY(hipMemcpy(dPos.p, positions, (size_t) nVerts * 12, hipMemcpyHostToDevice));
-    DEV_TRY(hipMemcpy(dIdx.p, indices, N * 12, hipMemcpyHostToDevice));
+    ct.nTris = nTris; ct.nVerts = nVerts;
+    DevBuf dLo, dHi, dBox, dBad, dKeys, dKeys2, dVals, dVals2, dTemp, dCnode[2], dClo[2], dChi[2], dNn, dKeep, dScan, dCounter;
+    DEV_TRY(ct.pos.alloc((size_t) nVerts * 12)); DEV_TRY(ct.idx.alloc(N * 12));
+    DEV_TRY(hipMemcpy(ct.pos.p, positions, (size_t) nVerts * 12, hipMemcpyHostToDevice));
+    DEV_TRY(hipMemcpy(ct.idx.p, indices, N * 12, hipMemcpyHostToDevice));
     DEV_TRY(dLo.alloc(N * 16)); DEV_TRY(dHi.alloc(N * 16)); DEV_TRY(dBox.alloc(24)); DEV_TRY(dBad.alloc(4));
     const float inf = std::numeric_limits<float>::infinity();
     const float boxInit[6] = { inf, inf, inf, -inf, -inf, -inf };
     DEV_TRY(hipMemcpy(dBox.p, boxInit, 24, hipMemcpyHostToDevice));
     DEV_TRY(hipMemset(dBad.p, 0, 4));
-    hipLaunchKernelGGL(k_prim_boxes, dim3(blocks(N)), dim3(256), 0, 0, dPos.as<float>(), dIdx.as<uint32_t>(), nVerts, nTris, dLo.as<float4>(), dHi.as<float4>(), dBad.as<int>());
+    hipLaunchKernelGGL(k_prim_boxes, dim3(blocks(N)), dim3(256), 0, 0, ct.pos.as<float>(), ct.idx.as<uint32_t>(), nVerts, nTris, dLo.as<float4>(), dHi.as<float4>(), dBad.as<int>());
     int bad = 0;
     DEV_TRY(hipMemcpy(&bad, dBad.p, 4, hipMemcpyDeviceToHost));
     if (bad & 1) return "vertex index out of range";
     if (bad & 2) return "non-finite vertex position";
     hipLaunchKernelGGL(k_scene_box, dim3(blocks(N)), dim3(256), 0, 0, dLo.as<float4>(), dHi.as<float4>(), nTris, dBox.as<float>());
-    float box[6];
-    DEV_TRY(hipMemcpy(box, dBox.p, 24, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 3; ++k) { out.sceneBox.lo[k] = box[k]; out.sceneBox.hi[k] = box[3 + k]; }
-
+    DEV_TRY(hipMemcpy(ct.box, dBox.p, 24, hipMemcpyDeviceToHost));
     lap("upload + boxes");
+
     // Morton codes and sort
     DEV_TRY(dKeys.alloc(N * 8)); DEV_TRY(dKeys2.alloc(N * 8)); DEV_TRY(dVals.alloc(N * 4)); DEV_TRY(dVals2.alloc(N * 4));
     hipLaunchKernelGGL(k_morton, dim3(blocks(N)), dim3(256), 0, 0, dLo.as<float4>(), dHi.as<float4>(), nTris, dBox.as<float>(), dKeys.as<unsigned long long>(), dVals.as<uint32_t>());
     size_t tempBytes = 0;
     DEV_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, dKeys.as<unsigned long long>(), dKeys2.as<unsigned long long>(), dVals.as<uint32_t>(), dVals2.as<uint32_t>(), (int) N, 0, 63));
     size_t scanBytes = 0;
-    DEV_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, (uint32_t *) nullptr, (uint32_t *) nullptr, (int) N));
+    DEV_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, (uint32_t *) nullptr, (uint32_t *) nullptr, (int) N + 1));
     DEV_TRY(dTemp.alloc(std::max(tempBytes, scanBytes)));
     DEV_TRY(hipcub::DeviceRadixSort::SortPairs(dTemp.p, tempBytes, dKeys.as<unsigned long long>(), dKeys2.as<unsigned long long>(), dVals.as<uint32_t>(), dVals2.as<uint32_t>(), (int) N, 0, 63));
-
     lap("morton + sort");
+
     // clustering
-    DEV_TRY(dNodes.alloc((2 * N) * sizeof(DNode)));
+    DEV_TRY(ct.nodes.alloc((2 * N) * sizeof(DNode))); DEV_TRY(ct.dp.alloc((2 * N) * sizeof(DDp)));
     for (int k = 0; k < 2; ++k) { DEV_TRY(dCnode[k].alloc(N * 4)); DEV_TRY(dClo[k].alloc(N * 16)); DEV_TRY(dChi[k].alloc(N * 16)); }
     DEV_TRY(dNn.alloc(N * 4)); DEV_TRY(dKeep.alloc((N + 1) * 4)); DEV_TRY(dScan.alloc((N + 1) * 4)); DEV_TRY(dCounter.alloc(4));
     DEV_TRY(hipMemset(dCounter.p, 0, 4));
-    hipLaunchKernelGGL(k_init_clusters, dim3(blocks(N)), dim3(256), 0, 0, dVals2.as<uint32_t>(), dLo.as<float4>(), dHi.as<float4>(), nTris, dNodes.as<DNode>(),
-                       dCnode[0].as<uint32_t>(), dClo[0].as<float4>(), dChi[0].as<float4>());
+    hipLaunchKernelGGL(k_init_clusters, dim3(blocks(N)), dim3(256), 0, 0, dVals2.as<uint32_t>(), dLo.as<float4>(), dHi.as<float4>(), nTris, ct.nodes.as<DNode>(),
+                       ct.dp.as<DDp>(), costTri, dCnode[0].as<uint32_t>(), dClo[0].as<float4>(), dChi[0].as<float4>());
     uint32_t n = nTris;
-    int cur = 0, iterations = 0;
+    int cur = 0;
+    ct.rounds = 0;
     while (n > 1) {
-        if (++iterations > 4096) return "device BVH build did not converge";
+        if (++ct.rounds > 4096) return "device BVH build did not converge";
         hipLaunchKernelGGL(k_nearest, dim3(blocks(n)), dim3(256), 0, 0, dClo[cur].as<float4>(), dChi[cur].as<float4>(), n, dNn.as<uint32_t>(), (uint32_t) gRadius);
-        hipLaunchKernelGGL(k_merge, dim3(blocks(n)), dim3(256), 0, 0, dNn.as<uint32_t>(), n, nTris, dCounter.as<uint32_t>(), dNodes.as<DNode>(),
-                           dCnode[cur].as<uint32_t>(), dClo[cur].as<float4>(), dChi[cur].as<float4>(), dKeep.as<uint32_t>());
+        hipLaunchKernelGGL(k_merge, dim3(blocks(n)), dim3(256), 0, 0, dNn.as<uint32_t>(), n, nTris, dCounter.as<uint32_t>(), ct.nodes.as<DNode>(), ct.dp.as<DDp>(),
+                           costNode, costTri, dCnode[cur].as<uint32_t>(), dClo[cur].as<float4>(), dChi[cur].as<float4>(), dKeep.as<uint32_t>());
         DEV_TRY(hipMemsetAsync(dKeep.as<uint32_t>() + n, 0, 4, 0));
         size_t sb = scanBytes;
         DEV_TRY(hipcub::DeviceScan::ExclusiveSum(dTemp.p, sb, dKeep.as<uint32_t>(), dScan.as<uint32_t>(), (int) n + 1));
@@ -237,13 +299,177 @@ const char *buildBinaryTreeDevice(const float *positions, uint32_t nVerts, const
         n = n2; cur ^= 1;
     }
     DEV_TRY(hipGetLastError());
+    DEV_TRY(hipMemcpy(&ct.root, dCnode[cur].p, 4, hipMemcpyDeviceToHost));
     lap("clustering");
-    if (verbose) fprintf(stderr, "mtsamd: device BVH %d clustering rounds\n", iterations);
-    uint32_t root = 0;
-    DEV_TRY(hipMemcpy(&root, dCnode[cur].p, 4, hipMemcpyDeviceToHost));
-    std::vector<DNode> dn(2 * N - 1);
-    DEV_TRY(hipMemcpy(dn.data(), dNodes.p, dn.size() * sizeof(DNode), hipMemcpyDeviceToHost));
+    if (gVerbose) fprintf(stderr, "mtsamd: device BVH %d clustering rounds\n", ct.rounds);
+    return "";
+}
 
+// ---- emission of the wide BVH on the device, one level per launch ---------------------------------------------------------
+struct EmitArgs {
+    const DNode *nodes; const DDp *dp;
+    const float *positions; const uint32_t *indices;
+    uint32_t *wideBin;          // wide node index -> binary node it represents
+    float4 *outNodes; float4 *outTris;
+    uint32_t nodeStride, triStride, nodeCapacity;
+    uint32_t *counters;         // [0] wide nodes allocated, [1] triangle records allocated, [2] overflow flag
+    double *sah; float rootArea, costNode, costTri;
+    uint32_t root, levelStart, levelEnd;
+};
+
+// roots of the cheapest representation of subtree n by at most j roots (iterative form of the host's Collector)
+__device__ inline void collectRoots(const DNode *nodes, const DDp *dp, uint32_t n, int j, uint32_t *kids, int &nk) {
+    uint32_t stackN[16]; int stackJ[16]; int sp = 0;
+    stackN[sp] = n; stackJ[sp++] = j;
+    while (sp > 0) {
+        n = stackN[--sp]; j = stackJ[sp];
+        while (true) {
+            const DNode &nd = nodes[n];
+            if (nd.left == kNone || j == 1) { kids[nk++] = n; break; }
+            if (j <= 7 && !((dp[n].take >> j) & 1)) { --j; continue; }
+            const int k = dp[n].k[j];
+            // the left part is expanded first so that the order of the roots matches the host builder's
+            stackN[sp] = nd.right; stackJ[sp++] = j - k;
+            n = nd.left; j = k;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_emit_level(EmitArgs a) {
+    const uint32_t w = a.levelStart + blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= a.levelEnd) return;
+    const uint32_t bn = a.wideBin[w];
+    const DNode &n2 = a.nodes[bn];
+    uint32_t kids[8];
+    int nk = 0;
+    if (n2.left == kNone || (bn == a.root && a.dp[bn].leaf)) {
+        kids[nk++] = bn;        // the whole scene fits one leaf
+    } else {
+        const int k = a.dp[bn].k[8];
+        collectRoots(a.nodes, a.dp, n2.left, k, kids, nk);
+        collectRoots(a.nodes, a.dp, n2.right, 8 - k, kids, nk);
+    }
+    // padded child boxes and node bounds
+    float clo[8][3], chi[8][3], nlo[3] = { INFINITY, INFINITY, INFINITY }, nhi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int i = 0; i < nk; ++i) {
+        const DNode &c = a.nodes[kids[i]];
+        for (int ax = 0; ax < 3; ++ax) {
+            const float m = fmaxf(fabsf(c.lo[ax]), fabsf(c.hi[ax]));
+            const float pad = m * 0x1p-20f + 1e-30f;
+            clo[i][ax] = c.lo[ax] - pad; chi[i][ax] = c.hi[ax] + pad;
+            nlo[ax] = fminf(nlo[ax], clo[i][ax]); nhi[ax] = fmaxf(nhi[ax], chi[i][ax]);
+        }
+    }
+    double sah = (double) (boxArea(nlo, nhi) / a.rootArea) * a.costNode;
+
+    // slot s is the first one visited by rays of sign octant s: it should hold the child lying furthest "behind" along
+    // the representative direction of that octant (greedy assignment, cheapest pair first)
+    int slotOf[8], childAt[8];
+    for (int i = 0; i < 8; ++i) { slotOf[i] = -1; childAt[i] = -1; }
+    const float nc[3] = { 0.5f * (nlo[0] + nhi[0]), 0.5f * (nlo[1] + nhi[1]), 0.5f * (nlo[2] + nhi[2]) };
+    for (int it = 0; it < nk; ++it) {
+        int bi = -1, bs = -1; float bc = INFINITY;
+        for (int i = 0; i < nk; ++i) {
+            if (slotOf[i] >= 0) continue;
+            for (int s = 0; s < 8; ++s) {
+                if (childAt[s] >= 0) continue;
+                float c = 0;
+                for (int ax = 0; ax < 3; ++ax) {
+                    const float d = 0.5f * (clo[i][ax] + chi[i][ax]) - nc[ax];
+                    c += ((s >> ax) & 1) ? -d : d;
+                }
+                if (c < bc) { bc = c; bi = i; bs = s; }
+            }
+        }
+        slotOf[bi] = bs; childAt[bs] = bi;
+    }
+
+    WideNode node;
+    memset(&node, 0, sizeof(node));
+    for (int ax = 0; ax < 3; ++ax) {
+        node.p[ax] = nlo[ax];
+        const float ext = nhi[ax] - nlo[ax];
+        int e = 1;
+        if (ext > 0) {
+            int ex;
+            frexpf(ext / 255.0f, &ex);      // ext/255 = m * 2^ex with m in [0.5,1)  => 2^ex >= ext/255
+            e = min(254, max(1, ex + 127));
+        }
+        node.e[ax] = (uint8_t) e;
+    }
+    uint32_t nInternal = 0, nLeafTris = 0;
+    for (int i = 0; i < nk; ++i) { if (a.dp[kids[i]].leaf) nLeafTris += a.nodes[kids[i]].count; else nInternal++; }
+    const uint32_t childBase = nInternal ? atomicAdd(&a.counters[0], nInternal) : 0u;
+    const uint32_t triBase = nLeafTris ? atomicAdd(&a.counters[1], nLeafTris) : 0u;
+    if (childBase + nInternal > a.nodeCapacity) { atomicOr(&a.counters[2], 1u); return; }
+    node.childBase = childBase; node.triBase = triBase;
+    uint32_t rank = 0, triOfs = 0;
+    for (int s = 0; s < 8; ++s) {
+        const int i = childAt[s];
+        if (i < 0) continue;
+        const DNode &c = a.nodes[kids[i]];
+        for (int ax = 0; ax < 3; ++ax) {
+            const double scale = (double) __uint_as_float((uint32_t) node.e[ax] << 23);
+            const double p = node.p[ax];
+            int lo = (int) floor(((double) clo[i][ax] - p) / scale);
+            int hi = (int) ceil(((double) chi[i][ax] - p) / scale);
+            lo = min(255, max(0, lo));
+            hi = min(255, max(0, hi));
+            // the decoded planes must enclose the padded child box
+            while (lo > 0 && p + lo * scale > (double) clo[i][ax]) --lo;
+            while (hi < 255 && p + hi * scale < (double) chi[i][ax]) ++hi;
+            node.qlo[ax][s] = (uint8_t) lo;
+            node.qhi[ax][s] = (uint8_t) hi;
+        }
+        if (a.dp[kids[i]].leaf) {
+            const uint32_t unary = (1u << c.count) - 1u;     // 1 -> 001, 2 -> 011, 3 -> 111
+            node.meta[s] = (uint8_t) ((unary << 5) | triOfs);
+            // the (at most three) triangles of the leaf: walk its little subtree, left to right
+            uint32_t st[4]; int sp = 0; uint32_t j = 0;
+            st[sp++] = kids[i];
+            while (sp > 0) {
+                const DNode &ln = a.nodes[st[--sp]];
+                if (ln.left != kNone) { st[sp++] = ln.right; st[sp++] = ln.left; continue; }
+                const uint32_t tri = ln.right;
+                TriRecord tr;
+                loadTriRecordHD(a.positions + 3 * (size_t) a.indices[3 * (size_t) tri], a.positions + 3 * (size_t) a.indices[3 * (size_t) tri + 1],
+                                a.positions + 3 * (size_t) a.indices[3 * (size_t) tri + 2], tr);
+                tr.tri = tri;
+                float4 *dst = a.outTris + (size_t) a.triStride * (triBase + triOfs + j);
+                const float4 *src = reinterpret_cast<const float4 *>(&tr);
+                dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+                ++j;
+            }
+            float plo[3] = { clo[i][0], clo[i][1], clo[i][2] }, phi[3] = { chi[i][0], chi[i][1], chi[i][2] };
+            sah += (double) (boxArea(plo, phi) / a.rootArea) * a.costTri * c.count;
+            triOfs += c.count;
+        } else {
+            node.imask |= (uint8_t) (1u << s);
+            node.meta[s] = (uint8_t) (0x20 | (24 + s));
+            a.wideBin[childBase + rank] = kids[i];      // internal children are laid out contiguously in slot order
+            ++rank;
+        }
+    }
+    float4 *dst = a.outNodes + (size_t) a.nodeStride * w;
+    const float4 *src = reinterpret_cast<const float4 *>(&node);
+    for (int k = 0; k < 5; ++k) dst[k] = src[k];
+    atomicAdd(a.sah, sah);
+}
+
+}  // namespace
+
+static float gCostNode = 1.0f, gCostTri = 0.5f;
+void setDeviceBuilderCosts(float costNode, float costTri) { gCostNode = costNode; gCostTri = costTri; }
+
+const char *buildBinaryTreeDevice(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BinaryTree &out) {
+    const size_t N = nTris;
+    ClusterTree ct;
+    const char *err = clusterOnDevice(positions, nVerts, indices, nTris, gCostNode, gCostTri, ct);
+    if (err && *err) return err;
+    for (int k = 0; k < 3; ++k) { out.sceneBox.lo[k] = ct.box[k]; out.sceneBox.hi[k] = ct.box[3 + k]; }
+    const uint32_t root = ct.root;
+    std::vector<DNode> dn(2 * N - 1);
+    DEV_TRY(hipMemcpy(dn.data(), ct.nodes.p, dn.size() * sizeof(DNode), hipMemcpyDeviceToHost));
     lap("download");
     // depth-first renumbering: parents before children, subtree triangles contiguous
     out.nodes.assign(2 * N, Node2());
@@ -277,6 +503,65 @@ const char *buildBinaryTreeDevice(const float *positions, uint32_t nVerts, const
         if (!h.isLeaf()) { h.first = out.nodes[h.left].first; h.count = out.nodes[h.left].count + out.nodes[h.right].count; }
     }
     lap("host renumbering");
+    return "";
+}
+
+// The whole build on the device: clustering, collapse tables, then the wide nodes and triangle records are written
+// level by level straight into device memory (the caller owns the two buffers afterwards).
+const char *buildWideDevice(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, uint32_t nodeStride, uint32_t triStride,
+                            void **outNodes, void **outTris, BVH &info) {
+    auto t0 = std::chrono::steady_clock::now();
+    const size_t N = nTris;
+    ClusterTree ct;
+    const char *err = clusterOnDevice(positions, nVerts, indices, nTris, gCostNode, gCostTri, ct);
+    if (err && *err) return err;
+    info.binarySeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (int k = 0; k < 3; ++k) { info.aabbMin[k] = ct.box[k]; info.aabbMax[k] = ct.box[3 + k]; }
+    const uint32_t capacity = (uint32_t) (N / 2 + 64);      // a wide node has at least two children; typical use is N/8
+    DevBuf dWideBin, dNodes, dTris, dCounters, dSah;
+    DEV_TRY(dWideBin.alloc((size_t) capacity * 4));
+    DEV_TRY(dNodes.alloc((size_t) capacity * nodeStride * 16)); DEV_TRY(dTris.alloc(N * triStride * 16));
+    DEV_TRY(hipMemset(dNodes.p, 0, (size_t) capacity * nodeStride * 16)); DEV_TRY(hipMemset(dTris.p, 0, N * triStride * 16));
+    DEV_TRY(dCounters.alloc(16)); DEV_TRY(dSah.alloc(8));
+    const uint32_t init[4] = { 1, 0, 0, 0 };
+    DEV_TRY(hipMemcpy(dCounters.p, init, 16, hipMemcpyHostToDevice));
+    DEV_TRY(hipMemset(dSah.p, 0, 8));
+    DEV_TRY(hipMemcpy(dWideBin.p, &ct.root, 4, hipMemcpyHostToDevice));
+    EmitArgs a;
+    a.nodes = ct.nodes.as<DNode>(); a.dp = ct.dp.as<DDp>(); a.positions = ct.pos.as<float>(); a.indices = ct.idx.as<uint32_t>();
+    a.wideBin = dWideBin.as<uint32_t>(); a.outNodes = dNodes.as<float4>(); a.outTris = dTris.as<float4>();
+    a.nodeStride = nodeStride; a.triStride = triStride; a.nodeCapacity = capacity;
+    a.counters = dCounters.as<uint32_t>(); a.sah = dSah.as<double>();
+    float lo[3] = { ct.box[0], ct.box[1], ct.box[2] }, hi[3] = { ct.box[3], ct.box[4], ct.box[5] };
+    Box sb; for (int k = 0; k < 3; ++k) { sb.lo[k] = lo[k]; sb.hi[k] = hi[k]; }
+    a.rootArea = std::max(sb.area(), 1e-30f); a.costNode = gCostNode; a.costTri = gCostTri;
+    a.root = ct.root;
+    uint32_t start = 0, end = 1, depth = 0;
+    while (start < end) {
+        if (++depth > (uint32_t) kMaxWideDepth) return "BVH too deep for the traversal stack";
+        a.levelStart = start; a.levelEnd = end;
+        hipLaunchKernelGGL(k_emit_level, dim3((end - start + 63) / 64), dim3(64), 0, 0, a);
+        uint32_t c[4];
+        DEV_TRY(hipMemcpy(c, dCounters.p, 16, hipMemcpyDeviceToHost));
+        if (c[2]) return "device BVH build ran out of node space";
+        start = end; end = c[0];
+    }
+    DEV_TRY(hipGetLastError());
+    uint32_t c[4];
+    DEV_TRY(hipMemcpy(c, dCounters.p, 16, hipMemcpyDeviceToHost));
+    if (c[1] != nTris) return "device BVH build lost triangles";
+    if (c[0] >= (1u << 24)) return "BVH has too many nodes for the 24-bit traversal stack entries";
+    DEV_TRY(hipMemcpy(&info.sahCost, dSah.p, 8, hipMemcpyDeviceToHost));
+    // hand over right-sized buffers
+    void *nodesOut = nullptr;
+    DEV_TRY(hipMalloc(&nodesOut, (size_t) c[0] * nodeStride * 16));
+    DEV_TRY(hipMemcpy(nodesOut, dNodes.p, (size_t) c[0] * nodeStride * 16, hipMemcpyDeviceToDevice));
+    *outNodes = nodesOut;
+    *outTris = dTris.p; dTris.p = nullptr;
+    info.nodes.clear(); info.tris.clear();
+    info.nodeCount = c[0]; info.triCount = c[1]; info.depth = depth; info.builder = BVH_BUILDER_DEVICE;
+    lap("collapse + emission");
+    info.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return "";
 }
 

@@ -47,6 +47,11 @@ struct BinaryTree {
 const char *buildBinaryTreeHost(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BinaryTree &out);
 // Device builder: Morton sort + parallel locally-ordered clustering on the current HIP device.
 const char *buildBinaryTreeDevice(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BinaryTree &out);
+// The whole build on the current HIP device: the wide nodes and triangle records are written into two device buffers
+// (hipMalloc'ed, handed to the caller); `info` receives counts, depth, bounds and timings, no host copies.
+const char *buildWideDevice(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, uint32_t nodeStride, uint32_t triStride,
+                            void **outNodes, void **outTris, BVH &info);
+void setDeviceBuilderCosts(float costNode, float costTri);
 // Optimal collapse to 8-wide nodes, slot assignment, quantisation, triangle records.
 const char *collapseToWide(const BinaryTree &tree, const float *positions, const uint32_t *indices, BVH &out);
 

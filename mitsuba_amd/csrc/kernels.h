@@ -377,6 +377,17 @@ __global__ void __launch_bounds__(256) k_film_tiled(DevScene sc, PassParams pp, 
     }
 }
 
+// After a device-side BVH build: every triangle record learns the BSDF type of its triangle's material (bits 28..30 of
+// the spare word), which the traversal hands on with the hit. The host-built path does the same on the host.
+__global__ void k_tag_triangle_records(float4 *tris, uint32_t triStride, uint32_t n, const float4 *shadeTris, const DevMaterial *materials) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 *rec = tris + (size_t) triStride * i;
+    const uint32_t tri = __float_as_uint(rec[2].z);
+    const uint32_t mat = __float_as_uint(shadeTris[6 * (size_t) tri].w) & 0xffffffu;
+    rec[2].w = __uint_as_float((uint32_t) materials[mat].type << 28);
+}
+
 // ---- batch kernels behind the parity entry points -------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_fill_isect(DevScene sc, const float *rays, const float4 *hits, uint32_t n, mtsamd_intersection *out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -3,6 +3,7 @@
 #include "../../include/mtsamd.h"
 #include "host_scene.h"
 #include "kernels.h"
+#include "bvh_internal.h"
 
 #include <atomic>
 #include <chrono>
@@ -150,10 +151,12 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
                 HIP_TRY(hipMemcpy(buf.ptr, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
                 return MTSAMD_OK;
             };
-            int rc2 = padded(s->nodes, h.bvh.nodes.data(), h.bvh.nodes.size(), sizeof(WideNode), (size_t) s->nodeStride * 16);
-            if (rc2 != MTSAMD_OK) return rc2;
-            rc2 = padded(s->tris, h.bvh.tris.data(), h.bvh.tris.size(), sizeof(TriRecord), (size_t) s->triStride * 16);
-            if (rc2 != MTSAMD_OK) return rc2;
+            if (!(h.bvh.builder == BVH_BUILDER_DEVICE && h.desc.n_triangles > 0)) {
+                int rc2 = padded(s->nodes, h.bvh.nodes.data(), h.bvh.nodes.size(), sizeof(WideNode), (size_t) s->nodeStride * 16);
+                if (rc2 != MTSAMD_OK) return rc2;
+                rc2 = padded(s->tris, h.bvh.tris.data(), h.bvh.tris.size(), sizeof(TriRecord), (size_t) s->triStride * 16);
+                if (rc2 != MTSAMD_OK) return rc2;
+            }
         }
         HIP_TRY(upload(s->shadeTris, h.shadeTris));
         if (!h.shadeUV.empty()) HIP_TRY(upload(s->shadeUV, h.shadeUV));
@@ -163,6 +166,17 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
         HIP_TRY(upload(s->emitterCdf, h.emitterCdf));
         HIP_TRY(upload(s->areaCdf, h.areaCdf));
         HIP_TRY(upload(s->rtrans, h.rtrans));
+        if (h.bvh.builder == BVH_BUILDER_DEVICE && h.desc.n_triangles > 0) {
+            // the acceleration structure is built where it will be used; the records then learn their BSDF types
+            void *dn = nullptr, *dt = nullptr;
+            const char *err = buildWideDevice(h.positions.data(), h.desc.n_vertices, h.indices.data(), h.desc.n_triangles, s->nodeStride, s->triStride, &dn, &dt, h.bvh);
+            if (err && *err) return fail(MTSAMD_EDEVICE, "%s", err);
+            s->nodes.ptr = dn; s->nodes.bytes = (size_t) h.bvh.nodeCount * s->nodeStride * 16;
+            s->tris.ptr = dt; s->tris.bytes = (size_t) h.bvh.triCount * s->triStride * 16;
+            hipLaunchKernelGGL(k_tag_triangle_records, dim3(blocksFor(h.bvh.triCount, 256)), dim3(256), 0, 0, s->tris.as<float4>(), s->triStride, h.bvh.triCount,
+                               s->shadeTris.as<float4>(), s->materials.as<DevMaterial>());
+            HIP_TRY(hipDeviceSynchronize());
+        }
         HIP_TRY(s->counters.ensure(CNT_WORDS * sizeof(uint32_t)));
         HIP_TRY(hipMemset(s->counters.ptr, 0, CNT_WORDS * sizeof(uint32_t)));
         HIP_TRY(hipStreamCreate(&s->stream));
@@ -190,7 +204,7 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
         if (const char *e = getenv("MTSAMD_CHUNK_MAX")) s->chunkMax = (uint32_t) std::min(65536, std::max(64, atoi(e)));
         if (const char *e = getenv("MTSAMD_TOP_NODES")) s->topNodes = (uint32_t) std::min(1800, std::max(0, atoi(e)));
         if (const char *e = getenv("MTSAMD_TRACE_BLOCK")) s->traceBlock = (unsigned) std::min(1024, std::max(64, atoi(e) / 64 * 64));
-        s->topNodes = std::min<uint32_t>(s->topNodes, (uint32_t) h.bvh.nodes.size());
+        s->topNodes = std::min<uint32_t>(s->topNodes, h.bvh.nodeCount);
         const size_t lds = traceLdsBytes(s->topNodes, s->traceBlock);
         if (lds > (size_t) prop.sharedMemPerBlock) {
             const void *fns[] = { (const void *) k_trace<TRACE_CLOSEST, false>, (const void *) k_trace<TRACE_CLOSEST, true>,
@@ -212,8 +226,8 @@ extern "C" void mtsamd_scene_destroy(mtsamd_scene *scene) { delete scene; }
 extern "C" int mtsamd_scene_bvh_info(const mtsamd_scene *scene, mtsamd_bvh_info *info) {
     if (!scene || !info) return fail(MTSAMD_EINVAL, "null argument");
     const BVH &b = scene->host.bvh;
-    info->n_nodes = (uint32_t) b.nodes.size(); info->n_triangles = (uint32_t) b.tris.size(); info->depth = b.depth;
-    info->node_bytes = b.nodes.size() * sizeof(WideNode); info->triangle_bytes = b.tris.size() * sizeof(TriRecord);
+    info->n_nodes = b.nodeCount; info->n_triangles = b.triCount; info->depth = b.depth;
+    info->node_bytes = (uint64_t) b.nodeCount * sizeof(WideNode); info->triangle_bytes = (uint64_t) b.triCount * sizeof(TriRecord);
     info->build_seconds = b.buildSeconds; info->sah_cost = b.sahCost;
     info->binary_seconds = b.binarySeconds; info->builder = b.builder; info->reserved = 0;
     return MTSAMD_OK;

@@ -395,3 +395,42 @@ def test_two_ranks_sample_and_tile_partition(tmp_path):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                           "--master-port", "29631", str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert "DIST_GPU_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_device_built_bvh_gives_the_same_answers(gpu, oracle_mod, monkeypatch):
+    """The tree built on the GPU (Morton sort + clustering) differs in topology, not in query results."""
+    sd = S.small_test_scene()
+    monkeypatch.setenv("MTSAMD_BVH_BUILDER", "host")
+    host = gpu.Scene(sd)
+    monkeypatch.setenv("MTSAMD_BVH_BUILDER", "device-binary")
+    mixed = gpu.Scene(sd)
+    monkeypatch.setenv("MTSAMD_BVH_BUILDER", "device")
+    dev = gpu.Scene(sd)
+    monkeypatch.delenv("MTSAMD_BVH_BUILDER")
+    assert (dev.bvh_info().builder, mixed.bvh_info().builder, host.bvh_info().builder) == (1, 2, 0)
+    assert dev.bvh_info().n_triangles == mixed.bvh_info().n_triangles == host.bvh_info().n_triangles == sd.n_triangles
+    assert dev.bvh_info().n_nodes == mixed.bvh_info().n_nodes          # same binary tree, same collapse, two implementations
+    o = oracle_mod.OracleScene(sd)
+    rays = np.concatenate([random_rays(sd, 50000), surface_rays(sd, o, 30000)])
+    hh, hd = host.trace(rays), dev.trace(rays)
+    for k in ("t", "u", "v", "shape", "prim"):
+        assert np.array_equal(hh[k], hd[k]), k
+    hm = mixed.trace(rays)
+    for k in ("t", "u", "v", "shape", "prim"):
+        assert np.array_equal(hh[k], hm[k]), k
+    assert np.array_equal(host.occluded(rays), dev.occluded(rays))
+    # degenerate inputs: one triangle, two coincident triangles
+    b = S.SceneBuilder()
+    m = b.add_material(S.diffuse())
+    p = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    b.add_mesh(p, np.array([[0, 1, 2]], np.uint32), m)
+    one = b.finish(S.make_camera([0.2, 0.2, 3], [0.2, 0.2, 0], [0, 1, 0], 40), S.make_film(16, 16), {})
+    r1 = np.array([[0.2, 0.2, 3, 1e-4, 0, 0, -1, np.inf]], np.float32)
+    assert gpu.Scene(one).trace(r1)["prim"][0] == 0
+    b.add_mesh(p, np.array([[0, 1, 2]], np.uint32), m)
+    two = b.finish(S.make_camera([0.2, 0.2, 3], [0.2, 0.2, 0], [0, 1, 0], 40), S.make_film(16, 16), {})
+    h2 = gpu.Scene(two).trace(r1)
+    assert h2["shape"][0] == 0 and h2["t"][0] == 3.0       # equal-distance tie goes to the lower triangle index
+    fh, sh = host.render(3, seed=8)
+    fd, sdv = dev.render(3, seed=8)
+    assert np.array_equal(fh, fd) and (sh.normal_rays, sh.shadow_rays) == (sdv.normal_rays, sdv.shadow_rays)
