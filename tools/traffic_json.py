@@ -29,5 +29,5 @@ write, nw = collect(sys.argv[2], "WRITE_SIZE")
 out = {"kernel": "k_trace<TRACE_CLOSEST>", "launches": nf,
        "fetch_kib_raw": fetch, "write_kib": write,
        "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024.0 / max(nf, 1),
-       "note": "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); bench.py --steps 1 --warmup 0, 32 spp pass"}
+       "note": "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); bench.py --steps 1 --warmup 0, one 128 spp pass"}
 print(json.dumps(out))
