@@ -71,6 +71,8 @@ struct mtsamd_scene {
     DeviceBuffer qbuf[2][5], hits, sbuf[3], sampleL, samplePos, counters, scratch[8];
     size_t capacity = 0;
     hipStream_t stream = nullptr;
+    hipStream_t shadowStream = nullptr;   // shadow rays of bounce k are traced next to the extension rays of bounce k+1
+    hipEvent_t evShaded = nullptr, evShadowed = nullptr;
     uint32_t *hostCounters = nullptr;     // pinned
     std::atomic<int> cancel{ 0 };
     bool countTraversal = false;
@@ -78,10 +80,14 @@ struct mtsamd_scene {
     // thresholds of the traversal loop
     unsigned traceGrid = 0, traceBlock = 256;
     uint32_t nodeStride = 5, triStride = 3;     // record strides in float4 units (padding buys line alignment)
+    uint64_t overlapBelow = 8u << 20;     // rays (shadow + next extend) below which the two traversals run side by side
     uint32_t refillBelow = 56, triShare = 16, topNodes = 73, chunkMax = 512;
 
     ~mtsamd_scene() {
         if (stream) (void) hipStreamDestroy(stream);
+        if (shadowStream) (void) hipStreamDestroy(shadowStream);
+        if (evShaded) (void) hipEventDestroy(evShaded);
+        if (evShadowed) (void) hipEventDestroy(evShadowed);
         if (hostCounters) (void) hipHostFree(hostCounters);
     }
 
@@ -98,6 +104,8 @@ struct mtsamd_scene {
     }
     int ensureWork(size_t n) {
         if (n <= capacity) return MTSAMD_OK;
+        // a failed growth leaves some buffers released: forget the old capacity so that the next call rebuilds all of them
+        capacity = 0;
         for (int i = 0; i < 2; ++i) {
             for (int j = 0; j < 4; ++j) HIP_TRY(qbuf[i][j].ensure(n * 16));
             HIP_TRY(qbuf[i][4].ensure(n * 4));
@@ -180,6 +188,9 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
         HIP_TRY(s->counters.ensure(CNT_WORDS * sizeof(uint32_t)));
         HIP_TRY(hipMemset(s->counters.ptr, 0, CNT_WORDS * sizeof(uint32_t)));
         HIP_TRY(hipStreamCreate(&s->stream));
+        HIP_TRY(hipStreamCreate(&s->shadowStream));
+        HIP_TRY(hipEventCreateWithFlags(&s->evShaded, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->evShadowed, hipEventDisableTiming));
         HIP_TRY(hipHostMalloc((void **) &s->hostCounters, CNT_WORDS * sizeof(uint32_t)));
         return MTSAMD_OK;
     };
@@ -201,6 +212,7 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         if (const char *e = getenv("MTSAMD_REFILL_BELOW")) s->refillBelow = (uint32_t) std::min(64, std::max(1, atoi(e)));
         if (const char *e = getenv("MTSAMD_TRI_SHARE")) s->triShare = (uint32_t) std::min(64, std::max(1, atoi(e)));
+        if (const char *e = getenv("MTSAMD_OVERLAP_BELOW")) s->overlapBelow = (uint64_t) std::max(0ll, atoll(e));
         if (const char *e = getenv("MTSAMD_CHUNK_MAX")) s->chunkMax = (uint32_t) std::min(65536, std::max(64, atoi(e)));
         if (const char *e = getenv("MTSAMD_TOP_NODES")) s->topNodes = (uint32_t) std::min(1800, std::max(0, atoi(e)));
         if (const char *e = getenv("MTSAMD_TRACE_BLOCK")) s->traceBlock = (unsigned) std::min(1024, std::max(64, atoi(e) / 64 * 64));
@@ -247,16 +259,16 @@ struct EventTimer {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool[5];
     bool enabled = false;
     hipStream_t stream = nullptr;
-    void begin(int cls) {
+    void begin(int cls, hipStream_t on = nullptr) {
         if (!enabled) return;
         hipEvent_t a, b;
         (void) hipEventCreate(&a); (void) hipEventCreate(&b);
-        (void) hipEventRecord(a, stream);
+        (void) hipEventRecord(a, on ? on : stream);
         pool[cls].push_back({ a, b });
     }
-    void end(int cls) {
+    void end(int cls, hipStream_t on = nullptr) {
         if (!enabled) return;
-        (void) hipEventRecord(pool[cls].back().second, stream);
+        (void) hipEventRecord(pool[cls].back().second, on ? on : stream);
     }
     double total(int cls) {
         double ms = 0;
@@ -321,9 +333,10 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
     timer.end(T_RAYGEN);
 
     uint64_t normalRays = 0, shadowRays = 0, iterations = 0;
+    bool shadowPending = false;
     const bool traceIters = getenv("MTSAMD_TRACE_ITERS") != nullptr;
     while (n > 0) {
-        if (s->cancel.load()) { (void) hipStreamSynchronize(st); return fail(MTSAMD_ECANCELLED, "render cancelled"); }
+        if (s->cancel.load()) { (void) hipStreamSynchronize(st); (void) hipStreamSynchronize(s->shadowStream); return fail(MTSAMD_ECANCELLED, "render cancelled"); }
         PathQueue qin = s->queue(cur), qout = s->queue(cur ^ 1);
         TraceArgs ta;
         memset(&ta, 0, sizeof(ta));
@@ -333,11 +346,14 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         launchTrace<TRACE_CLOSEST>(s, ta, st);
         timer.end(T_EXTEND);
         normalRays += n;
+        // the previous bounce's shadow rays (other stream) must have landed in sampleL and released their counter
+        if (shadowPending) { HIP_TRY(hipStreamWaitEvent(st, s->evShadowed, 0)); shadowPending = false; }
         // queue lengths and both ray hand-out counters start from zero for the rest of this bounce and the next extend
         HIP_TRY(hipMemsetAsync(cnt, 0, CNT_QUEUE_WORDS * sizeof(uint32_t), st));
         timer.begin(T_SHADE);
         hipLaunchKernelGGL(k_shade, dim3(blocksFor(n, kShadeBlock)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, cnt, n);
         timer.end(T_SHADE);
+        HIP_TRY(hipEventRecord(s->evShaded, st));
         HIP_TRY(hipMemcpyAsync(s->hostCounters, cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const uint32_t nNext = s->hostCounters[CNT_NEXT], nShadow = s->hostCounters[CNT_SHADOW];
@@ -346,9 +362,15 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
             memset(&sa, 0, sizeof(sa));
             sa.rayO = sq.rayO; sa.rayD = sq.rayD; sa.stride = 1; sa.n = nShadow;
             sa.fetchCounter = cnt + CNT_SHD_FETCH; sa.contrib = sq.contrib; sa.sampleL = sampleL; sa.stats = cnt64 + CNT64_SHD_NODES;
-            timer.begin(T_SHADOW);
-            launchTrace<TRACE_SHADOW_ACCUM>(s, sa, st);
-            timer.end(T_SHADOW);
+            // Launches that cannot fill the device by themselves go to a second stream: the shadow rays only need this
+            // bounce's shade and run beside the next bounce's extend, each hiding the other's ramp-up and drain.
+            const bool beside = (uint64_t) nShadow + nNext < s->overlapBelow;
+            hipStream_t sst = beside ? s->shadowStream : st;
+            if (beside) HIP_TRY(hipStreamWaitEvent(sst, s->evShaded, 0));
+            timer.begin(T_SHADOW, sst);
+            launchTrace<TRACE_SHADOW_ACCUM>(s, sa, sst);
+            timer.end(T_SHADOW, sst);
+            if (beside) { HIP_TRY(hipEventRecord(s->evShadowed, sst)); shadowPending = true; }
             shadowRays += nShadow;
         }
         if (traceIters) fprintf(stderr, "iter %llu n=%u shadow=%u next=%u\n", (unsigned long long) iterations, n, nShadow, nNext);
@@ -356,6 +378,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         cur ^= 1;
         ++iterations;
     }
+    if (shadowPending) { HIP_TRY(hipStreamWaitEvent(st, s->evShadowed, 0)); shadowPending = false; }
     if (liOut) {
         hipLaunchKernelGGL(k_copy_samples, dim3(blocksFor(nPaths, 256)), dim3(256), 0, st, sampleL, samplePos, (uint32_t) nPaths, liOut, liPos, liOffset);
     } else {
@@ -410,6 +433,13 @@ int renderCommon(mtsamd_scene *s, const mtsamd_render_opts *opts, float *filmDev
     timer.enabled = stats != nullptr;
     if (s->countTraversal) HIP_TRY(hipMemsetAsync(s->counters.ptr, 0, CNT_WORDS * sizeof(uint32_t), s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    // The work buffers are allocated before the clock starts; when the device cannot hold the chosen pass size the pass
+    // is halved until it fits (per-sample output needs the whole pass and fails instead).
+    while ((rc = s->ensureWork((size_t) w * h * sppPass)) != MTSAMD_OK) {
+        if (sppPass == 1 || liOutDev || o.spp_per_pass > 0) return rc;
+        (void) hipGetLastError();
+        sppPass = std::max(1, sppPass / 2);
+    }
     auto t0 = std::chrono::steady_clock::now();
     for (int done = 0; done < o.spp; done += sppPass) {
         PassParams pp;
