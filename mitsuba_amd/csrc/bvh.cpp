@@ -137,6 +137,30 @@ const char *buildBinaryTreeHost(const float *positions, uint32_t nVerts, const u
     return "";
 }
 
+// The same SAH sweep over arbitrary boxes (the device builder uses it for the top of its tree, over clusters)
+const char *buildBinaryOverBoxes(const std::vector<Box> &boxes, BinaryTree &out) {
+    const uint32_t n = (uint32_t) boxes.size();
+    Builder2 b2;
+    b2.prims.resize(n);
+    Box sceneBox; sceneBox.reset();
+    for (uint32_t i = 0; i < n; ++i) {
+        Prim &p = b2.prims[i];
+        p.tri = i; p.box = boxes[i];
+        for (int k = 0; k < 3; ++k) p.c[k] = 0.5f * (p.box.lo[k] + p.box.hi[k]);
+        sceneBox.grow(p.box);
+    }
+    b2.nodes.resize(2 * (size_t) n + 2);
+    b2.nextNode = 1;
+    b2.maxThreads = (int) std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    b2.build(0, 0, n, 0);
+    out.nNodes = b2.nextNode.load();
+    out.nodes.swap(b2.nodes);
+    out.primTri.resize(n);
+    for (uint32_t i = 0; i < n; ++i) out.primTri[i] = b2.prims[i].tri;
+    out.sceneBox = sceneBox;
+    return "";
+}
+
 const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BVH &out, int builder) {
     auto t0 = std::chrono::steady_clock::now();
     out.nodes.clear(); out.tris.clear(); out.depth = 0;

@@ -109,20 +109,20 @@ struct DDp { float c[8]; uint8_t k[9]; uint8_t take; uint8_t leaf; uint8_t pad; 
 
 constexpr uint32_t kMaxLeafTris = 3;
 
-__device__ inline float boxArea(const float *lo, const float *hi) {
+MTS_HD inline float boxArea(const float *lo, const float *hi) {
     const float d0 = hi[0] - lo[0], d1 = hi[1] - lo[1], d2 = hi[2] - lo[2];
     if (!(d0 >= 0 && d1 >= 0 && d2 >= 0)) return 0.0f;
     return 2.0f * (d0 * d1 + d0 * d2 + d1 * d2);
 }
 
-__device__ inline void dpLeaf(const DNode &nd, float costTri, DDp &d) {
+MTS_HD inline void dpLeaf(const DNode &nd, float costTri, DDp &d) {
     const float area = boxArea(nd.lo, nd.hi);
     for (int i = 1; i < 8; ++i) d.c[i] = area * costTri;
     d.c[0] = 0; d.take = 0; d.leaf = 1; d.pad = 0;
     for (int j = 0; j < 9; ++j) d.k[j] = 0;
 }
 
-__device__ inline void dpInner(const DNode &nd, const DDp &L, const DDp &R, float costNode, float costTri, DDp &d) {
+MTS_HD inline void dpInner(const DNode &nd, const DDp &L, const DDp &R, float costNode, float costTri, DDp &d) {
     const float area = boxArea(nd.lo, nd.hi);
     float dist[9];
     d.k[0] = d.k[1] = 0; d.c[0] = 0; d.pad = 0;
@@ -138,7 +138,7 @@ __device__ inline void dpInner(const DNode &nd, const DDp &L, const DDp &R, floa
     const float leafCost = nd.count <= kMaxLeafTris ? area * costTri * (float) nd.count : INFINITY;
     const float nodeCost = area * costNode + dist[8];
     d.leaf = leafCost <= nodeCost;
-    d.c[1] = fminf(leafCost, nodeCost);
+    d.c[1] = leafCost < nodeCost ? leafCost : nodeCost;
     d.take = 0;
     for (int j = 2; j <= 7; ++j) {
         if (dist[j] < d.c[j - 1]) { d.c[j] = dist[j]; d.take |= (uint8_t) (1u << j); }
@@ -217,6 +217,12 @@ __global__ void k_compact(const uint32_t *keep, const uint32_t *pos, uint32_t n,
     cnode2[p] = cnode[i]; clo2[p] = clo[i]; chi2[p] = chi[i];
 }
 
+__global__ void k_gather_clusters(const uint32_t *cnode, uint32_t n, const DNode *nodes, const DDp *dp, DNode *outNodes, DDp *outDp) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    outNodes[i] = nodes[cnode[i]]; outDp[i] = dp[cnode[i]];
+}
+
 inline unsigned blocks(size_t n) { return (unsigned) ((n + 255) / 256); }
 
 
@@ -283,7 +289,13 @@ static const char *clusterOnDevice(const float *positions, uint32_t nVerts, cons
     uint32_t n = nTris;
     int cur = 0;
     ct.rounds = 0;
-    while (n > 1) {
+    // Clustering stops when about N/32 clusters are left (never for small inputs): the top of the tree, where most
+    // node visits happen, is then built by a SAH sweep over the clusters on the host cores (a few milliseconds).
+    uint32_t stopAt = 1;
+    if (const char *e = getenv("MTSAMD_TOP_CLUSTERS")) stopAt = (uint32_t) std::max(1, atoi(e));
+    else if (nTris >= 65536) stopAt = nTris / 32;
+    uint32_t merged = 0;
+    while (n > stopAt) {
         if (++ct.rounds > 4096) return "device BVH build did not converge";
         hipLaunchKernelGGL(k_nearest, dim3(blocks(n)), dim3(256), 0, 0, dClo[cur].as<float4>(), dChi[cur].as<float4>(), n, dNn.as<uint32_t>(), (uint32_t) gRadius);
         hipLaunchKernelGGL(k_merge, dim3(blocks(n)), dim3(256), 0, 0, dNn.as<uint32_t>(), n, nTris, dCounter.as<uint32_t>(), ct.nodes.as<DNode>(), ct.dp.as<DDp>(),
@@ -296,11 +308,51 @@ static const char *clusterOnDevice(const float *positions, uint32_t nVerts, cons
         uint32_t n2 = 0;
         DEV_TRY(hipMemcpy(&n2, dScan.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost));
         if (n2 >= n) return "device BVH build made no progress";
+        merged += n - n2;
         n = n2; cur ^= 1;
     }
     DEV_TRY(hipGetLastError());
-    DEV_TRY(hipMemcpy(&ct.root, dCnode[cur].p, 4, hipMemcpyDeviceToHost));
     lap("clustering");
+    if (n == 1) {
+        DEV_TRY(hipMemcpy(&ct.root, dCnode[cur].p, 4, hipMemcpyDeviceToHost));
+    } else {
+        // top of the tree: SAH sweep over the remaining clusters on the host, collapse tables included
+        DevBuf dGn, dGd;
+        DEV_TRY(dGn.alloc((size_t) n * sizeof(DNode))); DEV_TRY(dGd.alloc((size_t) n * sizeof(DDp)));
+        hipLaunchKernelGGL(k_gather_clusters, dim3(blocks(n)), dim3(256), 0, 0, dCnode[cur].as<uint32_t>(), n, ct.nodes.as<DNode>(), ct.dp.as<DDp>(), dGn.as<DNode>(), dGd.as<DDp>());
+        std::vector<DNode> cn(n); std::vector<DDp> cd(n); std::vector<uint32_t> cid(n);
+        DEV_TRY(hipMemcpy(cn.data(), dGn.p, (size_t) n * sizeof(DNode), hipMemcpyDeviceToHost));
+        DEV_TRY(hipMemcpy(cd.data(), dGd.p, (size_t) n * sizeof(DDp), hipMemcpyDeviceToHost));
+        DEV_TRY(hipMemcpy(cid.data(), dCnode[cur].p, (size_t) n * 4, hipMemcpyDeviceToHost));
+        std::vector<Box> boxes(n);
+        for (uint32_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) { boxes[i].lo[k] = cn[i].lo[k]; boxes[i].hi[k] = cn[i].hi[k]; }
+        BinaryTree top;
+        const char *terr = buildBinaryOverBoxes(boxes, top);
+        if (terr && *terr) return terr;
+        // device ids: top leaves are the clusters, top internal nodes continue after the nodes made by clustering
+        const uint32_t base = nTris + merged;
+        std::vector<uint32_t> devId(top.nNodes);
+        uint32_t nextInternal = 0;
+        for (uint32_t t = 0; t < top.nNodes; ++t)
+            devId[t] = top.nodes[t].isLeaf() ? cid[top.primTri[top.nodes[t].first]] : base + nextInternal++;
+        if (base + nextInternal != 2 * nTris - 1) return "device BVH build: node count mismatch at the top of the tree";
+        std::vector<DNode> tn(nextInternal); std::vector<DDp> td(nextInternal);
+        std::vector<DDp> dpOf(top.nNodes); std::vector<uint32_t> cntOf(top.nNodes);
+        for (uint32_t t = top.nNodes; t-- > 0;) {       // children follow their parents: descending order is bottom-up
+            const Node2 &h = top.nodes[t];
+            if (h.isLeaf()) { const uint32_t c = top.primTri[h.first]; dpOf[t] = cd[c]; cntOf[t] = cn[c].count; continue; }
+            DNode d;
+            d.left = devId[h.left]; d.right = devId[h.right]; d.pad = 0;
+            for (int k = 0; k < 3; ++k) { d.lo[k] = h.box.lo[k]; d.hi[k] = h.box.hi[k]; }
+            d.count = cntOf[t] = cntOf[h.left] + cntOf[h.right];
+            dpInner(d, dpOf[h.left], dpOf[h.right], costNode, costTri, dpOf[t]);
+            tn[devId[t] - base] = d; td[devId[t] - base] = dpOf[t];
+        }
+        DEV_TRY(hipMemcpy(ct.nodes.as<DNode>() + base, tn.data(), tn.size() * sizeof(DNode), hipMemcpyHostToDevice));
+        DEV_TRY(hipMemcpy(ct.dp.as<DDp>() + base, td.data(), td.size() * sizeof(DDp), hipMemcpyHostToDevice));
+        ct.root = devId[0];
+        lap("top of the tree (host sweep)");
+    }
     if (gVerbose) fprintf(stderr, "mtsamd: device BVH %d clustering rounds\n", ct.rounds);
     return "";
 }

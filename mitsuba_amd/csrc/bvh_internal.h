@@ -45,6 +45,8 @@ struct BinaryTree {
 
 // Host builder: multithreaded binned SAH down to single triangles.
 const char *buildBinaryTreeHost(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BinaryTree &out);
+// The host sweep over arbitrary boxes; primTri holds the box order.
+const char *buildBinaryOverBoxes(const std::vector<Box> &boxes, BinaryTree &out);
 // Device builder: Morton sort + parallel locally-ordered clustering on the current HIP device.
 const char *buildBinaryTreeDevice(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BinaryTree &out);
 // The whole build on the current HIP device: the wide nodes and triangle records are written into two device buffers
