@@ -7,19 +7,6 @@ namespace mtsamd {
 
 static constexpr uint32_t kMiss = 0xFFFFFFFFu;
 
-// Appends one element per active lane to a queue: one atomic per wavefront (ballot + popcount + lane prefix).
-MTS_DEV uint32_t waveAppend(uint32_t *counter, bool active) {
-    const unsigned long long mask = __ballot(active);
-    if (mask == 0) return 0;
-    const uint32_t lane = __lane_id();
-    const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
-    uint32_t base = 0;
-    const int leader = __ffsll((long long) mask) - 1;
-    if ((int) lane == leader) base = atomicAdd(counter, (uint32_t) __popcll(mask));
-    base = __shfl(base, leader);
-    return base + prefix;
-}
-
 MTS_DEV uint64_t sampleKey(const DevScene &sc, const PassParams &pp, uint32_t slot, int &px, int &py, int &s) {
     const uint32_t pix = slot / (uint32_t) pp.spp;
     s = (int) (slot - pix * (uint32_t) pp.spp);
