@@ -30,16 +30,18 @@ enum {
     MTSAMD_EUNSUPPORTED = -4
 };
 
-/* BSDF plugins on the hot path (src/bsdfs/{diffuse,roughconductor,roughplastic,dielectric,ward}.cpp) */
+/* BSDF plugins on the hot path (src/bsdfs/{diffuse,roughconductor,roughplastic,dielectric,ward}.cpp) and their
+   smooth neighbours (src/bsdfs/{conductor,plastic}.cpp). The `twosided` adapter (src/bsdfs/twosided.cpp) is not a
+   type of its own: it is the two_sided / back_material pair of the record of the BRDF it wraps. */
 enum { MTSAMD_BSDF_DIFFUSE = 0, MTSAMD_BSDF_ROUGHCONDUCTOR = 1, MTSAMD_BSDF_ROUGHPLASTIC = 2,
-       MTSAMD_BSDF_DIELECTRIC = 3, MTSAMD_BSDF_WARD = 4 };
+       MTSAMD_BSDF_DIELECTRIC = 3, MTSAMD_BSDF_WARD = 4, MTSAMD_BSDF_CONDUCTOR = 5, MTSAMD_BSDF_PLASTIC = 6 };
 /* MicrofacetDistribution::EType (src/bsdfs/microfacet.h:48-57); Phong is not supported */
 enum { MTSAMD_DISTR_BECKMANN = 0, MTSAMD_DISTR_GGX = 1 };
 enum { MTSAMD_SHAPE_HAS_NORMALS = 1, MTSAMD_SHAPE_HAS_TEXCOORDS = 2 };
 /* Who builds the binary tree that is collapsed into the 8-wide BVH (ShapeKDTree::build in the reference,
-   src/librender/skdtree.cpp:68-110): a binned-SAH sweep on the host cores (best traversal speed, default) or Morton
-   sort + locally-ordered clustering on the GPU (faster build, a few percent more node visits per ray).
-   Selected with the environment variable MTSAMD_BVH_BUILDER=host|device when the scene is created. */
+   src/librender/skdtree.cpp:68-110): Morton sort + locally-ordered clustering on the GPU with a SAH sweep over the
+   resulting clusters for the top of the tree (default), or a binned-SAH sweep over all triangles on the host cores.
+   Selected with the environment variable MTSAMD_BVH_BUILDER=device|host when the scene is created. */
 enum { MTSAMD_BVH_HOST = 0, MTSAMD_BVH_DEVICE = 1 };
 
 /* One TriMesh (include/mitsuba/render/trimesh.h). Its triangles occupy
@@ -60,13 +62,13 @@ typedef struct {
     int32_t type;               /* MTSAMD_BSDF_* */
     int32_t distribution;       /* MTSAMD_DISTR_* */
     int32_t sample_visible;     /* microfacet.h m_sampleVisible (default true) */
-    int32_t variant;            /* ward: 0 ward, 1 ward-duer, 2 balanced; roughplastic: nonlinear flag */
+    int32_t variant;            /* ward: 0 ward, 1 ward-duer, 2 balanced; roughplastic, plastic: nonlinear flag */
     float alpha_u, alpha_v;
-    float int_ior, ext_ior;     /* dielectric, roughplastic */
+    float int_ior, ext_ior;     /* dielectric, roughplastic, plastic */
     float diffuse_reflectance[3];   /* diffuse: reflectance; roughplastic, ward: diffuseReflectance */
     float specular_reflectance[3];
     float specular_transmittance[3];
-    float eta[3], k[3];         /* roughconductor, before the division by ext_eta (roughconductor.cpp:189-190) */
+    float eta[3], k[3];         /* roughconductor, conductor: before the division by ext_eta (roughconductor.cpp:189-190) */
     float ext_eta;
     int32_t ensure_energy_conservation;   /* BSDF::m_ensureEnergyConservation (default true) */
     /* roughplastic: external rough transmittance reduced to 1-D, i.e. the state RoughPlastic::configure
@@ -75,6 +77,11 @@ typedef struct {
     uint32_t rtrans_n;
     float rtrans_diffuse_ext;   /* m_externalRoughTransmittance->evalDiffuse(alpha) */
     float rtrans_diffuse_int;   /* m_internalRoughTransmittance->evalDiffuse(alpha) */
+    /* TwoSidedBRDF (src/bsdfs/twosided.cpp:84-159): non-zero = this record is the BRDF nested in a `twosided`
+       adapter; back_material is the record used when the surface is seen from behind (second nested BRDF),
+       -1 = the same record on both sides. Only reflection-only BRDFs may be nested (twosided.cpp:103-105). */
+    int32_t two_sided;
+    int32_t back_material;
 } mtsamd_material;
 
 /* AreaLight attached to a mesh (src/emitters/area.cpp) */

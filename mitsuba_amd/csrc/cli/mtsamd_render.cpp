@@ -41,6 +41,10 @@ static void describe(const LoadedScene &s) {
     for (int i = 0; i < 16; ++i) printf("%s%.9g", i ? ", " : "", s.camera.to_world[i]);
     printf("], \"material_types\": [");
     for (size_t i = 0; i < s.materials.size(); ++i) printf("%s%d", i ? ", " : "", s.materials[i].type);
+    printf("], \"two_sided\": [");
+    for (size_t i = 0; i < s.materials.size(); ++i) printf("%s%d", i ? ", " : "", s.materials[i].two_sided);
+    printf("], \"back_materials\": [");
+    for (size_t i = 0; i < s.materials.size(); ++i) printf("%s%d", i ? ", " : "", s.materials[i].back_material);
     printf("], \"shape_triangles\": [");
     for (size_t i = 0; i < s.shapes.size(); ++i) printf("%s%u", i ? ", " : "", s.shapes[i].n_triangles);
     printf("]}\n");

@@ -233,8 +233,50 @@ float lookupIor(const Props &p, const char *key, const char *defName) {
 }
 
 // ---- BSDFs -------------------------------------------------------------------------------------------------------------------
-mtsamd_material makeBsdf(const Element &node, const LoadOptions &opts, LoadedScene &out) {
+uint32_t addMaterial(LoadedScene &out, const mtsamd_material &m);
+
+// A copy of an already added record for use as a nested BRDF. Rough-transmittance tables are matched to the
+// roughplastic records by order of appearance, so the copy brings a copy of its table.
+mtsamd_material copyMaterial(LoadedScene &out, uint32_t index) {
+    const mtsamd_material m = out.materials[index];
+    if (m.type == MTSAMD_BSDF_ROUGHPLASTIC) {
+        size_t ordinal = 0;
+        for (uint32_t i = 0; i < index; ++i) ordinal += out.materials[i].type == MTSAMD_BSDF_ROUGHPLASTIC;
+        const std::vector<float> table = out.rtransTables[ordinal];
+        out.rtransTables.push_back(table);
+    }
+    return m;
+}
+
+mtsamd_material makeBsdf(const Element &node, const LoadOptions &opts, LoadedScene &out, const std::map<std::string, uint32_t> *named = nullptr) {
     const std::string type = node.get("type");
+    if (type == "twosided") {                   // src/bsdfs/twosided.cpp:84-106,185-196
+        std::vector<const Element *> nested;
+        for (const auto &c : node.children)
+            if (c->tag == "bsdf" || c->tag == "ref") nested.push_back(c.get());
+        if (nested.empty()) throw Fail("A nested one-sided material is required!");
+        if (nested.size() > 2) throw Fail("No more than two nested BRDFs can be added!");
+        auto make = [&](const Element &c) {
+            if (c.tag == "ref") {
+                if (!named || !named->count(c.get("id"))) throw Fail("reference to unknown bsdf '" + c.get("id") + "'");
+                return copyMaterial(out, named->at(c.get("id")));
+            }
+            if (c.get("type") == "twosided") throw Fail("a <bsdf type=\"twosided\"> nested in another one is not supported");
+            return makeBsdf(c, opts, out, named);
+        };
+        // the record of the back side is appended first, so that records and their tables stay in the same order
+        int32_t back = -1;
+        if (nested.size() == 2) {
+            const mtsamd_material b = make(*nested[1]);
+            if (b.type == MTSAMD_BSDF_DIELECTRIC) throw Fail("Only materials without a transmission component can be nested!");
+            back = (int32_t) addMaterial(out, b);
+        }
+        mtsamd_material m = make(*nested[0]);
+        if (m.type == MTSAMD_BSDF_DIELECTRIC) throw Fail("Only materials without a transmission component can be nested!");
+        m.two_sided = 1;
+        m.back_material = back;
+        return m;
+    }
     for (const auto &c : node.children)
         if (c->tag == "texture" || c->tag == "bsdf")
             throw Fail("nested <" + c->tag + "> inside <bsdf type=\"" + type + "\"> is not supported");
@@ -254,6 +296,7 @@ mtsamd_material makeBsdf(const Element &node, const LoadOptions &opts, LoadedSce
     const double alphaU = p.count("alpha") ? alpha : getF(p, "alphaU", 0.1), alphaV = p.count("alpha") ? alpha : getF(p, "alphaV", 0.1);
     m.eta[0] = m.eta[1] = m.eta[2] = 0; m.k[0] = m.k[1] = m.k[2] = 1; m.ext_eta = 1.000277f;
     m.int_ior = 1.5046f; m.ext_ior = 1.000277f;
+    m.back_material = -1;
     for (int i = 0; i < 3; ++i) { m.diffuse_reflectance[i] = 0.5f; m.specular_reflectance[i] = 1.0f; m.specular_transmittance[i] = 1.0f; }
 
     if (type == "diffuse") {                    // src/bsdfs/diffuse.cpp:84-91
@@ -300,6 +343,20 @@ mtsamd_material makeBsdf(const Element &node, const LoadOptions &opts, LoadedSce
                                  &m.rtrans_diffuse_ext, &m.rtrans_diffuse_int) != MTSAMD_OK)
             throw Fail(mtsamd_last_error());
         m.rtrans_n = n;     // the pointer is set in desc(), once the table storage no longer moves
+    } else if (type == "conductor") {           // src/bsdfs/conductor.cpp:153-176
+        m.type = MTSAMD_BSDF_CONDUCTOR;
+        const std::string material = getS(p, "material", "Cu");
+        if (p.count("eta") && p.count("k")) { getRgb(p, "eta", 0, 0, 0, m.eta); getRgb(p, "k", 1, 1, 1, m.k); }
+        else if (lower(material) != "none")
+            throw Fail("conductor material preset '" + material + "' needs data/ior/*.spd spectral data; give RGB 'eta' and 'k' instead");
+        m.ext_eta = lookupIor(p, "extEta", "air");
+        getRgb(p, "specularReflectance", 1, 1, 1, m.specular_reflectance);
+    } else if (type == "plastic") {             // src/bsdfs/plastic.cpp:146-166
+        m.type = MTSAMD_BSDF_PLASTIC;
+        m.int_ior = lookupIor(p, "intIOR", "polypropylene"); m.ext_ior = lookupIor(p, "extIOR", "air");
+        m.variant = getB(p, "nonlinear", false) ? 1 : 0;
+        getRgb(p, "diffuseReflectance", 0.5f, 0.5f, 0.5f, m.diffuse_reflectance);
+        getRgb(p, "specularReflectance", 1, 1, 1, m.specular_reflectance);
     } else {
         throw Fail("BSDF type '" + type + "' is outside the path hot path of this core");
     }
@@ -638,7 +695,8 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
         out.integrator.max_depth = -1; out.integrator.rr_depth = 5; out.integrator.strict_normals = 0; out.integrator.hide_emitters = 0;
 
         auto bsdfIndex = [&](const Element &el) {
-            const uint32_t idx = addMaterial(out, makeBsdf(el, opts, out));
+            const mtsamd_material made = makeBsdf(el, opts, out, &namedBsdfs);
+            const uint32_t idx = addMaterial(out, made);
             if (el.has("id")) namedBsdfs[el.get("id")] = idx;
             return idx;
         };

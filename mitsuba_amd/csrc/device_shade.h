@@ -346,12 +346,12 @@ MTS_DEV float cosHemiPdf(V3 d) { return kInvPi * d.z; }
 // ---- BSDF::eval (value includes the cosine factor) -----------------------------------------------------------
 MTS_DEV V3 bsdfEval(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
     const V3 zero = mk(0.0f);
-    if (m.type == 3) return zero;                               // dielectric.cpp:228-253: no solid-angle lobe
+    if (m.type == 3 || m.type == 5) return zero;                // dielectric.cpp:228-253, conductor.cpp:225-239: no solid-angle lobe
     if (wi.z <= 0 || wo.z <= 0) return zero;
     const V3 diff = ld3(m.diffuse), spec = ld3(m.specular);
     switch (m.type) {
         case 0:                                                 // diffuse.cpp:110-118
-            if (!(m.typeFlags & EDiffuseReflection)) return zero;
+            if (!(m.ownFlags & EDiffuseReflection)) return zero;
             return diff * (kInvPi * wo.z);
         case 1: {                                               // roughconductor.cpp:257-294
             const V3 H = normalize(wo + wi);
@@ -386,6 +386,14 @@ MTS_DEV V3 bsdfEval(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
             }
             return result;
         }
+        case 6: {                                               // plastic.cpp:243-276, the diffuse lobe
+            float ct;
+            const float Fi = fresnelDielectricExt(wi.z, ct, m.eta), Fo = fresnelDielectricExt(wo.z, ct, m.eta);
+            V3 d = diff;
+            if (m.variant) d = d / (mk(1.0f) - d * m.fdrInt);
+            else d = d / (1 - m.fdrInt);
+            return d * (cosHemiPdf(wo) * m.invEta2 * (1 - Fi) * (1 - Fo));
+        }
         default: {                                              // ward.cpp:178-226
             V3 result = zero;
             const V3 H = wi + wo;
@@ -409,11 +417,11 @@ MTS_DEV V3 bsdfEval(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
 
 // ---- BSDF::pdf -----------------------------------------------------------------------------------------------
 MTS_DEV float bsdfPdf(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
-    if (m.type == 3) return 0.0f;
+    if (m.type == 3 || m.type == 5) return 0.0f;
     if (wi.z <= 0 || wo.z <= 0) return 0.0f;
     switch (m.type) {
         case 0:                                                 // diffuse.cpp:120-127
-            if (!(m.typeFlags & EDiffuseReflection)) return 0.0f;
+            if (!(m.ownFlags & EDiffuseReflection)) return 0.0f;
             return cosHemiPdf(wo);
         case 1: {                                               // roughconductor.cpp:296-321
             const V3 H = normalize(wo + wi);
@@ -433,6 +441,12 @@ MTS_DEV float bsdfPdf(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
             float result = prob * dwh_dwo * probSpecular;
             result += probDiffuse * cosHemiPdf(wo);
             return result;
+        }
+        case 6: {                                               // plastic.cpp:278-306
+            float ct;
+            const float Fi = fresnelDielectricExt(wi.z, ct, m.eta);
+            const float probSpecular = (Fi * m.specSamplingWeight) / (Fi * m.specSamplingWeight + (1 - Fi) * (1 - m.specSamplingWeight));
+            return cosHemiPdf(wo) * (1 - probSpecular);
         }
         default: {                                              // ward.cpp:228-264
             const V3 H = normalize(wi + wo);
@@ -455,7 +469,7 @@ MTS_DEV V3 bsdfSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx,
     const V3 diff = ld3(m.diffuse), spec = ld3(m.specular);
     switch (m.type) {
         case 0: {                                               // diffuse.cpp:140-150
-            if (!(m.typeFlags & EDiffuseReflection) || wi.z <= 0) return zero;
+            if (!(m.ownFlags & EDiffuseReflection) || wi.z <= 0) return zero;
             wo = squareToCosineHemisphere(sx, sy);
             sampledType = EDiffuseReflection;
             pdf = cosHemiPdf(wo);
@@ -516,6 +530,33 @@ MTS_DEV V3 bsdfSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx,
                 return ld3(m.transmittance) * (factor * factor);
             }
         }
+        case 5: {                                               // conductor.cpp:273-288
+            if (wi.z <= 0) return zero;
+            sampledType = EDeltaReflection;
+            wo = mk(-wi.x, -wi.y, wi.z);
+            pdf = 1;
+            return spec * fresnelConductorExact(wi.z, ld3(m.condEta), ld3(m.condK));
+        }
+        case 6: {                                               // plastic.cpp:373-440
+            if (wi.z <= 0) return zero;
+            float ct;
+            const float Fi = fresnelDielectricExt(wi.z, ct, m.eta);
+            const float probSpecular = (Fi * m.specSamplingWeight) / (Fi * m.specSamplingWeight + (1 - Fi) * (1 - m.specSamplingWeight));
+            if (sx < probSpecular) {
+                sampledType = EDeltaReflection;
+                wo = mk(-wi.x, -wi.y, wi.z);
+                pdf = probSpecular;
+                return spec * Fi / probSpecular;
+            }
+            sampledType = EDiffuseReflection;
+            wo = squareToCosineHemisphere((sx - probSpecular) / (1 - probSpecular), sy);
+            const float Fo = fresnelDielectricExt(wo.z, ct, m.eta);
+            V3 d = diff;
+            if (m.variant) d = d / (mk(1.0f) - d * m.fdrInt);
+            else d = d / (1 - m.fdrInt);
+            pdf = (1 - probSpecular) * cosHemiPdf(wo);
+            return d * (m.invEta2 * (1 - Fi) * (1 - Fo) / (1 - probSpecular));
+        }
         default: {                                              // ward.cpp:266-326
             bool choseSpecular = true;
             if (sx <= m.specSamplingWeight) sx /= m.specSamplingWeight;
@@ -544,6 +585,25 @@ MTS_DEV V3 bsdfSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx,
         }
     }
 }
+
+// ---- TwoSidedBRDF (src/bsdfs/twosided.cpp:108-183) ------------------------------------------------------------
+// m holds the record of the hit's material (index `self`). Seen from behind, a two-sided record hands over to its
+// back record (loaded over m when it is a different one) and the caller mirrors wi and wo in z.
+MTS_DEV void loadMaterial(const DevScene &sc, uint32_t index, DevMaterial &m) {
+    const float4 *mp = reinterpret_cast<const float4 *>(sc.materials + index);
+    float4 mv[sizeof(DevMaterial) / 16];
+#pragma unroll
+    for (int k = 0; k < (int) (sizeof(DevMaterial) / 16); ++k) mv[k] = mp[k];
+    memcpy(&m, mv, sizeof(DevMaterial));
+}
+
+MTS_DEV bool resolveTwoSided(const DevScene &sc, uint32_t self, float wiZ, DevMaterial &m) {
+    if (!m.twoSided || !(wiZ < 0)) return false;
+    if ((uint32_t) m.backMaterial != self) loadMaterial(sc, (uint32_t) m.backMaterial, m);
+    return true;
+}
+
+MTS_DEV V3 mirrorZ(V3 v) { return mk(v.x, v.y, -v.z); }
 
 // ---- DiscreteDistribution::sampleReuse on a device CDF (include/mitsuba/core/pmf.h:124-188) ---------------------
 MTS_DEV uint32_t cdfSampleReuse(const float *cdf, uint32_t n /* entries */, float &sample, float *pdfOut) {

@@ -22,9 +22,12 @@ struct alignas(16) DevMaterial {
     float invEta, invEta2, specSamplingWeight, fdrInt;      // fdrInt = internal evalDiffuse(alpha)
     float diffuse[3]; uint32_t rtransOffset;
     float specular[3]; uint32_t rtransN;
-    float transmittance[3]; float pad0;
-    float condEta[3]; float pad1;
-    float condK[3]; float pad2;
+    float transmittance[3];
+    int32_t twoSided;           // nested in a twosided adapter (src/bsdfs/twosided.cpp); typeFlags is then the adapter's
+    float condEta[3];
+    int32_t backMaterial;       // twosided: record that answers when the surface is seen from behind (may be this one)
+    float condK[3];
+    uint32_t ownFlags;          // BSDF type bits of this record's own components
 };
 
 struct DevShape {

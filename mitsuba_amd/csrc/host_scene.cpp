@@ -59,6 +59,32 @@ bool invert4(const float *m, float *out) {
     return true;
 }
 
+// fresnelDielectricExt for a ray arriving from outside (src/libcore/util.cpp:651-681), float like the reference
+float fresnelDielectricOutside(float cosThetaI, float eta) {
+    if (eta == 1) return 0.0f;
+    const float scale = 1 / eta;
+    const float cosThetaTSqr = 1 - (1 - cosThetaI * cosThetaI) * (scale * scale);
+    if (cosThetaTSqr <= 0.0f) return 1.0f;
+    const float cosThetaT = std::sqrt(cosThetaTSqr);
+    const float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    const float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    return 0.5f * (Rs * Rs + Rp * Rp);
+}
+
+// fresnelDiffuseReflectance(eta, fast = false) (src/libcore/util.cpp:806-859): integral over xi in [0,1] of the
+// Fresnel reflectance at cos(theta) = sqrt(xi). The reference integrates adaptively to a relative error of 1e-5;
+// composite Simpson over 2^16 panels in double is well inside that.
+float fresnelDiffuseReflectance(float eta) {
+    const int n = 1 << 16;
+    double sum = 0;
+    for (int i = 0; i <= n; ++i) {
+        const double xi = (double) i / n;
+        const double w = (i == 0 || i == n) ? 1.0 : ((i & 1) ? 4.0 : 2.0);
+        sum += w * (double) fresnelDielectricOutside((float) std::sqrt(xi), eta);
+    }
+    return (float) (sum / (3.0 * n));
+}
+
 void scale4(float x, float y, float z, float *m) { memset(m, 0, 64); m[0] = x; m[5] = y; m[10] = z; m[15] = 1; }
 void translate4(float x, float y, float z, float *m) { scale4(1, 1, 1, m); m[3] = x; m[7] = y; m[11] = z; }
 
@@ -117,7 +143,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         float diff[3], spec[3], trans[3];
         memcpy(diff, m.diffuse_reflectance, 12); memcpy(spec, m.specular_reflectance, 12); memcpy(trans, m.specular_transmittance, 12);
         const unsigned aniso = m.alpha_u != m.alpha_v ? EAnisotropic : 0u;
-        if (m.type != MTSAMD_BSDF_DIFFUSE && m.type != MTSAMD_BSDF_DIELECTRIC && m.type != MTSAMD_BSDF_WARD) {
+        if (m.type == MTSAMD_BSDF_ROUGHCONDUCTOR || m.type == MTSAMD_BSDF_ROUGHPLASTIC) {
             if (m.distribution != MTSAMD_DISTR_BECKMANN && m.distribution != MTSAMD_DISTR_GGX)
                 return "Specified an invalid distribution, must be \"beckmann\" or \"ggx\"";
         }
@@ -170,11 +196,47 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
                 dm.typeFlags = EGlossyReflection | EDiffuseReflection | EFrontSide | aniso;
                 break;
             }
+            case MTSAMD_BSDF_CONDUCTOR:         // conductor.cpp:172-175,187-200
+                ensureEnergy(ee, spec);
+                for (int c = 0; c < 3; ++c) {
+                    float recip = 1.0f / m.ext_eta;
+                    dm.condEta[c] = m.eta[c] * recip;
+                    dm.condK[c] = m.k[c] * recip;
+                }
+                dm.typeFlags = EDeltaReflection | EFrontSide;
+                break;
+            case MTSAMD_BSDF_PLASTIC: {         // plastic.cpp:148-156,187-216
+                if (m.int_ior < 0 || m.ext_ior < 0) return "The interior and exterior indices of refraction must be positive!";
+                ensureEnergy(ee, spec);
+                ensureEnergy(ee, diff);
+                dm.eta = m.int_ior / m.ext_ior;
+                dm.fdrInt = fresnelDiffuseReflectance(1 / dm.eta);
+                float dAvg = luminance(diff), sAvg = luminance(spec);
+                dm.specSamplingWeight = sAvg / (dAvg + sAvg);
+                dm.invEta2 = 1 / (dm.eta * dm.eta);
+                dm.typeFlags = EDeltaReflection | EDiffuseReflection | EFrontSide;
+                break;
+            }
             default:
                 return "unsupported BSDF type";
         }
         memcpy(dm.diffuse, diff, 12); memcpy(dm.specular, spec, 12); memcpy(dm.transmittance, trans, 12);
+        dm.ownFlags = dm.typeFlags;
+        dm.twoSided = m.two_sided != 0;
+        dm.backMaterial = (int32_t) i;
         hs.materials[i] = dm;
+    }
+    // TwoSidedBRDF::configure (twosided.cpp:84-106): the adapter shows the front BRDF's components on the front side
+    // and the back BRDF's on the back side
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        DevMaterial &dm = hs.materials[i];
+        if (!dm.twoSided) continue;
+        const int32_t b = d->materials[i].back_material;
+        if (b >= (int32_t) d->n_materials) return "twosided: back material index out of range";
+        if (b >= 0) dm.backMaterial = b;
+        const unsigned f = dm.ownFlags, k = hs.materials[dm.backMaterial].ownFlags;
+        if ((f | k) & ETransmission) return "Only materials without a transmission component can be nested!";
+        dm.typeFlags = (f ? ((f & ~EBackSide) | EFrontSide) : 0u) | (k ? ((k & ~EFrontSide) | EBackSide) : 0u);
     }
 
     // ---- shapes ----------------------------------------------------------------------------------------

@@ -133,13 +133,13 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
             fillIntersection(sc, tri, hit.y, hit.z, rayD, its);
             // the material record comes in as seven 16-byte loads issued together, not field by field
             DevMaterial bsdf;
-            {
-                const float4 *mp = reinterpret_cast<const float4 *>(sc.materials + its.material);
-                float4 mv[sizeof(DevMaterial) / 16];
-#pragma unroll
-                for (int k = 0; k < (int) (sizeof(DevMaterial) / 16); ++k) mv[k] = mp[k];
-                memcpy(&bsdf, mv, sizeof(DevMaterial));
-            }
+            loadMaterial(sc, its.material, bsdf);
+            // what the integrator asks of the BSDF as a whole (for a two-sided record: the adapter's type) ...
+            const uint32_t bsdfType = bsdf.typeFlags;
+            const float wiZ = its.wi.z;
+            // ... and the BRDF that answers on this side (twosided.cpp:108-183)
+            const bool flipped = resolveTwoSided(sc, its.material, wiZ, bsdf);
+            const V3 wiLocal = flipped ? mirrorZ(its.wi) : its.wi;
             float4 L = sampleL[slot];
             bool Lchanged = false, terminate = false;
             int depth;
@@ -182,25 +182,26 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
 
             // path.cpp:156-165
             if (!terminate && ((depth >= sc.maxDepth && sc.maxDepth > 0) ||
-                               (sc.strictNormals && dot(rayD, its.geoN) * its.wi.z >= 0)))
+                               (sc.strictNormals && dot(rayD, its.geoN) * wiZ >= 0)))
                 terminate = true;
 
             if (!terminate) {
                 // DirectSamplingRecord(its) (records.inl:160-164)
                 V3 refN = mk(0.0f);
-                if ((bsdf.typeFlags & (ETransmission | EBackSide)) == 0) refN = its.sh.n;
+                if ((bsdfType & (ETransmission | EBackSide)) == 0) refN = its.sh.n;
 
                 // direct illumination sampling (path.cpp:172-200)
-                if (bsdf.typeFlags & ESmooth) {
+                if (bsdfType & ESmooth) {
                     const float sx = rng.next1D(), sy = rng.next1D();
                     DirectRec dRec;
                     const V3 value = sampleEmitterDirect(sc, its.p, refN, sx, sy, dRec);
                     if (dRec.pdf != 0) {
                         V3 c = mk(0.0f);
                         const V3 wo = toLocal(its.sh, dRec.d);
-                        const V3 bsdfVal = bsdfEval(sc, bsdf, its.wi, wo);
+                        const V3 woSide = flipped ? mirrorZ(wo) : wo;
+                        const V3 bsdfVal = bsdfEval(sc, bsdf, wiLocal, woSide);
                         if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
-                            const float bPdf = bsdfPdf(sc, bsdf, its.wi, wo);    // area emitters: on surface, solid-angle measure
+                            const float bPdf = bsdfPdf(sc, bsdf, wiLocal, woSide);    // area emitters: on surface, solid-angle measure
                             c = throughput * value * bsdfVal * miWeight(dRec.pdf, bPdf);
                         }
                         wantShadow = true;
@@ -213,7 +214,8 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
                 // BSDF sampling (path.cpp:206-226)
                 const float bx = rng.next1D(), by = rng.next1D();
                 V3 woLocal; float bPdf, bEta; uint32_t sampledType;
-                const V3 bsdfWeight = bsdfSample(sc, bsdf, its.wi, bx, by, woLocal, bPdf, bEta, sampledType);
+                const V3 bsdfWeight = bsdfSample(sc, bsdf, wiLocal, bx, by, woLocal, bPdf, bEta, sampledType);
+                if (flipped && !isZero(bsdfWeight) && bPdf != 0) woLocal.z = -woLocal.z;      // twosided.cpp:172-181
                 if (!isZero(bsdfWeight)) {
                     if (sampledType != ENull) flags |= PF_SCATTERED;
                     const V3 wo = toWorld(its.sh, woLocal);
@@ -417,8 +419,10 @@ __global__ void k_hits_to_records(DevScene sc, const float4 *hits, uint32_t n, m
 __global__ void k_bsdf_evalpdf(DevScene sc, int material, int mode, uint32_t n, const float *wi, const float *wo, float *out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const DevMaterial &m = sc.materials[material];
-    const V3 a = ld3(wi, i), b = ld3(wo, i);
+    DevMaterial m;
+    loadMaterial(sc, (uint32_t) material, m);
+    V3 a = ld3(wi, i), b = ld3(wo, i);
+    if (resolveTwoSided(sc, (uint32_t) material, a.z, m)) { a = mirrorZ(a); b = mirrorZ(b); }
     if (mode == 0) { const V3 r = bsdfEval(sc, m, a, b); out[3 * (size_t) i] = r.x; out[3 * (size_t) i + 1] = r.y; out[3 * (size_t) i + 2] = r.z; }
     else out[i] = bsdfPdf(sc, m, a, b);
 }
@@ -427,9 +431,14 @@ __global__ void k_bsdf_sample(DevScene sc, int material, uint32_t n, const float
                               float *pdf, float *eta, uint32_t *sampledType) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const DevMaterial &m = sc.materials[material];
+    DevMaterial m;
+    loadMaterial(sc, (uint32_t) material, m);
+    V3 a = ld3(wi, i);
+    const bool flipped = resolveTwoSided(sc, (uint32_t) material, a.z, m);
+    if (flipped) a = mirrorZ(a);
     V3 o; float p, e; uint32_t t;
-    const V3 w = bsdfSample(sc, m, ld3(wi, i), sample[2 * (size_t) i], sample[2 * (size_t) i + 1], o, p, e, t);
+    const V3 w = bsdfSample(sc, m, a, sample[2 * (size_t) i], sample[2 * (size_t) i + 1], o, p, e, t);
+    if (flipped && !isZero(w) && p != 0) o.z = -o.z;
     wo[3 * (size_t) i] = o.x; wo[3 * (size_t) i + 1] = o.y; wo[3 * (size_t) i + 2] = o.z;
     weight[3 * (size_t) i] = w.x; weight[3 * (size_t) i + 1] = w.y; weight[3 * (size_t) i + 2] = w.z;
     pdf[i] = p; eta[i] = e; sampledType[i] = t;

@@ -197,9 +197,33 @@ def _ior(props, key, default):
     return float(v)
 
 
-def _make_bsdf(node, data_dir: Optional[str]) -> Dict:
+def _make_bsdf(node, data_dir: Optional[str], add_material=None, named: Optional[Dict] = None) -> Dict:
     t = node.get("type")
     p = _props(node)
+    if t == "twosided":     # src/bsdfs/twosided.cpp:84-106,185-196: one or two nested reflection-only BRDFs
+        nested = []
+        for c in node:
+            if c.tag == "bsdf":
+                if c.get("type") == "twosided":
+                    raise SceneFormatError("a <bsdf type=\"twosided\"> nested in another one is not supported")
+                nested.append(_make_bsdf(c, data_dir, add_material, named))
+            elif c.tag == "ref":
+                if named is None or c.get("id") not in named:
+                    raise SceneFormatError("reference to unknown bsdf '%s'" % c.get("id"))
+                nested.append(dict(named[c.get("id")]))
+        if not nested:
+            raise SceneFormatError("A nested one-sided material is required!")
+        if len(nested) > 2:
+            raise SceneFormatError("No more than two nested BRDFs can be added!")
+        for m in nested:
+            if m["type"] == S.BSDF_DIELECTRIC:
+                raise SceneFormatError("Only materials without a transmission component can be nested!")
+        back = -1
+        if len(nested) == 2:
+            if add_material is None:
+                raise SceneFormatError("twosided with two nested BRDFs needs a material list to add the second one to")
+            back = add_material(nested[1])
+        return S.twosided(nested[0], back)
     for c in node:
         if c.tag in ("texture", "bsdf"):
             raise SceneFormatError("nested <%s> inside a <bsdf type=\"%s\"> is not supported" % (c.tag, t))
@@ -246,6 +270,20 @@ def _make_bsdf(node, data_dir: Optional[str]) -> Dict:
                            diffuse_reflectance=p.get("diffuseReflectance", (0.5, 0.5, 0.5)),
                            specular_reflectance=p.get("specularReflectance", (1, 1, 1)), nonlinear=p.get("nonlinear", False),
                            sample_visible=p.get("sampleVisible", True), rtrans=rt)
+    elif t == "conductor":
+        material = p.get("material", "Cu")
+        if "eta" in p and "k" in p:
+            eta, k = p["eta"], p["k"]
+        elif material.lower() == "none":
+            eta, k = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
+        else:
+            raise SceneFormatError("conductor material preset '%s' needs data/ior/*.spd spectral data; give RGB "
+                                   "'eta' and 'k' instead" % material)
+        m = S.conductor(eta, k, specular_reflectance=p.get("specularReflectance", (1, 1, 1)), ext_eta=_ior(p, "extEta", "air"))
+    elif t == "plastic":
+        m = S.plastic(int_ior=_ior(p, "intIOR", "polypropylene"), ext_ior=_ior(p, "extIOR", "air"),
+                      diffuse_reflectance=p.get("diffuseReflectance", (0.5, 0.5, 0.5)),
+                      specular_reflectance=p.get("specularReflectance", (1, 1, 1)), nonlinear=p.get("nonlinear", False))
     else:
         raise SceneFormatError("BSDF type '%s' is outside the path hot path of this core" % t)
     m["ensure_energy_conservation"] = int(bool(ee))
@@ -267,10 +305,14 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
     camera = film = None
     integ = dict(max_depth=-1, rr_depth=5, strict_normals=0, hide_emitters=0)
 
+    named_records: Dict[str, Dict] = {}
+
     def bsdf_index(node) -> int:
-        idx = b.add_material(_make_bsdf(node, data_dir))
+        rec = _make_bsdf(node, data_dir, b.add_material, named_records)
+        idx = b.add_material(rec)
         if node.get("id"):
             named_bsdfs[node.get("id")] = idx
+            named_records[node.get("id")] = rec
         return idx
 
     default_bsdf = None

@@ -15,7 +15,7 @@ from typing import Dict, List, Optional
 
 import numpy as np
 
-BSDF_DIFFUSE, BSDF_ROUGHCONDUCTOR, BSDF_ROUGHPLASTIC, BSDF_DIELECTRIC, BSDF_WARD = range(5)
+BSDF_DIFFUSE, BSDF_ROUGHCONDUCTOR, BSDF_ROUGHPLASTIC, BSDF_DIELECTRIC, BSDF_WARD, BSDF_CONDUCTOR, BSDF_PLASTIC = range(7)
 DISTR_BECKMANN, DISTR_GGX = 0, 1
 SHAPE_HAS_NORMALS, SHAPE_HAS_TEXCOORDS = 1, 2
 
@@ -105,7 +105,7 @@ def _mat(**kw) -> Dict:
              diffuse_reflectance=(0.5, 0.5, 0.5), specular_reflectance=(1.0, 1.0, 1.0),
              specular_transmittance=(1.0, 1.0, 1.0), eta=(0.0, 0.0, 0.0), k=(1.0, 1.0, 1.0),
              ext_eta=1.000277, ensure_energy_conservation=1,
-             rtrans=None, rtrans_diffuse_ext=0.0, rtrans_diffuse_int=0.0)
+             rtrans=None, rtrans_diffuse_ext=0.0, rtrans_diffuse_int=0.0, two_sided=0, back_material=-1)
     m.update(kw)
     return m
 
@@ -154,6 +154,27 @@ def roughplastic(alpha=0.1, distribution="beckmann", int_ior=IOR["polypropylene"
                 specular_reflectance=tuple(specular_reflectance), variant=int(nonlinear),
                 sample_visible=int(sample_visible), rtrans=np.asarray(T, np.float32),
                 rtrans_diffuse_ext=float(d_ext), rtrans_diffuse_int=float(d_int))
+
+
+def conductor(eta, k, specular_reflectance=(1, 1, 1), ext_eta=IOR["air"]) -> Dict:
+    """src/bsdfs/conductor.cpp:153-176 with explicit RGB eta/k."""
+    return _mat(type=BSDF_CONDUCTOR, eta=tuple(eta), k=tuple(k), ext_eta=ext_eta,
+                specular_reflectance=tuple(specular_reflectance))
+
+
+def plastic(int_ior=IOR["polypropylene"], ext_ior=IOR["air"], diffuse_reflectance=(0.5, 0.5, 0.5),
+            specular_reflectance=(1, 1, 1), nonlinear=False) -> Dict:
+    """src/bsdfs/plastic.cpp:146-166"""
+    return _mat(type=BSDF_PLASTIC, int_ior=int_ior, ext_ior=ext_ior, diffuse_reflectance=tuple(diffuse_reflectance),
+                specular_reflectance=tuple(specular_reflectance), variant=int(nonlinear))
+
+
+def twosided(front: Dict, back_material: int = -1) -> Dict:
+    """src/bsdfs/twosided.cpp:84-106: the nested BRDF's record marked two-sided; back_material is the index of
+    the record of a second nested BRDF (the side seen from behind), -1 = the same BRDF on both sides."""
+    m = dict(front)
+    m["two_sided"], m["back_material"] = 1, int(back_material)
+    return m
 
 
 def _distr(name) -> int:
@@ -369,6 +390,43 @@ def cornell_box(width=512, height=512, max_depth=-1) -> SceneData:
 
     b.add_box([-82.5, 0, -82.5], [82.5, 165, 82.5], white, to_world=rot_y(-17, [185, 0, 169]))
     b.add_box([-82.5, 0, -82.5], [82.5, 330, 82.5], white, to_world=rot_y(20, [368, 0, 351]))
+    y = S - 0.5
+    b.add_quad([213, y, 227], [343, y, 227], [343, y, 332], [213, y, 332], light, radiance=(17.0, 12.0, 4.0))
+    cam = make_camera([278, 273, -800], [278, 273, 0], [0, 1, 0], 39.3077, near_clip=10, far_clip=2800)
+    return b.finish(cam, make_film(width, height), dict(max_depth=max_depth))
+
+
+def cornell_mixed(width=256, height=256, max_depth=-1) -> SceneData:
+    """The Cornell box with the smooth neighbours of the hot-path BSDFs: walls behind a `twosided` adapter, a smooth
+    `plastic` short box, a smooth `conductor` tall box, and a free-standing card whose two sides carry different
+    BRDFs (rough plastic towards the back wall, red diffuse towards the camera) and which the camera sees from behind."""
+    b = SceneBuilder()
+    white = b.add_material(twosided(diffuse((0.725, 0.71, 0.68))))
+    red = b.add_material(twosided(diffuse((0.63, 0.065, 0.05))))
+    green = b.add_material(diffuse((0.14, 0.45, 0.091)))
+    light = b.add_material(diffuse((0.78, 0.78, 0.78)))
+    shiny = b.add_material(plastic(int_ior=1.49, diffuse_reflectance=(0.2, 0.3, 0.6)))
+    metal = b.add_material(conductor(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14)))
+    card_back = b.add_material(diffuse((0.7, 0.1, 0.1)))
+    card = b.add_material(twosided(roughplastic(alpha=0.2, distribution="ggx", diffuse_reflectance=(0.1, 0.5, 0.2)), card_back))
+    S = 555.0
+    b.add_quad([0, 0, 0], [0, 0, S], [S, 0, S], [S, 0, 0], white)
+    b.add_quad([0, S, 0], [S, S, 0], [S, S, S], [0, S, S], white)
+    b.add_quad([0, 0, S], [0, S, S], [S, S, S], [S, 0, S], white)
+    b.add_quad([S, 0, 0], [S, 0, S], [S, S, S], [S, S, 0], red)
+    b.add_quad([0, 0, 0], [0, S, 0], [0, S, S], [0, 0, S], green)
+
+    def rot_y(deg, t):
+        a = math.radians(deg)
+        m = np.eye(4, dtype=np.float32)
+        m[0, 0], m[0, 2], m[2, 0], m[2, 2] = math.cos(a), math.sin(a), -math.sin(a), math.cos(a)
+        m[:3, 3] = t
+        return m
+
+    b.add_box([-82.5, 0, -82.5], [82.5, 165, 82.5], shiny, to_world=rot_y(-17, [185, 0, 169]))
+    b.add_box([-82.5, 0, -82.5], [82.5, 330, 82.5], metal, to_world=rot_y(20, [368, 0, 351]))
+    # the card: its front normal points at the back wall (+z), the camera looks at its back
+    b.add_quad([60, 250, 120], [230, 250, 150], [230, 420, 150], [60, 420, 120], card)
     y = S - 0.5
     b.add_quad([213, y, 227], [343, y, 227], [343, y, 332], [213, y, 332], light, radiance=(17.0, 12.0, 4.0))
     cam = make_camera([278, 273, -800], [278, 273, 0], [0, 1, 0], 39.3077, near_clip=10, far_clip=2800)

@@ -380,6 +380,19 @@ static void ensureEnergy2(bool enabled, Spectrum &a, Spectrum &b) {
     if (actualMax > 1.0f) { float scale = 0.99f * (1.0f / actualMax); a *= scale; b *= scale; }
 }
 
+// fresnelDiffuseReflectance(eta, fast = false) (src/libcore/util.cpp:806-859): the integral over [0,1] of
+// fresnelDielectricExt(sqrt(xi), eta). The reference runs an adaptive Gauss-Lobatto rule to a relative error of
+// 1e-5; a midpoint rule with 2^20 panels in double is far inside that.
+static float fresnelDiffuseReflectance(float eta) {
+    const int n = 1 << 20;
+    double sum = 0;
+    for (int i = 0; i < n; ++i) {
+        const double xi = (i + 0.5) / n;
+        sum += (double) fresnelDielectricExt((float) std::sqrt(xi), eta);
+    }
+    return (float) (sum / n);
+}
+
 void Material::configure() {
     bool ee = m.ensure_energy_conservation != 0;
     diffuse = toSpec(m.diffuse_reflectance);
@@ -422,7 +435,41 @@ void Material::configure() {
             type_flags = EGlossyReflection | EDiffuseReflection | EFrontSide | aniso;
             break;
         }
+        case ORC_BSDF_CONDUCTOR:   // src/bsdfs/conductor.cpp:172-175,187-200
+            ensureEnergy(ee, specular);
+            condEta = toSpec(m.eta) / m.ext_eta;
+            condK = toSpec(m.k) / m.ext_eta;
+            type_flags = EDeltaReflection | EFrontSide;
+            break;
+        case ORC_BSDF_PLASTIC: {   // src/bsdfs/plastic.cpp:156,187-216
+            ensureEnergy(ee, specular);
+            ensureEnergy(ee, diffuse);
+            eta = m.int_ior / m.ext_ior;
+            fdrInt = fresnelDiffuseReflectance(1 / eta);
+            float dAvg = luminance(diffuse), sAvg = luminance(specular);
+            specularSamplingWeight = sAvg / (dAvg + sAvg);
+            invEta2 = 1 / (eta * eta);
+            type_flags = EDeltaReflection | EDiffuseReflection | EFrontSide;
+            break;
+        }
     }
+    own_flags = type_flags;
+    back = nullptr;
+}
+
+// TwoSidedBRDF::configure (src/bsdfs/twosided.cpp:84-106): the adapter's components are the front BRDF's on the
+// front side and the back BRDF's on the back side; nesting a transmissive BSDF is an error.
+const char *linkTwoSided(std::vector<Material> &materials) {
+    for (Material &mat : materials) {
+        if (!mat.m.two_sided) continue;
+        const int b = mat.m.back_material;
+        if (b >= (int) materials.size()) return "twosided: back material index out of range";
+        mat.back = b < 0 ? &mat : &materials[b];
+        const unsigned f = mat.own_flags, k = mat.back->own_flags;
+        if ((f | k) & ETransmission) return "Only materials without a transmission component can be nested!";
+        mat.type_flags = (f ? ((f & ~EBackSide) | EFrontSide) : 0u) | (k ? ((k & ~EFrontSide) | EBackSide) : 0u);
+    }
+    return nullptr;
 }
 
 // ---- RoughTransmittance::eval in the fully reduced (1-D) state (src/bsdfs/rtrans.h:183-194,233) ---
@@ -444,11 +491,11 @@ static Vec3 sphericalDirection(float theta, float phi) {
 }
 
 // ---- eval -----------------------------------------------------------------------------------------
-Spectrum bsdfEval(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
+static Spectrum evalOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
     const orc_material &m = mat.m;
     switch (m.type) {
         case ORC_BSDF_DIFFUSE: {   // diffuse.cpp:110-118
-            if (!(mat.type_flags & EDiffuseReflection)) return Spectrum(0.0f);
+            if (!(mat.own_flags & EDiffuseReflection)) return Spectrum(0.0f);
             if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0) return Spectrum(0.0f);
             return mat.diffuse * (INV_PI_F * Frame::cosTheta(wo));
         }
@@ -507,16 +554,27 @@ Spectrum bsdfEval(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
             result += mat.diffuse * INV_PI_F;
             return result * Frame::cosTheta(wo);
         }
+        case ORC_BSDF_CONDUCTOR:   // conductor.cpp:225-239: a delta lobe only, zero for the solid-angle measure
+            return Spectrum(0.0f);
+        case ORC_BSDF_PLASTIC: {   // plastic.cpp:243-276, solid-angle measure: the diffuse lobe
+            if (Frame::cosTheta(wo) <= 0 || Frame::cosTheta(wi) <= 0) return Spectrum(0.0f);
+            float Fi = fresnelDielectricExt(Frame::cosTheta(wi), mat.eta);
+            float Fo = fresnelDielectricExt(Frame::cosTheta(wo), mat.eta);
+            Spectrum diff = mat.diffuse;
+            if (m.variant) diff = diff / (Spectrum(1.0f) - diff * mat.fdrInt);
+            else diff /= 1 - mat.fdrInt;
+            return diff * (squareToCosineHemispherePdf(wo) * mat.invEta2 * (1 - Fi) * (1 - Fo));
+        }
     }
     return Spectrum(0.0f);
 }
 
 // ---- pdf ------------------------------------------------------------------------------------------
-float bsdfPdf(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
+static float pdfOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
     const orc_material &m = mat.m;
     switch (m.type) {
         case ORC_BSDF_DIFFUSE:   // diffuse.cpp:120-127
-            if (!(mat.type_flags & EDiffuseReflection)) return 0.0f;
+            if (!(mat.own_flags & EDiffuseReflection)) return 0.0f;
             if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0) return 0.0f;
             return squareToCosineHemispherePdf(wo);
         case ORC_BSDF_ROUGHCONDUCTOR: {   // roughconductor.cpp:296-321
@@ -555,19 +613,28 @@ float bsdfPdf(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
             float diffuseProb = squareToCosineHemispherePdf(wo);
             return mat.specularSamplingWeight * specProb + (1 - mat.specularSamplingWeight) * diffuseProb;
         }
+        case ORC_BSDF_CONDUCTOR:   // conductor.cpp:241-255: zero for the solid-angle measure
+            return 0.0f;
+        case ORC_BSDF_PLASTIC: {   // plastic.cpp:278-306, solid-angle measure
+            if (Frame::cosTheta(wo) <= 0 || Frame::cosTheta(wi) <= 0) return 0.0f;
+            float Fi = fresnelDielectricExt(Frame::cosTheta(wi), mat.eta);
+            float probSpecular = (Fi * mat.specularSamplingWeight) /
+                (Fi * mat.specularSamplingWeight + (1 - Fi) * (1 - mat.specularSamplingWeight));
+            return squareToCosineHemispherePdf(wo) * (1 - probSpecular);
+        }
     }
     return 0.0f;
 }
 
 // ---- sample (the pdf-returning overload the integrator calls, path.cpp:209) --------------------------
-Spectrum bsdfSample(const Material &mat, const Vec3 &wi, const Vec2 &_sample, BSDFSample &out, float &pdf) {
+static Spectrum sampleOneSided(const Material &mat, const Vec3 &wi, const Vec2 &_sample, BSDFSample &out, float &pdf) {
     const orc_material &m = mat.m;
     pdf = 0;
     out.eta = 1.0f;
     out.sampledType = 0;
     switch (m.type) {
         case ORC_BSDF_DIFFUSE: {   // diffuse.cpp:140-150
-            if (!(mat.type_flags & EDiffuseReflection) || Frame::cosTheta(wi) <= 0) return Spectrum(0.0f);
+            if (!(mat.own_flags & EDiffuseReflection) || Frame::cosTheta(wi) <= 0) return Spectrum(0.0f);
             out.wo = squareToCosineHemisphere(_sample);
             out.eta = 1.0f;
             out.sampledType = EDiffuseReflection;
@@ -614,9 +681,9 @@ Spectrum bsdfSample(const Material &mat, const Vec3 &wi, const Vec2 &_sample, BS
                 out.wo = squareToCosineHemisphere(sample);
             }
             out.eta = 1.0f;
-            pdf = bsdfPdf(mat, wi, out.wo);
+            pdf = pdfOneSided(mat, wi, out.wo);
             if (pdf == 0) return Spectrum(0.0f);
-            return bsdfEval(mat, wi, out.wo) / pdf;
+            return evalOneSided(mat, wi, out.wo) / pdf;
         }
         case ORC_BSDF_DIELECTRIC: {   // dielectric.cpp:277-333 (both lobes enabled, ERadiance)
             float cosThetaT;
@@ -663,12 +730,61 @@ Spectrum bsdfSample(const Material &mat, const Vec3 &wi, const Vec2 &_sample, BS
                 out.sampledType = EDiffuseReflection;
             }
             out.eta = 1.0f;
-            pdf = bsdfPdf(mat, wi, out.wo);
+            pdf = pdfOneSided(mat, wi, out.wo);
             if (pdf == 0) return Spectrum(0.0f);
-            return bsdfEval(mat, wi, out.wo) / pdf;
+            return evalOneSided(mat, wi, out.wo) / pdf;
+        }
+        case ORC_BSDF_CONDUCTOR: {   // conductor.cpp:273-288
+            if (Frame::cosTheta(wi) <= 0) return Spectrum(0.0f);
+            out.sampledType = EDeltaReflection;
+            out.wo = Vec3(-wi.x, -wi.y, wi.z);
+            out.eta = 1.0f;
+            pdf = 1;
+            return mat.specular * fresnelConductorExact(Frame::cosTheta(wi), mat.condEta, mat.condK);
+        }
+        case ORC_BSDF_PLASTIC: {   // plastic.cpp:373-440 (both lobes enabled)
+            if (Frame::cosTheta(wi) <= 0) return Spectrum(0.0f);
+            float Fi = fresnelDielectricExt(Frame::cosTheta(wi), mat.eta);
+            out.eta = 1.0f;
+            float probSpecular = (Fi * mat.specularSamplingWeight) /
+                (Fi * mat.specularSamplingWeight + (1 - Fi) * (1 - mat.specularSamplingWeight));
+            if (_sample.x < probSpecular) {
+                out.sampledType = EDeltaReflection;
+                out.wo = Vec3(-wi.x, -wi.y, wi.z);
+                pdf = probSpecular;
+                return mat.specular * Fi / probSpecular;
+            } else {
+                out.sampledType = EDiffuseReflection;
+                out.wo = squareToCosineHemisphere(Vec2{ (_sample.x - probSpecular) / (1 - probSpecular), _sample.y });
+                float Fo = fresnelDielectricExt(Frame::cosTheta(out.wo), mat.eta);
+                Spectrum diff = mat.diffuse;
+                if (m.variant) diff = diff / (Spectrum(1.0f) - diff * mat.fdrInt);
+                else diff /= 1 - mat.fdrInt;
+                pdf = (1 - probSpecular) * squareToCosineHemispherePdf(out.wo);
+                return diff * (mat.invEta2 * (1 - Fi) * (1 - Fo) / (1 - probSpecular));
+            }
         }
     }
     return Spectrum(0.0f);
+}
+
+// ---- the entry points the integrator calls: the BRDF itself, or the same through the twosided adapter
+// (src/bsdfs/twosided.cpp:108-183: seen from behind, wi and wo are mirrored and the back BRDF answers) ----------
+Spectrum bsdfEval(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
+    if (!mat.m.two_sided || Frame::cosTheta(wi) > 0) return evalOneSided(mat, wi, wo);
+    return evalOneSided(*mat.back, Vec3(wi.x, wi.y, -wi.z), Vec3(wo.x, wo.y, -wo.z));
+}
+
+float bsdfPdf(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
+    if (!mat.m.two_sided || wi.z > 0) return pdfOneSided(mat, wi, wo);
+    return pdfOneSided(*mat.back, Vec3(wi.x, wi.y, -wi.z), Vec3(wo.x, wo.y, -wo.z));
+}
+
+Spectrum bsdfSample(const Material &mat, const Vec3 &wi, const Vec2 &sample, BSDFSample &out, float &pdf) {
+    if (!mat.m.two_sided || !(Frame::cosTheta(wi) < 0)) return sampleOneSided(mat, wi, sample, out, pdf);
+    Spectrum result = sampleOneSided(*mat.back, Vec3(wi.x, wi.y, -wi.z), sample, out, pdf);
+    if (!result.isZero() && pdf != 0) out.wo.z *= -1;
+    return result;
 }
 
 }  // namespace orc

@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE ONLY -- CPU oracle: microfacet distribution, Fresnel terms, warps and the
-// five BSDF models on the `path` hot path, restated from the reference files cited per function.
+// BSDF models on the `path` hot path (plus smooth conductor / plastic and the twosided adapter), restated from the reference files cited per function.
 #pragma once
 #include "scene.h"
 
@@ -59,5 +59,8 @@ struct BSDFSample {
 Spectrum bsdfEval(const Material &m, const Vec3 &wi, const Vec3 &wo);
 float bsdfPdf(const Material &m, const Vec3 &wi, const Vec3 &wo);
 Spectrum bsdfSample(const Material &m, const Vec3 &wi, const Vec2 &sample, BSDFSample &out, float &pdf);
+
+// TwoSidedBRDF::configure over the whole material list; returns an error message or nullptr
+const char *linkTwoSided(std::vector<Material> &materials);
 
 }  // namespace orc

@@ -12,7 +12,7 @@ extern "C" {
 #endif
 
 enum { ORC_BSDF_DIFFUSE = 0, ORC_BSDF_ROUGHCONDUCTOR = 1, ORC_BSDF_ROUGHPLASTIC = 2,
-       ORC_BSDF_DIELECTRIC = 3, ORC_BSDF_WARD = 4 };
+       ORC_BSDF_DIELECTRIC = 3, ORC_BSDF_WARD = 4, ORC_BSDF_CONDUCTOR = 5, ORC_BSDF_PLASTIC = 6 };
 enum { ORC_DISTR_BECKMANN = 0, ORC_DISTR_GGX = 1 };
 enum { ORC_SHAPE_HAS_NORMALS = 1, ORC_SHAPE_HAS_TEXCOORDS = 2 };
 
@@ -41,6 +41,8 @@ typedef struct {
     uint32_t rtrans_n;
     float rtrans_diffuse_ext;
     float rtrans_diffuse_int;
+    int32_t two_sided;          /* nested in a twosided adapter (src/bsdfs/twosided.cpp) */
+    int32_t back_material;      /* record seen from behind, -1 = the same one */
 } orc_material;
 
 typedef struct {

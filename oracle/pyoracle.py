@@ -26,7 +26,7 @@ class Material(C.Structure):
                 ("specular_transmittance", C.c_float * 3), ("eta", C.c_float * 3), ("k", C.c_float * 3),
                 ("ext_eta", C.c_float), ("ensure_energy_conservation", C.c_int32),
                 ("rtrans", _f32p), ("rtrans_n", C.c_uint32), ("rtrans_diffuse_ext", C.c_float),
-                ("rtrans_diffuse_int", C.c_float)]
+                ("rtrans_diffuse_int", C.c_float), ("two_sided", C.c_int32), ("back_material", C.c_int32)]
 
 
 class Emitter(C.Structure):
@@ -102,7 +102,8 @@ def fill_desc(sd, desc_cls=SceneDesc, shape_cls=Shape, mat_cls=Material, em_cls=
     for i, m in enumerate(sd.materials):
         c = mats[i]
         for k in ("type", "distribution", "sample_visible", "variant", "alpha_u", "alpha_v", "int_ior", "ext_ior",
-                  "ext_eta", "ensure_energy_conservation", "rtrans_diffuse_ext", "rtrans_diffuse_int"):
+                  "ext_eta", "ensure_energy_conservation", "rtrans_diffuse_ext", "rtrans_diffuse_int", "two_sided",
+                  "back_material"):
             setattr(c, k, m[k])
         for k in ("diffuse_reflectance", "specular_reflectance", "specular_transmittance", "eta", "k"):
             setattr(c, k, (C.c_float * 3)(*[float(x) for x in m[k]]))

@@ -52,7 +52,10 @@ struct Material {
     float eta = 1, invEta = 1, invEta2 = 1;
     float specularSamplingWeight = 0;
     std::vector<float> rtrans;
-    unsigned type_flags = 0;                     // BSDF::EBSDFType combined
+    float fdrInt = 0;                            // plastic: fresnelDiffuseReflectance(1/eta) (plastic.cpp:195)
+    unsigned own_flags = 0;                      // BSDF::EBSDFType combined over this BRDF's own components
+    unsigned type_flags = 0;                     // what the integrator sees: own_flags, or the twosided adapter's
+    const Material *back = nullptr;              // twosided: BRDF seen from behind (may be this one)
     void configure();
 };
 

@@ -116,9 +116,37 @@ def test_cli_obj_and_cube(scene_dir):
     assert abs(d["sum_texcoords"] - (4.0 + 24.0)) < 1e-5
 
 
+def test_cli_smooth_bsdfs_and_twosided(scene_dir, tmp_path):
+    """conductor / plastic / twosided (one and two nested BRDFs, inline and by reference) through both loaders."""
+    body = """
+      <bsdf type="plastic" id="pl"><float name="intIOR" value="1.6"/><rgb name="diffuseReflectance" value="0.1, 0.2, 0.3"/>
+        <boolean name="nonlinear" value="true"/></bsdf>
+      <shape type="serialized"><string name="filename" value="meshes.serialized"/><integer name="shapeIndex" value="0"/><bsdf type="conductor"><rgb name="eta" value="0.2, 0.9, 1.1"/><rgb name="k" value="3.9, 2.4, 2.1"/></bsdf></shape>
+      <shape type="serialized"><string name="filename" value="meshes.serialized"/><integer name="shapeIndex" value="0"/><ref id="pl"/></shape>
+      <shape type="serialized"><string name="filename" value="meshes.serialized"/><integer name="shapeIndex" value="0"/><bsdf type="twosided"><bsdf type="diffuse"/></bsdf></shape>
+      <shape type="serialized"><string name="filename" value="meshes.serialized"/><integer name="shapeIndex" value="0"/><bsdf type="twosided"><ref id="metal"/><ref id="pl"/></bsdf></shape>"""
+    f = tmp_path / "smooth.xml"
+    f.write_text(SCENE % body)
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    d = _describe(f)
+    sd, _ = loader.load_xml(str(f))
+    assert d["material_types"] == [m["type"] for m in sd.materials]
+    assert d["two_sided"] == [m["two_sided"] for m in sd.materials]
+    assert d["back_materials"] == [m["back_material"] for m in sd.materials]
+    from mitsuba_amd import scene as S
+    assert S.BSDF_CONDUCTOR in d["material_types"] and S.BSDF_PLASTIC in d["material_types"]
+    two = [i for i, t in enumerate(d["two_sided"]) if t]
+    assert len(two) == 2 and d["back_materials"][two[0]] == -1
+    back = d["back_materials"][two[1]]
+    assert d["material_types"][back] == S.BSDF_PLASTIC and d["material_types"][two[1]] == S.BSDF_ROUGHCONDUCTOR
+    assert sd.materials[back]["variant"] == 1 and abs(sd.materials[back]["int_ior"] - 1.6) < 1e-6
+
+
 def test_cli_rejects_unsupported_content(scene_dir, tmp_path):
     for body, needle in (('<shape type="sphere"/>', "not supported"),
-                         ('<shape type="cube"><bsdf type="plastic"/></shape>', "outside the path hot path"),
+                         ('<shape type="cube"><bsdf type="roughdielectric"/></shape>', "outside the path hot path"),
+                         ('<shape type="cube"><bsdf type="twosided"><bsdf type="dielectric"/></bsdf></shape>', "transmission component"),
+                         ('<shape type="cube"><bsdf type="twosided"/></shape>', "nested one-sided material is required"),
                          ('<emitter type="constant"/>', "only area emitters"),
                          ('<shape type="cube"><bsdf type="roughconductor"><string name="material" value="Au"/></bsdf></shape>', "spectral data")):
         f = tmp_path / "bad.xml"

@@ -14,7 +14,8 @@ MISS = 0xFFFFFFFF
 
 
 def _scenes():
-    return {"small": S.small_test_scene(), "cornell": S.cornell_box(96, 96), "veach": S.veach_bidir(128, 96)}
+    return {"small": S.small_test_scene(), "cornell": S.cornell_box(96, 96), "veach": S.veach_bidir(128, 96),
+            "mixed": S.cornell_mixed(96, 96)}
 
 
 @pytest.fixture(scope="module")
@@ -30,7 +31,7 @@ def test_rng_stream_matches(gpu, oracle_mod):
         assert np.array_equal(gpu.rng_stream(seed, key, 64), oracle_mod.rng_stream(seed, key, 64))
 
 
-@pytest.mark.parametrize("name", ["small", "cornell", "veach"])
+@pytest.mark.parametrize("name", ["small", "cornell", "veach", "mixed"])
 def test_closest_hit_parity(pairs, name):
     sd, g, o = pairs[name]
     rng = np.random.default_rng(2)
@@ -105,7 +106,13 @@ def material_pair(gpu, oracle_mod):
             S.dielectric(S.IOR["water"], S.IOR["air"]), S.dielectric(1.5, 1.0),
             S.ward(alpha=0.4, diffuse_reflectance=(0.0, 0.0, 0.0), specular_reflectance=(0.616, 0.4752, 0.352)),
             S.ward(alpha=0.2, variant="ward"), S.ward(alpha=0.15, alpha_v=0.3, variant="ward-duer"),
-            S.diffuse((1.4, 0.5, 0.2))]        # triggers ensureEnergyConservation scaling
+            S.diffuse((1.4, 0.5, 0.2)),        # triggers ensureEnergyConservation scaling
+            S.conductor(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), specular_reflectance=(0.9, 0.8, 0.7)),
+            S.plastic(int_ior=1.49, diffuse_reflectance=(0.5, 0.3, 0.2)),
+            S.plastic(int_ior=1.33, ext_ior=1.0, diffuse_reflectance=(0.2, 0.6, 0.4), nonlinear=True),
+            S.twosided(S.diffuse((0.6, 0.5, 0.4))),
+            S.twosided(S.roughconductor(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), alpha=0.15, distribution="ggx"), 6),
+            S.twosided(S.plastic(int_ior=1.49), 0)]
     b = S.SceneBuilder()
     for m in mats:
         b.add_material(m)
@@ -139,7 +146,7 @@ def test_bsdf_sample_parity(material_pair):
     n = 200000
     for mi in range(len(mats)):
         wi = _wi(n, rng)
-        if mats[mi]["type"] == S.BSDF_DIELECTRIC:
+        if mats[mi]["type"] == S.BSDF_DIELECTRIC or mats[mi]["two_sided"]:
             wi[::2, 2] *= -1
         s = rng.uniform(0, 1, (n, 2)).astype(np.float32)
         a, b = g.bsdf_sample(mi, wi, s), o.bsdf_sample(mi, wi, s)
@@ -171,7 +178,7 @@ def test_emitter_sampling_parity(pairs):
             assert np.allclose(x, y, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["small", "cornell", "veach"])
+@pytest.mark.parametrize("name", ["small", "cornell", "veach", "mixed"])
 def test_per_sample_radiance_parity(pairs, name):
     """MIPathTracer::Li per camera sample with the shared sample stream: same ray counts, same radiance."""
     sd, g, o = pairs[name]
@@ -220,7 +227,7 @@ def test_film_put_parity(pairs):
     assert np.allclose(fg, fo, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["small", "cornell"])
+@pytest.mark.parametrize("name", ["small", "cornell", "mixed"])
 def test_render_film_parity(pairs, name):
     sd, g, o = pairs[name]
     fg, sg = g.render(4, seed=9)
