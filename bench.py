@@ -99,10 +99,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal switches for a box with fewer GPUs than ranks: MTSAMD_DIST_BACKEND=gloo moves the collectives to the
+    # CPU, MTSAMD_SHARE_DEVICE=1 puts every rank on device 0. The driver's runs use neither.
+    backend = os.environ.get("MTSAMD_DIST_BACKEND", "nccl")
+    device_index = 0 if os.environ.get("MTSAMD_SHARE_DEVICE") else local_rank
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    capi.init(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
+    torch.cuda.set_device(device_index)
+    capi.init(device_index)
+    coll_device = "cuda" if backend == "nccl" else "cpu"
 
     sd, workload = build_scene(args)
     g = capi.Scene(sd)
@@ -147,11 +155,16 @@ def main():
         s = step(args.warmup + i)
         for k in acc:
             acc[k] += s[k]
-    render.reduce_film(film, world)
+    if world > 1 and backend != "nccl":
+        host_film = film.cpu()
+        render.reduce_film(host_film, world)
+        film.copy_(host_film)
+    else:
+        render.reduce_film(film, world)
     barrier()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed, float(acc["normal"] + acc["shadow"]), float(acc["paths"])], device="cuda", dtype=torch.float64)
+    t = torch.tensor([elapsed, float(acc["normal"] + acc["shadow"]), float(acc["paths"])], device=coll_device, dtype=torch.float64)
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
