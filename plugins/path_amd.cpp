@@ -153,10 +153,26 @@ private:
 			m.alpha_u = p.getFloat("alphaU", .1f); m.alpha_v = p.getFloat("alphaV", .1f);
 			rgb(p.getSpectrum("diffuseReflectance", Spectrum(.5f)), m.diffuse_reflectance);
 			rgb(p.getSpectrum("specularReflectance", Spectrum(.2f)), m.specular_reflectance);
+		} else if (type == "conductor") {
+			m.type = MTSAMD_BSDF_CONDUCTOR;
+			rgb(p.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular_reflectance);
+			rgb(p.getSpectrum("eta", Spectrum(0.0f)), m.eta);      /* "material" presets: resolve to eta/k first */
+			rgb(p.getSpectrum("k", Spectrum(1.0f)), m.k);
+			m.ext_eta = p.getFloat("extEta", 1.000277f);
+		} else if (type == "plastic") {
+			m.type = MTSAMD_BSDF_PLASTIC;
+			m.int_ior = p.getFloat("intIOR", 1.49f); m.ext_ior = p.getFloat("extIOR", 1.000277f);
+			m.variant = p.getBoolean("nonlinear", false) ? 1 : 0;
+			rgb(p.getSpectrum("diffuseReflectance", Spectrum(.5f)), m.diffuse_reflectance);
+			rgb(p.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular_reflectance);
 		} else {
+			/* "twosided": the library takes it as two_sided / back_material on the nested BRDF's record, but
+			   TwoSidedBRDF keeps its nested BRDFs private (src/bsdfs/twosided.cpp:231-232); with a getter added there,
+			   fill the record from getNestedBRDF(0) and append the record of getNestedBRDF(1) for back_material. */
 			Log(EWarn, "path_amd: BSDF plugin \"%s\" is not on the GPU path", type.c_str());
 			return false;
 		}
+		m.back_material = -1;
 		return true;
 	}
 
