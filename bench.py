@@ -72,25 +72,27 @@ def measured_traffic(args):
     rocprofv3 passes (tools/profile_round.sh), so the figure is read from the newest committed summary of those
     passes and only reported for the workload they were taken on; otherwise null."""
     import glob
-    if args.workload != "config3" or (args.width, args.height, args.spp_step) != (1920, 1080, 128):
+    if args.workload != "config3" or (args.width, args.height) != (1920, 1080):
         return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
     if not files:
         return None, None
     with open(files[-1]) as f:
         d = json.load(f)
+    if d.get("spp_step", 128) != args.spp_step:
+        return None, None
     return d["traffic_bytes_per_launch"], "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes)" % os.path.basename(files[-1])
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="config3")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp-step", type=int, default=128, help="samples per pixel per step and GPU")
+    ap.add_argument("--spp-step", type=int, default=256, help="samples per pixel per step and GPU")
     ap.add_argument("--partition", choices=("samples", "bands"), default="samples")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

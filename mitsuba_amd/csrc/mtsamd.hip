@@ -418,12 +418,13 @@ int renderCommon(mtsamd_scene *s, const mtsamd_render_opts *opts, float *filmDev
     int sppPass = o.spp_per_pass;
     if (sppPass <= 0) {
         // Paths in flight per pass: large passes keep the later, thinner bounces of the wavefront loop wide enough to
-        // fill the device (measured: 64 Mi paths 2.3, 128 Mi 2.7, 256 Mi 3.0 Grays/s on a 1M-triangle scene), so take up
-        // to 256 Mi paths as long as their work buffers (224 B per path) stay within a third of the free device memory.
+        // fill the device (measured on a 1M-triangle scene: 64 Mi paths 2.7, 128 Mi 3.0, 256 Mi 3.3, 512 Mi 3.6,
+        // 768 Mi 3.6 Grays/s), so take up to 512 Mi paths as long as their work buffers (224 B per path) stay within
+        // half of the free device memory.
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = (size_t) 16 << 30;
-        const size_t byMemory = std::max<size_t>(freeB / 3 / 224, (size_t) 1 << 20);
-        const size_t target = std::min<size_t>((size_t) 256 << 20, byMemory + s->capacity);
+        const size_t byMemory = std::max<size_t>(freeB / 2 / 224, (size_t) 1 << 20);
+        const size_t target = std::min<size_t>((size_t) 512 << 20, byMemory + s->capacity);
         sppPass = (int) std::max<size_t>(1, std::min<size_t>((size_t) o.spp, target / ((size_t) w * h)));
     }
     sppPass = std::min(sppPass, o.spp);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM-side traffic of the closest-hit traversal launches from two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE).
 
-  python tools/traffic_json.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> > profiles/rNN_traffic.json
+  python tools/traffic_json.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> [spp per pass] > profiles/rNN_traffic.json
 
 The counters are in KiB. On gfx950 FETCH_SIZE tallies 128-byte fabric requests at 64 bytes, so it is doubled; that
 calibration was made on wide streaming reads and is only an estimate for the scattered 16-byte loads of a traversal.
@@ -26,8 +26,9 @@ def collect(d, counter):
 
 fetch, nf = collect(sys.argv[1], "FETCH_SIZE")
 write, nw = collect(sys.argv[2], "WRITE_SIZE")
-out = {"kernel": "k_trace<TRACE_CLOSEST>", "launches": nf,
+spp = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+out = {"kernel": "k_trace<TRACE_CLOSEST>", "launches": nf, "spp_step": spp,
        "fetch_kib_raw": fetch, "write_kib": write,
        "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024.0 / max(nf, 1),
-       "note": "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); bench.py --steps 1 --warmup 0, one 128 spp pass"}
+       "note": "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B); bench.py --steps 1 --warmup 0, one pass of spp_step samples per pixel"}
 print(json.dumps(out))
