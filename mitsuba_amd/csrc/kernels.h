@@ -69,40 +69,59 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 1024), amdgpu_wav
 #endif
 static constexpr int kShadeBlock = MTS_SHADE_BLOCK;
 
+// ROUNDS: a workgroup sorts ROUNDS x kShadeBlock paths at once and shades them in ROUNDS sweeps of one path per
+// thread; the larger sort domain leaves fewer wavefronts that straddle two BSDF models.
+template <int ROUNDS>
 __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out,
                                                        ShadowQueue sq, float4 *sampleL, uint32_t *counters, uint32_t n) {
-    constexpr int kWaves = kShadeBlock / 64, kKeys = 8;
-    __shared__ uint32_t sCount[kKeys][kWaves];
-    __shared__ uint32_t sOrder[kShadeBlock];
+    constexpr int kWaves = kShadeBlock / 64, kKeys = 8, kCells = kKeys * ROUNDS * kWaves;
+    __shared__ uint32_t sCount[kCells];         // [key][round][wave]: count, then exclusive start
+    __shared__ uint32_t sOrder[kShadeBlock * ROUNDS];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t first = blockIdx.x * kShadeBlock;
+    const uint32_t first = blockIdx.x * (kShadeBlock * ROUNDS);
     {
-        const uint32_t i = first + tid;
-        uint32_t key = kKeys - 1;
-        if (i < n) {
-            const uint32_t w = __float_as_uint(hits[i].w);
-            if (w != kMiss) key = w >> 28;
-        }
-        uint32_t rank = 0;
+        uint32_t key[ROUNDS], rank[ROUNDS];
         const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-        for (uint32_t k = 0; k < (uint32_t) kKeys; ++k) {
-            const unsigned long long m = __ballot(key == k);
-            if (key == k) rank = (uint32_t) __popcll(m & below);
-            if (lane == 0) sCount[k][wave] = (uint32_t) __popcll(m);
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t i = first + r * kShadeBlock + tid;
+            key[r] = kKeys - 1;
+            if (i < n) {
+                const uint32_t w = __float_as_uint(hits[i].w);
+                if (w != kMiss) key[r] = w >> 28;
+            }
+            rank[r] = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < (uint32_t) kKeys; ++k) {
+                const unsigned long long m = __ballot(key[r] == k);
+                if (key[r] == k) rank[r] = (uint32_t) __popcll(m & below);
+                if (lane == 0) sCount[(k * ROUNDS + r) * kWaves + wave] = (uint32_t) __popcll(m);
+            }
         }
         __syncthreads();
-        // exclusive prefix over (key, wave) pairs in key-major order
-        uint32_t start = 0;
-        for (uint32_t k = 0; k < (uint32_t) kKeys; ++k)
-            for (uint32_t w = 0; w < (uint32_t) kWaves; ++w) {
-                const uint32_t c = sCount[k][w];
-                if (k < key || (k == key && w < wave)) start += c;
-            }
-        sOrder[start + rank] = tid;
+        // exclusive prefix over the cells in key-major order
+        constexpr int kCellsPerThread = (kCells + kShadeBlock - 1) / kShadeBlock;
+        uint32_t start[kCellsPerThread];
+#pragma unroll
+        for (int j = 0; j < kCellsPerThread; ++j) {
+            const uint32_t cell = j * kShadeBlock + tid;
+            start[j] = 0;
+            if (cell < (uint32_t) kCells)
+                for (uint32_t c = 0; c < cell; ++c) start[j] += sCount[c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kCellsPerThread; ++j)
+            if (j * kShadeBlock + tid < (uint32_t) kCells) sCount[j * kShadeBlock + tid] = start[j];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+            sOrder[sCount[(key[r] * ROUNDS + r) * kWaves + wave] + rank[r]] = r * kShadeBlock + tid;
         __syncthreads();
     }
-    const uint32_t i = first + sOrder[tid];
+    __shared__ uint32_t sWaveShadow[kWaves], sWaveNext[kWaves], sBase[2];
+  for (int round = 0; round < ROUNDS; ++round) {
+    const uint32_t i = first + sOrder[round * kShadeBlock + tid];
     bool alive = false, wantShadow = false;
     float4 oRayO = make_float4(0, 0, 0, 0), oRayD = oRayO, oThr = oRayO, sRayO = oRayO, sRayD = oRayO, sContrib = oRayO;
     uint4 oMisc = make_uint4(0, 0, 0, 0);
@@ -242,7 +261,6 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
     // Queue slots are reserved once per workgroup (two atomics per workgroup, not per wavefront: thousands of
     // wavefronts hammering the same two counters serialise at the L2): wave totals go through LDS, thread 0 reserves
     // the workgroup's ranges, every wave adds the totals of the waves before it.
-    __shared__ uint32_t sWaveShadow[kWaves], sWaveNext[kWaves], sBase[2];
     const unsigned long long below = (1ull << lane) - 1ull;
     const unsigned long long mShadow = __ballot(wantShadow), mNext = __ballot(alive);
     if (lane == 0) { sWaveShadow[wave] = (uint32_t) __popcll(mShadow); sWaveNext[wave] = (uint32_t) __popcll(mNext); }
@@ -258,6 +276,8 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
     for (uint32_t w = 0; w < wave; ++w) { si += sWaveShadow[w]; oi += sWaveNext[w]; }
     if (wantShadow) { sq.rayO[si] = sRayO; sq.rayD[si] = sRayD; sq.contrib[si] = sContrib; }
     if (alive) { out.rayO[oi] = oRayO; out.rayD[oi] = oRayD; out.thr[oi] = oThr; out.misc[oi] = oMisc; out.bsdfPdf[oi] = oPdf; }
+    if (ROUNDS > 1) __syncthreads();        // the reservation cells are reused by the next sweep
+  }
 }
 
 // ---- K6 film: ImageBlock::put in gather form (include/mitsuba/render/imageblock.h:144-189). One thread per film

@@ -81,6 +81,8 @@ struct mtsamd_scene {
     unsigned traceGrid = 0, traceBlock = 256;
     uint32_t nodeStride = 5, triStride = 3;     // record strides in float4 units (padding buys line alignment)
     uint64_t overlapBelow = 8u << 20;     // rays (shadow + next extend) below which the two traversals run side by side
+    int shadeRounds = 8;                  // sweeps per shade workgroup (1, 2, 4, 8 or 16) ...
+    uint32_t shadeRoundsAbove = 4u << 20; // ... for queues of at least this many paths
     uint32_t refillBelow = 56, triShare = 16, topNodes = 73, chunkMax = 512;
 
     ~mtsamd_scene() {
@@ -213,6 +215,8 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
         if (const char *e = getenv("MTSAMD_REFILL_BELOW")) s->refillBelow = (uint32_t) std::min(64, std::max(1, atoi(e)));
         if (const char *e = getenv("MTSAMD_TRI_SHARE")) s->triShare = (uint32_t) std::min(64, std::max(1, atoi(e)));
         if (const char *e = getenv("MTSAMD_OVERLAP_BELOW")) s->overlapBelow = (uint64_t) std::max(0ll, atoll(e));
+        if (const char *e = getenv("MTSAMD_SHADE_ROUNDS")) s->shadeRounds = atoi(e);
+        if (const char *e = getenv("MTSAMD_SHADE_ROUNDS_ABOVE")) s->shadeRoundsAbove = (uint32_t) std::max(0ll, atoll(e));
         if (const char *e = getenv("MTSAMD_CHUNK_MAX")) s->chunkMax = (uint32_t) std::min(65536, std::max(64, atoi(e)));
         if (const char *e = getenv("MTSAMD_TOP_NODES")) s->topNodes = (uint32_t) std::min(1800, std::max(0, atoi(e)));
         if (const char *e = getenv("MTSAMD_TRACE_BLOCK")) s->traceBlock = (unsigned) std::min(1024, std::max(64, atoi(e) / 64 * 64));
@@ -351,7 +355,15 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         // queue lengths and both ray hand-out counters start from zero for the rest of this bounce and the next extend
         HIP_TRY(hipMemsetAsync(cnt, 0, CNT_QUEUE_WORDS * sizeof(uint32_t), st));
         timer.begin(T_SHADE);
-        hipLaunchKernelGGL(k_shade, dim3(blocksFor(n, kShadeBlock)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, cnt, n);
+        // large queues: several sweeps per workgroup (purer wavefronts); small ones: one, to keep every CU busy
+        const int rounds = n >= s->shadeRoundsAbove ? s->shadeRounds : 1;
+#define MTS_LAUNCH_SHADE(R) hipLaunchKernelGGL(k_shade<R>, dim3(blocksFor(n, kShadeBlock * R)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, cnt, n)
+        if (rounds >= 16) MTS_LAUNCH_SHADE(16);
+        else if (rounds >= 8) MTS_LAUNCH_SHADE(8);
+        else if (rounds >= 4) MTS_LAUNCH_SHADE(4);
+        else if (rounds >= 2) MTS_LAUNCH_SHADE(2);
+        else MTS_LAUNCH_SHADE(1);
+#undef MTS_LAUNCH_SHADE
         timer.end(T_SHADE);
         HIP_TRY(hipEventRecord(s->evShaded, st));
         HIP_TRY(hipMemcpyAsync(s->hostCounters, cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
