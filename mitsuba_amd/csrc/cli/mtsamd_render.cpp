@@ -3,7 +3,7 @@
 // plays for the reference (src/mitsuba/mitsuba.cpp:129-397, film output src/films/hdrfilm.cpp:481-537).
 //
 //   mtsamd-render scene.xml -o out.pfm [--spp N] [--size W H] [--seed S] [--device D] [--data-dir DIR]
-//                 [--max-depth N] [--describe] [--film out.raw]
+//                 [--max-depth N] [--describe] [--film out.raw] [-D name=value ...]
 //
 // --describe prints a JSON summary of the loaded scene and exits without touching the GPU.
 // --film also stores the unnormalised (R,G,B,alpha,weight) float32 film.
@@ -20,7 +20,7 @@ using namespace mtsamd_host;
 
 static int usage() {
     fprintf(stderr, "usage: mtsamd-render scene.xml -o out.pfm [--spp N] [--size W H] [--seed S] [--device D] [--data-dir DIR] "
-                    "[--max-depth N] [--describe] [--film out.raw]\n");
+                    "[--max-depth N] [--describe] [--film out.raw] [-D name=value ...]\n");
     return 2;
 }
 
@@ -71,6 +71,12 @@ int main(int argc, char **argv) {
         else if (a == "--max-depth") opts.maxDepth = atoi(next("--max-depth"));
         else if (a == "--film") filmPath = next("--film");
         else if (a == "--describe") describeOnly = true;
+        else if (a.rfind("-D", 0) == 0) {       // -Dname=value or -D name=value, like `mitsuba -D` (src/mitsuba/mitsuba.cpp:168-174)
+            const std::string kv = a.size() > 2 ? a.substr(2) : std::string(next("-D"));
+            const size_t eq = kv.find('=');
+            if (eq == std::string::npos || eq == 0) { fprintf(stderr, "-D expects name=value\n"); return usage(); }
+            opts.params[kv.substr(0, eq)] = kv.substr(eq + 1);
+        }
         else if (!a.empty() && a[0] == '-') return usage();
         else scenePath = a;
     }

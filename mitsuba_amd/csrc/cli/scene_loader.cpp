@@ -4,6 +4,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -399,7 +400,7 @@ void applyToWorld(Mesh &mesh, const Mat4 &md) {
 }
 
 // TriMesh::computeNormals (src/librender/trimesh.cpp:636-672): angle-weighted face normals
-void computeNormals(Mesh &mesh) {
+void computeNormals(Mesh &mesh, bool flip) {
     const size_t nv = mesh.positions.size() / 3, nt = mesh.indices.size() / 3;
     mesh.normals.assign(nv * 3, 0.0f);
     const float *P = mesh.positions.data();
@@ -432,7 +433,8 @@ void computeNormals(Mesh &mesh) {
     }
     for (size_t v = 0; v < nv; ++v) {
         float *n = &mesh.normals[3 * v];
-        const float len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        float len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        if (flip) len *= -1;
         if (len != 0) { n[0] /= len; n[1] /= len; n[2] /= len; } else { n[0] = 1; n[1] = 0; n[2] = 0; }
     }
 }
@@ -681,6 +683,201 @@ std::string writePfm(const std::string &path, const float *rgba, int width, int 
     return "";
 }
 
+// Stanford PLY (src/shapes/ply.cpp:91-137,202-316): ASCII and both binary byte orders; vertex properties x y z,
+// nx ny nz, u|texture_u|s and v|texture_v|t (anything else, vertex colours included, is skipped); faces are
+// triangles or quads through vertex_indices|vertex_index, a quad (a,b,c,d) becoming (a,b,c) and (d,a,c).
+// Positions and normals stay in object space here; the caller applies toWorld.
+namespace {
+struct PlyProperty { std::string name; int type = 0, countType = 0; bool isList = false; };
+struct PlyElement { std::string name; size_t count = 0; std::vector<PlyProperty> props; };
+
+// type codes: 1 int8, 2 uint8, 3 int16, 4 uint16, 5 int32, 6 uint32, 7 float32, 8 float64
+int plyType(const std::string &t) {
+    static const std::pair<const char *, int> names[] = {
+        { "char", 1 }, { "int8", 1 }, { "uchar", 2 }, { "uint8", 2 }, { "short", 3 }, { "int16", 3 }, { "ushort", 4 }, { "uint16", 4 },
+        { "int", 5 }, { "int32", 5 }, { "uint", 6 }, { "uint32", 6 }, { "float", 7 }, { "float32", 7 }, { "double", 8 }, { "float64", 8 } };
+    for (const auto &n : names) if (t == n.first) return n.second;
+    throw Fail("PLY: unknown property type '" + t + "'");
+}
+int plySize(int type) { static const int size[] = { 0, 1, 1, 2, 2, 4, 4, 4, 8 }; return size[type]; }
+
+struct PlyReader {
+    const std::vector<uint8_t> &data;
+    size_t pos;
+    int format;     // 0 ascii, 1 little endian, 2 big endian
+    double next(int type) {
+        if (format == 0) {
+            while (pos < data.size() && std::isspace(data[pos])) ++pos;
+            const size_t b = pos;
+            while (pos < data.size() && !std::isspace(data[pos])) ++pos;
+            if (b == pos) throw Fail("PLY: unexpected end of file");
+            return std::stod(std::string((const char *) &data[b], pos - b));
+        }
+        const int n = plySize(type);
+        if (pos + n > data.size()) throw Fail("PLY: unexpected end of file");
+        uint8_t raw[8];
+        for (int i = 0; i < n; ++i) raw[i] = data[pos + (format == 1 ? i : n - 1 - i)];     // to little endian
+        pos += n;
+        switch (type) {
+            case 1: { int8_t v; memcpy(&v, raw, 1); return v; }
+            case 2: return raw[0];
+            case 3: { int16_t v; memcpy(&v, raw, 2); return v; }
+            case 4: { uint16_t v; memcpy(&v, raw, 2); return v; }
+            case 5: { int32_t v; memcpy(&v, raw, 4); return v; }
+            case 6: { uint32_t v; memcpy(&v, raw, 4); return v; }
+            case 7: { float v; memcpy(&v, raw, 4); return v; }
+            default: { double v; memcpy(&v, raw, 8); return v; }
+        }
+    }
+};
+}  // namespace
+
+std::string loadPly(const std::string &path, Mesh &out) {
+    try {
+        std::vector<uint8_t> data;
+        if (!readFile(path, data)) return "PLY file \"" + path + "\" could not be found!";
+        // header: lines up to end_header
+        size_t pos = 0;
+        auto line = [&]() {
+            const size_t b = pos;
+            while (pos < data.size() && data[pos] != '\n') ++pos;
+            std::string l((const char *) &data[b], pos - b);
+            if (pos < data.size()) ++pos;
+            if (!l.empty() && l.back() == '\r') l.pop_back();
+            return l;
+        };
+        if (line() != "ply") return "\"" + path + "\" is not a PLY file";
+        int format = -1;
+        std::vector<PlyElement> elements;
+        for (;;) {
+            if (pos >= data.size()) return "PLY: header has no end_header";
+            std::istringstream is(line());
+            std::string key;
+            is >> key;
+            if (key == "end_header") break;
+            if (key == "format") {
+                std::string f; is >> f;
+                format = f == "ascii" ? 0 : f == "binary_little_endian" ? 1 : f == "binary_big_endian" ? 2 : -1;
+                if (format < 0) return "PLY: unknown format '" + f + "'";
+            } else if (key == "element") {
+                PlyElement e; is >> e.name >> e.count; elements.push_back(e);
+            } else if (key == "property") {
+                if (elements.empty()) return "PLY: property outside an element";
+                PlyProperty pr; std::string t; is >> t;
+                if (t == "list") { std::string ct, it; is >> ct >> it >> pr.name; pr.isList = true; pr.countType = plyType(ct); pr.type = plyType(it); }
+                else { pr.type = plyType(t); is >> pr.name; }
+                elements.back().props.push_back(pr);
+            }       // comment, obj_info: ignored
+        }
+        if (format < 0) return "PLY: header has no format line";
+        PlyReader rd{ data, pos, format };
+        out = Mesh();
+        size_t slash = path.find_last_of('/');
+        out.name = path.substr(slash == std::string::npos ? 0 : slash + 1);
+        for (const PlyElement &e : elements) {
+            if (e.name == "vertex") {
+                int slot[8];    // x y z nx ny nz u v -> property index
+                std::fill(slot, slot + 8, -1);
+                for (size_t k = 0; k < e.props.size(); ++k) {
+                    const std::string &n = e.props[k].name;
+                    if (e.props[k].isList) continue;
+                    if (n == "x") slot[0] = (int) k; else if (n == "y") slot[1] = (int) k; else if (n == "z") slot[2] = (int) k;
+                    else if (n == "nx") slot[3] = (int) k; else if (n == "ny") slot[4] = (int) k; else if (n == "nz") slot[5] = (int) k;
+                    else if (n == "u" || n == "texture_u" || n == "s") slot[6] = (int) k;
+                    else if (n == "v" || n == "texture_v" || n == "t") slot[7] = (int) k;
+                }
+                if (slot[0] < 0 || slot[1] < 0 || slot[2] < 0) return "PLY: vertices have no x/y/z";
+                const bool hasN = slot[3] >= 0, hasUV = slot[6] >= 0;       // the reference keys on nx and on u (ply.cpp:205-218)
+                out.positions.resize(e.count * 3);
+                if (hasN) out.normals.assign(e.count * 3, 0.0f);
+                if (hasUV) out.texcoords.assign(e.count * 2, 0.0f);
+                std::vector<double> row(e.props.size());
+                for (size_t v = 0; v < e.count; ++v) {
+                    for (size_t k = 0; k < e.props.size(); ++k) {
+                        if (e.props[k].isList) { const size_t c = (size_t) rd.next(e.props[k].countType); for (size_t j = 0; j < c; ++j) rd.next(e.props[k].type); row[k] = 0; }
+                        else row[k] = rd.next(e.props[k].type);
+                    }
+                    for (int c = 0; c < 3; ++c) out.positions[3 * v + c] = (float) row[slot[c]];
+                    if (hasN) for (int c = 0; c < 3; ++c) if (slot[3 + c] >= 0) out.normals[3 * v + c] = (float) row[slot[3 + c]];
+                    if (hasUV) for (int c = 0; c < 2; ++c) if (slot[6 + c] >= 0) out.texcoords[2 * v + c] = (float) row[slot[6 + c]];
+                }
+            } else if (e.name == "face") {
+                const size_t nVerts = out.positions.size() / 3;
+                for (size_t f = 0; f < e.count; ++f)
+                    for (const PlyProperty &pr : e.props) {
+                        if (!pr.isList) { rd.next(pr.type); continue; }
+                        const size_t c = (size_t) rd.next(pr.countType);
+                        const bool indices = pr.name == "vertex_indices" || pr.name == "vertex_index";
+                        if (indices && c != 3 && c != 4)
+                            return "Encountered a face with " + std::to_string(c) + " vertices! Only triangle and quad-based PLY meshes are supported for now.";
+                        uint32_t face[4] = { 0, 0, 0, 0 };
+                        for (size_t j = 0; j < c; ++j) {
+                            const double v = rd.next(pr.type);
+                            if (indices) {
+                                if (v < 0 || (size_t) v >= nVerts) return "PLY: vertex index out of range";
+                                face[j] = (uint32_t) v;
+                            }
+                        }
+                        if (!indices) continue;
+                        out.indices.insert(out.indices.end(), { face[0], face[1], face[2] });
+                        if (c == 4) out.indices.insert(out.indices.end(), { face[3], face[0], face[2] });
+                    }
+            } else {
+                for (size_t i = 0; i < e.count; ++i)
+                    for (const PlyProperty &pr : e.props) {
+                        if (pr.isList) { const size_t c = (size_t) rd.next(pr.countType); for (size_t j = 0; j < c; ++j) rd.next(pr.type); }
+                        else rd.next(pr.type);
+                    }
+            }
+        }
+        if (out.indices.empty() || out.positions.empty()) return "Unable to load \"" + path + "\" (no triangles or vertices found)!";
+        return "";
+    } catch (const std::exception &e) {
+        return e.what();
+    }
+}
+
+namespace {
+// SceneHandler::startElement (src/librender/scenehandler.cpp:207-223): "$name" in any attribute value is replaced by the
+// parameter's value, longest-sorting names first; <default name= value=> defines a parameter unless it is already set
+// (:684-688). Runs in document order, so a default only affects what follows it.
+void substituteParameters(Element &el, std::map<std::string, std::string> &params) {
+    for (auto &kv : el.attrs) {
+        std::string &v = kv.second;
+        if (v.find('$') == std::string::npos) continue;
+        for (auto it = params.rbegin(); it != params.rend(); ++it) {
+            const std::string needle = "$" + it->first;
+            size_t pos = 0;
+            while ((pos = v.find(needle, pos)) != std::string::npos) { v.replace(pos, needle.size(), it->second); ++pos; }
+        }
+        if (v.find('$') != std::string::npos && v.find('[') == std::string::npos)
+            throw Fail("The scene referenced an undefined parameter: \"" + v + "\"");
+    }
+    if (el.tag == "default" && !params.count(el.get("name"))) params[el.get("name")] = el.get("value");
+    for (auto &c : el.children) substituteParameters(*c, params);
+}
+
+// <include filename=.../> (scenehandler.cpp:658-682): the included file is a scene of its own whose children join the
+// including scene; parameters and named objects are shared. Relative names resolve against the including file.
+void expandIncludes(Element &scene, const std::string &base, std::map<std::string, std::string> &params, int depth) {
+    if (depth > 16) throw Fail("<include> nesting is too deep");
+    std::vector<std::unique_ptr<Element>> flat;
+    for (auto &c : scene.children) {
+        substituteParameters(*c, params);
+        if (c->tag != "include") { flat.push_back(std::move(c)); continue; }
+        const std::string file = joinPath(base, c->get("filename"));
+        std::vector<uint8_t> bytes;
+        if (!readFile(file, bytes)) throw Fail("cannot read included file " + file);
+        const std::string text((const char *) bytes.data(), bytes.size());
+        std::unique_ptr<Element> inc = xml_lite::Parser(text).parse();
+        if (inc->tag != "scene") throw Fail("included file " + file + ": root element must be <scene>");
+        expandIncludes(*inc, dirOf(file), params, depth + 1);
+        for (auto &ic : inc->children) flat.push_back(std::move(ic));
+    }
+    scene.children = std::move(flat);
+}
+}  // namespace
+
 std::string loadSceneXml(const std::string &path, const LoadOptions &opts, LoadedScene &out) {
     try {
         std::vector<uint8_t> bytes;
@@ -689,6 +886,8 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
         std::unique_ptr<Element> root = xml_lite::Parser(text).parse();
         if (root->tag != "scene") return "root element must be <scene>";
         const std::string base = dirOf(path);
+        std::map<std::string, std::string> params = opts.params;
+        expandIncludes(*root, base, params, 0);
         std::map<std::string, uint32_t> namedBsdfs;
         int defaultBsdf = -1;
         bool haveSensor = false;
@@ -700,8 +899,15 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
             if (el.has("id")) namedBsdfs[el.get("id")] = idx;
             return idx;
         };
-        for (const auto &el : root->children)
+        for (const auto &el : root->children) {
             if (el->tag == "bsdf") bsdfIndex(*el);
+            else if (el->tag == "alias") {      // scenehandler.cpp:646-656
+                const std::string id = el->get("id"), as = el->get("as");
+                if (!namedBsdfs.count(id)) return "Referenced object '" + id + "' not found!";
+                if (namedBsdfs.count(as)) return "Duplicate ID '" + as + "' used in scene description!";
+                namedBsdfs[as] = namedBsdfs[id];
+            }
+        }
 
         for (const auto &elp : root->children) {
             const Element &el = *elp;
@@ -780,20 +986,33 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
                 std::string err;
                 if (type == "serialized") err = loadSerialized(joinPath(base, getS(p, "filename", "")), (int) getF(p, "shapeIndex", 0), mesh);
                 else if (type == "obj") err = loadObj(joinPath(base, getS(p, "filename", "")), getB(p, "flipTexCoords", true), mesh);
+                else if (type == "ply") err = loadPly(joinPath(base, getS(p, "filename", "")), mesh);
                 else if (type == "cube") makeCube(mesh);
                 else return "shape type '" + type + "' is not supported (triangle meshes only)";
                 if (!err.empty()) return err;
-                if (getB(p, "flipNormals", false)) return "flipNormals is not supported";
+                if (p.count("maxSmoothAngle")) return "maxSmoothAngle (TriMesh::rebuildTopology) is not supported";
                 const bool faceNormals = getB(p, "faceNormals", false) || mesh.faceNormals;
+                const bool flipNormals = getB(p, "flipNormals", false);
                 if (faceNormals) mesh.normals.clear();
                 applyToWorld(mesh, p.count("toWorld") ? p.at("toWorld").t : Mat4::identity());
-                if (mesh.normals.empty() && !faceNormals) computeNormals(mesh);
+                // TriMesh::computeNormals (src/librender/trimesh.cpp:606-672): flipNormals swaps the winding of a
+                // face-normal mesh, negates given vertex normals, and negates computed ones
+                if (faceNormals) {
+                    if (flipNormals)
+                        for (size_t t = 0; t + 2 < mesh.indices.size(); t += 3) std::swap(mesh.indices[t], mesh.indices[t + 1]);
+                } else if (!mesh.normals.empty()) {
+                    if (flipNormals) for (float &c : mesh.normals) c *= -1;
+                } else {
+                    computeNormals(mesh, flipNormals);
+                }
                 addMesh(out, mesh, (uint32_t) mat, emitter ? radiance : nullptr, weight);
             } else if (el.tag == "bsdf") {
                 // handled above
             } else if (el.tag == "emitter") {
                 return "only area emitters attached to shapes are supported (found a scene-level <emitter type=\"" + el.get("type") + "\">)";
-            } else if (el.tag == "medium" || el.tag == "texture" || el.tag == "include" || el.tag == "default" || el.tag == "alias") {
+            } else if (el.tag == "default" || el.tag == "alias") {
+                // handled above
+            } else if (el.tag == "medium" || el.tag == "texture") {
                 if (el.tag == "medium") continue;   // a medium no shape refers to is inert
                 return "<" + el.tag + "> is not supported";
             }

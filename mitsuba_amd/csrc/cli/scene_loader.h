@@ -1,12 +1,14 @@
 // Host-side scene ingest in C++ for the subset of the Mitsuba 0.5 scene format that the `path` hot path needs:
 // the XML description (src/librender/scenehandler.cpp:306-693) restricted to scene / integrator / sensor / sampler /
-// film / rfilter / bsdf / shape / emitter / ref / transform and the scalar property tags; triangle meshes from
-// `.serialized` containers (src/librender/trimesh.cpp:175-294), Wavefront OBJ files (src/shapes/obj.cpp, whole file as
-// one mesh) and the `cube` plugin (src/shapes/cube.cpp). Everything else is rejected with a message -- nothing is
+// film / rfilter / bsdf / shape / emitter / ref / transform / include / default / alias and the scalar property tags
+// with "$parameter" substitution; triangle meshes from `.serialized` containers (src/librender/trimesh.cpp:175-294),
+// Wavefront OBJ files (src/shapes/obj.cpp, whole file as one mesh), Stanford PLY files (src/shapes/ply.cpp) and the
+// `cube` plugin (src/shapes/cube.cpp). Everything else is rejected with a message -- nothing is
 // silently substituted. The result owns flat arrays and hands out a mtsamd_scene_desc for the C ABI.
 #pragma once
 #include "../../../include/mtsamd.h"
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -16,6 +18,7 @@ struct LoadOptions {
     int width = 0, height = 0;          // override the film size when both are positive
     std::string dataDir;                // directory that holds microfacet/<distribution>.dat (roughplastic)
     int maxDepth = 0;                   // non-zero: override the integrator's maxDepth
+    std::map<std::string, std::string> params;   // -D name=value: values for "$name" in the scene file
 };
 
 struct LoadedScene {
@@ -46,6 +49,7 @@ struct Mesh {
 // Each loader returns an empty string on success or an error message.
 std::string loadSerialized(const std::string &path, int shapeIndex, Mesh &out);
 std::string loadObj(const std::string &path, bool flipTexCoords, Mesh &out);
+std::string loadPly(const std::string &path, Mesh &out);
 void makeCube(Mesh &out);
 std::string loadSceneXml(const std::string &path, const LoadOptions &opts, LoadedScene &out);
 

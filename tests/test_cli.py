@@ -142,6 +142,74 @@ def test_cli_smooth_bsdfs_and_twosided(scene_dir, tmp_path):
     assert sd.materials[back]["variant"] == 1 and abs(sd.materials[back]["int_ior"] - 1.6) < 1e-6
 
 
+def _write_ply(path, fmt, pos, nrm, faces):
+    """Vertices with normals, a colour and a list property to skip over; an extra element before the faces."""
+    head = ["ply", "format %s 1.0" % fmt, "comment test", "element vertex %d" % len(pos)]
+    head += ["property float x", "property float y", "property float z", "property uchar red",
+             "property float nx", "property float ny", "property float nz", "property list uchar int junk"]
+    head += ["element edge 2", "property int a", "property short b"]
+    head += ["element face %d" % len(faces), "property uchar flag", "property list uchar uint vertex_indices", "end_header"]
+    data = ("\n".join(head) + "\n").encode()
+    if fmt == "ascii":
+        lines = ["%r %r %r 200 %r %r %r 2 7 8" % (*map(float, p), *map(float, n)) for p, n in zip(pos, nrm)]
+        lines += ["1 2", "3 4"]
+        lines += ["1 %d %s" % (len(f), " ".join(map(str, f))) for f in faces]
+        data += ("\n".join(lines) + "\n").encode()
+    else:
+        e = "<" if fmt == "binary_little_endian" else ">"
+        for p, n in zip(pos, nrm):
+            data += struct.pack(e + "fffBfffBii", *map(float, p), 200, *map(float, n), 2, 7, 8)
+        data += struct.pack(e + "ihih", 1, 2, 3, 4)
+        for f in faces:
+            data += struct.pack(e + "BB%dI" % len(f), 1, len(f), *f)
+    open(path, "wb").write(data)
+
+
+def test_cli_ply_parameters_include_alias(scene_dir, tmp_path):
+    """Loader fidelity: PLY meshes in all three encodings (quads split like ply.cpp:299-313), $parameters with <default> and
+    -D, <include>, <alias>, flipNormals."""
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    pos = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0.25], [0, 1, 0], [2, 0.5, 0.5]], np.float32)
+    nrm = np.array([[0, 0, 1], [0, 0, 1], [0, 0.6, 0.8], [0, 0, 1], [1, 0, 0]], np.float32)
+    faces = [[0, 1, 2, 3], [1, 4, 2]]
+    (tmp_path / "mats.xml").write_text('<scene version="0.5.0"><bsdf type="diffuse" id="inc"><rgb name="reflectance" value="$refl"/></bsdf></scene>')
+    descs = {}
+    for fmt in ("ascii", "binary_little_endian", "binary_big_endian"):
+        _write_ply(str(tmp_path / (fmt + ".ply")), fmt, pos, nrm, faces)
+        body = ('<include filename="mats.xml"/><alias id="inc" as="other"/>'
+                '<shape type="ply"><string name="filename" value="%s.ply"/><ref id="other"/>'
+                '<transform name="toWorld"><translate x="1" y="2" z="3"/></transform></shape>' % fmt)
+        f = tmp_path / (fmt + ".xml")
+        # a <default> only reaches what follows it in the file (scenehandler.cpp:684-688)
+        f.write_text((SCENE % body).replace('name="sampleCount" value="8"', 'name="sampleCount" value="$spp"')
+                     .replace('<scene version="0.5.0">', '<scene version="0.5.0"><default name="spp" value="16"/><default name="refl" value="0.25"/>'))
+        descs[fmt] = _describe(f)
+    base = _describe(scene_dir / "scene.xml")
+    for fmt, d in descs.items():
+        assert d["sample_count"] == 16, fmt
+        assert d["shape_triangles"][-1] == 3 and d["vertices"] - base["vertices"] == 5
+        assert abs(d["sum_positions"] - base["sum_positions"] - float(pos.sum() + 5 * 6)) < 1e-4
+        assert abs(d["sum_normals"] - base["sum_normals"] - float(nrm.sum())) < 1e-4
+        # quad (0,1,2,3) -> (0,1,2) + (3,0,2); indices are offset by the vertices before this mesh
+        assert d["sum_indices"] - base["sum_indices"] == (0 + 1 + 2) + (3 + 0 + 2) + (1 + 4 + 2) + 9 * base["vertices"]
+        assert d["materials"] == base["materials"] + 1          # the aliased reference adds no record
+    assert descs["ascii"] == descs["binary_little_endian"] == descs["binary_big_endian"]
+    f = tmp_path / "ascii.xml"
+    assert _describe(f, "-D", "spp=32")["sample_count"] == 32 and _describe(f, "-Dspp=64")["sample_count"] == 64
+    # flipNormals negates given normals (trimesh.cpp:624-627)
+    g = tmp_path / "flip.xml"
+    g.write_text(f.read_text().replace('<ref id="other"/>', '<ref id="other"/><boolean name="flipNormals" value="true"/>'))
+    assert abs(_describe(g)["sum_normals"] - base["sum_normals"] + float(nrm.sum())) < 1e-4
+    # an undefined parameter and a pentagon are errors, with the reference's wording
+    bad = tmp_path / "bad.xml"
+    bad.write_text(f.read_text().replace("$spp", "$nope"))
+    out = subprocess.run([CLI, str(bad), "--describe"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "undefined parameter" in out.stderr
+    _write_ply(str(tmp_path / "ascii.ply"), "ascii", pos, nrm, [[0, 1, 2, 3, 4]])
+    out = subprocess.run([CLI, str(f), "--describe"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "Only triangle and quad-based PLY meshes" in out.stderr
+
+
 def test_cli_rejects_unsupported_content(scene_dir, tmp_path):
     for body, needle in (('<shape type="sphere"/>', "not supported"),
                          ('<shape type="cube"><bsdf type="roughdielectric"/></shape>', "outside the path hot path"),
