@@ -233,7 +233,7 @@ MTS_DEV bool testNextTriangle(const DevScene &sc, LaneRay &r) {
 }
 
 // What a traversal kernel does with a finished ray
-enum TraceMode { TRACE_CLOSEST = 0, TRACE_SHADOW_ACCUM = 1, TRACE_OCCLUDED = 2 };
+enum TraceMode { TRACE_CLOSEST = 0, TRACE_OCCLUDED = 1 };
 
 struct TraceArgs {
     const float4 *rayO, *rayD;      // origin.xyz + mint, direction.xyz + maxt of ray i at [i * stride]
@@ -242,8 +242,6 @@ struct TraceArgs {
     uint32_t *fetchCounter;         // zero at launch; waves take chunks of `chunk` consecutive rays from it
     uint32_t chunk;
     float4 *hits;                   // TRACE_CLOSEST: (t, u, v, triangle) per ray
-    const float4 *contrib;          // TRACE_SHADOW_ACCUM: rgb + sample slot per ray ...
-    float4 *sampleL;                // ... added to sampleL[slot] when the ray is unoccluded
     uint8_t *occluded;              // TRACE_OCCLUDED: one byte per ray
     unsigned long long *stats;      // COUNT: [0] node visits, [1] triangle tests
     uint32_t refillBelow;           // refill idle lanes when fewer than this many lanes hold a ray
@@ -254,16 +252,6 @@ template <int MODE>
 MTS_DEV void laneFinish(const TraceArgs &a, uint32_t ray, const LaneRay &r, bool occluded) {
     if (MODE == TRACE_CLOSEST) {
         a.hits[ray] = make_float4(r.hit.t, r.hit.u, r.hit.v, __uint_as_float(r.hit.tri));
-    } else if (MODE == TRACE_SHADOW_ACCUM) {
-        if (!occluded) {
-            const float4 c = a.contrib[ray];
-            if (c.x != 0 || c.y != 0 || c.z != 0) {
-                const uint32_t slot = __float_as_uint(c.w);
-                float4 L = a.sampleL[slot];
-                L.x += c.x; L.y += c.y; L.z += c.z;
-                a.sampleL[slot] = L;
-            }
-        }
     } else {
         a.occluded[ray] = occluded ? 1 : 0;
     }

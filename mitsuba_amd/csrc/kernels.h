@@ -38,11 +38,10 @@ __global__ void __launch_bounds__(256) k_raygen(DevScene sc, PassParams pp, Path
     samplePos[i] = make_float2(posx, posy);
 }
 
-// ---- K2 extend / K4 shadow-connect / batch queries: one persistent traversal kernel, three ways of finishing a ray.
+// ---- K2 extend / K4 shadow-connect / batch queries: one persistent traversal kernel, two ways of finishing a ray.
 //   TRACE_CLOSEST       closest hit for every live path (Scene::rayIntersect(ray, its))
-//   TRACE_SHADOW_ACCUM  any-hit test for the emitter samples; unoccluded ones add their weighted contribution
-//                       (the visibility test inside Scene::sampleEmitterDirect, src/librender/scene.cpp:839-843)
-//   TRACE_OCCLUDED      any-hit test, one byte per ray
+//   TRACE_OCCLUDED      any-hit test, one byte per ray: the visibility test inside Scene::sampleEmitterDirect
+//                       (src/librender/scene.cpp:839-843); k_shadow_accumulate then adds the unoccluded samples' values
 #ifndef MTS_TRACE_WAVES
 #define MTS_TRACE_WAVES 5
 #endif
@@ -278,6 +277,19 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
     if (alive) { out.rayO[oi] = oRayO; out.rayD[oi] = oRayD; out.thr[oi] = oThr; out.misc[oi] = oMisc; out.bsdfPdf[oi] = oPdf; }
     if (ROUNDS > 1) __syncthreads();        // the reservation cells are reused by the next sweep
   }
+}
+
+// ---- K4b: the value of an unoccluded emitter sample joins the path's radiance (path.cpp:196-198). One thread per
+// shadow ray in queue order; a sample slot occurs at most once per bounce, so plain loads and stores suffice.
+__global__ void __launch_bounds__(256) k_shadow_accumulate(uint32_t n, const uint8_t *occluded, const float4 *contrib, float4 *sampleL) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || occluded[i]) return;
+    const float4 c = contrib[i];
+    if (c.x == 0 && c.y == 0 && c.z == 0) return;
+    const uint32_t slot = __float_as_uint(c.w);
+    float4 L = sampleL[slot];
+    L.x += c.x; L.y += c.y; L.z += c.z;
+    sampleL[slot] = L;
 }
 
 // ---- K6 film: ImageBlock::put in gather form (include/mitsuba/render/imageblock.h:144-189). One thread per film
