@@ -158,7 +158,9 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
             // ... and the BRDF that answers on this side (twosided.cpp:108-183)
             const bool flipped = resolveTwoSided(sc, its.material, wiZ, bsdf);
             const V3 wiLocal = flipped ? mirrorZ(its.wi) : its.wi;
-            float4 L = sampleL[slot];
+            // The sample's radiance is only fetched where something is added to it: at the camera vertex it still is
+            // what k_raygen wrote (zero), later only paths that hit an emitter touch it.
+            float4 L = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             bool Lchanged = false, terminate = false;
             int depth;
 
@@ -185,7 +187,10 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
                         lumPdf *= em.pdfDiscrete;
                     }
                     const V3 c = throughput * value * miWeight(in.bsdfPdf[i], lumPdf);
-                    L.x += c.x; L.y += c.y; L.z += c.z; Lchanged = true;
+                    if (c.x != 0 || c.y != 0 || c.z != 0) {
+                        L = sampleL[slot];
+                        L.x += c.x; L.y += c.y; L.z += c.z; Lchanged = true;
+                    }
                 }
                 // Russian roulette (path.cpp:276-286) ...
                 if ((int) prevDepth >= sc.rrDepth) {
