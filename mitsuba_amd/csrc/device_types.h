@@ -90,7 +90,18 @@ struct PassParams {
     int32_t spp;                // samples per pixel in this pass
     int32_t sppTotal, sampleBase;
     uint32_t seed;
+    uint32_t sppMagic, wMagic;  // ceil(2^32 / spp), ceil(2^32 / w) (0 for a divisor of 1): see divideBy
 };
+
+// n / d for 32-bit n through one multiply-high: with m = ceil(2^32 / d) the product's high word is the quotient or
+// one more, which the remainder test corrects. The GPU has no integer divide instruction; a generic n / d costs ~35.
+__host__ __device__ inline uint32_t divisionMagic(uint32_t d) { return d <= 1 ? 0u : (uint32_t) ((0x100000000ull + d - 1) / d); }
+__device__ inline uint32_t divideBy(uint32_t n, uint32_t d, uint32_t magic) {
+    if (magic == 0) return n;
+    uint32_t q = __umulhi(n, magic);
+    if (q * d > n) --q;
+    return q;
+}
 
 // counters[] layout in device memory: four 32-bit queue counters (next-queue length, shadow-queue length, and the
 // ray hand-out counters of the closest-hit and the any-hit traversal launches), then 64-bit traversal statistics

@@ -8,10 +8,11 @@ namespace mtsamd {
 static constexpr uint32_t kMiss = 0xFFFFFFFFu;
 
 MTS_DEV uint64_t sampleKey(const DevScene &sc, const PassParams &pp, uint32_t slot, int &px, int &py, int &s) {
-    const uint32_t pix = slot / (uint32_t) pp.spp;
+    const uint32_t pix = divideBy(slot, (uint32_t) pp.spp, pp.sppMagic);
     s = (int) (slot - pix * (uint32_t) pp.spp);
-    py = pp.y0 + (int) (pix / (uint32_t) pp.w);
-    px = pp.x0 + (int) (pix % (uint32_t) pp.w);
+    const uint32_t row = divideBy(pix, (uint32_t) pp.w, pp.wMagic);
+    py = pp.y0 + (int) row;
+    px = pp.x0 + (int) (pix - row * (uint32_t) pp.w);
     const uint64_t pixelIndex = (uint64_t) py * (uint64_t) sc.cropW + (uint64_t) px;
     return pixelIndex * (uint64_t) pp.sppTotal + (uint64_t) (pp.sampleBase + s);
 }

@@ -463,6 +463,7 @@ int renderCommon(mtsamd_scene *s, const mtsamd_render_opts *opts, float *filmDev
         pp.x0 = o.x0; pp.y0 = o.y0; pp.w = w; pp.h = h;
         pp.spp = std::min(sppPass, o.spp - done);
         pp.sppTotal = o.spp_total; pp.sampleBase = o.sample_offset + done; pp.seed = o.seed;
+        pp.sppMagic = divisionMagic((uint32_t) pp.spp); pp.wMagic = divisionMagic((uint32_t) pp.w);
         rc = renderPass(s, pp, filmDev, liOutDev, liPosDev, 0, stats, timer);
         if (rc != MTSAMD_OK) return rc;
     }
