@@ -273,8 +273,12 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
     if (tid == 0) {
         uint32_t ts = 0, tn = 0;
         for (int w = 0; w < kWaves; ++w) { ts += sWaveShadow[w]; tn += sWaveNext[w]; }
-        sBase[0] = ts ? atomicAdd(&counters[CNT_SHADOW], ts) : 0u;
-        sBase[1] = tn ? atomicAdd(&counters[CNT_NEXT], tn) : 0u;
+        // both queue lengths live in one 64-bit word (next in the low half, shadow in the high half): one atomic
+        static_assert(CNT_NEXT == 0 && CNT_SHADOW == 1, "the two queue counters form one 64-bit word");
+        unsigned long long old = 0;
+        if (ts | tn) old = atomicAdd(reinterpret_cast<unsigned long long *>(counters), (unsigned long long) tn | ((unsigned long long) ts << 32));
+        sBase[0] = (uint32_t) (old >> 32);
+        sBase[1] = (uint32_t) old;
     }
     __syncthreads();
     uint32_t si = sBase[0] + (uint32_t) __popcll(mShadow & below), oi = sBase[1] + (uint32_t) __popcll(mNext & below);
