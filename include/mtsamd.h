@@ -84,7 +84,9 @@ typedef struct {
     int32_t back_material;
 } mtsamd_material;
 
-/* AreaLight attached to a mesh (src/emitters/area.cpp) */
+/* AreaLight attached to a mesh (src/emitters/area.cpp) or, with shape = -1, the constant environment emitter
+   (src/emitters/constant.cpp; at most one per scene, src/librender/scene.cpp:509-513). For an area light the
+   shape's `emitter` field must point back at this record. */
 typedef struct {
     int32_t shape;
     float radiance[3];

@@ -1009,7 +1009,14 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
             } else if (el.tag == "bsdf") {
                 // handled above
             } else if (el.tag == "emitter") {
-                return "only area emitters attached to shapes are supported (found a scene-level <emitter type=\"" + el.get("type") + "\">)";
+                if (el.get("type") != "constant")
+                    return "only area emitters and the constant environment emitter are supported (found a scene-level <emitter type=\"" + el.get("type") + "\">)";
+                const Props ep = parseProps(el);    // src/emitters/constant.cpp:47-50
+                mtsamd_emitter e;
+                e.shape = -1;
+                getRgb(ep, "radiance", 1, 1, 1, e.radiance);
+                e.sampling_weight = (float) getF(ep, "samplingWeight", 1.0);
+                out.emitters.push_back(e);
             } else if (el.tag == "default" || el.tag == "alias") {
                 // handled above
             } else if (el.tag == "medium" || el.tag == "texture") {

@@ -624,6 +624,71 @@ MTS_DEV uint32_t cdfSampleReuse(const float *cdf, uint32_t n /* entries */, floa
 
 struct DirectRec { V3 d; float dist, pdf; };
 
+// warp::squareToUniformSphere (src/libcore/warp.cpp:25-31)
+MTS_DEV V3 squareToUniformSphere(float sx, float sy) {
+    const float z = 1.0f - 2.0f * sy;
+    const float r = safeSqrt(1.0f - z * z);
+    float sinPhi, cosPhi;
+    sincosf(2.0f * kPi * sx, &sinPhi, &cosPhi);
+    return mk(r * cosPhi, r * sinPhi, z);
+}
+
+// Far intersection of a ray with the environment sphere, or false when the origin is not inside it: solveQuadratic
+// (src/libcore/util.cpp:447-485) through BSphere::rayIntersect (include/mitsuba/core/bsphere.h:88-95) with the
+// "nearT < 0 && farT > 0" test of constant.cpp:201-206
+MTS_DEV bool environmentExit(const DevScene &sc, V3 ro, V3 rd, float &farT) {
+    const V3 o = ro - ld3(sc.envCenter);
+    const float A = dot(rd, rd), B = 2 * dot(o, rd), C = dot(o, o) - sc.envRadius * sc.envRadius;
+    float x0, x1;
+    if (A == 0) {
+        if (B == 0) return false;
+        x0 = x1 = -C / B;
+    } else {
+        const float discrim = B * B - 4.0f * A * C;
+        if (discrim < 0) return false;
+        const float sqrtDiscrim = sqrtf(discrim);
+        const float temp = B < 0 ? -0.5f * (B - sqrtDiscrim) : -0.5f * (B + sqrtDiscrim);
+        x0 = temp / A;
+        x1 = C / temp;
+        if (x0 > x1) { const float t = x0; x0 = x1; x1 = t; }
+    }
+    farT = x1;
+    return x0 < 0 && x1 > 0;
+}
+
+// ConstantBackgroundEmitter::sampleDirect (src/emitters/constant.cpp:178-216) inside Scene::sampleEmitterDirect
+// (src/librender/scene.cpp:828-852): a sample on the back side of the reference normal keeps its pdf (so its
+// shadow ray is still traced and counted) but carries no radiance.
+MTS_DEV V3 sampleEnvironmentDirect(const DevScene &sc, V3 ref, V3 refN, float sx, float sy, float emPdf, DirectRec &dRec) {
+    V3 d;
+    float pdf;
+    const bool haveN = !isZero(refN);
+    if (haveN) {
+        d = squareToCosineHemisphere(sx, sy);
+        pdf = cosHemiPdf(d);
+        Frame3 f;
+        f.n = refN;
+        coordinateSystem(refN, f.s, f.t);
+        d = toWorld(f, d);
+    } else {
+        d = squareToUniformSphere(sx, sy);
+        pdf = 0.07957747154594766788f;
+    }
+    float farT;
+    if (!environmentExit(sc, ref, d, farT)) return mk(0.0f);
+    dRec.d = d; dRec.dist = farT;
+    dRec.pdf = pdf * emPdf;
+    if (haveN && dot(d, refN) <= 0) return mk(0.0f);
+    return (ld3(sc.envRadiance) / pdf) / emPdf;
+}
+
+// ConstantBackgroundEmitter::pdfDirect, solid-angle measure (constant.cpp:218-233), times pdfEmitterDiscrete;
+// refCos is the cosine to the reference normal or -2 when there is none
+MTS_DEV float environmentPdfDirect(const DevScene &sc, float refCos) {
+    const float pdfSA = refCos > -1.5f ? kInvPi * fmaxf(0.0f, refCos) : 0.07957747154594766788f;
+    return pdfSA * sc.envPdfDiscrete;
+}
+
 // Scene::sampleEmitterDirect without the shadow ray (src/librender/scene.cpp:828-852) -> AreaLight::sampleDirect
 // (src/emitters/area.cpp:158-173) -> Shape::sampleDirect (src/librender/shape.cpp:102-115) -> TriMesh::samplePosition
 // (src/librender/trimesh.cpp:412-423) -> Triangle::sample (src/libcore/triangle.cpp:24-59)
@@ -632,6 +697,7 @@ MTS_DEV V3 sampleEmitterDirect(const DevScene &sc, V3 ref, V3 refN, float sx, fl
     if (sc.nEmitters == 0) return mk(0.0f);
     float emPdf;
     const uint32_t index = cdfSampleReuse(sc.emitterCdf, sc.nEmitters, sx, &emPdf);
+    if ((int32_t) index == sc.envEmitter) return sampleEnvironmentDirect(sc, ref, refN, sx, sy, emPdf, dRec);
     const DevEmitter em = sc.emitters[index];
     const uint32_t triIdx = cdfSampleReuse(sc.areaCdf + em.cdfOffset, em.nTris, sy, nullptr);
     const uint32_t t = em.firstTri + triIdx;

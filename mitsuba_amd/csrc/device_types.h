@@ -67,6 +67,10 @@ struct DevScene {
     float filterRadius;
     float filterValues[32];
     int32_t maxDepth, rrDepth, strictNormals, hideEmitters;
+    // constant environment emitter (src/emitters/constant.cpp): its index in `emitters` or -1, radiance, the sphere
+    // it sits on (1.5 x the bounding sphere of scene and camera) and its share of the emitter choice
+    int32_t envEmitter;
+    float envRadiance[3], envCenter[3], envRadius, envPdfDiscrete;
 };
 
 // Wavefront queue of live paths (structure of arrays, one float4/uint4 stream each)
@@ -76,6 +80,10 @@ struct PathQueue {
     float4 *thr;        // throughput.rgb, eta
     uint4 *misc;        // sample slot, depth | flags << 16, rng state lo, rng state hi
     float *bsdfPdf;     // pdf of the BSDF sample that produced this ray
+    // Only with an environment emitter: cosine between the ray and the reference normal of the vertex it left
+    // (DirectSamplingRecord::refN, records.inl:160-164), -2 where that normal is zero; what
+    // ConstantBackgroundEmitter::pdfDirect needs when the ray escapes
+    float *refCos;
 };
 
 struct ShadowQueue {

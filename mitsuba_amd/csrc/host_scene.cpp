@@ -307,7 +307,18 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
     hs.emitterCdf.assign(1, 0.0f);
     for (uint32_t e = 0; e < d->n_emitters; ++e) {
         const mtsamd_emitter &em = d->emitters[e];
-        if (em.shape < 0 || (uint32_t) em.shape >= d->n_shapes) return "emitter shape out of range";
+        if (em.shape < 0) {     // constant environment emitter (src/emitters/constant.cpp); one at most (scene.cpp:509-513)
+            if (hs.envEmitter >= 0) return "The scene may only contain one environment emitter";
+            hs.envEmitter = (int32_t) e;
+            DevEmitter de;
+            memset(&de, 0, sizeof(de));
+            memcpy(de.radiance, em.radiance, 12);
+            de.shape = 0xffffffffu;
+            hs.emitters[e] = de;
+            hs.emitterCdf.push_back(hs.emitterCdf.back() + em.sampling_weight);
+            continue;
+        }
+        if ((uint32_t) em.shape >= d->n_shapes) return "emitter shape out of range";
         if (hs.shapes[em.shape].emitter != (int32_t) e) return "shape/emitter cross reference mismatch";
         const DevShape &sh = hs.shapes[em.shape];
         if (sh.nTris == 0) return "Encountered an empty triangle mesh!";
@@ -400,6 +411,22 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
             for (int i = 0; i < 3; ++i) hi[i] = hi[i] + ((hi[i] - lo[i]) * eps + eps);
         }
         for (int i = 0; i < 3; ++i) { p.aabbMin[i] = lo[i]; p.aabbMax[i] = hi[i]; }
+    }
+    p.envEmitter = hs.envEmitter;
+    if (hs.envEmitter >= 0) {
+        // Scene::initializeBidirectional (scene.cpp:386-413): kd-tree bounds grown by the sensor position; AABB::getBSphere
+        // (aabb.cpp:44-47); ConstantBackgroundEmitter::createShape (constant.cpp:68-72) takes 1.5 x that radius
+        float lo[3], hi[3], c[3], r2 = 0;
+        const float cam[3] = { d->camera.to_world[3], d->camera.to_world[7], d->camera.to_world[11] };
+        for (int i = 0; i < 3; ++i) {
+            lo[i] = std::min(p.aabbMin[i], cam[i]); hi[i] = std::max(p.aabbMax[i], cam[i]);
+            c[i] = (hi[i] + lo[i]) * 0.5f;
+        }
+        for (int i = 0; i < 3; ++i) r2 += (c[i] - hi[i]) * (c[i] - hi[i]);
+        memcpy(p.envCenter, c, 12);
+        p.envRadius = std::max(1e-4f, std::sqrt(r2) * 1.5f);
+        memcpy(p.envRadiance, hs.emitters[hs.envEmitter].radiance, 12);
+        p.envPdfDiscrete = hs.emitters[hs.envEmitter].pdfDiscrete;
     }
     // camera (perspective.cpp:126-157, transform.cpp:99-123)
     {

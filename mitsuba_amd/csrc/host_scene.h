@@ -21,6 +21,7 @@ struct HostScene {
     DevScene params;        // scalar members filled; pointers left null until upload
     mtsamd_scene_desc desc; // copy of the scalar parts of the description
     bool hasNormals = false, hasTexcoords = false;
+    int32_t envEmitter = -1;    // index of the constant environment emitter in `emitters`, if any
 };
 
 // Returns an empty string on success.

@@ -71,7 +71,8 @@ static constexpr int kShadeBlock = MTS_SHADE_BLOCK;
 
 // ROUNDS: a workgroup sorts ROUNDS x kShadeBlock paths at once and shades them in ROUNDS sweeps of one path per
 // thread; the larger sort domain leaves fewer wavefronts that straddle two BSDF models.
-template <int ROUNDS>
+// ENV: the scene has an environment emitter (rays that leave the scene are shaded too, one more queue stream).
+template <int ROUNDS, bool ENV>
 __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out,
                                                        ShadowQueue sq, float4 *sampleL, uint32_t *counters, uint32_t n) {
     constexpr int kWaves = kShadeBlock / 64, kKeys = 8, kCells = kKeys * ROUNDS * kWaves;
@@ -125,12 +126,12 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
     bool alive = false, wantShadow = false;
     float4 oRayO = make_float4(0, 0, 0, 0), oRayD = oRayO, oThr = oRayO, sRayO = oRayO, sRayD = oRayO, sContrib = oRayO;
     uint4 oMisc = make_uint4(0, 0, 0, 0);
-    float oPdf = 0;
+    float oPdf = 0, oRefCos = 0;
 
     if (i < n) {
         const float4 hit = hits[i];
         const uint32_t triWord = __float_as_uint(hit.w);
-        if (triWord != kMiss) {     // a miss ends the path: no environment emitter on this path (path.cpp:136-143,245-247)
+        if (triWord != kMiss) {
             const uint32_t tri = triWord & kTriIndexMask;
             const float4 rd = in.rayD[i], th = in.thr[i];
             const uint4 misc = in.misc[i];
@@ -256,10 +257,37 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
                         oThr = make_float4(throughput.x, throughput.y, throughput.z, eta);
                         oMisc = make_uint4(slot, (uint32_t) depth | (nf << 16), (uint32_t) rng.state, (uint32_t) (rng.state >> 32));
                         oPdf = bPdf;
+                        if (ENV) oRefCos = isZero(refN) ? -2.0f : dot(wo, refN);
                     }
                 }
             }
             if (Lchanged) sampleL[slot] = L;
+        } else if (ENV) {
+            // the ray left the scene and there is an environment emitter
+            const uint4 misc = in.misc[i];
+            const uint32_t slot = misc.x, prevDepth = misc.y & 0xffffu, flags = misc.y >> 16;
+            const float4 th = in.thr[i];
+            const V3 throughput = mk(th.x, th.y, th.z), radiance = ld3(sc.envRadiance);
+            if (prevDepth == 0) {
+                // camera ray (path.cpp:136-143): alpha stays 0 (records.inl:121-137)
+                if (!sc.hideEmitters) {
+                    const V3 c = throughput * radiance;
+                    sampleL[slot] = make_float4(c.x, c.y, c.z, 0.0f);
+                }
+            } else if (!(sc.hideEmitters && !(flags & PF_SCATTERED))) {
+                // ray from BSDF sampling (path.cpp:233-247,257-264): MIS against ConstantBackgroundEmitter::pdfDirect
+                const float4 ro = in.rayO[i], rd = in.rayD[i];
+                float farT;
+                if (environmentExit(sc, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), farT)) {     // fillDirectSamplingRecord (constant.cpp:245-261)
+                    const float lumPdf = (flags & PF_PREV_DELTA) ? 0.0f : environmentPdfDirect(sc, in.refCos[i]);
+                    const V3 c = throughput * radiance * miWeight(in.bsdfPdf[i], lumPdf);
+                    if (c.x != 0 || c.y != 0 || c.z != 0) {
+                        float4 L = sampleL[slot];
+                        L.x += c.x; L.y += c.y; L.z += c.z;
+                        sampleL[slot] = L;
+                    }
+                }
+            }
         }
     }
 
@@ -284,7 +312,10 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
     uint32_t si = sBase[0] + (uint32_t) __popcll(mShadow & below), oi = sBase[1] + (uint32_t) __popcll(mNext & below);
     for (uint32_t w = 0; w < wave; ++w) { si += sWaveShadow[w]; oi += sWaveNext[w]; }
     if (wantShadow) { sq.rayO[si] = sRayO; sq.rayD[si] = sRayD; sq.contrib[si] = sContrib; }
-    if (alive) { out.rayO[oi] = oRayO; out.rayD[oi] = oRayD; out.thr[oi] = oThr; out.misc[oi] = oMisc; out.bsdfPdf[oi] = oPdf; }
+    if (alive) {
+        out.rayO[oi] = oRayO; out.rayD[oi] = oRayD; out.thr[oi] = oThr; out.misc[oi] = oMisc; out.bsdfPdf[oi] = oPdf;
+        if (ENV) out.refCos[oi] = oRefCos;
+    }
     if (ROUNDS > 1) __syncthreads();        // the reservation cells are reused by the next sweep
   }
 }

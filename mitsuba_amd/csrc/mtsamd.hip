@@ -68,7 +68,7 @@ struct mtsamd_scene {
     DeviceBuffer nodes, tris, shadeTris, shadeUV, shapes, materials, emitters,
         emitterCdf, areaCdf, rtrans;
     // work buffers of the wavefront loop
-    DeviceBuffer qbuf[2][5], hits, sbuf[3], sampleL, samplePos, shadowFlags, counters, scratch[8];
+    DeviceBuffer qbuf[2][6], hits, sbuf[3], sampleL, samplePos, shadowFlags, counters, scratch[8];
     size_t capacity = 0;
     hipStream_t stream = nullptr;
     hipStream_t shadowStream = nullptr;   // shadow rays of bounce k are traced next to the extension rays of bounce k+1
@@ -97,6 +97,7 @@ struct mtsamd_scene {
         PathQueue q;
         q.rayO = qbuf[i][0].as<float4>(); q.rayD = qbuf[i][1].as<float4>(); q.thr = qbuf[i][2].as<float4>();
         q.misc = qbuf[i][3].as<uint4>(); q.bsdfPdf = qbuf[i][4].as<float>();
+        q.refCos = host.envEmitter >= 0 ? qbuf[i][5].as<float>() : nullptr;
         return q;
     }
     ShadowQueue shadowQueue() const {
@@ -111,6 +112,7 @@ struct mtsamd_scene {
         for (int i = 0; i < 2; ++i) {
             for (int j = 0; j < 4; ++j) HIP_TRY(qbuf[i][j].ensure(n * 16));
             HIP_TRY(qbuf[i][4].ensure(n * 4));
+            if (host.envEmitter >= 0) HIP_TRY(qbuf[i][5].ensure(n * 4));
         }
         HIP_TRY(hits.ensure(n * 16));
         for (int j = 0; j < 3; ++j) HIP_TRY(sbuf[j].ensure(n * 16));
@@ -357,7 +359,9 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         timer.begin(T_SHADE);
         // large queues: several sweeps per workgroup (purer wavefronts); small ones: one, to keep every CU busy
         const int rounds = n >= s->shadeRoundsAbove ? s->shadeRounds : 1;
-#define MTS_LAUNCH_SHADE(R) hipLaunchKernelGGL(k_shade<R>, dim3(blocksFor(n, kShadeBlock * R)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, cnt, n)
+#define MTS_LAUNCH_SHADE(R) do { \
+            if (sc.envEmitter >= 0) hipLaunchKernelGGL((k_shade<R, true>), dim3(blocksFor(n, kShadeBlock * R)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, cnt, n); \
+            else hipLaunchKernelGGL((k_shade<R, false>), dim3(blocksFor(n, kShadeBlock * R)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, cnt, n); } while (0)
         if (rounds >= 16) MTS_LAUNCH_SHADE(16);
         else if (rounds >= 8) MTS_LAUNCH_SHADE(8);
         else if (rounds >= 4) MTS_LAUNCH_SHADE(4);

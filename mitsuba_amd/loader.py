@@ -404,6 +404,12 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
                 normals = S.vertex_normals(mesh["positions"], mesh["indices"].astype(np.int64))
             b.add_mesh(mesh["positions"], mesh["indices"], mat, normals=normals, texcoords=mesh.get("texcoords"),
                        radiance=radiance, sampling_weight=weight)
+        elif el.tag == "emitter":
+            if el.get("type") != "constant":
+                raise SceneFormatError("only area emitters and the constant environment emitter are supported "
+                                       "(found a scene-level <emitter type=\"%s\">)" % el.get("type"))
+            p = _props(el)
+            b.add_constant_emitter(p.get("radiance", (1.0, 1.0, 1.0)), p.get("samplingWeight", 1.0))
     if camera is None:
         raise SceneFormatError("scene has no sensor")
     if integrator_override:

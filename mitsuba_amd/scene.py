@@ -222,6 +222,11 @@ class SceneBuilder:
         self.materials.append(m)
         return len(self.materials) - 1
 
+    def add_constant_emitter(self, radiance=(1.0, 1.0, 1.0), sampling_weight=1.0) -> int:
+        """Constant environment emitter (src/emitters/constant.cpp): an emitter record without a shape."""
+        self.emitters.append(dict(shape=-1, radiance=tuple(float(x) for x in radiance), sampling_weight=float(sampling_weight)))
+        return len(self.emitters) - 1
+
     def add_mesh(self, positions, indices, material: int, normals=None, texcoords=None, radiance=None,
                  sampling_weight=1.0) -> int:
         positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
@@ -494,8 +499,9 @@ def config5(width=3840, height=2160) -> SceneData:
                             max_depth=16, emitters_grid=32)
 
 
-def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1) -> SceneData:
-    """A few hundred triangles with every BSDF type present; used by the parity tests."""
+def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_weight=1.0, hide_emitters=0) -> SceneData:
+    """A few hundred triangles with every BSDF type present; used by the parity tests. `sky` adds a constant
+    environment emitter of that radiance next to the two area lights."""
     rng = np.random.default_rng(7)
     b = SceneBuilder()
     mats = [b.add_material(diffuse((0.6, 0.5, 0.4))),
@@ -515,8 +521,10 @@ def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1) -> SceneData:
     b.add_mesh(gp, gf, m_ground)
     b.add_quad([-2, -2, 6], [-2, 2, 6], [2, 2, 6], [2, -2, 6], m_ground, radiance=(15, 14, 12))
     b.add_quad([4, -1, 3.5], [4, 1, 3.5], [5, 1, 4.5], [5, -1, 4.5], m_ground, radiance=(6, 9, 12), sampling_weight=0.5)
+    if sky is not None:
+        b.add_constant_emitter(sky, sky_weight)
     cam = make_camera([0.5, -11, 5.5], [0, 0, 0.8], [0, 0, 1], 40.0, near_clip=0.1, far_clip=100)
-    return b.finish(cam, make_film(width, height), dict(max_depth=max_depth))
+    return b.finish(cam, make_film(width, height), dict(max_depth=max_depth, hide_emitters=hide_emitters))
 
 
 def veach_bidir(width=1024, height=768, max_depth=-1, golden_dir=None) -> SceneData:

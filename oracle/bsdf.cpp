@@ -31,6 +31,14 @@ Vec3 squareToCosineHemisphere(const Vec2 &sample) {
     return Vec3(p.x, p.y, z);
 }
 
+Vec3 squareToUniformSphere(const Vec2 &sample) {
+    float z = 1.0f - 2.0f * sample.y;
+    float r = safe_sqrt(1.0f - z * z);
+    float sinPhi, cosPhi;
+    sincos_(2.0f * M_PI_F * sample.x, &sinPhi, &cosPhi);
+    return Vec3(r * cosPhi, r * sinPhi, z);
+}
+
 Vec2 squareToUniformTriangle(const Vec2 &sample) {
     float a = safe_sqrt(1.0f - sample.x);
     return Vec2{ 1 - a, a * sample.y };

@@ -10,6 +10,7 @@ Vec2 squareToUniformDiskConcentric(const Vec2 &sample);   // warp.cpp:89-110
 Vec3 squareToCosineHemisphere(const Vec2 &sample);        // warp.cpp:51-60
 inline float squareToCosineHemispherePdf(const Vec3 &d) { return INV_PI_F * Frame::cosTheta(d); }  // warp.h:56
 Vec2 squareToUniformTriangle(const Vec2 &sample);         // warp.cpp:84-87
+Vec3 squareToUniformSphere(const Vec2 &sample);           // warp.cpp:25-31
 
 // ---- src/libcore/math.cpp:25-86 --------------------------------------------------------------
 float erfinv(float x);

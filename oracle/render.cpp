@@ -149,9 +149,16 @@ std::string Scene::build(const orc_scene_desc *d) {
     // Per-emitter-shape area distribution (TriMesh::prepareSamplingTable, trimesh.cpp:388-403)
     areaDistr.assign(d->n_shapes, DiscreteDistribution());
     invSurfaceArea.assign(d->n_shapes, 0.0f);
+    envEmitter = -1;
     for (uint32_t e = 0; e < d->n_emitters; ++e) {
         int s = emitters[e].shape;
-        if (s < 0 || (uint32_t) s >= d->n_shapes) return "emitter shape out of range";
+        if (s < 0) {    // constant environment emitter; only one is allowed (scene.cpp:509-513)
+            if (envEmitter >= 0) return "The scene may only contain one environment emitter";
+            envEmitter = (int) e;
+            emitterPDF.append(emitters[e].sampling_weight);
+            continue;
+        }
+        if ((uint32_t) s >= d->n_shapes) return "emitter shape out of range";
         if (shapes[s].emitter != (int32_t) e) return "shape/emitter cross reference mismatch";
         DiscreteDistribution &ad = areaDistr[s];
         for (uint32_t j = 0; j < shapes[s].n_triangles; ++j) {
@@ -166,6 +173,15 @@ std::string Scene::build(const orc_scene_desc *d) {
     if (d->n_emitters) emitterPDF.normalize();
 
     buildKDTree();
+
+    if (envEmitter >= 0) {
+        // Scene::initializeBidirectional (scene.cpp:386-413): kd-tree bounds grown by the sensor's position;
+        // AABB::getBSphere (aabb.cpp:44-47); ConstantBackgroundEmitter::createShape (constant.cpp:68-72)
+        AABB box = aabb;
+        box.expandBy(Vec3(d->camera.to_world[3], d->camera.to_world[7], d->camera.to_world[11]));
+        envCenter = (box.max + box.min) * 0.5f;
+        envRadius = std::max(Epsilon, (envCenter - box.max).length() * 1.5f);
+    }
 
     // Camera (perspective.cpp:126-157)
     const orc_film &f = d->film;
@@ -192,6 +208,31 @@ std::string Scene::build(const orc_scene_desc *d) {
     return "";
 }
 
+// solveQuadratic (src/libcore/util.cpp:447-485) and BSphere::rayIntersect (include/mitsuba/core/bsphere.h:88-95)
+static bool solveQuadratic(float a, float b, float c, float &x0, float &x1) {
+    if (a == 0) {
+        if (b != 0) { x0 = x1 = -c / b; return true; }
+        return false;
+    }
+    float discrim = b * b - 4.0f * a * c;
+    if (discrim < 0) return false;
+    float temp, sqrtDiscrim = std::sqrt(discrim);
+    if (b < 0) temp = -0.5f * (b - sqrtDiscrim);
+    else temp = -0.5f * (b + sqrtDiscrim);
+    x0 = temp / a;
+    x1 = c / temp;
+    if (x0 > x1) std::swap(x0, x1);
+    return true;
+}
+
+static bool sphereIntersect(const Vec3 &center, float radius, const Vec3 &ro, const Vec3 &rd, float &nearHit, float &farHit) {
+    Vec3 o = ro - center;
+    float A = rd.lengthSquared();
+    float B = 2 * dot(o, rd);
+    float C = o.lengthSquared() - radius * radius;
+    return solveQuadratic(A, B, C, nearHit, farHit);
+}
+
 // ---- Emitter sampling --------------------------------------------------------------------------------
 struct DirectSample {
     Vec3 p, n, d;
@@ -207,6 +248,35 @@ static Spectrum sampleEmitterDirect(const Scene &sc, const Vec3 &ref, const Vec3
     float emPdf;
     size_t index = sc.emitterPDF.sampleReuse(sample.x, emPdf);
     const orc_emitter &em = sc.emitters[index];
+    if (em.shape < 0) {     // ConstantBackgroundEmitter::sampleDirect (constant.cpp:178-216)
+        Vec3 d;
+        float pdf;
+        if (!refN.isZero()) {
+            d = squareToCosineHemisphere(sample);
+            pdf = squareToCosineHemispherePdf(d);
+            d = Frame(refN).toWorld(d);
+        } else {
+            d = squareToUniformSphere(sample);
+            pdf = INV_FOURPI_F;
+        }
+        float nearT, farT;
+        dRec.pdf = 0.0f;
+        if (!sphereIntersect(sc.envCenter, sc.envRadius, ref, d, nearT, farT)) return Spectrum(0.0f);
+        if (!(nearT < 0 && farT > 0)) return Spectrum(0.0f);
+        dRec.p = ref + d * farT;
+        dRec.n = normalize(sc.envCenter - dRec.p);
+        dRec.d = d;
+        dRec.dist = farT;
+        dRec.pdf = pdf;
+        dRec.emitter = (int) index;
+        Spectrum value(0.0f);
+        if (!(!refN.isZero() && dot(dRec.d, refN) <= 0))
+            value = Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]) / pdf;
+        // Scene::sampleEmitterDirect (scene.cpp:838-847): the pdf is non-zero here, so the sample counts
+        dRec.pdf *= emPdf;
+        value /= emPdf;
+        return value;
+    }
     const orc_shape &sh = sc.shapes[em.shape];
     size_t triIdx = sc.areaDistr[em.shape].sampleReuse(sample.y);
     uint32_t t = sh.first_triangle + (uint32_t) triIdx;
@@ -241,6 +311,12 @@ static Spectrum sampleEmitterDirect(const Scene &sc, const Vec3 &ref, const Vec3
     return value;
 }
 
+// ConstantBackgroundEmitter::pdfDirect in the solid-angle measure (constant.cpp:218-233) times pdfEmitterDiscrete
+static float envPdfDirect(const Scene &sc, const Vec3 &d, const Vec3 &refN) {
+    float pdfSA = !refN.isZero() ? INV_PI_F * std::max(0.0f, dot(d, refN)) : INV_FOURPI_F;
+    return pdfSA * sc.emitters[sc.envEmitter].sampling_weight * sc.emitterPDF.normalization;
+}
+
 static inline float miWeight(float pdfA, float pdfB) {
     pdfA *= pdfA; pdfB *= pdfB;
     return pdfA / (pdfA + pdfB);
@@ -267,7 +343,13 @@ static Spectrum Li(const Scene &sc, const Ray &r, Pcg32 &rng, float &alpha, RayC
     float eta = 1.0f;
 
     while (depth <= ig.max_depth || ig.max_depth < 0) {
-        if (!its.isValid()) break;     // no environment emitter on this path
+        if (!its.isValid()) {          // path.cpp:136-143
+            if (sc.envEmitter >= 0 && emittedRadiance && (!ig.hide_emitters || scattered)) {
+                const orc_emitter &em = sc.emitters[sc.envEmitter];
+                Li += throughput * Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]);
+            }
+            break;
+        }
         const orc_shape &shape = sc.shapes[its.shape];
         const Material &bsdf = sc.materials[shape.material];
 
@@ -316,7 +398,7 @@ static Spectrum Li(const Scene &sc, const Ray &r, Pcg32 &rng, float &alpha, RayC
         float woDotGeoN = dot(its.geoFrame.n, wo);
         if (ig.strict_normals && woDotGeoN * Frame::cosTheta(bs.wo) <= 0) break;
 
-        bool hitEmitter = false;
+        bool hitEmitter = false, hitEnvironment = false;
         Spectrum value;
         Vec3 refP = its.p;
         ray = Ray(its.p, wo);
@@ -329,7 +411,14 @@ static Spectrum Li(const Scene &sc, const Ray &r, Pcg32 &rng, float &alpha, RayC
                 hitEmitter = true;
             }
         } else {
-            break;
+            // path.cpp:233-247: the environment emitter, if there is one
+            if (sc.envEmitter < 0) break;
+            if (ig.hide_emitters && !scattered) break;
+            const orc_emitter &em = sc.emitters[sc.envEmitter];
+            value = Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]);
+            float nearT, farT;     // fillDirectSamplingRecord (constant.cpp:245-261)
+            if (!sphereIntersect(sc.envCenter, sc.envRadius, ray.o, ray.d, nearT, farT) || nearT > 0 || farT < 0) break;
+            hitEnvironment = true;
         }
         (void) refP;
 
@@ -346,6 +435,9 @@ static Spectrum Li(const Scene &sc, const Ray &r, Pcg32 &rng, float &alpha, RayC
                     lumPdf = sc.invSurfaceArea[its.shape] * (its.t * its.t) / absDot(ray.d, its.shFrame.n);
                 lumPdf *= sc.emitters[hs.emitter].sampling_weight * sc.emitterPDF.normalization;
             }
+            Li += throughput * value * miWeight(bsdfPdf_, lumPdf);
+        } else if (hitEnvironment) {
+            const float lumPdf = !(bs.sampledType & EDelta) ? envPdfDirect(sc, ray.d, refN) : 0.0f;
             Li += throughput * value * miWeight(bsdfPdf_, lumPdf);
         }
 

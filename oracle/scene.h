@@ -100,6 +100,11 @@ struct Scene {
     std::vector<DiscreteDistribution> areaDistr;   // per shape (emitters only)
     std::vector<float> invSurfaceArea;
     DiscreteDistribution emitterPDF;
+    // constant environment emitter (src/emitters/constant.cpp): index in `emitters` or -1, and the bounding sphere
+    // it is placed on (1.5 x the sphere around the scene bounds and the camera position, constant.cpp:68-72)
+    int envEmitter = -1;
+    Vec3 envCenter;
+    float envRadius = 0;
 
     // kd-tree
     std::vector<TriAccel> triAccel;

@@ -20,6 +20,7 @@ static const float DeltaEpsilon = 1e-3f;
 static const float M_PI_F = 3.14159265358979323846f;
 static const float INV_PI_F = 0.31830988618379067154f;
 static const float INV_TWOPI_F = 0.15915494309189533577f;
+static const float INV_FOURPI_F = 0.07957747154594766788f;
 static const float RCPOVERFLOW_F = 0x1p-128f;
 
 struct Vec2 { float x, y; };

@@ -230,8 +230,20 @@ private:
 			}
 			shapes.push_back(s);
 		}
+		/* the constant environment emitter (src/emitters/constant.cpp) travels as an emitter record without a shape */
+		if (const Emitter *env = scene->getEnvironmentEmitter()) {
+			if (env->getProperties().getPluginName() != "constant") {
+				Log(EWarn, "path_amd: environment emitter \"%s\" is not on the GPU path", env->getProperties().getPluginName().c_str());
+				return false;
+			}
+			mtsamd_emitter me;
+			me.shape = -1;
+			rgb(env->getProperties().getSpectrum("radiance", Spectrum::getD65()), me.radiance);
+			me.sampling_weight = env->getSamplingWeight();
+			emitters.push_back(me);
+		}
 		if (emitters.size() != scene->getEmitters().size()) {
-			Log(EWarn, "path_amd: environment / delta emitters are not supported"); return false;
+			Log(EWarn, "path_amd: delta emitters and image-based environments are not supported"); return false;
 		}
 
 		mtsamd_scene_desc d;

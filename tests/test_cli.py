@@ -210,12 +210,22 @@ def test_cli_ply_parameters_include_alias(scene_dir, tmp_path):
     assert out.returncode == 1 and "Only triangle and quad-based PLY meshes" in out.stderr
 
 
+def test_cli_constant_emitter(scene_dir, tmp_path):
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    f = tmp_path / "sky.xml"
+    f.write_text(SCENE % '<emitter type="constant"><rgb name="radiance" value="0.5, 0.75, 1.25"/><float name="samplingWeight" value="2"/></emitter>')
+    d = _describe(f)
+    sd, _ = loader.load_xml(str(f))
+    assert d["emitters"] == len(sd.emitters) == 2
+    assert sd.emitters[1]["shape"] == -1 and sd.emitters[1]["radiance"] == (0.5, 0.75, 1.25) and sd.emitters[1]["sampling_weight"] == 2.0
+
+
 def test_cli_rejects_unsupported_content(scene_dir, tmp_path):
     for body, needle in (('<shape type="sphere"/>', "not supported"),
                          ('<shape type="cube"><bsdf type="roughdielectric"/></shape>', "outside the path hot path"),
                          ('<shape type="cube"><bsdf type="twosided"><bsdf type="dielectric"/></bsdf></shape>', "transmission component"),
                          ('<shape type="cube"><bsdf type="twosided"/></shape>', "nested one-sided material is required"),
-                         ('<emitter type="constant"/>', "only area emitters"),
+                         ('<emitter type="envmap"/>', "only area emitters and the constant environment emitter"),
                          ('<shape type="cube"><bsdf type="roughconductor"><string name="material" value="Au"/></bsdf></shape>', "spectral data")):
         f = tmp_path / "bad.xml"
         f.write_text(SCENE % body)

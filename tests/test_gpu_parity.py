@@ -15,7 +15,8 @@ MISS = 0xFFFFFFFF
 
 def _scenes():
     return {"small": S.small_test_scene(), "cornell": S.cornell_box(96, 96), "veach": S.veach_bidir(128, 96),
-            "mixed": S.cornell_mixed(96, 96)}
+            "mixed": S.cornell_mixed(96, 96), "sky": S.small_test_scene(sky=(0.6, 0.8, 1.2), sky_weight=2.0),
+            "sky_hidden": S.small_test_scene(sky=(0.6, 0.8, 1.2), hide_emitters=1)}
 
 
 @pytest.fixture(scope="module")
@@ -162,7 +163,7 @@ def test_bsdf_sample_parity(material_pair):
 
 
 def test_emitter_sampling_parity(pairs):
-    for name in ("small", "veach"):
+    for name in ("small", "veach", "sky"):
         sd, g, o = pairs[name]
         rng = np.random.default_rng(31)
         n = 100000
@@ -175,10 +176,13 @@ def test_emitter_sampling_parity(pairs):
         a, b = g.sample_emitter_direct(ref, refn, s), o.sample_emitter_direct(ref, refn, s)
         assert np.array_equal(a[2] == 0, b[2] == 0)
         for x, y in zip(a, b):
-            assert np.allclose(x, y, rtol=1e-5, atol=1e-6)
+            if name == "sky":       # directions come out of sincos and a sphere intersection: last-bit differences
+                assert np.mean(np.isclose(x, y, rtol=1e-4, atol=1e-5)) > 0.9999
+            else:
+                assert np.allclose(x, y, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["small", "cornell", "veach", "mixed"])
+@pytest.mark.parametrize("name", ["small", "cornell", "veach", "mixed", "sky", "sky_hidden"])
 def test_per_sample_radiance_parity(pairs, name):
     """MIPathTracer::Li per camera sample with the shared sample stream: same ray counts, same radiance."""
     sd, g, o = pairs[name]
@@ -227,7 +231,7 @@ def test_film_put_parity(pairs):
     assert np.allclose(fg, fo, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["small", "cornell", "mixed"])
+@pytest.mark.parametrize("name", ["small", "cornell", "mixed", "sky"])
 def test_render_film_parity(pairs, name):
     sd, g, o = pairs[name]
     fg, sg = g.render(4, seed=9)
