@@ -216,6 +216,11 @@ int mtsamd_film_develop(const mtsamd_scene *scene, const float *film_host, float
 int mtsamd_trace(mtsamd_scene *scene, uint64_t n, const float *rays, mtsamd_hit *hits);
 /* Scene::rayIntersect(ray) shadow query (src/librender/skdtree.cpp:207-226) */
 int mtsamd_occluded(mtsamd_scene *scene, uint64_t n, const float *rays, uint8_t *occluded);
+/* The same two queries for callers whose rays already live in device memory (same layouts, device pointers of the
+   device the scene was created on). kernel_seconds, if not NULL, receives the duration of the traversal launch
+   measured with HIP events on the library's stream. */
+int mtsamd_trace_device(mtsamd_scene *scene, uint64_t n, const float *rays_device, mtsamd_hit *hits_device, double *kernel_seconds);
+int mtsamd_occluded_device(mtsamd_scene *scene, uint64_t n, const float *rays_device, uint8_t *occluded_device, double *kernel_seconds);
 /* rayIntersect + fillIntersectionRecord (include/mitsuba/render/skdtree.h:343-428) */
 int mtsamd_intersect(mtsamd_scene *scene, uint64_t n, const float *rays, mtsamd_intersection *its);
 

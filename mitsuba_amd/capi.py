@@ -263,6 +263,18 @@ class Scene:
         _check(self.L.mtsamd_occluded(self.h, C.c_uint64(rays.shape[0]), _fp(rays), out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def trace_device(self, rays_ptr: int, n: int, hits_ptr: int) -> float:
+        """Closest-hit query on n rays in device memory (8 floats each) into n device hit records (20 bytes each);
+        returns the traversal launch's duration in seconds."""
+        sec = C.c_double(0)
+        _check(self.L.mtsamd_trace_device(self.h, C.c_uint64(n), C.c_void_p(rays_ptr), C.c_void_p(hits_ptr), C.byref(sec)))
+        return sec.value
+
+    def occluded_device(self, rays_ptr: int, n: int, out_ptr: int) -> float:
+        sec = C.c_double(0)
+        _check(self.L.mtsamd_occluded_device(self.h, C.c_uint64(n), C.c_void_p(rays_ptr), C.c_void_p(out_ptr), C.byref(sec)))
+        return sec.value
+
     def intersect(self, rays):
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         its = np.zeros(rays.shape[0], ISECT_DTYPE)

@@ -612,6 +612,50 @@ extern "C" int mtsamd_occluded(mtsamd_scene *s, uint64_t n, const float *rays, u
     return MTSAMD_OK;
 }
 
+namespace {
+// A pair of events around one launch on the library's stream
+struct LaunchClock {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t st;
+    explicit LaunchClock(hipStream_t s) : st(s) { (void) hipEventCreate(&a); (void) hipEventCreate(&b); (void) hipEventRecord(a, st); }
+    double stop() {
+        (void) hipEventRecord(b, st); (void) hipEventSynchronize(b);
+        float ms = 0; (void) hipEventElapsedTime(&ms, a, b);
+        return ms * 1e-3;
+    }
+    ~LaunchClock() { if (a) (void) hipEventDestroy(a); if (b) (void) hipEventDestroy(b); }
+};
+}  // namespace
+
+extern "C" int mtsamd_trace_device(mtsamd_scene *s, uint64_t n, const float *raysDev, mtsamd_hit *hitsDev, double *kernelSeconds) {
+    TRY(checkBatch(s, n));
+    if (kernelSeconds) *kernelSeconds = 0;
+    if (n == 0) return MTSAMD_OK;
+    if (!raysDev || !hitsDev) return fail(MTSAMD_EINVAL, "null argument");
+    Staging sg; void *dH;
+    TRY(sg.out(n * 16, &dH));
+    {
+        LaunchClock clock(s->stream);
+        TRY(traceBatch<TRACE_CLOSEST>(s, raysDev, n, (float4 *) dH, nullptr));
+        if (kernelSeconds) *kernelSeconds = clock.stop();
+    }
+    hipLaunchKernelGGL(k_hits_to_records, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, (const float4 *) dH, (uint32_t) n, hitsDev);
+    return finish(s->stream);
+}
+
+extern "C" int mtsamd_occluded_device(mtsamd_scene *s, uint64_t n, const float *raysDev, uint8_t *occludedDev, double *kernelSeconds) {
+    TRY(checkBatch(s, n));
+    if (kernelSeconds) *kernelSeconds = 0;
+    if (n == 0) return MTSAMD_OK;
+    if (!raysDev || !occludedDev) return fail(MTSAMD_EINVAL, "null argument");
+    {
+        LaunchClock clock(s->stream);
+        TRY(traceBatch<TRACE_OCCLUDED>(s, raysDev, n, nullptr, occludedDev));
+        if (kernelSeconds) *kernelSeconds = clock.stop();
+    }
+    return finish(s->stream);
+}
+
 extern "C" int mtsamd_intersect(mtsamd_scene *s, uint64_t n, const float *rays, mtsamd_intersection *its) {
     TRY(checkBatch(s, n));
     if (n == 0) return MTSAMD_OK;

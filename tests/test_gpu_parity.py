@@ -79,6 +79,25 @@ def test_intersection_record_parity(pairs, name):
         assert np.allclose(a, b, rtol=1e-5, atol=1e-6), f
 
 
+def test_device_resident_queries_match_host_queries(pairs):
+    """mtsamd_trace_device / mtsamd_occluded_device: same answers as the host-array entry points."""
+    import torch
+    sd, g, o = pairs["small"]
+    rays = random_rays(sd, 50000, seed=12)
+    d_rays = torch.tensor(rays, device="cuda")
+    d_hits = torch.zeros(rays.shape[0], 5, device="cuda", dtype=torch.float32)
+    d_occ = torch.zeros(rays.shape[0], device="cuda", dtype=torch.uint8)
+    t1 = g.trace_device(d_rays.data_ptr(), rays.shape[0], d_hits.data_ptr())
+    t2 = g.occluded_device(d_rays.data_ptr(), rays.shape[0], d_occ.data_ptr())
+    assert t1 > 0 and t2 > 0
+    h = g.trace(rays)
+    got = d_hits.cpu().numpy()
+    assert np.array_equal(got[:, 0], h["t"]) and np.array_equal(got[:, 1], h["u"]) and np.array_equal(got[:, 2], h["v"])
+    assert np.array_equal(got.view(np.uint32)[:, 3], h["shape"]) and np.array_equal(got.view(np.uint32)[:, 4], h["prim"])
+    assert np.array_equal(d_occ.cpu().numpy(), g.occluded(rays))
+    assert g.trace_device(0, 0, 0) == 0.0
+
+
 def test_camera_rays(pairs):
     for name in ("small", "cornell", "veach"):
         sd, g, o = pairs[name]
