@@ -385,4 +385,35 @@ MTS_DEV void traceLoop(const DevScene &sc, const TraceArgs &a, LdsFloat4 *topTre
     }
 }
 
+// Traversal of the rays the lanes of one wavefront hold right now, nothing fetched and nothing refilled: the same
+// node / triangle phases as traceLoop, run until every lane has finished. `busy` says which lanes hold a ray (prepared
+// with laneStart); for ANY_HIT it comes back true on the lanes whose ray was occluded. BVH nodes are read from global
+// memory only (no LDS copy of the top levels).
+template <bool ANY_HIT>
+MTS_DEV void traceHeldRays(const DevScene &sc, LaneRay &r, bool &busy, LdsUint2 *ldsStack, uint32_t triShare) {
+    uint2 spill[kSpillStack];
+    int sp = 0;
+    bool occluded = false;
+    while (true) {
+        const bool hasTri = busy && r.tg.y != 0;
+        const uint32_t nTri = (uint32_t) __popcll(__ballot(hasTri));
+        const uint32_t nBusy = (uint32_t) __popcll(__ballot(busy));
+        if (nBusy == 0) break;
+        if (nTri == nBusy || nTri * 64u >= triShare * nBusy) {
+            if (hasTri) {
+                const bool accepted = testNextTriangle(sc, r);
+                if (ANY_HIT && accepted) { occluded = true; busy = false; r.tg.y = 0; }
+            }
+        } else if (busy && !hasTri) {
+            bool go = true;
+            if (!((r.ng.y >> 8) & 0xffu)) {
+                if (sp == 0) { busy = false; go = false; }
+                else MTS_STACK_POP(r.ng);
+            }
+            if (go) visitNode(sc, r, nullptr, 0u, ldsStack, spill, sp);
+        }
+    }
+    if (ANY_HIT) busy = occluded;
+}
+
 }  // namespace mtsamd

@@ -113,8 +113,10 @@ __device__ inline uint32_t divideBy(uint32_t n, uint32_t d, uint32_t magic) {
 
 // counters[] layout in device memory: four 32-bit queue counters (next-queue length, shadow-queue length, and the
 // ray hand-out counters of the closest-hit and the any-hit traversal launches), then 64-bit traversal statistics
-// (extend nodes, extend triangles, shadow nodes, shadow triangles) addressed as uint64 index 2..5
+// (extend nodes, extend triangles, shadow nodes, shadow triangles) addressed as uint64 index 2..5, and the two ray
+// counts of the kernel that finishes a pass (uint64 index 8, 9)
 enum { CNT_NEXT = 0, CNT_SHADOW = 1, CNT_EXT_FETCH = 2, CNT_SHD_FETCH = 3, CNT_QUEUE_WORDS = 4,
-       CNT64_EXT_NODES = 2, CNT64_EXT_TRIS = 3, CNT64_SHD_NODES = 4, CNT64_SHD_TRIS = 5, CNT64_EXT_EMPTY = 6, CNT64_EXT_STALE = 7, CNT_WORDS = 16 };
+       CNT64_EXT_NODES = 2, CNT64_EXT_TRIS = 3, CNT64_SHD_NODES = 4, CNT64_SHD_TRIS = 5, CNT64_EXT_EMPTY = 6, CNT64_EXT_STALE = 7,
+       CNT64_TAIL_NORMAL = 8, CNT64_TAIL_SHADOW = 9, CNT_WORDS = 20 };
 
 }  // namespace mtsamd

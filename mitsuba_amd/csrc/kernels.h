@@ -55,6 +55,205 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 1024), amdgpu_wav
     traceLoop<MODE, COUNT>(sc, a, topTree, stacks, rayBuf, (LdsUint *) (rayBuf + 2 * blockDim.x));
 }
 
+// What shading one vertex produces: the extension ray with the path state that travels with it, and the shadow ray of
+// the emitter sample with the radiance it carries if unoccluded.
+struct ShadeOut {
+    bool alive = false, wantShadow = false;
+    float4 oRayO = make_float4(0, 0, 0, 0), oRayD = oRayO, oThr = oRayO, sRayO = oRayO, sRayD = oRayO, sContrib = oRayO;
+    uint4 oMisc = make_uint4(0, 0, 0, 0);
+    float oPdf = 0, oRefCos = 0;
+};
+
+// Path state as the shading code reads it: from the queue arrays (wavefront kernels) ...
+struct QueuedPath {
+    PathQueue q;
+    uint32_t i;
+    MTS_DEV float4 rayO() const { return q.rayO[i]; }
+    MTS_DEV float4 rayD() const { return q.rayD[i]; }
+    MTS_DEV float4 thr() const { return q.thr[i]; }
+    MTS_DEV uint4 misc() const { return q.misc[i]; }
+    MTS_DEV float bsdfPdf() const { return q.bsdfPdf[i]; }
+    MTS_DEV float refCos() const { return q.refCos[i]; }
+};
+// ... or from registers (the kernel that follows a path through all its remaining bounces)
+struct HeldPath {
+    float4 ro, rd, th;
+    uint4 mi;
+    float pdf, rc;
+    MTS_DEV float4 rayO() const { return ro; }
+    MTS_DEV float4 rayD() const { return rd; }
+    MTS_DEV float4 thr() const { return th; }
+    MTS_DEV uint4 misc() const { return mi; }
+    MTS_DEV float bsdfPdf() const { return pdf; }
+    MTS_DEV float refCos() const { return rc; }
+};
+
+// One vertex of MIPathTracer::Li (src/integrators/path/path.cpp:135-287) for the path `in` whose ray produced `hit`.
+// Radiance gathered at this vertex goes to sampleL[slot] directly; the rest comes back in `o`.
+template <bool ENV, typename Path>
+MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &in, const float4 hit, float4 *sampleL, ShadeOut &o) {
+    const uint32_t triWord = __float_as_uint(hit.w);
+    if (triWord != kMiss) {
+        const uint32_t tri = triWord & kTriIndexMask;
+        const float4 rd = in.rayD(), th = in.thr();
+        const uint4 misc = in.misc();
+        const V3 rayD = mk(rd.x, rd.y, rd.z);
+        const uint32_t slot = misc.x;
+        const uint32_t prevDepth = misc.y & 0xffffu;
+        uint32_t flags = misc.y >> 16;
+        Rng rng;
+        {
+            int px, py, s;
+            const uint64_t key = sampleKey(sc, pp, slot, px, py, s);
+            rng.inc = (key << 1) | 1u;
+            rng.state = (uint64_t) misc.z | ((uint64_t) misc.w << 32);
+        }
+        V3 throughput = mk(th.x, th.y, th.z);
+        float eta = th.w;
+
+        Isect its;
+        fillIntersection(sc, tri, hit.y, hit.z, rayD, its);
+        // the material record comes in as seven 16-byte loads issued together, not field by field
+        DevMaterial bsdf;
+        loadMaterial(sc, its.material, bsdf);
+        // what the integrator asks of the BSDF as a whole (for a two-sided record: the adapter's type) ...
+        const uint32_t bsdfType = bsdf.typeFlags;
+        const float wiZ = its.wi.z;
+        // ... and the BRDF that answers on this side (twosided.cpp:108-183)
+        const bool flipped = resolveTwoSided(sc, its.material, wiZ, bsdf);
+        const V3 wiLocal = flipped ? mirrorZ(its.wi) : its.wi;
+        // The sample's radiance is only fetched where something is added to it: at the camera vertex it still is
+        // what k_raygen wrote (zero), later only paths that hit an emitter touch it.
+        float4 L = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        bool Lchanged = false, terminate = false;
+        int depth;
+
+        if (prevDepth == 0) {
+            // camera vertex: alpha (records.inl:121-137) and directly visible emitters (path.cpp:148-150)
+            depth = 1;
+            L.w = 1.0f; Lchanged = true;
+            if (its.emitter >= 0 && !sc.hideEmitters) {
+                if (dot(its.sh.n, -rayD) > 0) {     // AreaLight::eval (area.cpp:104-109)
+                    const V3 c = throughput * ld3(sc.emitters[its.emitter].radiance);
+                    L.x += c.x; L.y += c.y; L.z += c.z;
+                }
+            }
+        } else {
+            // emitter reached by BSDF sampling: MIS against the emitter-sampling pdf (path.cpp:228-232,257-264)
+            if (its.emitter >= 0) {
+                const DevEmitter em = sc.emitters[its.emitter];
+                const V3 value = dot(its.sh.n, -rayD) > 0 ? ld3(em.radiance) : mk(0.0f);
+                float lumPdf = 0;
+                if (!(flags & PF_PREV_DELTA)) {
+                    // pdfEmitterDirect (scene.cpp:949-952) -> AreaLight::pdfDirect (area.cpp:175-183) -> Shape::pdfDirect (shape.cpp:117-121)
+                    if ((flags & PF_REFN_OK) && dot(rayD, its.sh.n) < 0)
+                        lumPdf = em.invArea * (hit.x * hit.x) / fabsf(dot(rayD, its.sh.n));
+                    lumPdf *= em.pdfDiscrete;
+                }
+                const V3 c = throughput * value * miWeight(in.bsdfPdf(), lumPdf);
+                if (c.x != 0 || c.y != 0 || c.z != 0) {
+                    L = sampleL[slot];
+                    L.x += c.x; L.y += c.y; L.z += c.z; Lchanged = true;
+                }
+            }
+            // Russian roulette (path.cpp:276-286) ...
+            if ((int) prevDepth >= sc.rrDepth) {
+                const float q = fminf(maxComp(throughput) * eta * eta, 0.95f);
+                if (rng.next1D() >= q) terminate = true;
+                throughput = throughput / q;
+            }
+            depth = (int) prevDepth + 1;
+            // ... and the loop condition (path.cpp:135)
+            if (!(depth <= sc.maxDepth || sc.maxDepth < 0)) terminate = true;
+        }
+
+        // path.cpp:156-165
+        if (!terminate && ((depth >= sc.maxDepth && sc.maxDepth > 0) ||
+                           (sc.strictNormals && dot(rayD, its.geoN) * wiZ >= 0)))
+            terminate = true;
+
+        if (!terminate) {
+            // DirectSamplingRecord(its) (records.inl:160-164)
+            V3 refN = mk(0.0f);
+            if ((bsdfType & (ETransmission | EBackSide)) == 0) refN = its.sh.n;
+
+            // direct illumination sampling (path.cpp:172-200)
+            if (bsdfType & ESmooth) {
+                const float sx = rng.next1D(), sy = rng.next1D();
+                DirectRec dRec;
+                const V3 value = sampleEmitterDirect(sc, its.p, refN, sx, sy, dRec);
+                if (dRec.pdf != 0) {
+                    V3 c = mk(0.0f);
+                    const V3 wo = toLocal(its.sh, dRec.d);
+                    const V3 woSide = flipped ? mirrorZ(wo) : wo;
+                    const V3 bsdfVal = bsdfEval(sc, bsdf, wiLocal, woSide);
+                    if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
+                        const float bPdf = bsdfPdf(sc, bsdf, wiLocal, woSide);    // area emitters: on surface, solid-angle measure
+                        c = throughput * value * bsdfVal * miWeight(dRec.pdf, bPdf);
+                    }
+                    o.wantShadow = true;
+                    o.sRayO = make_float4(its.p.x, its.p.y, its.p.z, kEpsilon);
+                    o.sRayD = make_float4(dRec.d.x, dRec.d.y, dRec.d.z, dRec.dist * (1 - kShadowEpsilon));   // scene.cpp:840-841
+                    o.sContrib = make_float4(c.x, c.y, c.z, __uint_as_float(slot));
+                }
+            }
+
+            // BSDF sampling (path.cpp:206-226)
+            const float bx = rng.next1D(), by = rng.next1D();
+            V3 woLocal; float bPdf, bEta; uint32_t sampledType;
+            const V3 bsdfWeight = bsdfSample(sc, bsdf, wiLocal, bx, by, woLocal, bPdf, bEta, sampledType);
+            if (flipped && !isZero(bsdfWeight) && bPdf != 0) woLocal.z = -woLocal.z;      // twosided.cpp:172-181
+            if (!isZero(bsdfWeight)) {
+                if (sampledType != ENull) flags |= PF_SCATTERED;
+                const V3 wo = toWorld(its.sh, woLocal);
+                const float woDotGeoN = dot(its.geoN, wo);
+                if (!(sc.strictNormals && woDotGeoN * woLocal.z <= 0)) {
+                    o.alive = true;
+                    throughput = throughput * bsdfWeight;   // path.cpp:252-253
+                    eta *= bEta;
+                    uint32_t nf = flags & PF_SCATTERED;
+                    if (sampledType & EDelta) nf |= PF_PREV_DELTA;
+                    if (dot(wo, refN) >= 0) nf |= PF_REFN_OK;
+                    o.oRayO = make_float4(its.p.x, its.p.y, its.p.z, kEpsilon);     // Ray(its.p, wo, time): mint = Epsilon, maxt = inf
+                    o.oRayD = make_float4(wo.x, wo.y, wo.z, kInf);
+                    o.oThr = make_float4(throughput.x, throughput.y, throughput.z, eta);
+                    o.oMisc = make_uint4(slot, (uint32_t) depth | (nf << 16), (uint32_t) rng.state, (uint32_t) (rng.state >> 32));
+                    o.oPdf = bPdf;
+                    if (ENV) o.oRefCos = isZero(refN) ? -2.0f : dot(wo, refN);
+                }
+            }
+        }
+        if (Lchanged) sampleL[slot] = L;
+    } else if (ENV) {
+        // the ray left the scene and there is an environment emitter
+        const uint4 misc = in.misc();
+        const uint32_t slot = misc.x, prevDepth = misc.y & 0xffffu, flags = misc.y >> 16;
+        const float4 th = in.thr();
+        const V3 throughput = mk(th.x, th.y, th.z), radiance = ld3(sc.envRadiance);
+        if (prevDepth == 0) {
+            // camera ray (path.cpp:136-143): alpha stays 0 (records.inl:121-137)
+            if (!sc.hideEmitters) {
+                const V3 c = throughput * radiance;
+                sampleL[slot] = make_float4(c.x, c.y, c.z, 0.0f);
+            }
+        } else if (!(sc.hideEmitters && !(flags & PF_SCATTERED))) {
+            // ray from BSDF sampling (path.cpp:233-247,257-264): MIS against ConstantBackgroundEmitter::pdfDirect
+            const float4 ro = in.rayO(), rd = in.rayD();
+            float farT;
+            if (environmentExit(sc, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), farT)) {     // fillDirectSamplingRecord (constant.cpp:245-261)
+                const float lumPdf = (flags & PF_PREV_DELTA) ? 0.0f : environmentPdfDirect(sc, in.refCos());
+                const V3 c = throughput * radiance * miWeight(in.bsdfPdf(), lumPdf);
+                if (c.x != 0 || c.y != 0 || c.z != 0) {
+                    float4 L = sampleL[slot];
+                    L.x += c.x; L.y += c.y; L.z += c.z;
+                    sampleL[slot] = L;
+                }
+            }
+        }
+    }
+
+}
+
 // ---- K3 shade: one vertex of MIPathTracer::Li per live path (src/integrators/path/path.cpp:135-287) --------------------
 // The loop body of the reference is cut at the extension-ray trace: everything after `scene->rayIntersect(ray, its)`
 // (:226) for vertex k runs at the start of the invocation that shades vertex k+1. Queue entries carry the depth of
@@ -123,173 +322,9 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
     __shared__ uint32_t sWaveShadow[kWaves], sWaveNext[kWaves], sBase[2];
   for (int round = 0; round < ROUNDS; ++round) {
     const uint32_t i = first + sOrder[round * kShadeBlock + tid];
-    bool alive = false, wantShadow = false;
-    float4 oRayO = make_float4(0, 0, 0, 0), oRayD = oRayO, oThr = oRayO, sRayO = oRayO, sRayD = oRayO, sContrib = oRayO;
-    uint4 oMisc = make_uint4(0, 0, 0, 0);
-    float oPdf = 0, oRefCos = 0;
-
-    if (i < n) {
-        const float4 hit = hits[i];
-        const uint32_t triWord = __float_as_uint(hit.w);
-        if (triWord != kMiss) {
-            const uint32_t tri = triWord & kTriIndexMask;
-            const float4 rd = in.rayD[i], th = in.thr[i];
-            const uint4 misc = in.misc[i];
-            const V3 rayD = mk(rd.x, rd.y, rd.z);
-            const uint32_t slot = misc.x;
-            const uint32_t prevDepth = misc.y & 0xffffu;
-            uint32_t flags = misc.y >> 16;
-            Rng rng;
-            {
-                int px, py, s;
-                const uint64_t key = sampleKey(sc, pp, slot, px, py, s);
-                rng.inc = (key << 1) | 1u;
-                rng.state = (uint64_t) misc.z | ((uint64_t) misc.w << 32);
-            }
-            V3 throughput = mk(th.x, th.y, th.z);
-            float eta = th.w;
-
-            Isect its;
-            fillIntersection(sc, tri, hit.y, hit.z, rayD, its);
-            // the material record comes in as seven 16-byte loads issued together, not field by field
-            DevMaterial bsdf;
-            loadMaterial(sc, its.material, bsdf);
-            // what the integrator asks of the BSDF as a whole (for a two-sided record: the adapter's type) ...
-            const uint32_t bsdfType = bsdf.typeFlags;
-            const float wiZ = its.wi.z;
-            // ... and the BRDF that answers on this side (twosided.cpp:108-183)
-            const bool flipped = resolveTwoSided(sc, its.material, wiZ, bsdf);
-            const V3 wiLocal = flipped ? mirrorZ(its.wi) : its.wi;
-            // The sample's radiance is only fetched where something is added to it: at the camera vertex it still is
-            // what k_raygen wrote (zero), later only paths that hit an emitter touch it.
-            float4 L = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            bool Lchanged = false, terminate = false;
-            int depth;
-
-            if (prevDepth == 0) {
-                // camera vertex: alpha (records.inl:121-137) and directly visible emitters (path.cpp:148-150)
-                depth = 1;
-                L.w = 1.0f; Lchanged = true;
-                if (its.emitter >= 0 && !sc.hideEmitters) {
-                    if (dot(its.sh.n, -rayD) > 0) {     // AreaLight::eval (area.cpp:104-109)
-                        const V3 c = throughput * ld3(sc.emitters[its.emitter].radiance);
-                        L.x += c.x; L.y += c.y; L.z += c.z;
-                    }
-                }
-            } else {
-                // emitter reached by BSDF sampling: MIS against the emitter-sampling pdf (path.cpp:228-232,257-264)
-                if (its.emitter >= 0) {
-                    const DevEmitter em = sc.emitters[its.emitter];
-                    const V3 value = dot(its.sh.n, -rayD) > 0 ? ld3(em.radiance) : mk(0.0f);
-                    float lumPdf = 0;
-                    if (!(flags & PF_PREV_DELTA)) {
-                        // pdfEmitterDirect (scene.cpp:949-952) -> AreaLight::pdfDirect (area.cpp:175-183) -> Shape::pdfDirect (shape.cpp:117-121)
-                        if ((flags & PF_REFN_OK) && dot(rayD, its.sh.n) < 0)
-                            lumPdf = em.invArea * (hit.x * hit.x) / fabsf(dot(rayD, its.sh.n));
-                        lumPdf *= em.pdfDiscrete;
-                    }
-                    const V3 c = throughput * value * miWeight(in.bsdfPdf[i], lumPdf);
-                    if (c.x != 0 || c.y != 0 || c.z != 0) {
-                        L = sampleL[slot];
-                        L.x += c.x; L.y += c.y; L.z += c.z; Lchanged = true;
-                    }
-                }
-                // Russian roulette (path.cpp:276-286) ...
-                if ((int) prevDepth >= sc.rrDepth) {
-                    const float q = fminf(maxComp(throughput) * eta * eta, 0.95f);
-                    if (rng.next1D() >= q) terminate = true;
-                    throughput = throughput / q;
-                }
-                depth = (int) prevDepth + 1;
-                // ... and the loop condition (path.cpp:135)
-                if (!(depth <= sc.maxDepth || sc.maxDepth < 0)) terminate = true;
-            }
-
-            // path.cpp:156-165
-            if (!terminate && ((depth >= sc.maxDepth && sc.maxDepth > 0) ||
-                               (sc.strictNormals && dot(rayD, its.geoN) * wiZ >= 0)))
-                terminate = true;
-
-            if (!terminate) {
-                // DirectSamplingRecord(its) (records.inl:160-164)
-                V3 refN = mk(0.0f);
-                if ((bsdfType & (ETransmission | EBackSide)) == 0) refN = its.sh.n;
-
-                // direct illumination sampling (path.cpp:172-200)
-                if (bsdfType & ESmooth) {
-                    const float sx = rng.next1D(), sy = rng.next1D();
-                    DirectRec dRec;
-                    const V3 value = sampleEmitterDirect(sc, its.p, refN, sx, sy, dRec);
-                    if (dRec.pdf != 0) {
-                        V3 c = mk(0.0f);
-                        const V3 wo = toLocal(its.sh, dRec.d);
-                        const V3 woSide = flipped ? mirrorZ(wo) : wo;
-                        const V3 bsdfVal = bsdfEval(sc, bsdf, wiLocal, woSide);
-                        if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
-                            const float bPdf = bsdfPdf(sc, bsdf, wiLocal, woSide);    // area emitters: on surface, solid-angle measure
-                            c = throughput * value * bsdfVal * miWeight(dRec.pdf, bPdf);
-                        }
-                        wantShadow = true;
-                        sRayO = make_float4(its.p.x, its.p.y, its.p.z, kEpsilon);
-                        sRayD = make_float4(dRec.d.x, dRec.d.y, dRec.d.z, dRec.dist * (1 - kShadowEpsilon));   // scene.cpp:840-841
-                        sContrib = make_float4(c.x, c.y, c.z, __uint_as_float(slot));
-                    }
-                }
-
-                // BSDF sampling (path.cpp:206-226)
-                const float bx = rng.next1D(), by = rng.next1D();
-                V3 woLocal; float bPdf, bEta; uint32_t sampledType;
-                const V3 bsdfWeight = bsdfSample(sc, bsdf, wiLocal, bx, by, woLocal, bPdf, bEta, sampledType);
-                if (flipped && !isZero(bsdfWeight) && bPdf != 0) woLocal.z = -woLocal.z;      // twosided.cpp:172-181
-                if (!isZero(bsdfWeight)) {
-                    if (sampledType != ENull) flags |= PF_SCATTERED;
-                    const V3 wo = toWorld(its.sh, woLocal);
-                    const float woDotGeoN = dot(its.geoN, wo);
-                    if (!(sc.strictNormals && woDotGeoN * woLocal.z <= 0)) {
-                        alive = true;
-                        throughput = throughput * bsdfWeight;   // path.cpp:252-253
-                        eta *= bEta;
-                        uint32_t nf = flags & PF_SCATTERED;
-                        if (sampledType & EDelta) nf |= PF_PREV_DELTA;
-                        if (dot(wo, refN) >= 0) nf |= PF_REFN_OK;
-                        oRayO = make_float4(its.p.x, its.p.y, its.p.z, kEpsilon);     // Ray(its.p, wo, time): mint = Epsilon, maxt = inf
-                        oRayD = make_float4(wo.x, wo.y, wo.z, kInf);
-                        oThr = make_float4(throughput.x, throughput.y, throughput.z, eta);
-                        oMisc = make_uint4(slot, (uint32_t) depth | (nf << 16), (uint32_t) rng.state, (uint32_t) (rng.state >> 32));
-                        oPdf = bPdf;
-                        if (ENV) oRefCos = isZero(refN) ? -2.0f : dot(wo, refN);
-                    }
-                }
-            }
-            if (Lchanged) sampleL[slot] = L;
-        } else if (ENV) {
-            // the ray left the scene and there is an environment emitter
-            const uint4 misc = in.misc[i];
-            const uint32_t slot = misc.x, prevDepth = misc.y & 0xffffu, flags = misc.y >> 16;
-            const float4 th = in.thr[i];
-            const V3 throughput = mk(th.x, th.y, th.z), radiance = ld3(sc.envRadiance);
-            if (prevDepth == 0) {
-                // camera ray (path.cpp:136-143): alpha stays 0 (records.inl:121-137)
-                if (!sc.hideEmitters) {
-                    const V3 c = throughput * radiance;
-                    sampleL[slot] = make_float4(c.x, c.y, c.z, 0.0f);
-                }
-            } else if (!(sc.hideEmitters && !(flags & PF_SCATTERED))) {
-                // ray from BSDF sampling (path.cpp:233-247,257-264): MIS against ConstantBackgroundEmitter::pdfDirect
-                const float4 ro = in.rayO[i], rd = in.rayD[i];
-                float farT;
-                if (environmentExit(sc, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), farT)) {     // fillDirectSamplingRecord (constant.cpp:245-261)
-                    const float lumPdf = (flags & PF_PREV_DELTA) ? 0.0f : environmentPdfDirect(sc, in.refCos[i]);
-                    const V3 c = throughput * radiance * miWeight(in.bsdfPdf[i], lumPdf);
-                    if (c.x != 0 || c.y != 0 || c.z != 0) {
-                        float4 L = sampleL[slot];
-                        L.x += c.x; L.y += c.y; L.z += c.z;
-                        sampleL[slot] = L;
-                    }
-                }
-            }
-        }
-    }
+    ShadeOut o;
+    if (i < n) shadeVertex<ENV>(sc, pp, QueuedPath{ in, i }, hits[i], sampleL, o);
+    const bool alive = o.alive, wantShadow = o.wantShadow;
 
     // Queue slots are reserved once per workgroup (two atomics per workgroup, not per wavefront: thousands of
     // wavefronts hammering the same two counters serialise at the L2): wave totals go through LDS, thread 0 reserves
@@ -311,13 +346,78 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
     __syncthreads();
     uint32_t si = sBase[0] + (uint32_t) __popcll(mShadow & below), oi = sBase[1] + (uint32_t) __popcll(mNext & below);
     for (uint32_t w = 0; w < wave; ++w) { si += sWaveShadow[w]; oi += sWaveNext[w]; }
-    if (wantShadow) { sq.rayO[si] = sRayO; sq.rayD[si] = sRayD; sq.contrib[si] = sContrib; }
+    if (wantShadow) { sq.rayO[si] = o.sRayO; sq.rayD[si] = o.sRayD; sq.contrib[si] = o.sContrib; }
     if (alive) {
-        out.rayO[oi] = oRayO; out.rayD[oi] = oRayD; out.thr[oi] = oThr; out.misc[oi] = oMisc; out.bsdfPdf[oi] = oPdf;
-        if (ENV) out.refCos[oi] = oRefCos;
+        out.rayO[oi] = o.oRayO; out.rayD[oi] = o.oRayD; out.thr[oi] = o.oThr; out.misc[oi] = o.oMisc; out.bsdfPdf[oi] = o.oPdf;
+        if (ENV) out.refCos[oi] = o.oRefCos;
     }
     if (ROUNDS > 1) __syncthreads();        // the reservation cells are reused by the next sweep
   }
+}
+
+// ---- The thin end of a pass: once few paths are left, one launch follows each of them through all its remaining
+// bounces (extend, shade, shadow ray, next extend ...) instead of three launches and a host round trip per bounce.
+// One lane per path, one workgroup per wavefront; the lanes of a wavefront stay in step bounce by bounce. Same
+// functions as the wavefront kernels, hence the same results. counts[0] / counts[1] receive the closest-hit and
+// shadow rays traced (the reference's two ray counters).
+static constexpr int kTailBlock = 64;
+template <bool ENV>
+__global__ void __launch_bounds__(kTailBlock) k_tail(DevScene sc, PassParams pp, PathQueue in, float4 *sampleL, uint32_t n,
+                                                     uint32_t triShare, unsigned long long *counts) {
+    __shared__ uint2 sStack[kLdsStack * kTailBlock];
+    LdsUint2 *ldsStack = (LdsUint2 *) sStack;
+    const uint32_t i = blockIdx.x * kTailBlock + threadIdx.x;
+    bool active = i < n;
+    HeldPath path;
+    path.ro = path.rd = path.th = make_float4(0, 0, 0, 0); path.mi = make_uint4(0, 0, 0, 0); path.pdf = 0; path.rc = 0;
+    if (active) {
+        path.ro = in.rayO[i]; path.rd = in.rayD[i]; path.th = in.thr[i]; path.mi = in.misc[i]; path.pdf = in.bsdfPdf[i];
+        if (ENV) path.rc = in.refCos[i];
+    }
+    uint32_t nNormal = 0, nShadow = 0;
+    while (__ballot(active)) {
+        // extend (Scene::rayIntersect(ray, its))
+        LaneRay r;
+        r.tg = make_uint2(0u, 0u); r.ng = make_uint2(0u, 0u);
+        r.hit.t = kInf; r.hit.u = 0; r.hit.v = 0; r.hit.tri = 0xFFFFFFFFu;
+        bool busy = false;
+        if (active) {
+            ++nNormal;
+            float mint, maxt;
+            if (rayInterval(sc, mk(path.ro.x, path.ro.y, path.ro.z), mk(path.rd.x, path.rd.y, path.rd.z), path.ro.w, path.rd.w, false, mint, maxt)) {
+                laneStart(r, mk(path.ro.x, path.ro.y, path.ro.z), mk(path.rd.x, path.rd.y, path.rd.z), mint, maxt);
+                busy = true;
+            }
+        }
+        traceHeldRays<false>(sc, r, busy, ldsStack, triShare);
+        // shade
+        ShadeOut o;
+        if (active) shadeVertex<ENV>(sc, pp, path, make_float4(r.hit.t, r.hit.u, r.hit.v, __uint_as_float(r.hit.tri)), sampleL, o);
+        // shadow ray of the emitter sample (scene.cpp:839-843), then path.cpp:196-198
+        const bool wantShadow = active && o.wantShadow;
+        busy = false;
+        if (wantShadow) {
+            ++nShadow;
+            float mint, maxt;
+            if (rayInterval(sc, mk(o.sRayO.x, o.sRayO.y, o.sRayO.z), mk(o.sRayD.x, o.sRayD.y, o.sRayD.z), o.sRayO.w, o.sRayD.w, true, mint, maxt)) {
+                laneStart(r, mk(o.sRayO.x, o.sRayO.y, o.sRayO.z), mk(o.sRayD.x, o.sRayD.y, o.sRayD.z), mint, maxt);
+                busy = true;
+            }
+        }
+        traceHeldRays<true>(sc, r, busy, ldsStack, triShare);
+        if (wantShadow && !busy && (o.sContrib.x != 0 || o.sContrib.y != 0 || o.sContrib.z != 0)) {
+            const uint32_t slot = __float_as_uint(o.sContrib.w);
+            float4 L = sampleL[slot];
+            L.x += o.sContrib.x; L.y += o.sContrib.y; L.z += o.sContrib.z;
+            sampleL[slot] = L;
+        }
+        // next bounce
+        active = active && o.alive;
+        if (active) { path.ro = o.oRayO; path.rd = o.oRayD; path.th = o.oThr; path.mi = o.oMisc; path.pdf = o.oPdf; path.rc = o.oRefCos; }
+    }
+    // one pair of atomics per wavefront
+    for (int off = 32; off > 0; off >>= 1) { nNormal += __shfl_down(nNormal, off); nShadow += __shfl_down(nShadow, off); }
+    if (threadIdx.x == 0) { atomicAdd(&counts[0], (unsigned long long) nNormal); atomicAdd(&counts[1], (unsigned long long) nShadow); }
 }
 
 // ---- K4b: the value of an unoccluded emitter sample joins the path's radiance (path.cpp:196-198). One thread per

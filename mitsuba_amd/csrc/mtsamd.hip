@@ -74,6 +74,7 @@ struct mtsamd_scene {
     hipStream_t shadowStream = nullptr;   // shadow rays of bounce k are traced next to the extension rays of bounce k+1
     hipEvent_t evShaded = nullptr, evShadowed = nullptr;
     uint32_t *hostCounters = nullptr;     // pinned
+    unsigned long long *hostTail = nullptr;   // pinned: ray counts of the kernel that finishes a pass
     std::atomic<int> cancel{ 0 };
     bool countTraversal = false;
     // traversal launch shape: persistent workgroups (as many as fit on the device) and the lane-refill / triangle-phase
@@ -81,6 +82,7 @@ struct mtsamd_scene {
     unsigned traceGrid = 0, traceBlock = 256;
     uint32_t nodeStride = 5, triStride = 3;     // record strides in float4 units (padding buys line alignment)
     uint64_t overlapBelow = 8u << 20;     // rays (shadow + next extend) below which the two traversals run side by side
+    uint32_t tailBelow = 1u << 18;        // paths below which one launch finishes the pass (0 = never)
     int shadeRounds = 8;                  // sweeps per shade workgroup (1, 2, 4, 8 or 16) ...
     uint32_t shadeRoundsAbove = 4u << 20; // ... for queues of at least this many paths
     uint32_t refillBelow = 56, triShare = 16, topNodes = 73, chunkMax = 512;
@@ -91,6 +93,7 @@ struct mtsamd_scene {
         if (evShaded) (void) hipEventDestroy(evShaded);
         if (evShadowed) (void) hipEventDestroy(evShadowed);
         if (hostCounters) (void) hipHostFree(hostCounters);
+        if (hostTail) (void) hipHostFree(hostTail);
     }
 
     PathQueue queue(int i) const {
@@ -197,6 +200,7 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
         HIP_TRY(hipEventCreateWithFlags(&s->evShaded, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s->evShadowed, hipEventDisableTiming));
         HIP_TRY(hipHostMalloc((void **) &s->hostCounters, CNT_WORDS * sizeof(uint32_t)));
+        HIP_TRY(hipHostMalloc((void **) &s->hostTail, 2 * sizeof(unsigned long long)));
         return MTSAMD_OK;
     };
     int rc = up();
@@ -218,6 +222,7 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
         if (const char *e = getenv("MTSAMD_REFILL_BELOW")) s->refillBelow = (uint32_t) std::min(64, std::max(1, atoi(e)));
         if (const char *e = getenv("MTSAMD_TRI_SHARE")) s->triShare = (uint32_t) std::min(64, std::max(1, atoi(e)));
         if (const char *e = getenv("MTSAMD_OVERLAP_BELOW")) s->overlapBelow = (uint64_t) std::max(0ll, atoll(e));
+        if (const char *e = getenv("MTSAMD_TAIL_BELOW")) s->tailBelow = (uint32_t) std::max(0ll, atoll(e));
         if (const char *e = getenv("MTSAMD_SHADE_ROUNDS")) s->shadeRounds = atoi(e);
         if (const char *e = getenv("MTSAMD_SHADE_ROUNDS_ABOVE")) s->shadeRoundsAbove = (uint32_t) std::max(0ll, atoll(e));
         if (const char *e = getenv("MTSAMD_CHUNK_MAX")) s->chunkMax = (uint32_t) std::min(65536, std::max(64, atoi(e)));
@@ -342,6 +347,23 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
     bool shadowPending = false;
     const bool traceIters = getenv("MTSAMD_TRACE_ITERS") != nullptr;
     while (n > 0) {
+        // Few paths left: one launch takes them through all their remaining bounces. (The tail of a pass is a
+        // long run of bounces on a handful of paths inside dielectrics; three launches and a host round trip for
+        // each of them cost far more than the rays.) Counting runs keep to the wavefront kernels, which count.
+        if (n <= s->tailBelow && !s->countTraversal) {
+            if (shadowPending) { HIP_TRY(hipStreamWaitEvent(st, s->evShadowed, 0)); shadowPending = false; }
+            unsigned long long *tailCounts = cnt64 + CNT64_TAIL_NORMAL;
+            HIP_TRY(hipMemsetAsync(tailCounts, 0, 2 * sizeof(unsigned long long), st));
+            timer.begin(T_EXTEND);
+            if (sc.envEmitter >= 0) hipLaunchKernelGGL((k_tail<true>), dim3(blocksFor(n, kTailBlock)), dim3(kTailBlock), 0, st, sc, pp, s->queue(cur), sampleL, n, s->triShare, tailCounts);
+            else hipLaunchKernelGGL((k_tail<false>), dim3(blocksFor(n, kTailBlock)), dim3(kTailBlock), 0, st, sc, pp, s->queue(cur), sampleL, n, s->triShare, tailCounts);
+            timer.end(T_EXTEND);
+            HIP_TRY(hipMemcpyAsync(s->hostTail, tailCounts, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            normalRays += s->hostTail[0]; shadowRays += s->hostTail[1];
+            ++iterations;
+            break;
+        }
         if (s->cancel.load()) { (void) hipStreamSynchronize(st); (void) hipStreamSynchronize(s->shadowStream); return fail(MTSAMD_ECANCELLED, "render cancelled"); }
         PathQueue qin = s->queue(cur), qout = s->queue(cur ^ 1);
         TraceArgs ta;

@@ -216,6 +216,24 @@ def test_per_sample_radiance_parity(pairs, name):
     assert abs(Lg[..., :3].mean() - Lo[..., :3].mean()) < 2e-3 * Lo[..., :3].mean() + 1e-6
 
 
+@pytest.mark.parametrize("name", ["small", "mixed", "sky"])
+def test_pass_finishing_kernel_matches_wavefront_loop(gpu, name, monkeypatch):
+    """Below MTSAMD_TAIL_BELOW live paths one launch follows each path to its end; above, every bounce is an extend /
+    shade / shadow round of launches. Both run the same shading and traversal code: identical radiance and ray counts."""
+    sd = _scenes()[name]
+    out = {}
+    for below in ("0", "1000000", "3000"):         # never / from the first bounce / for the last few thousand paths
+        monkeypatch.setenv("MTSAMD_TAIL_BELOW", below)
+        g = gpu.Scene(sd)
+        out[below] = g.li(4, seed=5)
+    L0, p0, s0 = out["0"]
+    for below in ("1000000", "3000"):
+        L, p, st = out[below]
+        assert (st.normal_rays, st.shadow_rays) == (s0.normal_rays, s0.shadow_rays)
+        assert np.array_equal(L, L0) and np.array_equal(p, p0)
+    assert out["1000000"][2].bounce_iterations == 1 and s0.bounce_iterations > 3
+
+
 def test_max_depth_and_rr_variants(gpu, oracle_mod):
     for md, rr in ((1, 5), (2, 5), (3, 1), (6, 2)):
         sd = S.small_test_scene(max_depth=md)
