@@ -149,6 +149,10 @@ typedef struct {
     /* interior-node visits and triangle tests of the closest-hit and of the shadow queries; filled only while
        traversal counting is enabled (mtsamd_scene_set_counting) */
     uint64_t node_visits, tri_tests, shadow_node_visits, shadow_tri_tests;
+    /* the launch that follows the last few paths of a pass through all their remaining bounces: its device time and
+       the closest-hit / shadow rays it traced (already contained in normal_rays / shadow_rays, not in extend_ms) */
+    double tail_ms;
+    uint64_t tail_normal_rays, tail_shadow_rays;
 } mtsamd_stats;
 
 typedef struct {

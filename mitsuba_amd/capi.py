@@ -69,7 +69,8 @@ class Stats(C.Structure):
                 ("extend_ms", C.c_double), ("shade_ms", C.c_double), ("shadow_ms", C.c_double), ("film_ms", C.c_double),
                 ("raygen_ms", C.c_double), ("extend_launches", C.c_uint64), ("shadow_launches", C.c_uint64),
                 ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
-                ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64)]
+                ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64),
+                ("tail_ms", C.c_double), ("tail_normal_rays", C.c_uint64), ("tail_shadow_rays", C.c_uint64)]
 
 
 class BvhInfo(C.Structure):

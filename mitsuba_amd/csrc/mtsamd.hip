@@ -267,7 +267,7 @@ extern "C" int mtsamd_scene_set_counting(mtsamd_scene *scene, int enabled) {
 namespace {
 
 struct EventTimer {
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool[5];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool[6];
     bool enabled = false;
     hipStream_t stream = nullptr;
     void begin(int cls, hipStream_t on = nullptr) {
@@ -292,7 +292,7 @@ struct EventTimer {
         return ms;
     }
 };
-enum { T_RAYGEN = 0, T_EXTEND = 1, T_SHADE = 2, T_SHADOW = 3, T_FILM = 4 };
+enum { T_RAYGEN = 0, T_EXTEND = 1, T_SHADE = 2, T_SHADOW = 3, T_FILM = 4, T_TAIL = 5 };
 
 int checkOpts(const mtsamd_scene *s, const mtsamd_render_opts *o, mtsamd_render_opts &r) {
     if (!s || !o) return fail(MTSAMD_EINVAL, "null argument");
@@ -344,6 +344,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
     timer.end(T_RAYGEN);
 
     uint64_t normalRays = 0, shadowRays = 0, iterations = 0;
+    bool tailLaunch = false;
     bool shadowPending = false;
     const bool traceIters = getenv("MTSAMD_TRACE_ITERS") != nullptr;
     while (n > 0) {
@@ -354,14 +355,16 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
             if (shadowPending) { HIP_TRY(hipStreamWaitEvent(st, s->evShadowed, 0)); shadowPending = false; }
             unsigned long long *tailCounts = cnt64 + CNT64_TAIL_NORMAL;
             HIP_TRY(hipMemsetAsync(tailCounts, 0, 2 * sizeof(unsigned long long), st));
-            timer.begin(T_EXTEND);
+            timer.begin(T_TAIL);
             if (sc.envEmitter >= 0) hipLaunchKernelGGL((k_tail<true>), dim3(blocksFor(n, kTailBlock)), dim3(kTailBlock), 0, st, sc, pp, s->queue(cur), sampleL, n, s->triShare, tailCounts);
             else hipLaunchKernelGGL((k_tail<false>), dim3(blocksFor(n, kTailBlock)), dim3(kTailBlock), 0, st, sc, pp, s->queue(cur), sampleL, n, s->triShare, tailCounts);
-            timer.end(T_EXTEND);
+            timer.end(T_TAIL);
             HIP_TRY(hipMemcpyAsync(s->hostTail, tailCounts, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             normalRays += s->hostTail[0]; shadowRays += s->hostTail[1];
+            if (stats) { stats->tail_normal_rays += s->hostTail[0]; stats->tail_shadow_rays += s->hostTail[1]; }
             ++iterations;
+            tailLaunch = true;
             break;
         }
         if (s->cancel.load()) { (void) hipStreamSynchronize(st); (void) hipStreamSynchronize(s->shadowStream); return fail(MTSAMD_ECANCELLED, "render cancelled"); }
@@ -444,7 +447,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
     if (stats) {
         stats->normal_rays += normalRays; stats->shadow_rays += shadowRays; stats->paths += nPaths;
         stats->bounce_iterations += iterations;
-        stats->extend_launches += iterations;
+        stats->extend_launches += iterations - (tailLaunch ? 1 : 0);
     }
     return MTSAMD_OK;
 }
@@ -497,7 +500,7 @@ int renderCommon(mtsamd_scene *s, const mtsamd_render_opts *opts, float *filmDev
     if (stats) {
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         stats->raygen_ms = timer.total(T_RAYGEN); stats->extend_ms = timer.total(T_EXTEND); stats->shade_ms = timer.total(T_SHADE);
-        stats->shadow_ms = timer.total(T_SHADOW); stats->film_ms = timer.total(T_FILM);
+        stats->shadow_ms = timer.total(T_SHADOW); stats->film_ms = timer.total(T_FILM); stats->tail_ms = timer.total(T_TAIL);
         if (s->countTraversal) {
             unsigned long long c[CNT_WORDS / 2];
             HIP_TRY(hipMemcpy(c, s->counters.ptr, sizeof(c), hipMemcpyDeviceToHost));
