@@ -31,10 +31,11 @@ enum {
 };
 
 /* BSDF plugins on the hot path (src/bsdfs/{diffuse,roughconductor,roughplastic,dielectric,ward}.cpp) and their
-   smooth neighbours (src/bsdfs/{conductor,plastic}.cpp). The `twosided` adapter (src/bsdfs/twosided.cpp) is not a
+   neighbours (src/bsdfs/{conductor,plastic,roughdielectric}.cpp). The `twosided` adapter (src/bsdfs/twosided.cpp) is not a
    type of its own: it is the two_sided / back_material pair of the record of the BRDF it wraps. */
 enum { MTSAMD_BSDF_DIFFUSE = 0, MTSAMD_BSDF_ROUGHCONDUCTOR = 1, MTSAMD_BSDF_ROUGHPLASTIC = 2,
-       MTSAMD_BSDF_DIELECTRIC = 3, MTSAMD_BSDF_WARD = 4, MTSAMD_BSDF_CONDUCTOR = 5, MTSAMD_BSDF_PLASTIC = 6 };
+       MTSAMD_BSDF_DIELECTRIC = 3, MTSAMD_BSDF_WARD = 4, MTSAMD_BSDF_CONDUCTOR = 5, MTSAMD_BSDF_PLASTIC = 6,
+       MTSAMD_BSDF_ROUGHDIELECTRIC = 7 };
 /* MicrofacetDistribution::EType (src/bsdfs/microfacet.h:48-57); Phong is not supported */
 enum { MTSAMD_DISTR_BECKMANN = 0, MTSAMD_DISTR_GGX = 1 };
 enum { MTSAMD_SHAPE_HAS_NORMALS = 1, MTSAMD_SHAPE_HAS_TEXCOORDS = 2 };
@@ -64,7 +65,7 @@ typedef struct {
     int32_t sample_visible;     /* microfacet.h m_sampleVisible (default true) */
     int32_t variant;            /* ward: 0 ward, 1 ward-duer, 2 balanced; roughplastic, plastic: nonlinear flag */
     float alpha_u, alpha_v;
-    float int_ior, ext_ior;     /* dielectric, roughplastic, plastic */
+    float int_ior, ext_ior;     /* dielectric, roughplastic, plastic, roughdielectric */
     float diffuse_reflectance[3];   /* diffuse: reflectance; roughplastic, ward: diffuseReflectance */
     float specular_reflectance[3];
     float specular_transmittance[3];
@@ -230,11 +231,12 @@ int mtsamd_intersect(mtsamd_scene *scene, uint64_t n, const float *rays, mtsamd_
 
 /* BSDF::eval / pdf / sample(bRec, pdf, sample) in the local shading frame, ERadiance mode, all components.
    wi, wo: n*3; sample: n*2; eval -> n*3 (value includes the cosine factor); sample -> wo n*3, weight n*3,
-   pdf n, eta n, sampled_type n (BSDF::EBSDFType bits) */
+   pdf n, eta n, sampled_type n (BSDF::EBSDFType bits). sampler_1d (n values, may be NULL = 0.5): the number a BSDF
+   flagged EUsesSampler (roughdielectric) takes from the sampler itself, bRec.sampler->next1D() */
 int mtsamd_bsdf_eval(mtsamd_scene *scene, int material, uint64_t n, const float *wi, const float *wo, float *out);
 int mtsamd_bsdf_pdf(mtsamd_scene *scene, int material, uint64_t n, const float *wi, const float *wo, float *out);
 int mtsamd_bsdf_sample(mtsamd_scene *scene, int material, uint64_t n, const float *wi, const float *sample,
-                       float *wo, float *weight, float *pdf, float *eta, uint32_t *sampled_type);
+                       float *wo, float *weight, float *pdf, float *eta, uint32_t *sampled_type, const float *sampler_1d);
 
 /* Scene::sampleEmitterDirect without the visibility test (src/librender/scene.cpp:828-852):
    ref n*3, ref_n n*3 (DirectSamplingRecord::refN), sample n*2 -> d n*3, dist n, pdf n, value n*3 */

@@ -294,13 +294,14 @@ class Scene:
         _check(self.L.mtsamd_bsdf_pdf(self.h, int(mat), C.c_uint64(wi.shape[0]), _fp(wi), _fp(wo), _fp(out)))
         return out
 
-    def bsdf_sample(self, mat, wi, sample):
+    def bsdf_sample(self, mat, wi, sample, sampler_1d=None):
         wi, sample = np.ascontiguousarray(wi, np.float32), np.ascontiguousarray(sample, np.float32)
         n = wi.shape[0]
         wo, w = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
         pdf, eta, typ = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint32)
+        extra = None if sampler_1d is None else np.ascontiguousarray(sampler_1d, np.float32)
         _check(self.L.mtsamd_bsdf_sample(self.h, int(mat), C.c_uint64(n), _fp(wi), _fp(sample), _fp(wo), _fp(w), _fp(pdf),
-                                         _fp(eta), typ.ctypes.data_as(_u32p)))
+                                         _fp(eta), typ.ctypes.data_as(_u32p), None if extra is None else _fp(extra)))
         return wo, w, pdf, eta, typ
 
     def sample_emitter_direct(self, ref, ref_n, sample):

@@ -269,11 +269,11 @@ mtsamd_material makeBsdf(const Element &node, const LoadOptions &opts, LoadedSce
         int32_t back = -1;
         if (nested.size() == 2) {
             const mtsamd_material b = make(*nested[1]);
-            if (b.type == MTSAMD_BSDF_DIELECTRIC) throw Fail("Only materials without a transmission component can be nested!");
+            if (b.type == MTSAMD_BSDF_DIELECTRIC || b.type == MTSAMD_BSDF_ROUGHDIELECTRIC) throw Fail("Only materials without a transmission component can be nested!");
             back = (int32_t) addMaterial(out, b);
         }
         mtsamd_material m = make(*nested[0]);
-        if (m.type == MTSAMD_BSDF_DIELECTRIC) throw Fail("Only materials without a transmission component can be nested!");
+        if (m.type == MTSAMD_BSDF_DIELECTRIC || m.type == MTSAMD_BSDF_ROUGHDIELECTRIC) throw Fail("Only materials without a transmission component can be nested!");
         m.two_sided = 1;
         m.back_material = back;
         return m;
@@ -344,6 +344,13 @@ mtsamd_material makeBsdf(const Element &node, const LoadOptions &opts, LoadedSce
                                  &m.rtrans_diffuse_ext, &m.rtrans_diffuse_int) != MTSAMD_OK)
             throw Fail(mtsamd_last_error());
         m.rtrans_n = n;     // the pointer is set in desc(), once the table storage no longer moves
+    } else if (type == "roughdielectric") {     // src/bsdfs/roughdielectric.cpp:183-211
+        m.type = MTSAMD_BSDF_ROUGHDIELECTRIC;
+        m.distribution = distribution();
+        m.alpha_u = (float) alphaU; m.alpha_v = (float) alphaV;
+        m.int_ior = lookupIor(p, "intIOR", "bk7"); m.ext_ior = lookupIor(p, "extIOR", "air");
+        getRgb(p, "specularReflectance", 1, 1, 1, m.specular_reflectance);
+        getRgb(p, "specularTransmittance", 1, 1, 1, m.specular_transmittance);
     } else if (type == "conductor") {           // src/bsdfs/conductor.cpp:153-176
         m.type = MTSAMD_BSDF_CONDUCTOR;
         const std::string material = getS(p, "material", "Cu");

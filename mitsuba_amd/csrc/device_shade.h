@@ -185,6 +185,7 @@ struct Microfacet {
         type = type_; alphaU = fmaxf(au, 1e-4f); alphaV = fmaxf(av, 1e-4f); sampleVisible = sv;    // :67-74
     }
     MTS_DEV bool isotropic() const { return alphaU == alphaV; }
+    MTS_DEV void scaleAlpha(float v) { alphaU *= v; alphaV *= v; }     // :178-183
 
     MTS_DEV float eval(V3 m) const {   // :191-234
         if (m.z <= 0) return 0.0f;
@@ -344,9 +345,29 @@ MTS_DEV V3 reflectM(V3 wi, V3 m) { return 2 * dot(wi, m) * m - wi; }
 MTS_DEV float cosHemiPdf(V3 d) { return kInvPi * d.z; }
 
 // ---- BSDF::eval (value includes the cosine factor) -----------------------------------------------------------
+// RD = false compiles the rough dielectric out (kernels of scenes that have none: fewer live registers).
+template <bool RD = true>
 MTS_DEV V3 bsdfEval(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
     const V3 zero = mk(0.0f);
     if (m.type == 3 || m.type == 5) return zero;                // dielectric.cpp:228-253, conductor.cpp:225-239: no solid-angle lobe
+    if (RD && m.type == 7) {                                    // roughdielectric.cpp:276-346
+        if (wi.z == 0) return zero;
+        const bool reflect = wi.z * wo.z > 0;
+        const float etaSide = wi.z > 0 ? m.eta : m.invEta;
+        V3 H = reflect ? normalize(wo + wi) : normalize(wi + wo * etaSide);
+        H = H * copysignf(1.0f, H.z);
+        Microfacet distr; distr.init(m.distribution, m.alphaU, m.alphaV, m.sampleVisible != 0);
+        const float D = distr.eval(H);
+        if (D == 0) return zero;
+        float ct;
+        const float F = fresnelDielectricExt(dot(wi, H), ct, m.eta);
+        const float G = distr.G(wi, wo, H);
+        if (reflect) return ld3(m.specular) * (F * D * G / (4.0f * fabsf(wi.z)));
+        const float sqrtDenom = dot(wi, H) + etaSide * dot(wo, H);
+        const float value = ((1 - F) * D * G * etaSide * etaSide * dot(wi, H) * dot(wo, H)) / (wi.z * sqrtDenom * sqrtDenom);
+        const float factor = wi.z > 0 ? m.invEta : m.eta;      // ERadiance
+        return ld3(m.transmittance) * fabsf(value * factor * factor);
+    }
     if (wi.z <= 0 || wo.z <= 0) return zero;
     const V3 diff = ld3(m.diffuse), spec = ld3(m.specular);
     switch (m.type) {
@@ -416,8 +437,31 @@ MTS_DEV V3 bsdfEval(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
 }
 
 // ---- BSDF::pdf -----------------------------------------------------------------------------------------------
+template <bool RD = true>
 MTS_DEV float bsdfPdf(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
     if (m.type == 3 || m.type == 5) return 0.0f;
+    if (RD && m.type == 7) {                                    // roughdielectric.cpp:348-414
+        const bool reflect = wi.z * wo.z > 0;
+        const float etaSide = wi.z > 0 ? m.eta : m.invEta;
+        V3 H;
+        float dwh_dwo;
+        if (reflect) {
+            H = normalize(wo + wi);
+            dwh_dwo = 1.0f / (4.0f * dot(wo, H));
+        } else {
+            H = normalize(wi + wo * etaSide);
+            const float sqrtDenom = dot(wi, H) + etaSide * dot(wo, H);
+            dwh_dwo = (etaSide * etaSide * dot(wo, H)) / (sqrtDenom * sqrtDenom);
+        }
+        H = H * copysignf(1.0f, H.z);
+        Microfacet sampleDistr; sampleDistr.init(m.distribution, m.alphaU, m.alphaV, m.sampleVisible != 0);
+        if (!sampleDistr.sampleVisible) sampleDistr.scaleAlpha(1.2f - 0.2f * sqrtf(fabsf(wi.z)));
+        float prob = sampleDistr.pdf(wi * copysignf(1.0f, wi.z), H);
+        float ct;
+        const float F = fresnelDielectricExt(dot(wi, H), ct, m.eta);
+        prob *= reflect ? F : (1 - F);
+        return fabsf(prob * dwh_dwo);
+    }
     if (wi.z <= 0 || wo.z <= 0) return 0.0f;
     switch (m.type) {
         case 0:                                                 // diffuse.cpp:120-127
@@ -462,7 +506,10 @@ MTS_DEV float bsdfPdf(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
 }
 
 // ---- BSDF::sample(bRec, pdf, sample) -----------------------------------------------------------------------------
-MTS_DEV V3 bsdfSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, V3 &wo, float &pdf, float &eta,
+// su: the number a BSDF flagged EUsesSampler (roughdielectric) takes from the sampler itself, bRec.sampler->next1D()
+MTS_DEV bool bsdfUsesSampler(const DevMaterial &m) { return m.type == 7; }
+template <bool RD = true>
+MTS_DEV V3 bsdfSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, float su, V3 &wo, float &pdf, float &eta,
                       uint32_t &sampledType) {
     const V3 zero = mk(0.0f);
     pdf = 0; eta = 1.0f; sampledType = 0; wo = zero;
@@ -508,9 +555,9 @@ MTS_DEV V3 bsdfSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx,
                 sampledType = EDiffuseReflection;
                 wo = squareToCosineHemisphere(sx, sy);
             }
-            pdf = bsdfPdf(sc, m, wi, wo);
+            pdf = bsdfPdf<false>(sc, m, wi, wo);
             if (pdf == 0) return zero;
-            return bsdfEval(sc, m, wi, wo) / pdf;
+            return bsdfEval<false>(sc, m, wi, wo) / pdf;
         }
         case 3: {                                               // dielectric.cpp:277-308 (both lobes, ERadiance)
             float cosThetaT;
@@ -529,6 +576,44 @@ MTS_DEV V3 bsdfSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx,
                 const float factor = cosThetaT < 0 ? m.invEta : m.eta;
                 return ld3(m.transmittance) * (factor * factor);
             }
+        }
+        case 7: {                                               // roughdielectric.cpp:511-613 (both lobes, ERadiance)
+            if (!RD) return zero;
+            Microfacet distr; distr.init(m.distribution, m.alphaU, m.alphaV, m.sampleVisible != 0);
+            Microfacet sampleDistr = distr;
+            if (!distr.sampleVisible) sampleDistr.scaleAlpha(1.2f - 0.2f * sqrtf(fabsf(wi.z)));
+            float microfacetPdf;
+            const V3 mm = sampleDistr.sample(wi * copysignf(1.0f, wi.z), sx, sy, microfacetPdf);
+            if (microfacetPdf == 0) return zero;
+            pdf = microfacetPdf;
+            float cosThetaT;
+            const float F = fresnelDielectricExt(dot(wi, mm), cosThetaT, m.eta);
+            V3 weight = mk(1.0f);
+            const bool sampleReflection = !(su > F);
+            pdf *= sampleReflection ? F : 1 - F;
+            float dwh_dwo;
+            if (sampleReflection) {
+                wo = reflectM(wi, mm);
+                sampledType = EGlossyReflection;
+                if (wi.z * wo.z <= 0) return zero;
+                weight = weight * spec;
+                dwh_dwo = 1.0f / (4.0f * dot(wo, mm));
+            } else {
+                if (cosThetaT == 0) return zero;
+                const float e = cosThetaT < 0 ? 1 / m.eta : m.eta;      // refract(wi, m, eta, cosThetaT) (util.cpp:767-772)
+                wo = mm * (dot(wi, mm) * e + cosThetaT) - wi * e;
+                eta = cosThetaT < 0 ? m.eta : m.invEta;
+                sampledType = EGlossyTransmission;
+                if (wi.z * wo.z >= 0) return zero;
+                const float factor = cosThetaT < 0 ? m.invEta : m.eta;
+                weight = weight * (ld3(m.transmittance) * (factor * factor));
+                const float sqrtDenom = dot(wi, mm) + eta * dot(wo, mm);
+                dwh_dwo = (eta * eta * dot(wo, mm)) / (sqrtDenom * sqrtDenom);
+            }
+            if (distr.sampleVisible) weight = weight * distr.smithG1(wo, mm);
+            else weight = weight * fabsf(distr.eval(mm) * distr.G(wi, wo, mm) * dot(wi, mm) / (microfacetPdf * wi.z));
+            pdf *= fabsf(dwh_dwo);
+            return weight;
         }
         case 5: {                                               // conductor.cpp:273-288
             if (wi.z <= 0) return zero;
@@ -579,9 +664,9 @@ MTS_DEV V3 bsdfSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx,
                 wo = squareToCosineHemisphere(sx, sy);
                 sampledType = EDiffuseReflection;
             }
-            pdf = bsdfPdf(sc, m, wi, wo);
+            pdf = bsdfPdf<false>(sc, m, wi, wo);
             if (pdf == 0) return zero;
-            return bsdfEval(sc, m, wi, wo) / pdf;
+            return bsdfEval<false>(sc, m, wi, wo) / pdf;
         }
     }
 }

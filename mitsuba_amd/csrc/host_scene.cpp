@@ -143,7 +143,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         float diff[3], spec[3], trans[3];
         memcpy(diff, m.diffuse_reflectance, 12); memcpy(spec, m.specular_reflectance, 12); memcpy(trans, m.specular_transmittance, 12);
         const unsigned aniso = m.alpha_u != m.alpha_v ? EAnisotropic : 0u;
-        if (m.type == MTSAMD_BSDF_ROUGHCONDUCTOR || m.type == MTSAMD_BSDF_ROUGHPLASTIC) {
+        if (m.type == MTSAMD_BSDF_ROUGHCONDUCTOR || m.type == MTSAMD_BSDF_ROUGHPLASTIC || m.type == MTSAMD_BSDF_ROUGHDIELECTRIC) {
             if (m.distribution != MTSAMD_DISTR_BECKMANN && m.distribution != MTSAMD_DISTR_GGX)
                 return "Specified an invalid distribution, must be \"beckmann\" or \"ggx\"";
         }
@@ -196,6 +196,15 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
                 dm.typeFlags = EGlossyReflection | EDiffuseReflection | EFrontSide | aniso;
                 break;
             }
+            case MTSAMD_BSDF_ROUGHDIELECTRIC:   // roughdielectric.cpp:183-211,245-274
+                if (m.int_ior < 0 || m.ext_ior < 0 || m.int_ior == m.ext_ior)
+                    return "The interior and exterior indices of refraction must be positive and differ!";
+                ensureEnergy(ee, spec);
+                ensureEnergy(ee, trans);
+                dm.eta = m.int_ior / m.ext_ior;
+                dm.invEta = 1 / dm.eta;
+                dm.typeFlags = EGlossyReflection | EGlossyTransmission | EFrontSide | EBackSide | ENonSymmetric | aniso;
+                break;
             case MTSAMD_BSDF_CONDUCTOR:         // conductor.cpp:172-175,187-200
                 ensureEnergy(ee, spec);
                 for (int c = 0; c < 3; ++c) {

@@ -90,7 +90,7 @@ struct HeldPath {
 
 // One vertex of MIPathTracer::Li (src/integrators/path/path.cpp:135-287) for the path `in` whose ray produced `hit`.
 // Radiance gathered at this vertex goes to sampleL[slot] directly; the rest comes back in `o`.
-template <bool ENV, typename Path>
+template <bool ENV, bool RD, typename Path>
 MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &in, const float4 hit, float4 *sampleL, ShadeOut &o) {
     const uint32_t triWord = __float_as_uint(hit.w);
     if (triWord != kMiss) {
@@ -186,9 +186,9 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                     V3 c = mk(0.0f);
                     const V3 wo = toLocal(its.sh, dRec.d);
                     const V3 woSide = flipped ? mirrorZ(wo) : wo;
-                    const V3 bsdfVal = bsdfEval(sc, bsdf, wiLocal, woSide);
+                    const V3 bsdfVal = bsdfEval<RD>(sc, bsdf, wiLocal, woSide);
                     if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
-                        const float bPdf = bsdfPdf(sc, bsdf, wiLocal, woSide);    // area emitters: on surface, solid-angle measure
+                        const float bPdf = bsdfPdf<RD>(sc, bsdf, wiLocal, woSide);    // area emitters: on surface, solid-angle measure
                         c = throughput * value * bsdfVal * miWeight(dRec.pdf, bPdf);
                     }
                     o.wantShadow = true;
@@ -201,7 +201,8 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             // BSDF sampling (path.cpp:206-226)
             const float bx = rng.next1D(), by = rng.next1D();
             V3 woLocal; float bPdf, bEta; uint32_t sampledType;
-            const V3 bsdfWeight = bsdfSample(sc, bsdf, wiLocal, bx, by, woLocal, bPdf, bEta, sampledType);
+            const float bu = RD && bsdfUsesSampler(bsdf) ? rng.next1D() : 0.0f;     // bRec.sampler->next1D() inside BSDF::sample
+            const V3 bsdfWeight = bsdfSample<RD>(sc, bsdf, wiLocal, bx, by, bu, woLocal, bPdf, bEta, sampledType);
             if (flipped && !isZero(bsdfWeight) && bPdf != 0) woLocal.z = -woLocal.z;      // twosided.cpp:172-181
             if (!isZero(bsdfWeight)) {
                 if (sampledType != ENull) flags |= PF_SCATTERED;
@@ -271,10 +272,11 @@ static constexpr int kShadeBlock = MTS_SHADE_BLOCK;
 // ROUNDS: a workgroup sorts ROUNDS x kShadeBlock paths at once and shades them in ROUNDS sweeps of one path per
 // thread; the larger sort domain leaves fewer wavefronts that straddle two BSDF models.
 // ENV: the scene has an environment emitter (rays that leave the scene are shaded too, one more queue stream).
-template <int ROUNDS, bool ENV>
+// RD: the scene has a rough dielectric material.
+template <int ROUNDS, bool ENV, bool RD>
 __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out,
                                                        ShadowQueue sq, float4 *sampleL, uint32_t *counters, uint32_t n) {
-    constexpr int kWaves = kShadeBlock / 64, kKeys = 8, kCells = kKeys * ROUNDS * kWaves;
+    constexpr int kWaves = kShadeBlock / 64, kKeys = 9, kCells = kKeys * ROUNDS * kWaves;   // BSDF models 0..7, misses
     __shared__ uint32_t sCount[kCells];         // [key][round][wave]: count, then exclusive start
     __shared__ uint32_t sOrder[kShadeBlock * ROUNDS];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -323,7 +325,7 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
   for (int round = 0; round < ROUNDS; ++round) {
     const uint32_t i = first + sOrder[round * kShadeBlock + tid];
     ShadeOut o;
-    if (i < n) shadeVertex<ENV>(sc, pp, QueuedPath{ in, i }, hits[i], sampleL, o);
+    if (i < n) shadeVertex<ENV, RD>(sc, pp, QueuedPath{ in, i }, hits[i], sampleL, o);
     const bool alive = o.alive, wantShadow = o.wantShadow;
 
     // Queue slots are reserved once per workgroup (two atomics per workgroup, not per wavefront: thousands of
@@ -361,7 +363,7 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
 // functions as the wavefront kernels, hence the same results. counts[0] / counts[1] receive the closest-hit and
 // shadow rays traced (the reference's two ray counters).
 static constexpr int kTailBlock = 64;
-template <bool ENV>
+template <bool ENV, bool RD>
 __global__ void __launch_bounds__(kTailBlock) k_tail(DevScene sc, PassParams pp, PathQueue in, float4 *sampleL, uint32_t n,
                                                      uint32_t triShare, unsigned long long *counts) {
     __shared__ uint2 sStack[kLdsStack * kTailBlock];
@@ -392,7 +394,7 @@ __global__ void __launch_bounds__(kTailBlock) k_tail(DevScene sc, PassParams pp,
         traceHeldRays<false>(sc, r, busy, ldsStack, triShare);
         // shade
         ShadeOut o;
-        if (active) shadeVertex<ENV>(sc, pp, path, make_float4(r.hit.t, r.hit.u, r.hit.v, __uint_as_float(r.hit.tri)), sampleL, o);
+        if (active) shadeVertex<ENV, RD>(sc, pp, path, make_float4(r.hit.t, r.hit.u, r.hit.v, __uint_as_float(r.hit.tri)), sampleL, o);
         // shadow ray of the emitter sample (scene.cpp:839-843), then path.cpp:196-198
         const bool wantShadow = active && o.wantShadow;
         busy = false;
@@ -600,8 +602,8 @@ __global__ void k_bsdf_evalpdf(DevScene sc, int material, int mode, uint32_t n, 
     else out[i] = bsdfPdf(sc, m, a, b);
 }
 
-__global__ void k_bsdf_sample(DevScene sc, int material, uint32_t n, const float *wi, const float *sample, float *wo, float *weight,
-                              float *pdf, float *eta, uint32_t *sampledType) {
+__global__ void k_bsdf_sample(DevScene sc, int material, uint32_t n, const float *wi, const float *sample, const float *sampler1D,
+                              float *wo, float *weight, float *pdf, float *eta, uint32_t *sampledType) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     DevMaterial m;
@@ -610,7 +612,7 @@ __global__ void k_bsdf_sample(DevScene sc, int material, uint32_t n, const float
     const bool flipped = resolveTwoSided(sc, (uint32_t) material, a.z, m);
     if (flipped) a = mirrorZ(a);
     V3 o; float p, e; uint32_t t;
-    const V3 w = bsdfSample(sc, m, a, sample[2 * (size_t) i], sample[2 * (size_t) i + 1], o, p, e, t);
+    const V3 w = bsdfSample(sc, m, a, sample[2 * (size_t) i], sample[2 * (size_t) i + 1], sampler1D ? sampler1D[i] : 0.5f, o, p, e, t);
     if (flipped && !isZero(w) && p != 0) o.z = -o.z;
     wo[3 * (size_t) i] = o.x; wo[3 * (size_t) i + 1] = o.y; wo[3 * (size_t) i + 2] = o.z;
     weight[3 * (size_t) i] = w.x; weight[3 * (size_t) i + 1] = w.y; weight[3 * (size_t) i + 2] = w.z;

@@ -82,8 +82,9 @@ struct mtsamd_scene {
     unsigned traceGrid = 0, traceBlock = 256;
     uint32_t nodeStride = 5, triStride = 3;     // record strides in float4 units (padding buys line alignment)
     uint64_t overlapBelow = 8u << 20;     // rays (shadow + next extend) below which the two traversals run side by side
+    bool roughDielectric = false;         // some material is a rough dielectric (selects the kernels that know it)
     uint32_t tailBelow = 1u << 18;        // paths below which one launch finishes the pass (0 = never)
-    int shadeRounds = 8;                  // sweeps per shade workgroup (1, 2, 4, 8 or 16) ...
+    int shadeRounds = 8;                  // sweeps per shade workgroup: 8, or 1 when set below 2 ...
     uint32_t shadeRoundsAbove = 4u << 20; // ... for queues of at least this many paths
     uint32_t refillBelow = 56, triShare = 16, topNodes = 73, chunkMax = 512;
 
@@ -156,6 +157,7 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
     (void) hipGetDevice(&s->device);
 
     HostScene &h = s->host;
+    for (const DevMaterial &m : h.materials) s->roughDielectric |= m.type == MTSAMD_BSDF_ROUGHDIELECTRIC;
     if (const char *e = getenv("MTSAMD_NODE_STRIDE")) s->nodeStride = (uint32_t) std::min(16, std::max(5, atoi(e)));
     if (const char *e = getenv("MTSAMD_TRI_STRIDE")) s->triStride = (uint32_t) std::min(16, std::max(3, atoi(e)));
     auto up = [&]() -> int {
@@ -356,8 +358,10 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
             unsigned long long *tailCounts = cnt64 + CNT64_TAIL_NORMAL;
             HIP_TRY(hipMemsetAsync(tailCounts, 0, 2 * sizeof(unsigned long long), st));
             timer.begin(T_TAIL);
-            if (sc.envEmitter >= 0) hipLaunchKernelGGL((k_tail<true>), dim3(blocksFor(n, kTailBlock)), dim3(kTailBlock), 0, st, sc, pp, s->queue(cur), sampleL, n, s->triShare, tailCounts);
-            else hipLaunchKernelGGL((k_tail<false>), dim3(blocksFor(n, kTailBlock)), dim3(kTailBlock), 0, st, sc, pp, s->queue(cur), sampleL, n, s->triShare, tailCounts);
+#define MTS_LAUNCH_TAIL(E, R) hipLaunchKernelGGL((k_tail<E, R>), dim3(blocksFor(n, kTailBlock)), dim3(kTailBlock), 0, st, sc, pp, s->queue(cur), sampleL, n, s->triShare, tailCounts)
+            if (sc.envEmitter >= 0) { if (s->roughDielectric) MTS_LAUNCH_TAIL(true, true); else MTS_LAUNCH_TAIL(true, false); }
+            else { if (s->roughDielectric) MTS_LAUNCH_TAIL(false, true); else MTS_LAUNCH_TAIL(false, false); }
+#undef MTS_LAUNCH_TAIL
             timer.end(T_TAIL);
             HIP_TRY(hipMemcpyAsync(s->hostTail, tailCounts, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -384,14 +388,14 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         timer.begin(T_SHADE);
         // large queues: several sweeps per workgroup (purer wavefronts); small ones: one, to keep every CU busy
         const int rounds = n >= s->shadeRoundsAbove ? s->shadeRounds : 1;
+#define MTS_LAUNCH_SHADE_AS(R, E, D) hipLaunchKernelGGL((k_shade<R, E, D>), dim3(blocksFor(n, kShadeBlock * R)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, cnt, n)
 #define MTS_LAUNCH_SHADE(R) do { \
-            if (sc.envEmitter >= 0) hipLaunchKernelGGL((k_shade<R, true>), dim3(blocksFor(n, kShadeBlock * R)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, cnt, n); \
-            else hipLaunchKernelGGL((k_shade<R, false>), dim3(blocksFor(n, kShadeBlock * R)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, cnt, n); } while (0)
-        if (rounds >= 16) MTS_LAUNCH_SHADE(16);
-        else if (rounds >= 8) MTS_LAUNCH_SHADE(8);
-        else if (rounds >= 4) MTS_LAUNCH_SHADE(4);
-        else if (rounds >= 2) MTS_LAUNCH_SHADE(2);
+            if (sc.envEmitter >= 0) { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true); else MTS_LAUNCH_SHADE_AS(R, true, false); } \
+            else { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, false, true); else MTS_LAUNCH_SHADE_AS(R, false, false); } } while (0)
+        // (sweeps per workgroup: 8 for large queues, 1 for small ones; MTSAMD_SHADE_ROUNDS=1 switches the sweeps off)
+        if (rounds >= 2) MTS_LAUNCH_SHADE(8);
         else MTS_LAUNCH_SHADE(1);
+#undef MTS_LAUNCH_SHADE_AS
 #undef MTS_LAUNCH_SHADE
         timer.end(T_SHADE);
         HIP_TRY(hipEventRecord(s->evShaded, st));
@@ -716,16 +720,18 @@ extern "C" int mtsamd_bsdf_pdf(mtsamd_scene *s, int material, uint64_t n, const 
 }
 
 extern "C" int mtsamd_bsdf_sample(mtsamd_scene *s, int material, uint64_t n, const float *wi, const float *sample,
-                                  float *wo, float *weight, float *pdf, float *eta, uint32_t *sampled_type) {
+                                  float *wo, float *weight, float *pdf, float *eta, uint32_t *sampled_type, const float *sampler_1d) {
     TRY(checkBatch(s, n));
     if (material < 0 || (uint32_t) material >= s->dev.nMaterials) return fail(MTSAMD_EINVAL, "material index out of range");
     if (n == 0) return MTSAMD_OK;
     if (!wi || !sample || !wo || !weight || !pdf || !eta || !sampled_type) return fail(MTSAMD_EINVAL, "null argument");
     Staging sg; void *dI, *dS, *dWo, *dW, *dP, *dE, *dT;
+    void *dU = nullptr;
     TRY(sg.in(wi, n * 12, &dI)); TRY(sg.in(sample, n * 8, &dS));
+    if (sampler_1d) TRY(sg.in(sampler_1d, n * 4, &dU));
     TRY(sg.out(n * 12, &dWo)); TRY(sg.out(n * 12, &dW)); TRY(sg.out(n * 4, &dP)); TRY(sg.out(n * 4, &dE)); TRY(sg.out(n * 4, &dT));
     hipLaunchKernelGGL(k_bsdf_sample, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, material, (uint32_t) n, (const float *) dI,
-                       (const float *) dS, (float *) dWo, (float *) dW, (float *) dP, (float *) dE, (uint32_t *) dT);
+                       (const float *) dS, (const float *) dU, (float *) dWo, (float *) dW, (float *) dP, (float *) dE, (uint32_t *) dT);
     TRY(finish(s->stream));
     HIP_TRY(hipMemcpy(wo, dWo, n * 12, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(weight, dW, n * 12, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(pdf, dP, n * 4, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(eta, dE, n * 4, hipMemcpyDeviceToHost));

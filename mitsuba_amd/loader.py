@@ -216,7 +216,7 @@ def _make_bsdf(node, data_dir: Optional[str], add_material=None, named: Optional
         if len(nested) > 2:
             raise SceneFormatError("No more than two nested BRDFs can be added!")
         for m in nested:
-            if m["type"] == S.BSDF_DIELECTRIC:
+            if m["type"] in (S.BSDF_DIELECTRIC, S.BSDF_ROUGHDIELECTRIC):
                 raise SceneFormatError("Only materials without a transmission component can be nested!")
         back = -1
         if len(nested) == 2:
@@ -270,6 +270,12 @@ def _make_bsdf(node, data_dir: Optional[str], add_material=None, named: Optional
                            diffuse_reflectance=p.get("diffuseReflectance", (0.5, 0.5, 0.5)),
                            specular_reflectance=p.get("specularReflectance", (1, 1, 1)), nonlinear=p.get("nonlinear", False),
                            sample_visible=p.get("sampleVisible", True), rtrans=rt)
+    elif t == "roughdielectric":
+        if distr in ("phong", "as"):
+            raise SceneFormatError("the Phong/Ashikhmin-Shirley microfacet distribution is not supported")
+        m = S.roughdielectric(alpha=au, alpha_v=av, distribution=distr, int_ior=_ior(p, "intIOR", "bk7"), ext_ior=_ior(p, "extIOR", "air"),
+                              specular_reflectance=p.get("specularReflectance", (1, 1, 1)),
+                              specular_transmittance=p.get("specularTransmittance", (1, 1, 1)), sample_visible=p.get("sampleVisible", True))
     elif t == "conductor":
         material = p.get("material", "Cu")
         if "eta" in p and "k" in p:

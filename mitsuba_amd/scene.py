@@ -15,7 +15,8 @@ from typing import Dict, List, Optional
 
 import numpy as np
 
-BSDF_DIFFUSE, BSDF_ROUGHCONDUCTOR, BSDF_ROUGHPLASTIC, BSDF_DIELECTRIC, BSDF_WARD, BSDF_CONDUCTOR, BSDF_PLASTIC = range(7)
+BSDF_DIFFUSE, BSDF_ROUGHCONDUCTOR, BSDF_ROUGHPLASTIC, BSDF_DIELECTRIC, BSDF_WARD, BSDF_CONDUCTOR, BSDF_PLASTIC, \
+    BSDF_ROUGHDIELECTRIC = range(8)
 DISTR_BECKMANN, DISTR_GGX = 0, 1
 SHAPE_HAS_NORMALS, SHAPE_HAS_TEXCOORDS = 1, 2
 
@@ -167,6 +168,15 @@ def plastic(int_ior=IOR["polypropylene"], ext_ior=IOR["air"], diffuse_reflectanc
     """src/bsdfs/plastic.cpp:146-166"""
     return _mat(type=BSDF_PLASTIC, int_ior=int_ior, ext_ior=ext_ior, diffuse_reflectance=tuple(diffuse_reflectance),
                 specular_reflectance=tuple(specular_reflectance), variant=int(nonlinear))
+
+
+def roughdielectric(alpha=0.1, distribution="beckmann", int_ior=IOR["bk7"], ext_ior=IOR["air"], specular_reflectance=(1, 1, 1),
+                    specular_transmittance=(1, 1, 1), sample_visible=True, alpha_v=None) -> Dict:
+    """src/bsdfs/roughdielectric.cpp:183-211"""
+    return _mat(type=BSDF_ROUGHDIELECTRIC, distribution=_distr(distribution), alpha_u=alpha,
+                alpha_v=alpha if alpha_v is None else alpha_v, int_ior=int_ior, ext_ior=ext_ior,
+                specular_reflectance=tuple(specular_reflectance), specular_transmittance=tuple(specular_transmittance),
+                sample_visible=int(sample_visible))
 
 
 def twosided(front: Dict, back_material: int = -1) -> Dict:
@@ -402,8 +412,8 @@ def cornell_box(width=512, height=512, max_depth=-1) -> SceneData:
 
 
 def cornell_mixed(width=256, height=256, max_depth=-1) -> SceneData:
-    """The Cornell box with the smooth neighbours of the hot-path BSDFs: walls behind a `twosided` adapter, a smooth
-    `plastic` short box, a smooth `conductor` tall box, and a free-standing card whose two sides carry different
+    """The Cornell box with the neighbours of the hot-path BSDFs: walls behind a `twosided` adapter, a smooth
+    `plastic` short box, a smooth `conductor` tall box, a `roughdielectric` blob, and a free-standing card whose two sides carry different
     BRDFs (rough plastic towards the back wall, red diffuse towards the camera) and which the camera sees from behind."""
     b = SceneBuilder()
     white = b.add_material(twosided(diffuse((0.725, 0.71, 0.68))))
@@ -430,6 +440,10 @@ def cornell_mixed(width=256, height=256, max_depth=-1) -> SceneData:
 
     b.add_box([-82.5, 0, -82.5], [82.5, 165, 82.5], shiny, to_world=rot_y(-17, [185, 0, 169]))
     b.add_box([-82.5, 0, -82.5], [82.5, 330, 82.5], metal, to_world=rot_y(20, [368, 0, 351]))
+    # a frosted-glass blob in front of the tall box
+    frosted = b.add_material(roughdielectric(alpha=0.15, distribution="ggx", int_ior=1.5, ext_ior=1.0))
+    bp, bf, bn = blob(2, np.random.default_rng(11), radius=60.0)
+    b.add_mesh(bp + np.float32([420, 70, 120]), bf, frosted, normals=bn)
     # the card: its front normal points at the back wall (+z), the camera looks at its back
     b.add_quad([60, 250, 120], [230, 250, 150], [230, 420, 150], [60, 420, 120], card)
     y = S - 0.5

@@ -449,6 +449,13 @@ void Material::configure() {
             condK = toSpec(m.k) / m.ext_eta;
             type_flags = EDeltaReflection | EFrontSide;
             break;
+        case ORC_BSDF_ROUGHDIELECTRIC:   // src/bsdfs/roughdielectric.cpp:183-211,245-274
+            ensureEnergy(ee, specular);
+            ensureEnergy(ee, transmittance);
+            eta = m.int_ior / m.ext_ior;
+            invEta = 1 / eta;
+            type_flags = EGlossyReflection | EGlossyTransmission | EFrontSide | EBackSide | ENonSymmetric | aniso;
+            break;
         case ORC_BSDF_PLASTIC: {   // src/bsdfs/plastic.cpp:156,187-216
             ensureEnergy(ee, specular);
             ensureEnergy(ee, diffuse);
@@ -562,6 +569,33 @@ static Spectrum evalOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo
             result += mat.diffuse * INV_PI_F;
             return result * Frame::cosTheta(wo);
         }
+        case ORC_BSDF_ROUGHDIELECTRIC: {   // roughdielectric.cpp:276-346
+            if (Frame::cosTheta(wi) == 0) return Spectrum(0.0f);
+            bool reflect_ = Frame::cosTheta(wi) * Frame::cosTheta(wo) > 0;
+            Vec3 H;
+            if (reflect_) {
+                H = normalize(wo + wi);
+            } else {
+                float eta_ = Frame::cosTheta(wi) > 0 ? mat.eta : mat.invEta;
+                H = normalize(wi + wo * eta_);
+            }
+            H = H * signum(Frame::cosTheta(H));
+            MicrofacetDistribution distr(m.distribution, m.alpha_u, m.alpha_v, m.sample_visible != 0);
+            const float D = distr.eval(H);
+            if (D == 0) return Spectrum(0.0f);
+            const float F = fresnelDielectricExt(dot(wi, H), mat.eta);
+            const float G = distr.G(wi, wo, H);
+            if (reflect_) {
+                float value = F * D * G / (4.0f * std::abs(Frame::cosTheta(wi)));
+                return mat.specular * value;
+            } else {
+                float eta_ = Frame::cosTheta(wi) > 0.0f ? mat.eta : mat.invEta;
+                float sqrtDenom = dot(wi, H) + eta_ * dot(wo, H);
+                float value = ((1 - F) * D * G * eta_ * eta_ * dot(wi, H) * dot(wo, H)) / (Frame::cosTheta(wi) * sqrtDenom * sqrtDenom);
+                float factor = Frame::cosTheta(wi) > 0 ? mat.invEta : mat.eta;     // ERadiance
+                return mat.transmittance * std::abs(value * factor * factor);
+            }
+        }
         case ORC_BSDF_CONDUCTOR:   // conductor.cpp:225-239: a delta lobe only, zero for the solid-angle measure
             return Spectrum(0.0f);
         case ORC_BSDF_PLASTIC: {   // plastic.cpp:243-276, solid-angle measure: the diffuse lobe
@@ -621,6 +655,27 @@ static float pdfOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
             float diffuseProb = squareToCosineHemispherePdf(wo);
             return mat.specularSamplingWeight * specProb + (1 - mat.specularSamplingWeight) * diffuseProb;
         }
+        case ORC_BSDF_ROUGHDIELECTRIC: {   // roughdielectric.cpp:348-414
+            bool reflect_ = Frame::cosTheta(wi) * Frame::cosTheta(wo) > 0;
+            Vec3 H;
+            float dwh_dwo;
+            if (reflect_) {
+                H = normalize(wo + wi);
+                dwh_dwo = 1.0f / (4.0f * dot(wo, H));
+            } else {
+                float eta_ = Frame::cosTheta(wi) > 0 ? mat.eta : mat.invEta;
+                H = normalize(wi + wo * eta_);
+                float sqrtDenom = dot(wi, H) + eta_ * dot(wo, H);
+                dwh_dwo = (eta_ * eta_ * dot(wo, H)) / (sqrtDenom * sqrtDenom);
+            }
+            H = H * signum(Frame::cosTheta(H));
+            MicrofacetDistribution sampleDistr(m.distribution, m.alpha_u, m.alpha_v, m.sample_visible != 0);
+            if (!sampleDistr.sampleVisible) sampleDistr.scaleAlpha(1.2f - 0.2f * std::sqrt(std::abs(Frame::cosTheta(wi))));
+            float prob = sampleDistr.pdf(wi * signum(Frame::cosTheta(wi)), H);
+            float F = fresnelDielectricExt(dot(wi, H), mat.eta);
+            prob *= reflect_ ? F : (1 - F);
+            return std::abs(prob * dwh_dwo);
+        }
         case ORC_BSDF_CONDUCTOR:   // conductor.cpp:241-255: zero for the solid-angle measure
             return 0.0f;
         case ORC_BSDF_PLASTIC: {   // plastic.cpp:278-306, solid-angle measure
@@ -635,7 +690,7 @@ static float pdfOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
 }
 
 // ---- sample (the pdf-returning overload the integrator calls, path.cpp:209) --------------------------
-static Spectrum sampleOneSided(const Material &mat, const Vec3 &wi, const Vec2 &_sample, BSDFSample &out, float &pdf) {
+static Spectrum sampleOneSided(const Material &mat, const Vec3 &wi, const Vec2 &_sample, BSDFSample &out, float &pdf, Sampler1D *sampler1D) {
     const orc_material &m = mat.m;
     pdf = 0;
     out.eta = 1.0f;
@@ -742,6 +797,47 @@ static Spectrum sampleOneSided(const Material &mat, const Vec3 &wi, const Vec2 &
             if (pdf == 0) return Spectrum(0.0f);
             return evalOneSided(mat, wi, out.wo) / pdf;
         }
+        case ORC_BSDF_ROUGHDIELECTRIC: {   // roughdielectric.cpp:511-613 (both lobes enabled, ERadiance)
+            MicrofacetDistribution distr(m.distribution, m.alpha_u, m.alpha_v, m.sample_visible != 0);
+            MicrofacetDistribution sampleDistr(distr);
+            if (!distr.sampleVisible) sampleDistr.scaleAlpha(1.2f - 0.2f * std::sqrt(std::abs(Frame::cosTheta(wi))));
+            float microfacetPDF;
+            const Vec3 mm = sampleDistr.sample(wi * signum(Frame::cosTheta(wi)), _sample, microfacetPDF);
+            if (microfacetPDF == 0) return Spectrum(0.0f);
+            pdf = microfacetPDF;
+            float cosThetaT;
+            float F = fresnelDielectricExt(dot(wi, mm), cosThetaT, mat.eta);
+            Spectrum weight(1.0f);
+            bool sampleReflection = true;
+            if ((sampler1D ? sampler1D->next1D() : 0.5f) > F) { sampleReflection = false; pdf *= 1 - F; }
+            else pdf *= F;
+            float dwh_dwo;
+            if (sampleReflection) {
+                out.wo = reflect(wi, mm);
+                out.eta = 1.0f;
+                out.sampledType = EGlossyReflection;
+                if (Frame::cosTheta(wi) * Frame::cosTheta(out.wo) <= 0) return Spectrum(0.0f);
+                weight *= mat.specular;
+                dwh_dwo = 1.0f / (4.0f * dot(out.wo, mm));
+            } else {
+                if (cosThetaT == 0) return Spectrum(0.0f);
+                {   // refract(wi, m, eta, cosThetaT) (src/libcore/util.cpp:767-772)
+                    float e = cosThetaT < 0 ? 1 / mat.eta : mat.eta;
+                    out.wo = mm * (dot(wi, mm) * e + cosThetaT) - wi * e;
+                }
+                out.eta = cosThetaT < 0 ? mat.eta : mat.invEta;
+                out.sampledType = EGlossyTransmission;
+                if (Frame::cosTheta(wi) * Frame::cosTheta(out.wo) >= 0) return Spectrum(0.0f);
+                float factor = cosThetaT < 0 ? mat.invEta : mat.eta;
+                weight *= mat.transmittance * (factor * factor);
+                float sqrtDenom = dot(wi, mm) + out.eta * dot(out.wo, mm);
+                dwh_dwo = (out.eta * out.eta * dot(out.wo, mm)) / (sqrtDenom * sqrtDenom);
+            }
+            if (distr.sampleVisible) weight *= distr.smithG1(out.wo, mm);
+            else weight *= std::abs(distr.eval(mm) * distr.G(wi, out.wo, mm) * dot(wi, mm) / (microfacetPDF * Frame::cosTheta(wi)));
+            pdf *= std::abs(dwh_dwo);
+            return weight;
+        }
         case ORC_BSDF_CONDUCTOR: {   // conductor.cpp:273-288
             if (Frame::cosTheta(wi) <= 0) return Spectrum(0.0f);
             out.sampledType = EDeltaReflection;
@@ -788,9 +884,9 @@ float bsdfPdf(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
     return pdfOneSided(*mat.back, Vec3(wi.x, wi.y, -wi.z), Vec3(wo.x, wo.y, -wo.z));
 }
 
-Spectrum bsdfSample(const Material &mat, const Vec3 &wi, const Vec2 &sample, BSDFSample &out, float &pdf) {
-    if (!mat.m.two_sided || !(Frame::cosTheta(wi) < 0)) return sampleOneSided(mat, wi, sample, out, pdf);
-    Spectrum result = sampleOneSided(*mat.back, Vec3(wi.x, wi.y, -wi.z), sample, out, pdf);
+Spectrum bsdfSample(const Material &mat, const Vec3 &wi, const Vec2 &sample, BSDFSample &out, float &pdf, Sampler1D *sampler1D) {
+    if (!mat.m.two_sided || !(Frame::cosTheta(wi) < 0)) return sampleOneSided(mat, wi, sample, out, pdf, sampler1D);
+    Spectrum result = sampleOneSided(*mat.back, Vec3(wi.x, wi.y, -wi.z), sample, out, pdf, sampler1D);
     if (!result.isZero() && pdf != 0) out.wo.z *= -1;
     return result;
 }

@@ -35,6 +35,7 @@ struct MicrofacetDistribution {
     MicrofacetDistribution(int type_, float au, float av, bool sv)
         : type(type_), alphaU(std::max(au, 1e-4f)), alphaV(std::max(av, 1e-4f)), sampleVisible(sv) {}
     bool isIsotropic() const { return alphaU == alphaV; }
+    void scaleAlpha(float value) { alphaU *= value; alphaV *= value; }   // :178-183
     float getAlpha() const { return alphaU; }
     float eval(const Vec3 &m) const;                                    // :191-234
     Vec3 sample(const Vec3 &wi, const Vec2 &sample, float &pdf) const;  // :240-249
@@ -59,7 +60,10 @@ struct BSDFSample {
 // eval returns f * cos(theta_o); measure is solid angle for all smooth lobes
 Spectrum bsdfEval(const Material &m, const Vec3 &wi, const Vec3 &wo);
 float bsdfPdf(const Material &m, const Vec3 &wi, const Vec3 &wo);
-Spectrum bsdfSample(const Material &m, const Vec3 &wi, const Vec2 &sample, BSDFSample &out, float &pdf);
+// `sampler1D` stands for bRec.sampler->next1D(): BSDFs flagged EUsesSampler (roughdielectric) draw one more number
+// from the sample stream, after the 2-D sample; it is called at most once and only by them.
+struct Sampler1D { virtual float next1D() = 0; virtual ~Sampler1D() {} };
+Spectrum bsdfSample(const Material &m, const Vec3 &wi, const Vec2 &sample, BSDFSample &out, float &pdf, Sampler1D *sampler1D = nullptr);
 
 // TwoSidedBRDF::configure over the whole material list; returns an error message or nullptr
 const char *linkTwoSided(std::vector<Material> &materials);

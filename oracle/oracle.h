@@ -12,7 +12,8 @@ extern "C" {
 #endif
 
 enum { ORC_BSDF_DIFFUSE = 0, ORC_BSDF_ROUGHCONDUCTOR = 1, ORC_BSDF_ROUGHPLASTIC = 2,
-       ORC_BSDF_DIELECTRIC = 3, ORC_BSDF_WARD = 4, ORC_BSDF_CONDUCTOR = 5, ORC_BSDF_PLASTIC = 6 };
+       ORC_BSDF_DIELECTRIC = 3, ORC_BSDF_WARD = 4, ORC_BSDF_CONDUCTOR = 5, ORC_BSDF_PLASTIC = 6,
+       ORC_BSDF_ROUGHDIELECTRIC = 7 };
 enum { ORC_DISTR_BECKMANN = 0, ORC_DISTR_GGX = 1 };
 enum { ORC_SHAPE_HAS_NORMALS = 1, ORC_SHAPE_HAS_TEXCOORDS = 2 };
 
@@ -119,8 +120,9 @@ int orc_occluded(const orc_scene *s, uint64_t n, const float *rays, uint8_t *out
    eval -> out[n*3] (f*cos), pdf -> out[n], sample -> wo[n*3], weight[n*3], pdf[n], eta[n], type[n] */
 int orc_bsdf_eval(const orc_scene *s, int material, uint64_t n, const float *wi, const float *wo, float *out);
 int orc_bsdf_pdf(const orc_scene *s, int material, uint64_t n, const float *wi, const float *wo, float *out);
+/* sampler_1d (n values, may be NULL = 0.5): the number a BSDF flagged EUsesSampler takes from the sampler itself */
 int orc_bsdf_sample(const orc_scene *s, int material, uint64_t n, const float *wi, const float *sample,
-                    float *wo, float *weight, float *pdf, float *eta, uint32_t *sampled_type);
+                    float *wo, float *weight, float *pdf, float *eta, uint32_t *sampled_type, const float *sampler_1d);
 
 /* Emitter sampling without the visibility test: ref[n*3], ref_n[n*3], sample[n*2] ->
    d[n*3], dist[n], pdf[n], value[n*3] (value = radiance/pdf/emPdf, 0 if rejected) */

@@ -390,7 +390,9 @@ static Spectrum Li(const Scene &sc, const Ray &r, Pcg32 &rng, float &alpha, RayC
 
         float bsdfPdf_;
         BSDFSample bs;
-        Spectrum bsdfWeight = bsdfSample(bsdf, its.wi, rng.next2D(), bs, bsdfPdf_);
+        struct StreamTap : Sampler1D { Pcg32 &r; explicit StreamTap(Pcg32 &r_) : r(r_) {} float next1D() override { return r.next1D(); } } tap(rng);
+        const Vec2 bsdfSample2D = rng.next2D();     // drawn before anything the BSDF takes from the sampler itself
+        Spectrum bsdfWeight = bsdfSample(bsdf, its.wi, bsdfSample2D, bs, bsdfPdf_, &tap);
         if (bsdfWeight.isZero()) break;
         scattered |= bs.sampledType != ENull;
 
@@ -586,13 +588,15 @@ extern "C" int orc_bsdf_pdf(const orc_scene *s, int material, uint64_t n, const 
 }
 
 extern "C" int orc_bsdf_sample(const orc_scene *s, int material, uint64_t n, const float *wi, const float *sample,
-                               float *wo, float *weight, float *pdf, float *eta, uint32_t *sampled_type) {
+                               float *wo, float *weight, float *pdf, float *eta, uint32_t *sampled_type, const float *sampler_1d) {
     if (material < 0 || (size_t) material >= s->s.materials.size()) return -1;
     const Material &m = s->s.materials[material];
+    struct Fixed : Sampler1D { float v = 0.5f; float next1D() override { return v; } } fixed;
     for (uint64_t i = 0; i < n; ++i) {
         BSDFSample bs;
         float p;
-        Spectrum w = bsdfSample(m, Vec3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), Vec2{ sample[2 * i], sample[2 * i + 1] }, bs, p);
+        fixed.v = sampler_1d ? sampler_1d[i] : 0.5f;
+        Spectrum w = bsdfSample(m, Vec3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), Vec2{ sample[2 * i], sample[2 * i + 1] }, bs, p, &fixed);
         wo[3 * i] = bs.wo.x; wo[3 * i + 1] = bs.wo.y; wo[3 * i + 2] = bs.wo.z;
         weight[3 * i] = w.x; weight[3 * i + 1] = w.y; weight[3 * i + 2] = w.z;
         pdf[i] = p; eta[i] = bs.eta; sampled_type[i] = bs.sampledType;

@@ -153,6 +153,14 @@ private:
 			m.alpha_u = p.getFloat("alphaU", .1f); m.alpha_v = p.getFloat("alphaV", .1f);
 			rgb(p.getSpectrum("diffuseReflectance", Spectrum(.5f)), m.diffuse_reflectance);
 			rgb(p.getSpectrum("specularReflectance", Spectrum(.2f)), m.specular_reflectance);
+		} else if (type == "roughdielectric") {
+			m.type = MTSAMD_BSDF_ROUGHDIELECTRIC;
+			m.distribution = distribution(p);
+			Float a = p.getFloat("alpha", 0.1f);
+			m.alpha_u = p.getFloat("alphaU", a); m.alpha_v = p.getFloat("alphaV", a);
+			m.int_ior = p.getFloat("intIOR", 1.5046f); m.ext_ior = p.getFloat("extIOR", 1.000277f);
+			rgb(p.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular_reflectance);
+			rgb(p.getSpectrum("specularTransmittance", Spectrum(1.0f)), m.specular_transmittance);
 		} else if (type == "conductor") {
 			m.type = MTSAMD_BSDF_CONDUCTOR;
 			rgb(p.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular_reflectance);

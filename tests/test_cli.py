@@ -222,7 +222,7 @@ def test_cli_constant_emitter(scene_dir, tmp_path):
 
 def test_cli_rejects_unsupported_content(scene_dir, tmp_path):
     for body, needle in (('<shape type="sphere"/>', "not supported"),
-                         ('<shape type="cube"><bsdf type="roughdielectric"/></shape>', "outside the path hot path"),
+                         ('<shape type="cube"><bsdf type="coating"/></shape>', "outside the path hot path"),
                          ('<shape type="cube"><bsdf type="twosided"><bsdf type="dielectric"/></bsdf></shape>', "transmission component"),
                          ('<shape type="cube"><bsdf type="twosided"/></shape>', "nested one-sided material is required"),
                          ('<emitter type="envmap"/>', "only area emitters and the constant environment emitter"),

@@ -132,7 +132,10 @@ def material_pair(gpu, oracle_mod):
             S.plastic(int_ior=1.33, ext_ior=1.0, diffuse_reflectance=(0.2, 0.6, 0.4), nonlinear=True),
             S.twosided(S.diffuse((0.6, 0.5, 0.4))),
             S.twosided(S.roughconductor(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), alpha=0.15, distribution="ggx"), 6),
-            S.twosided(S.plastic(int_ior=1.49), 0)]
+            S.twosided(S.plastic(int_ior=1.49), 0),
+            S.roughdielectric(alpha=0.2, distribution="ggx", int_ior=1.5, ext_ior=1.0),
+            S.roughdielectric(alpha=0.3, distribution="beckmann", sample_visible=False, specular_transmittance=(0.9, 0.8, 0.7)),
+            S.roughdielectric(alpha=0.1, alpha_v=0.25, distribution="beckmann", int_ior=S.IOR["water"])]
     b = S.SceneBuilder()
     for m in mats:
         b.add_material(m)
@@ -166,15 +169,16 @@ def test_bsdf_sample_parity(material_pair):
     n = 200000
     for mi in range(len(mats)):
         wi = _wi(n, rng)
-        if mats[mi]["type"] == S.BSDF_DIELECTRIC or mats[mi]["two_sided"]:
+        if mats[mi]["type"] in (S.BSDF_DIELECTRIC, S.BSDF_ROUGHDIELECTRIC) or mats[mi]["two_sided"]:
             wi[::2, 2] *= -1
         s = rng.uniform(0, 1, (n, 2)).astype(np.float32)
-        a, b = g.bsdf_sample(mi, wi, s), o.bsdf_sample(mi, wi, s)
+        u = rng.uniform(0, 1, n).astype(np.float32)       # what an EUsesSampler BSDF draws from the sampler itself
+        a, b = g.bsdf_sample(mi, wi, s, u), o.bsdf_sample(mi, wi, s, u)
         same_type = a[4] == b[4]
         assert same_type.mean() > 0.9999, mi          # a lobe choice can flip when a sample sits on the threshold
         ok = same_type
         # the Beckmann visible-normal sampler is an iterative root find: allow 1e-3 there, 1e-4 elsewhere
-        tol = 1e-3 if (mats[mi]["distribution"] == 0 and mats[mi]["type"] in (1, 2)) else 1e-4
+        tol = 1e-3 if (mats[mi]["distribution"] == 0 and mats[mi]["type"] in (1, 2, 7)) else 1e-4
         assert np.mean(np.all(_close(a[0][ok], b[0][ok], tol, 1e-5), axis=1)) > 0.999, ("wo", mi)
         assert np.mean(np.all(_close(a[1][ok], b[1][ok], 10 * tol, 1e-5), axis=1)) > 0.998, ("weight", mi)
         assert np.mean(_close(a[2][ok], b[2][ok], 10 * tol, 1e-5)) > 0.998, ("pdf", mi)
