@@ -323,19 +323,26 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
     }
     __shared__ uint32_t sWaveShadow[kWaves], sWaveNext[kWaves], sBase[2];
   for (int round = 0; round < ROUNDS; ++round) {
-    const uint32_t i = first + sOrder[round * kShadeBlock + tid];
+    // The thread's coordinates are made opaque per sweep so that nothing derived from them is carried in registers
+    // across the shading code (the register allocator would spill it there).
+    uint32_t tidS = threadIdx.x;
+    asm volatile("" : "+v"(tidS));
+    const uint32_t i = first + sOrder[round * kShadeBlock + tidS];
     ShadeOut o;
     if (i < n) shadeVertex<ENV, RD>(sc, pp, QueuedPath{ in, i }, hits[i], sampleL, o);
     const bool alive = o.alive, wantShadow = o.wantShadow;
+    uint32_t tidL = threadIdx.x;
+    asm volatile("" : "+v"(tidL));
+    const uint32_t laneL = tidL & 63u, waveL = tidL >> 6;
 
     // Queue slots are reserved once per workgroup (two atomics per workgroup, not per wavefront: thousands of
     // wavefronts hammering the same two counters serialise at the L2): wave totals go through LDS, thread 0 reserves
     // the workgroup's ranges, every wave adds the totals of the waves before it.
-    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long below = (1ull << laneL) - 1ull;
     const unsigned long long mShadow = __ballot(wantShadow), mNext = __ballot(alive);
-    if (lane == 0) { sWaveShadow[wave] = (uint32_t) __popcll(mShadow); sWaveNext[wave] = (uint32_t) __popcll(mNext); }
+    if (laneL == 0) { sWaveShadow[waveL] = (uint32_t) __popcll(mShadow); sWaveNext[waveL] = (uint32_t) __popcll(mNext); }
     __syncthreads();
-    if (tid == 0) {
+    if (tidL == 0) {
         uint32_t ts = 0, tn = 0;
         for (int w = 0; w < kWaves; ++w) { ts += sWaveShadow[w]; tn += sWaveNext[w]; }
         // both queue lengths live in one 64-bit word (next in the low half, shadow in the high half): one atomic
@@ -347,7 +354,7 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
     }
     __syncthreads();
     uint32_t si = sBase[0] + (uint32_t) __popcll(mShadow & below), oi = sBase[1] + (uint32_t) __popcll(mNext & below);
-    for (uint32_t w = 0; w < wave; ++w) { si += sWaveShadow[w]; oi += sWaveNext[w]; }
+    for (uint32_t w = 0; w < waveL; ++w) { si += sWaveShadow[w]; oi += sWaveNext[w]; }
     if (wantShadow) { sq.rayO[si] = o.sRayO; sq.rayD[si] = o.sRayD; sq.contrib[si] = o.sContrib; }
     if (alive) {
         out.rayO[oi] = o.oRayO; out.rayD[oi] = o.oRayD; out.thr[oi] = o.oThr; out.misc[oi] = o.oMisc; out.bsdfPdf[oi] = o.oPdf;
