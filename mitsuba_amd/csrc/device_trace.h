@@ -23,6 +23,7 @@ static constexpr int kNodeFloat4 = 5;       // a wide node is 5 x float4
 // these are the top levels every ray walks through), then kLdsStack stack entries per lane,
 // and a buffer of one prepared ray (two float4 and its index) per lane from which idle lanes are refilled.
 static constexpr int kRayBufBytes = 36;     // per lane
+static constexpr int kFetchHeads = 8, kFetchHeadStride = 16;    // one hand-out counter per XCD, 64 bytes apart
 inline size_t traceLdsBytes(uint32_t topNodes, uint32_t blockThreads) {
     return (size_t) topNodes * kNodeFloat4 * 16 + (size_t) kLdsStack * blockThreads * 8 + (size_t) kRayBufBytes * blockThreads;
 }
@@ -239,7 +240,12 @@ struct TraceArgs {
     const float4 *rayO, *rayD;      // origin.xyz + mint, direction.xyz + maxt of ray i at [i * stride]
     uint32_t stride, n;
     uint32_t topNodes;              // number of leading BVH nodes staged in LDS (<= node count)
-    uint32_t *fetchCounter;         // zero at launch; waves take chunks of `chunk` consecutive rays from it
+    // Ray hand-out: the rays are cut into `segments` contiguous ranges of `segmentLen` rays, each with a head counter
+    // of its own (zero at launch, kFetchHeadStride words apart). A wave starts on the range of its own XCD, so that
+    // the rays one XCD's L2 sees stay neighbours in the queue, takes chunks of `chunk` rays from it and moves on to the
+    // next range when that one is empty.
+    uint32_t *fetchHeads;
+    uint32_t segments, segmentLen;
     uint32_t chunk;
     float4 *hits;                   // TRACE_CLOSEST: (t, u, v, triangle) per ray
     uint8_t *occluded;              // TRACE_OCCLUDED: one byte per ray
@@ -283,6 +289,8 @@ MTS_DEV void traceLoop(const DevScene &sc, const TraceArgs &a, LdsFloat4 *topTre
     int ray = -1;               // index of the ray this lane holds, -1 = idle
     bool exhausted = false;     // wave-uniform: the counter has run past the last ray
     uint32_t chunkNext = 0, chunkEnd = 0;   // wave-uniform: the part of the wave's current chunk not prepared yet
+    // wave-uniform: the range this wave draws from (first its XCD's: HW_REG_XCC_ID, bits 3:0) and how many it found empty
+    uint32_t seg = ((uint32_t) __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) % a.segments, segTried = 0;
     uint32_t bufHead = 0, bufCount = 0;     // wave-uniform: prepared rays waiting in LDS
     uint32_t nv = 0, nt = 0, ne = 0, ns = 0;
 
@@ -290,12 +298,19 @@ MTS_DEV void traceLoop(const DevScene &sc, const TraceArgs &a, LdsFloat4 *topTre
         const unsigned long long idleMask = __ballot(ray < 0);
         // ---- producer: prepare the next 64 rays of the chunk when the buffer has run dry
         if (idleMask && bufCount == 0 && !exhausted) {
-            if (chunkNext >= chunkEnd) {
+            while (chunkNext >= chunkEnd && segTried < a.segments) {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(a.fetchCounter, a.chunk);
+                if (lane == 0) base = atomicAdd(a.fetchHeads + seg * kFetchHeadStride, a.chunk);
                 base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
-                chunkNext = base < a.n ? base : a.n;
-                chunkEnd = base + a.chunk < a.n ? base + a.chunk : a.n;
+                const uint32_t segFirst = seg * a.segmentLen;
+                const uint32_t segEnd = segFirst + a.segmentLen < a.n ? segFirst + a.segmentLen : a.n;
+                if (segFirst < a.n && base < segEnd - segFirst) {
+                    chunkNext = segFirst + base;
+                    chunkEnd = chunkNext + a.chunk < segEnd ? chunkNext + a.chunk : segEnd;
+                } else {        // this range is handed out: on to the next one
+                    seg = seg + 1 < a.segments ? seg + 1 : 0;
+                    ++segTried;
+                }
             }
             if (chunkNext >= chunkEnd) {
                 exhausted = true;

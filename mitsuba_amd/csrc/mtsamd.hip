@@ -68,7 +68,7 @@ struct mtsamd_scene {
     DeviceBuffer nodes, tris, shadeTris, shadeUV, shapes, materials, emitters,
         emitterCdf, areaCdf, rtrans;
     // work buffers of the wavefront loop
-    DeviceBuffer qbuf[2][6], hits, sbuf[3], sampleL, samplePos, shadowFlags, counters, scratch[8];
+    DeviceBuffer fetchHeads, qbuf[2][6], hits, sbuf[3], sampleL, samplePos, shadowFlags, counters, scratch[8];
     size_t capacity = 0;
     hipStream_t stream = nullptr;
     hipStream_t shadowStream = nullptr;   // shadow rays of bounce k are traced next to the extension rays of bounce k+1
@@ -83,6 +83,7 @@ struct mtsamd_scene {
     uint32_t nodeStride = 5, triStride = 3;     // record strides in float4 units (padding buys line alignment)
     uint64_t overlapBelow = 8u << 20;     // rays (shadow + next extend) below which the two traversals run side by side
     bool roughDielectric = false;         // some material is a rough dielectric (selects the kernels that know it)
+    uint32_t xcdRanges = 8;               // ranges of rays with a hand-out counter each (8 = one per XCD, 1 = one for all)
     uint32_t tailBelow = 1u << 18;        // paths below which one launch finishes the pass (0 = never)
     int shadeRounds = 8;                  // sweeps per shade workgroup: 8, or 1 when set below 2 ...
     uint32_t shadeRoundsAbove = 4u << 20; // ... for queues of at least this many paths
@@ -196,6 +197,7 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
             HIP_TRY(hipDeviceSynchronize());
         }
         HIP_TRY(s->counters.ensure(CNT_WORDS * sizeof(uint32_t)));
+        HIP_TRY(s->fetchHeads.ensure(2 * kFetchHeads * kFetchHeadStride * sizeof(uint32_t)));
         HIP_TRY(hipMemset(s->counters.ptr, 0, CNT_WORDS * sizeof(uint32_t)));
         HIP_TRY(hipStreamCreate(&s->stream));
         HIP_TRY(hipStreamCreate(&s->shadowStream));
@@ -224,6 +226,7 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
         if (const char *e = getenv("MTSAMD_REFILL_BELOW")) s->refillBelow = (uint32_t) std::min(64, std::max(1, atoi(e)));
         if (const char *e = getenv("MTSAMD_TRI_SHARE")) s->triShare = (uint32_t) std::min(64, std::max(1, atoi(e)));
         if (const char *e = getenv("MTSAMD_OVERLAP_BELOW")) s->overlapBelow = (uint64_t) std::max(0ll, atoll(e));
+        if (const char *e = getenv("MTSAMD_XCD_RANGES")) s->xcdRanges = (uint32_t) std::min(8, std::max(1, atoi(e)));
         if (const char *e = getenv("MTSAMD_TAIL_BELOW")) s->tailBelow = (uint32_t) std::max(0ll, atoll(e));
         if (const char *e = getenv("MTSAMD_SHADE_ROUNDS")) s->shadeRounds = atoi(e);
         if (const char *e = getenv("MTSAMD_SHADE_ROUNDS_ABOVE")) s->shadeRoundsAbove = (uint32_t) std::max(0ll, atoll(e));
@@ -316,6 +319,11 @@ void launchTrace(mtsamd_scene *s, TraceArgs a, hipStream_t st) {
     // chunk of rays a wave takes per atomic: large enough to make the counter cheap, small enough to balance the tail
     const uint64_t waves = (uint64_t) grid * (s->traceBlock / 64);
     a.chunk = (uint32_t) std::min<uint64_t>(s->chunkMax, std::max<uint64_t>(64, (a.n / (waves * 8)) / 64 * 64));
+    // hand-out counters: one range of rays per XCD (MTSAMD_XCD_RANGES=1: a single range)
+    a.segments = s->xcdRanges;
+    a.segmentLen = (uint32_t) (((uint64_t) a.n + a.segments - 1) / a.segments + 63) / 64 * 64;
+    a.fetchHeads = s->fetchHeads.as<uint32_t>() + (MODE == TRACE_CLOSEST ? 0 : kFetchHeads * kFetchHeadStride);
+    (void) hipMemsetAsync(a.fetchHeads, 0, kFetchHeads * kFetchHeadStride * sizeof(uint32_t), st);
     const size_t lds = traceLdsBytes(s->topNodes, s->traceBlock);
     if (s->countTraversal) hipLaunchKernelGGL((k_trace<MODE, true>), dim3(grid), dim3(s->traceBlock), lds, st, s->dev, a);
     else hipLaunchKernelGGL((k_trace<MODE, false>), dim3(grid), dim3(s->traceBlock), lds, st, s->dev, a);
@@ -376,7 +384,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         TraceArgs ta;
         memset(&ta, 0, sizeof(ta));
         ta.rayO = qin.rayO; ta.rayD = qin.rayD; ta.stride = 1; ta.n = n;
-        ta.fetchCounter = cnt + CNT_EXT_FETCH; ta.hits = hits; ta.stats = cnt64 + CNT64_EXT_NODES;
+        ta.hits = hits; ta.stats = cnt64 + CNT64_EXT_NODES;
         timer.begin(T_EXTEND);
         launchTrace<TRACE_CLOSEST>(s, ta, st);
         timer.end(T_EXTEND);
@@ -406,7 +414,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
             TraceArgs sa;
             memset(&sa, 0, sizeof(sa));
             sa.rayO = sq.rayO; sa.rayD = sq.rayD; sa.stride = 1; sa.n = nShadow;
-            sa.fetchCounter = cnt + CNT_SHD_FETCH; sa.occluded = s->shadowFlags.as<uint8_t>(); sa.stats = cnt64 + CNT64_SHD_NODES;
+            sa.occluded = s->shadowFlags.as<uint8_t>(); sa.stats = cnt64 + CNT64_SHD_NODES;
             // Launches that cannot fill the device by themselves go to a second stream: the shadow rays only need this
             // bounce's shade and run beside the next bounce's extend, each hiding the other's ramp-up and drain.
             const bool beside = (uint64_t) nShadow + nNext < s->overlapBelow;
@@ -596,12 +604,10 @@ int finish(hipStream_t st) {
 // Batch query over host-layout rays (8 floats each: origin, mint, direction, maxt) already on the device.
 template <int MODE>
 int traceBatch(mtsamd_scene *s, const void *raysDev, uint64_t n, float4 *hitsDev, uint8_t *occludedDev) {
-    uint32_t *cnt = s->counters.as<uint32_t>();
-    HIP_TRY(hipMemsetAsync(cnt + CNT_EXT_FETCH, 0, sizeof(uint32_t), s->stream));
     TraceArgs a;
     memset(&a, 0, sizeof(a));
     a.rayO = (const float4 *) raysDev; a.rayD = a.rayO + 1; a.stride = 2; a.n = (uint32_t) n;
-    a.fetchCounter = cnt + CNT_EXT_FETCH; a.hits = hitsDev; a.occluded = occludedDev;
+    a.hits = hitsDev; a.occluded = occludedDev;
     a.stats = s->counters.as<unsigned long long>() + CNT64_EXT_NODES;
     launchTrace<MODE>(s, a, s->stream);
     return MTSAMD_OK;
