@@ -1,8 +1,8 @@
 // mtsamd-render: standalone caller of the C ABI. Loads a Mitsuba 0.5 scene file (the subset scene_loader.h lists),
-// renders it with the `path` integrator on one MI355X and writes a PFM image, the role `mitsuba scene.xml -o out`
+// renders it with the `path` integrator on one MI355X and writes a PFM or OpenEXR image, the role `mitsuba scene.xml -o out`
 // plays for the reference (src/mitsuba/mitsuba.cpp:129-397, film output src/films/hdrfilm.cpp:481-537).
 //
-//   mtsamd-render scene.xml -o out.pfm [--spp N] [--size W H] [--seed S] [--device D] [--data-dir DIR]
+//   mtsamd-render scene.xml -o out.pfm|out.exr [--spp N] [--size W H] [--seed S] [--device D] [--data-dir DIR]
 //                 [--max-depth N] [--describe] [--film out.raw] [-D name=value ...]
 //
 // --describe prints a JSON summary of the loaded scene and exits without touching the GPU.
@@ -19,7 +19,7 @@
 using namespace mtsamd_host;
 
 static int usage() {
-    fprintf(stderr, "usage: mtsamd-render scene.xml -o out.pfm [--spp N] [--size W H] [--seed S] [--device D] [--data-dir DIR] "
+    fprintf(stderr, "usage: mtsamd-render scene.xml -o out.pfm|out.exr [--spp N] [--size W H] [--seed S] [--device D] [--data-dir DIR] "
                     "[--max-depth N] [--describe] [--film out.raw] [-D name=value ...]\n");
     return 2;
 }
@@ -108,7 +108,9 @@ int main(int argc, char **argv) {
     mtsamd_film_develop(handle, film.data(), rgba.data());
     mtsamd_scene_destroy(handle);
 
-    const std::string werr = writePfm(outPath, rgba.data(), W, H);
+    // the extension picks the container, like HDRFilm's fileFormat: .exr -> OpenEXR, anything else -> PFM
+    const bool exr = outPath.size() >= 4 && outPath.compare(outPath.size() - 4, 4, ".exr") == 0;
+    const std::string werr = exr ? writeExr(outPath, rgba.data(), W, H) : writePfm(outPath, rgba.data(), W, H);
     if (!werr.empty()) { fprintf(stderr, "mtsamd-render: %s\n", werr.c_str()); return 1; }
     if (!filmPath.empty()) {
         FILE *f = fopen(filmPath.c_str(), "wb");

@@ -690,6 +690,47 @@ std::string writePfm(const std::string &path, const float *rgba, int width, int 
     return "";
 }
 
+// OpenEXR, the format HDRFilm writes by default (src/films/hdrfilm.cpp:213-223, Bitmap::writeOpenEXR in
+// src/libcore/bitmap.cpp): here a single-part scan-line file, version 2, three 32-bit float channels (B, G, R in the
+// file's alphabetical order), no compression, rows top to bottom. Any OpenEXR reader opens it; the reference's
+// default of half-precision samples with PIZ compression is a storage choice, not a different image.
+std::string writeExr(const std::string &path, const float *rgba, int width, int height) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return "cannot write " + path;
+    std::vector<uint8_t> h;
+    auto put = [&](const void *p, size_t n) { h.insert(h.end(), (const uint8_t *) p, (const uint8_t *) p + n); };
+    auto putStr = [&](const char *z) { put(z, strlen(z) + 1); };
+    auto putI = [&](int32_t v) { put(&v, 4); };
+    auto putF = [&](float v) { put(&v, 4); };
+    auto attr = [&](const char *name, const char *type, int32_t size) { putStr(name); putStr(type); putI(size); };
+    putI(20000630); putI(2);
+    attr("channels", "chlist", 3 * 18 + 1);
+    for (const char *c : { "B", "G", "R" }) { putStr(c); putI(2 /* FLOAT */); putI(0); putI(1); putI(1); }
+    h.push_back(0);
+    attr("compression", "compression", 1); h.push_back(0);
+    attr("dataWindow", "box2i", 16); putI(0); putI(0); putI(width - 1); putI(height - 1);
+    attr("displayWindow", "box2i", 16); putI(0); putI(0); putI(width - 1); putI(height - 1);
+    attr("lineOrder", "lineOrder", 1); h.push_back(0);
+    attr("pixelAspectRatio", "float", 4); putF(1.0f);
+    attr("screenWindowCenter", "v2f", 8); putF(0.0f); putF(0.0f);
+    attr("screenWindowWidth", "float", 4); putF(1.0f);
+    h.push_back(0);
+    const uint64_t rowBytes = 8 + (uint64_t) width * 12;
+    uint64_t offset = h.size() + (uint64_t) height * 8;
+    for (int y = 0; y < height; ++y, offset += rowBytes) put(&offset, 8);
+    fwrite(h.data(), 1, h.size(), f);
+    std::vector<float> row((size_t) width * 3);
+    for (int y = 0; y < height; ++y) {
+        const int32_t head[2] = { y, (int32_t) (width * 12) };
+        fwrite(head, 4, 2, f);
+        for (int c = 0; c < 3; ++c)         // B, G, R planes of the row
+            for (int x = 0; x < width; ++x) row[(size_t) c * width + x] = rgba[4 * ((size_t) y * width + x) + (2 - c)];
+        fwrite(row.data(), sizeof(float), row.size(), f);
+    }
+    fclose(f);
+    return "";
+}
+
 // Stanford PLY (src/shapes/ply.cpp:91-137,202-316): ASCII and both binary byte orders; vertex properties x y z,
 // nx ny nz, u|texture_u|s and v|texture_v|t (anything else, vertex colours included, is skipped); faces are
 // triangles or quads through vertex_indices|vertex_index, a quad (a,b,c,d) becoming (a,b,c) and (d,a,c).

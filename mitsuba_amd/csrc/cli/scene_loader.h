@@ -55,5 +55,7 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
 
 // Portable float map, the format HDRFilm writes for ".pfm" (src/films/hdrfilm.cpp:226-227): RGB, bottom row first.
 std::string writePfm(const std::string &path, const float *rgba, int width, int height);
+// OpenEXR (HDRFilm's default container): RGB, 32-bit float, uncompressed scan lines, top row first.
+std::string writeExr(const std::string &path, const float *rgba, int width, int height);
 
 }  // namespace mtsamd_host

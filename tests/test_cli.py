@@ -258,3 +258,40 @@ def test_cli_render_matches_binding(scene_dir, tmp_path):
     w = film_cli[..., 4:5]
     assert np.allclose(img, np.where(w != 0, film_cli[..., :3] / np.where(w != 0, w, 1), 0), rtol=1e-5, atol=1e-6)
     assert img.mean() > 0.01
+    # the same render as OpenEXR: header attributes, offset table and the B, G, R planes of every scan line
+    exr = tmp_path / "out.exr"
+    out = subprocess.run([CLI, str(scene_dir / "scene.xml"), "-o", str(exr), "--spp", "8", "--seed", "3"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert np.allclose(_read_exr(str(exr)), img, rtol=1e-6, atol=0)
+
+
+def _read_exr(path):
+    """Minimal reader for uncompressed single-part scan-line OpenEXR files with 32-bit float channels."""
+    b = open(path, "rb").read()
+    assert struct.unpack_from("<ii", b, 0) == (20000630, 2)
+    pos, attrs = 8, {}
+    while b[pos] != 0:
+        e = b.index(b"\0", pos); name = b[pos:e].decode(); pos = e + 1
+        e = b.index(b"\0", pos); typ = b[pos:e].decode(); pos = e + 1
+        size, = struct.unpack_from("<i", b, pos); pos += 4
+        attrs[name] = (typ, b[pos:pos + size]); pos += size
+    pos += 1
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    chans, p = [], 0
+    cl = attrs["channels"][1]
+    while cl[p] != 0:
+        e = cl.index(b"\0", p); chans.append(cl[p:e].decode()); p = e + 1
+        assert struct.unpack_from("<i", cl, p)[0] == 2       # FLOAT
+        p += 16
+    assert chans == ["B", "G", "R"]
+    offsets = struct.unpack_from("<%dQ" % h, b, pos)
+    img = np.zeros((h, w, 3), np.float32)
+    for y in range(h):
+        yy, size = struct.unpack_from("<ii", b, offsets[y])
+        assert yy == y and size == w * 12
+        row = np.frombuffer(b, np.float32, 3 * w, offsets[y] + 8).reshape(3, w)
+        img[y] = row[::-1].T
+    return img
