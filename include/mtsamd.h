@@ -85,13 +85,22 @@ typedef struct {
     int32_t back_material;
 } mtsamd_material;
 
-/* AreaLight attached to a mesh (src/emitters/area.cpp) or, with shape = -1, the constant environment emitter
-   (src/emitters/constant.cpp; at most one per scene, src/librender/scene.cpp:509-513). For an area light the
-   shape's `emitter` field must point back at this record. */
+/* Emitter record. type MTSAMD_EMITTER_SURFACE: an AreaLight attached to a mesh (src/emitters/area.cpp; the shape's
+   `emitter` field must point back at this record) or, with shape = -1, the constant environment emitter
+   (src/emitters/constant.cpp; at most one per scene, src/librender/scene.cpp:509-513).
+   The other types have no surface and are only reached by emitter sampling: MTSAMD_EMITTER_POINT
+   (src/emitters/point.cpp, `radiance` = intensity), MTSAMD_EMITTER_SPOT (src/emitters/spot.cpp, `radiance` = intensity,
+   constant texture) and MTSAMD_EMITTER_DIRECTIONAL (src/emitters/directional.cpp, `radiance` = irradiance); they take
+   their position and direction (+z) from to_world, and `shape` is ignored. */
+enum { MTSAMD_EMITTER_SURFACE = 0, MTSAMD_EMITTER_POINT = 1, MTSAMD_EMITTER_SPOT = 2, MTSAMD_EMITTER_DIRECTIONAL = 3 };
 typedef struct {
     int32_t shape;
     float radiance[3];
     float sampling_weight;      /* Emitter::getSamplingWeight() */
+    int32_t type;
+    float to_world[16];         /* row-major emitter-to-world (Emitter::getWorldTransform) */
+    float cutoff_angle;         /* spot: degrees (spot.cpp:70) */
+    float beam_width;           /* spot: degrees (spot.cpp:71) */
 } mtsamd_emitter;
 
 /* PerspectiveCamera (src/sensors/perspective.cpp) */

@@ -47,6 +47,15 @@ static void describe(const LoadedScene &s) {
     for (size_t i = 0; i < s.materials.size(); ++i) printf("%s%d", i ? ", " : "", s.materials[i].back_material);
     printf("], \"shape_triangles\": [");
     for (size_t i = 0; i < s.shapes.size(); ++i) printf("%s%u", i ? ", " : "", s.shapes[i].n_triangles);
+    printf("], \"emitter_records\": [");
+    for (size_t i = 0; i < s.emitters.size(); ++i) {
+        const mtsamd_emitter &e = s.emitters[i];
+        printf("%s{\"type\": %d, \"shape\": %d, \"radiance\": [%.9g, %.9g, %.9g], \"sampling_weight\": %.9g, \"cutoff_angle\": %.9g, "
+               "\"beam_width\": %.9g, \"to_world\": [", i ? ", " : "", e.type, e.shape, e.radiance[0], e.radiance[1], e.radiance[2],
+               e.sampling_weight, e.cutoff_angle, e.beam_width);
+        for (int k = 0; k < 16; ++k) printf("%s%.9g", k ? ", " : "", e.to_world[k]);
+        printf("]}");
+    }
     printf("]}\n");
 }
 

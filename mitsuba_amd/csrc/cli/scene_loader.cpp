@@ -153,7 +153,7 @@ Mat4 parseTransform(const Element &node) {
 
 // ---- properties ---------------------------------------------------------------------------------------------------------
 struct Value {
-    enum Kind { Float, Int, Bool, String, Rgb, Transform } kind = Float;
+    enum Kind { Float, Int, Bool, String, Rgb, Transform, Vec3 } kind = Float;     // Vec3 (<point>, <vector>) uses `rgb`
     double f = 0; long i = 0; bool b = false; std::string s; float rgb[3] = { 0, 0, 0 }; Mat4 t;
 };
 typedef std::map<std::string, Value> Props;
@@ -202,6 +202,11 @@ Props parseProps(const Element &node) {
         else if (c.tag == "string") { v.kind = Value::String; v.s = c.get("value"); }
         else if (c.tag == "rgb" || c.tag == "srgb" || c.tag == "spectrum") { v.kind = Value::Rgb; parseSpectrum(c, v.rgb); }
         else if (c.tag == "transform") { v.kind = Value::Transform; v.t = parseTransform(c); }
+        else if (c.tag == "point" || c.tag == "vector") {   // scenehandler.cpp:443-459
+            v.kind = Value::Vec3;
+            const char *axes[3] = { "x", "y", "z" };
+            for (int i = 0; i < 3; ++i) v.rgb[i] = c.has(axes[i]) ? (float) std::stod(c.get(axes[i])) : 0.0f;
+        }
         else continue;
         out[name] = v;
     }
@@ -470,6 +475,7 @@ void addMesh(LoadedScene &out, const Mesh &mesh, uint32_t material, const float 
     if (!mesh.texcoords.empty()) { out.texcoords.insert(out.texcoords.end(), mesh.texcoords.begin(), mesh.texcoords.end()); out.anyTexcoords = true; }
     if (radiance) {
         mtsamd_emitter e;
+        memset(&e, 0, sizeof(e));
         e.shape = (int32_t) out.shapes.size();
         memcpy(e.radiance, radiance, 12);
         e.sampling_weight = samplingWeight;
@@ -1057,13 +1063,57 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
             } else if (el.tag == "bsdf") {
                 // handled above
             } else if (el.tag == "emitter") {
-                if (el.get("type") != "constant")
-                    return "only area emitters and the constant environment emitter are supported (found a scene-level <emitter type=\"" + el.get("type") + "\">)";
-                const Props ep = parseProps(el);    // src/emitters/constant.cpp:47-50
+                const std::string etype = el.get("type");
+                const Props ep = parseProps(el);
                 mtsamd_emitter e;
+                memset(&e, 0, sizeof(e));
                 e.shape = -1;
-                getRgb(ep, "radiance", 1, 1, 1, e.radiance);
                 e.sampling_weight = (float) getF(ep, "samplingWeight", 1.0);
+                Mat4 toWorld = ep.count("toWorld") ? ep.at("toWorld").t : Mat4::identity();
+                if (etype == "constant") {          // src/emitters/constant.cpp:47-50
+                    getRgb(ep, "radiance", 1, 1, 1, e.radiance);
+                } else if (etype == "point") {      // src/emitters/point.cpp:58-69
+                    e.type = MTSAMD_EMITTER_POINT;
+                    getRgb(ep, "intensity", 1, 1, 1, e.radiance);
+                    if (ep.count("position")) {
+                        if (ep.count("toWorld")) return "Only one of the parameters 'position' and 'toWorld' can be used!";
+                        for (int i = 0; i < 3; ++i) toWorld.m[4 * i + 3] = ep.at("position").rgb[i];
+                    }
+                } else if (etype == "spot") {       // src/emitters/spot.cpp:67-78
+                    e.type = MTSAMD_EMITTER_SPOT;
+                    getRgb(ep, "intensity", 1, 1, 1, e.radiance);
+                    for (const auto &cp : el.children)
+                        if (cp->tag == "texture") return "spot emitter: only a constant texture is supported";
+                    float tex[3];
+                    getRgb(ep, "texture", 1, 1, 1, tex);
+                    for (int i = 0; i < 3; ++i) e.radiance[i] *= tex[i];
+                    e.cutoff_angle = (float) getF(ep, "cutoffAngle", 20);
+                    e.beam_width = (float) getF(ep, "beamWidth", e.cutoff_angle * 3.0f / 4.0f);
+                    if (!(e.cutoff_angle >= e.beam_width)) return "spot emitter: the cutoff angle must not be smaller than the beam width";
+                } else if (etype == "directional") {    // src/emitters/directional.cpp:56-73
+                    e.type = MTSAMD_EMITTER_DIRECTIONAL;
+                    getRgb(ep, "irradiance", 1, 1, 1, e.radiance);
+                    if (ep.count("direction")) {
+                        if (ep.count("toWorld")) return "Only one of the parameters 'direction' and 'toWorld' can be used at a time!";
+                        const float *v = ep.at("direction").rgb;
+                        const float len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                        if (len == 0) return "directional emitter: the direction is zero";
+                        const float a[3] = { v[0] / len, v[1] / len, v[2] / len };
+                        float c[3];     // coordinateSystem (src/libcore/util.cpp:592-601): u = cross(c, a)
+                        if (std::fabs(a[0]) > std::fabs(a[1])) {
+                            const float inv = 1.0f / std::sqrt(a[0] * a[0] + a[2] * a[2]);
+                            c[0] = a[2] * inv; c[1] = 0.0f; c[2] = -a[0] * inv;
+                        } else {
+                            const float inv = 1.0f / std::sqrt(a[1] * a[1] + a[2] * a[2]);
+                            c[0] = 0.0f; c[1] = a[2] * inv; c[2] = -a[1] * inv;
+                        }
+                        const float u[3] = { c[1] * a[2] - c[2] * a[1], c[2] * a[0] - c[0] * a[2], c[0] * a[1] - c[1] * a[0] };
+                        toWorld = lookAt({ 0, 0, 0 }, { a[0], a[1], a[2] }, { u[0], u[1], u[2] });
+                    }
+                } else {
+                    return "emitter type '" + etype + "' is not supported (area, constant, point, spot, directional)";
+                }
+                for (int i = 0; i < 16; ++i) e.to_world[i] = (float) toWorld.m[i];
                 out.emitters.push_back(e);
             } else if (el.tag == "default" || el.tag == "alias") {
                 // handled above

@@ -707,7 +707,7 @@ MTS_DEV uint32_t cdfSampleReuse(const float *cdf, uint32_t n /* entries */, floa
     return index;
 }
 
-struct DirectRec { V3 d; float dist, pdf; };
+struct DirectRec { V3 d; float dist, pdf; bool delta; };
 
 // warp::squareToUniformSphere (src/libcore/warp.cpp:25-31)
 MTS_DEV V3 squareToUniformSphere(float sx, float sy) {
@@ -774,16 +774,51 @@ MTS_DEV float environmentPdfDirect(const DevScene &sc, float refCos) {
     return pdfSA * sc.envPdfDiscrete;
 }
 
+// PointEmitter::sampleDirect (src/emitters/point.cpp:131-147), SpotEmitter::sampleDirect with falloffCurve
+// (src/emitters/spot.cpp:105-125,184-200) and DirectionalEmitter::sampleDirect (src/emitters/directional.cpp:159-180)
+// inside Scene::sampleEmitterDirect: one position or direction, discrete measure
+MTS_DEV V3 sampleDeltaDirect(const DevScene &sc, const DevEmitter &em, V3 ref, float emPdf, DirectRec &dRec) {
+    const DevDeltaEmitter de = sc.deltaEmitters[em.delta];
+    V3 value = ld3(em.radiance);
+    if (em.kind == 4) {
+        const V3 d = ld3(de.direction);
+        const float distance = dot(ref - ld3(de.position), d);
+        if (distance < 0) return mk(0.0f);
+        dRec.d = -d;
+        dRec.dist = distance;
+    } else {
+        V3 d = ld3(de.position) - ref;
+        const float dist = length(d);
+        const float invDist = 1.0f / dist;
+        d = d * invDist;
+        dRec.d = d; dRec.dist = dist;
+        if (em.kind == 3) {
+            const float cosTheta = dot(ld3(de.toLocalZ), -d);
+            float falloff = 1.0f;
+            if (cosTheta <= de.cosCutoff) falloff = 0.0f;
+            else if (cosTheta < de.cosBeam) falloff = (de.cutoffAngle - acosf(cosTheta)) * de.invTransitionWidth;
+            value = value * falloff;
+        }
+        value = value * (invDist * invDist);
+    }
+    dRec.pdf = emPdf;
+    dRec.delta = true;
+    return value / emPdf;
+}
+
 // Scene::sampleEmitterDirect without the shadow ray (src/librender/scene.cpp:828-852) -> AreaLight::sampleDirect
 // (src/emitters/area.cpp:158-173) -> Shape::sampleDirect (src/librender/shape.cpp:102-115) -> TriMesh::samplePosition
 // (src/librender/trimesh.cpp:412-423) -> Triangle::sample (src/libcore/triangle.cpp:24-59)
+// EXT: the scene has emitters that are not area lights.
+template <bool EXT = true>
 MTS_DEV V3 sampleEmitterDirect(const DevScene &sc, V3 ref, V3 refN, float sx, float sy, DirectRec &dRec) {
-    dRec.pdf = 0; dRec.dist = 0; dRec.d = mk(0.0f);
+    dRec.pdf = 0; dRec.dist = 0; dRec.d = mk(0.0f); dRec.delta = false;
     if (sc.nEmitters == 0) return mk(0.0f);
     float emPdf;
     const uint32_t index = cdfSampleReuse(sc.emitterCdf, sc.nEmitters, sx, &emPdf);
-    if ((int32_t) index == sc.envEmitter) return sampleEnvironmentDirect(sc, ref, refN, sx, sy, emPdf, dRec);
+    if (EXT && (int32_t) index == sc.envEmitter) return sampleEnvironmentDirect(sc, ref, refN, sx, sy, emPdf, dRec);
     const DevEmitter em = sc.emitters[index];
+    if (EXT && em.kind >= 2) return sampleDeltaDirect(sc, em, ref, emPdf, dRec);
     const uint32_t triIdx = cdfSampleReuse(sc.areaCdf + em.cdfOffset, em.nTris, sy, nullptr);
     const uint32_t t = em.firstTri + triIdx;
     const float4 *g = sc.shadeTris + 6 * (size_t) t;

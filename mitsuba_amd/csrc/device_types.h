@@ -40,7 +40,21 @@ struct alignas(16) DevEmitter {
     float radiance[3];
     float pdfDiscrete;      // samplingWeight * normalization (scene.h:848-850)
     uint32_t shape, firstTri, nTris, cdfOffset;
-    float invArea, pad[3];
+    float invArea;
+    uint32_t kind;          // 0 area light, 1 constant environment, 2 point, 3 spot, 4 directional
+    uint32_t delta;         // kinds 2..4: index of the record in DevScene::deltaEmitters
+    float pad;
+};
+
+// Emitter without a surface (src/emitters/point.cpp, spot.cpp, directional.cpp)
+struct alignas(16) DevDeltaEmitter {
+    float position[3];      // point, spot; directional: centre of the disk the light starts from (directional.cpp:161-162)
+    float cosCutoff;
+    float direction[3];     // directional: trafo(Vector(0, 0, 1))
+    float cosBeam;
+    float toLocalZ[3];      // spot: third row of the inverse transform's linear part (Frame::cosTheta of the local direction)
+    float cutoffAngle;
+    float invTransitionWidth, pad[3];
 };
 
 struct DevScene {
@@ -55,6 +69,7 @@ struct DevScene {
     const DevShape *shapes;
     const DevMaterial *materials;
     const DevEmitter *emitters;
+    const DevDeltaEmitter *deltaEmitters;
     const float *emitterCdf;    // nEmitters + 1
     const float *areaCdf;       // concatenated per-emitter triangle CDFs (nTris + 1 each)
     const float *rtrans;        // concatenated reduced transmittance tables

@@ -316,6 +316,41 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
     hs.emitterCdf.assign(1, 0.0f);
     for (uint32_t e = 0; e < d->n_emitters; ++e) {
         const mtsamd_emitter &em = d->emitters[e];
+        if (em.type != MTSAMD_EMITTER_SURFACE) {
+            // PointEmitter, SpotEmitter, DirectionalEmitter: no surface, reached by emitter sampling only
+            if (em.type < MTSAMD_EMITTER_POINT || em.type > MTSAMD_EMITTER_DIRECTIONAL) return "unknown emitter type";
+            DevEmitter de;
+            memset(&de, 0, sizeof(de));
+            memcpy(de.radiance, em.radiance, 12);
+            de.shape = 0xffffffffu;
+            de.kind = (uint32_t) em.type + 1;
+            de.delta = (uint32_t) hs.deltaEmitters.size();
+            DevDeltaEmitter dd;
+            memset(&dd, 0, sizeof(dd));
+            const float *M = em.to_world;
+            dd.position[0] = M[3]; dd.position[1] = M[7]; dd.position[2] = M[11];
+            dd.direction[0] = M[2]; dd.direction[1] = M[6]; dd.direction[2] = M[10];
+            // third row of the inverse of the linear part (cofactors over the determinant)
+            const double a = M[0], b = M[1], c = M[2], p = M[4], q = M[5], r = M[6], g = M[8], h = M[9], i = M[10];
+            const double det = a * (q * i - r * h) - b * (p * i - r * g) + c * (p * h - q * g);
+            if (det == 0) return "singular emitter transform";
+            dd.toLocalZ[0] = (float) ((p * h - q * g) / det);
+            dd.toLocalZ[1] = (float) ((b * g - a * h) / det);
+            dd.toLocalZ[2] = (float) ((a * q - b * p) / det);
+            if (em.type == MTSAMD_EMITTER_SPOT) {   // spot.cpp:70-74,89-94
+                const float cutoff = em.cutoff_angle * (3.14159265358979323846f / 180.0f), beam = em.beam_width * (3.14159265358979323846f / 180.0f);
+                if (!(cutoff >= beam)) return "spot emitter: the cutoff angle must not be smaller than the beam width";
+                dd.cutoffAngle = cutoff;
+                dd.cosBeam = std::cos(beam);
+                dd.cosCutoff = std::cos(cutoff);
+                dd.invTransitionWidth = 1.0f / (cutoff - beam);
+            }
+            hs.deltaEmitters.push_back(dd);
+            hs.emitters[e] = de;
+            hs.emitterCdf.push_back(hs.emitterCdf.back() + em.sampling_weight);
+            hs.extEmitters = true;
+            continue;
+        }
         if (em.shape < 0) {     // constant environment emitter (src/emitters/constant.cpp); one at most (scene.cpp:509-513)
             if (hs.envEmitter >= 0) return "The scene may only contain one environment emitter";
             hs.envEmitter = (int32_t) e;
@@ -323,8 +358,10 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
             memset(&de, 0, sizeof(de));
             memcpy(de.radiance, em.radiance, 12);
             de.shape = 0xffffffffu;
+            de.kind = 1;
             hs.emitters[e] = de;
             hs.emitterCdf.push_back(hs.emitterCdf.back() + em.sampling_weight);
+            hs.extEmitters = true;
             continue;
         }
         if ((uint32_t) em.shape >= d->n_shapes) return "emitter shape out of range";
@@ -436,6 +473,19 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         p.envRadius = std::max(1e-4f, std::sqrt(r2) * 1.5f);
         memcpy(p.envRadiance, hs.emitters[hs.envEmitter].radiance, 12);
         p.envPdfDiscrete = hs.emitters[hs.envEmitter].pdfDiscrete;
+    }
+    if (!hs.deltaEmitters.empty()) {
+        // DirectionalEmitter::createShape (directional.cpp:88-94): 1.1 x the bounding sphere (aabb.cpp:44-47) of the
+        // kd-tree bounds; the light starts from the disk at center - d * radius (directional.cpp:161-162)
+        float c[3], r2 = 0;
+        for (int i = 0; i < 3; ++i) c[i] = (p.aabbMax[i] + p.aabbMin[i]) * 0.5f;
+        for (int i = 0; i < 3; ++i) r2 += (c[i] - p.aabbMax[i]) * (c[i] - p.aabbMax[i]);
+        const float radius = std::sqrt(r2) * 1.1f;
+        for (uint32_t e = 0; e < d->n_emitters; ++e) {
+            if (hs.emitters[e].kind != 4) continue;
+            DevDeltaEmitter &dd = hs.deltaEmitters[hs.emitters[e].delta];
+            for (int i = 0; i < 3; ++i) dd.position[i] = c[i] - dd.direction[i] * radius;
+        }
     }
     // camera (perspective.cpp:126-157, transform.cpp:99-123)
     {

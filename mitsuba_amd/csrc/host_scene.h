@@ -22,6 +22,8 @@ struct HostScene {
     mtsamd_scene_desc desc; // copy of the scalar parts of the description
     bool hasNormals = false, hasTexcoords = false;
     int32_t envEmitter = -1;    // index of the constant environment emitter in `emitters`, if any
+    std::vector<DevDeltaEmitter> deltaEmitters;     // point, spot and directional emitters
+    bool extEmitters = false;   // some emitter is not an area light (selects the kernels that know the other kinds)
 };
 
 // Returns an empty string on success.

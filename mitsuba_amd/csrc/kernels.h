@@ -181,14 +181,15 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             if (bsdfType & ESmooth) {
                 const float sx = rng.next1D(), sy = rng.next1D();
                 DirectRec dRec;
-                const V3 value = sampleEmitterDirect(sc, its.p, refN, sx, sy, dRec);
+                const V3 value = sampleEmitterDirect<ENV>(sc, its.p, refN, sx, sy, dRec);
                 if (dRec.pdf != 0) {
                     V3 c = mk(0.0f);
                     const V3 wo = toLocal(its.sh, dRec.d);
                     const V3 woSide = flipped ? mirrorZ(wo) : wo;
                     const V3 bsdfVal = bsdfEval<RD>(sc, bsdf, wiLocal, woSide);
                     if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
-                        const float bPdf = bsdfPdf<RD>(sc, bsdf, wiLocal, woSide);    // area emitters: on surface, solid-angle measure
+                        // path.cpp:192-193: only emitters with a surface, sampled in the solid-angle measure, compete with BSDF sampling
+                        const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdf<RD>(sc, bsdf, wiLocal, woSide);
                         c = throughput * value * bsdfVal * miWeight(dRec.pdf, bPdf);
                     }
                     o.wantShadow = true;
@@ -225,7 +226,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             }
         }
         if (Lchanged) sampleL[slot] = L;
-    } else if (ENV) {
+    } else if (ENV && sc.envEmitter >= 0) {
         // the ray left the scene and there is an environment emitter
         const uint4 misc = in.misc();
         const uint32_t slot = misc.x, prevDepth = misc.y & 0xffffu, flags = misc.y >> 16;
@@ -271,7 +272,8 @@ static constexpr int kShadeBlock = MTS_SHADE_BLOCK;
 
 // ROUNDS: a workgroup sorts ROUNDS x kShadeBlock paths at once and shades them in ROUNDS sweeps of one path per
 // thread; the larger sort domain leaves fewer wavefronts that straddle two BSDF models.
-// ENV: the scene has an environment emitter (rays that leave the scene are shaded too, one more queue stream).
+// ENV: the scene has emitters other than area lights: an environment emitter (rays that leave the scene are shaded
+// too, one more queue stream), point, spot or directional lights.
 // RD: the scene has a rough dielectric material.
 template <int ROUNDS, bool ENV, bool RD>
 __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out,

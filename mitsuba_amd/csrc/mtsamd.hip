@@ -65,7 +65,7 @@ struct mtsamd_scene {
     HostScene host;
     DevScene dev;
     int device = 0;
-    DeviceBuffer nodes, tris, shadeTris, shadeUV, shapes, materials, emitters,
+    DeviceBuffer nodes, tris, shadeTris, shadeUV, shapes, materials, emitters, deltaEmitters,
         emitterCdf, areaCdf, rtrans;
     // work buffers of the wavefront loop
     DeviceBuffer fetchHeads, qbuf[2][6], hits, sbuf[3], sampleL, samplePos, shadowFlags, counters, scratch[8];
@@ -102,7 +102,7 @@ struct mtsamd_scene {
         PathQueue q;
         q.rayO = qbuf[i][0].as<float4>(); q.rayD = qbuf[i][1].as<float4>(); q.thr = qbuf[i][2].as<float4>();
         q.misc = qbuf[i][3].as<uint4>(); q.bsdfPdf = qbuf[i][4].as<float>();
-        q.refCos = host.envEmitter >= 0 ? qbuf[i][5].as<float>() : nullptr;
+        q.refCos = host.extEmitters ? qbuf[i][5].as<float>() : nullptr;
         return q;
     }
     ShadowQueue shadowQueue() const {
@@ -117,7 +117,7 @@ struct mtsamd_scene {
         for (int i = 0; i < 2; ++i) {
             for (int j = 0; j < 4; ++j) HIP_TRY(qbuf[i][j].ensure(n * 16));
             HIP_TRY(qbuf[i][4].ensure(n * 4));
-            if (host.envEmitter >= 0) HIP_TRY(qbuf[i][5].ensure(n * 4));
+            if (host.extEmitters) HIP_TRY(qbuf[i][5].ensure(n * 4));
         }
         HIP_TRY(hits.ensure(n * 16));
         for (int j = 0; j < 3; ++j) HIP_TRY(sbuf[j].ensure(n * 16));
@@ -182,6 +182,7 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
         HIP_TRY(upload(s->shapes, h.shapes));
         HIP_TRY(upload(s->materials, h.materials));
         HIP_TRY(upload(s->emitters, h.emitters));
+        HIP_TRY(upload(s->deltaEmitters, h.deltaEmitters));
         HIP_TRY(upload(s->emitterCdf, h.emitterCdf));
         HIP_TRY(upload(s->areaCdf, h.areaCdf));
         HIP_TRY(upload(s->rtrans, h.rtrans));
@@ -216,6 +217,7 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
     d.shadeTris = s->shadeTris.as<float4>();
     d.shadeUV = h.shadeUV.empty() ? nullptr : s->shadeUV.as<float4>();
     d.shapes = s->shapes.as<DevShape>(); d.materials = s->materials.as<DevMaterial>(); d.emitters = s->emitters.as<DevEmitter>();
+    d.deltaEmitters = s->deltaEmitters.as<DevDeltaEmitter>();
     d.emitterCdf = s->emitterCdf.as<float>(); d.areaCdf = s->areaCdf.as<float>(); d.rtrans = s->rtrans.as<float>();
     s->dev = d;
     const char *ct = getenv("MTSAMD_COUNT_TRAVERSAL");
@@ -367,7 +369,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
             HIP_TRY(hipMemsetAsync(tailCounts, 0, 2 * sizeof(unsigned long long), st));
             timer.begin(T_TAIL);
 #define MTS_LAUNCH_TAIL(E, R) hipLaunchKernelGGL((k_tail<E, R>), dim3(blocksFor(n, kTailBlock)), dim3(kTailBlock), 0, st, sc, pp, s->queue(cur), sampleL, n, s->triShare, tailCounts)
-            if (sc.envEmitter >= 0) { if (s->roughDielectric) MTS_LAUNCH_TAIL(true, true); else MTS_LAUNCH_TAIL(true, false); }
+            if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_TAIL(true, true); else MTS_LAUNCH_TAIL(true, false); }
             else { if (s->roughDielectric) MTS_LAUNCH_TAIL(false, true); else MTS_LAUNCH_TAIL(false, false); }
 #undef MTS_LAUNCH_TAIL
             timer.end(T_TAIL);
@@ -398,7 +400,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         const int rounds = n >= s->shadeRoundsAbove ? s->shadeRounds : 1;
 #define MTS_LAUNCH_SHADE_AS(R, E, D) hipLaunchKernelGGL((k_shade<R, E, D>), dim3(blocksFor(n, kShadeBlock * R)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, cnt, n)
 #define MTS_LAUNCH_SHADE(R) do { \
-            if (sc.envEmitter >= 0) { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true); else MTS_LAUNCH_SHADE_AS(R, true, false); } \
+            if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true); else MTS_LAUNCH_SHADE_AS(R, true, false); } \
             else { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, false, true); else MTS_LAUNCH_SHADE_AS(R, false, false); } } while (0)
         // (sweeps per workgroup: 8 for large queues, 1 for small ones; MTSAMD_SHADE_ROUNDS=1 switches the sweeps off)
         if (rounds >= 2) MTS_LAUNCH_SHADE(8);

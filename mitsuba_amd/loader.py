@@ -185,6 +185,8 @@ def _props(node) -> Dict:
             out[n] = _spectrum(c)
         elif c.tag == "transform":
             out[n] = _transform(c)
+        elif c.tag in ("point", "vector"):      # scenehandler.cpp:443-459
+            out[n] = tuple(float(c.get(k, 0)) for k in "xyz")
     return out
 
 
@@ -411,11 +413,31 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
             b.add_mesh(mesh["positions"], mesh["indices"], mat, normals=normals, texcoords=mesh.get("texcoords"),
                        radiance=radiance, sampling_weight=weight)
         elif el.tag == "emitter":
-            if el.get("type") != "constant":
-                raise SceneFormatError("only area emitters and the constant environment emitter are supported "
-                                       "(found a scene-level <emitter type=\"%s\">)" % el.get("type"))
+            t = el.get("type")
             p = _props(el)
-            b.add_constant_emitter(p.get("radiance", (1.0, 1.0, 1.0)), p.get("samplingWeight", 1.0))
+            weight = p.get("samplingWeight", 1.0)
+            if t == "constant":         # src/emitters/constant.cpp:47-50
+                b.add_constant_emitter(p.get("radiance", (1.0, 1.0, 1.0)), weight)
+            elif t == "point":          # src/emitters/point.cpp:58-69
+                m = np.array(p.get("toWorld", np.eye(4)), np.float32)
+                if "position" in p:
+                    if "toWorld" in p:
+                        raise SceneFormatError("Only one of the parameters 'position' and 'toWorld' can be used!")
+                    m[:3, 3] = p["position"]
+                b._add_delta_emitter(S.EMITTER_POINT, p.get("intensity", (1.0, 1.0, 1.0)), m, weight)
+            elif t == "spot":           # src/emitters/spot.cpp:67-78
+                if any(c.tag == "texture" for c in el):
+                    raise SceneFormatError("spot emitter: only a constant texture is supported")
+                value = np.float32(p.get("intensity", (1.0, 1.0, 1.0))) * np.float32(p.get("texture", (1.0, 1.0, 1.0)))
+                b.add_spot_emitter(p.get("toWorld", np.eye(4, dtype=np.float32)), value, p.get("cutoffAngle", 20.0), p.get("beamWidth"), weight)
+            elif t == "directional":    # src/emitters/directional.cpp:56-73
+                if "direction" in p and "toWorld" in p:
+                    raise SceneFormatError("Only one of the parameters 'direction' and 'toWorld' can be used at a time!")
+                b.add_directional_emitter(direction=p.get("direction"), irradiance=p.get("irradiance", (1.0, 1.0, 1.0)),
+                                          to_world=None if "direction" in p else p.get("toWorld", np.eye(4, dtype=np.float32)),
+                                          sampling_weight=weight)
+            else:
+                raise SceneFormatError("emitter type '%s' is not supported (area, constant, point, spot, directional)" % t)
     if camera is None:
         raise SceneFormatError("scene has no sensor")
     if integrator_override:

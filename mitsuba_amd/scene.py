@@ -19,6 +19,7 @@ BSDF_DIFFUSE, BSDF_ROUGHCONDUCTOR, BSDF_ROUGHPLASTIC, BSDF_DIELECTRIC, BSDF_WARD
     BSDF_ROUGHDIELECTRIC = range(8)
 DISTR_BECKMANN, DISTR_GGX = 0, 1
 SHAPE_HAS_NORMALS, SHAPE_HAS_TEXCOORDS = 1, 2
+EMITTER_SURFACE, EMITTER_POINT, EMITTER_SPOT, EMITTER_DIRECTIONAL = range(4)
 
 _DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
@@ -40,6 +41,18 @@ def look_at(origin, target, up) -> np.ndarray:
     m = np.eye(4, dtype=np.float32)
     m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = left, new_up, d, o
     return m
+
+
+def coordinate_system(a):
+    """(b, c) of coordinateSystem(a, b, c) (src/libcore/util.cpp:592-601)."""
+    a = np.asarray(a, np.float32)
+    if abs(a[0]) > abs(a[1]):
+        inv = np.float32(1.0) / np.float32(np.sqrt(a[0] * a[0] + a[2] * a[2]))
+        c = np.array([a[2] * inv, 0.0, -a[0] * inv], np.float32)
+    else:
+        inv = np.float32(1.0) / np.float32(np.sqrt(a[1] * a[1] + a[2] * a[2]))
+        c = np.array([0.0, a[2] * inv, -a[1] * inv], np.float32)
+    return np.cross(c, a).astype(np.float32), c
 
 
 def gaussian_filter(stddev: float = 0.5):
@@ -236,6 +249,36 @@ class SceneBuilder:
         """Constant environment emitter (src/emitters/constant.cpp): an emitter record without a shape."""
         self.emitters.append(dict(shape=-1, radiance=tuple(float(x) for x in radiance), sampling_weight=float(sampling_weight)))
         return len(self.emitters) - 1
+
+    def _add_delta_emitter(self, kind, value, to_world, sampling_weight, **extra) -> int:
+        self.emitters.append(dict(shape=-1, type=kind, radiance=tuple(float(x) for x in value),
+                                  to_world=np.asarray(to_world, np.float32).reshape(4, 4), sampling_weight=float(sampling_weight), **extra))
+        return len(self.emitters) - 1
+
+    def add_point_emitter(self, position, intensity=(1.0, 1.0, 1.0), sampling_weight=1.0) -> int:
+        """Point light (src/emitters/point.cpp)."""
+        m = np.eye(4, dtype=np.float32)
+        m[:3, 3] = position
+        return self._add_delta_emitter(EMITTER_POINT, intensity, m, sampling_weight)
+
+    def add_spot_emitter(self, to_world, intensity=(1.0, 1.0, 1.0), cutoff_angle=20.0, beam_width=None, sampling_weight=1.0) -> int:
+        """Spot light looking along +z of `to_world` (src/emitters/spot.cpp); beam width defaults to 3/4 of the cutoff angle."""
+        cutoff_angle = np.float32(cutoff_angle)
+        if beam_width is None:
+            beam_width = cutoff_angle * np.float32(3.0) / np.float32(4.0)
+        if not cutoff_angle >= beam_width:      # spot.cpp:74
+            raise ValueError("spot emitter: the cutoff angle must not be smaller than the beam width")
+        return self._add_delta_emitter(EMITTER_SPOT, intensity, to_world, sampling_weight,
+                                       cutoff_angle=float(cutoff_angle), beam_width=float(np.float32(beam_width)))
+
+    def add_directional_emitter(self, direction=None, irradiance=(1.0, 1.0, 1.0), to_world=None, sampling_weight=1.0) -> int:
+        """Directional light (src/emitters/directional.cpp): either a direction (turned into a look-at transform as
+        directional.cpp:64-67 does) or an emitter-to-world rotation whose +z is the direction."""
+        if to_world is None:
+            d = np.asarray(direction, np.float32)
+            d = d / np.float32(np.linalg.norm(d))
+            to_world = look_at((0.0, 0.0, 0.0), d, coordinate_system(d)[0])
+        return self._add_delta_emitter(EMITTER_DIRECTIONAL, irradiance, to_world, sampling_weight)
 
     def add_mesh(self, positions, indices, material: int, normals=None, texcoords=None, radiance=None,
                  sampling_weight=1.0) -> int:
@@ -513,9 +556,9 @@ def config5(width=3840, height=2160) -> SceneData:
                             max_depth=16, emitters_grid=32)
 
 
-def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_weight=1.0, hide_emitters=0) -> SceneData:
+def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_weight=1.0, hide_emitters=0, lamps=False, area_lights=True) -> SceneData:
     """A few hundred triangles with every BSDF type present; used by the parity tests. `sky` adds a constant
-    environment emitter of that radiance next to the two area lights."""
+    environment emitter of that radiance next to the two area lights; `lamps` adds a point, a spot and a directional light."""
     rng = np.random.default_rng(7)
     b = SceneBuilder()
     mats = [b.add_material(diffuse((0.6, 0.5, 0.4))),
@@ -533,10 +576,15 @@ def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_
         b.add_mesh(p + c, f, m, normals=n if k != 0 else None, texcoords=uv)
     gp, gf = grid(6, 6, (-7, -6), (7, 6), 0.0)
     b.add_mesh(gp, gf, m_ground)
-    b.add_quad([-2, -2, 6], [-2, 2, 6], [2, 2, 6], [2, -2, 6], m_ground, radiance=(15, 14, 12))
-    b.add_quad([4, -1, 3.5], [4, 1, 3.5], [5, 1, 4.5], [5, -1, 4.5], m_ground, radiance=(6, 9, 12), sampling_weight=0.5)
+    b.add_quad([-2, -2, 6], [-2, 2, 6], [2, 2, 6], [2, -2, 6], m_ground, radiance=(15, 14, 12) if area_lights else None)
+    b.add_quad([4, -1, 3.5], [4, 1, 3.5], [5, 1, 4.5], [5, -1, 4.5], m_ground, radiance=(6, 9, 12) if area_lights else None, sampling_weight=0.5)
     if sky is not None:
         b.add_constant_emitter(sky, sky_weight)
+    if lamps:
+        b.add_point_emitter([-3.0, -4.0, 3.0], (30.0, 20.0, 10.0))
+        b.add_spot_emitter(look_at([3.0, -5.0, 5.0], [1.0, 0.0, 0.5], [0, 0, 1]), (200.0, 300.0, 400.0), cutoff_angle=25.0, beam_width=12.0,
+                           sampling_weight=2.0)
+        b.add_directional_emitter(direction=[0.3, 0.4, -1.0], irradiance=(0.8, 0.7, 0.6), sampling_weight=0.5)
     cam = make_camera([0.5, -11, 5.5], [0, 0, 0.8], [0, 0, 1], 40.0, near_clip=0.1, far_clip=100)
     return b.finish(cam, make_film(width, height), dict(max_depth=max_depth, hide_emitters=hide_emitters))
 

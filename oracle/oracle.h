@@ -46,10 +46,16 @@ typedef struct {
     int32_t back_material;      /* record seen from behind, -1 = the same one */
 } orc_material;
 
+/* type 0: attached to `shape` (area light) or, with shape = -1, the constant environment emitter;
+   1: point (src/emitters/point.cpp), 2: spot (src/emitters/spot.cpp), 3: directional (src/emitters/directional.cpp).
+   `radiance` holds the intensity of a point/spot light and the irradiance of a directional one. */
 typedef struct {
     int32_t shape;
     float radiance[3];
     float sampling_weight;
+    int32_t type;
+    float to_world[16];         /* row-major emitter-to-world; the emitter looks along +z */
+    float cutoff_angle, beam_width;     /* spot, degrees */
 } orc_emitter;
 
 typedef struct {

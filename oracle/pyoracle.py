@@ -30,7 +30,8 @@ class Material(C.Structure):
 
 
 class Emitter(C.Structure):
-    _fields_ = [("shape", C.c_int32), ("radiance", C.c_float * 3), ("sampling_weight", C.c_float)]
+    _fields_ = [("shape", C.c_int32), ("radiance", C.c_float * 3), ("sampling_weight", C.c_float), ("type", C.c_int32),
+                ("to_world", C.c_float * 16), ("cutoff_angle", C.c_float), ("beam_width", C.c_float)]
 
 
 class Camera(C.Structure):
@@ -116,6 +117,9 @@ def fill_desc(sd, desc_cls=SceneDesc, shape_cls=Shape, mat_cls=Material, em_cls=
         ems[i].shape = e["shape"]
         ems[i].radiance = (C.c_float * 3)(*e["radiance"])
         ems[i].sampling_weight = e["sampling_weight"]
+        ems[i].type = e.get("type", 0)
+        ems[i].to_world = (C.c_float * 16)(*np.asarray(e.get("to_world", np.eye(4)), np.float32).reshape(-1))
+        ems[i].cutoff_angle, ems[i].beam_width = e.get("cutoff_angle", 20.0), e.get("beam_width", 15.0)
     keep += [shapes, mats, ems]
     d.n_shapes, d.n_materials, d.n_emitters = len(sd.shapes), len(sd.materials), len(sd.emitters)
     d.shapes, d.materials, d.emitters = shapes, mats, ems

@@ -152,6 +152,11 @@ std::string Scene::build(const orc_scene_desc *d) {
     envEmitter = -1;
     for (uint32_t e = 0; e < d->n_emitters; ++e) {
         int s = emitters[e].shape;
+        if (emitters[e].type != 0) {    // point, spot, directional: no surface
+            if (emitters[e].type < 1 || emitters[e].type > 3) return "unknown emitter type";
+            emitterPDF.append(emitters[e].sampling_weight);
+            continue;
+        }
         if (s < 0) {    // constant environment emitter; only one is allowed (scene.cpp:509-513)
             if (envEmitter >= 0) return "The scene may only contain one environment emitter";
             envEmitter = (int) e;
@@ -181,6 +186,37 @@ std::string Scene::build(const orc_scene_desc *d) {
         box.expandBy(Vec3(d->camera.to_world[3], d->camera.to_world[7], d->camera.to_world[11]));
         envCenter = (box.max + box.min) * 0.5f;
         envRadius = std::max(Epsilon, (envCenter - box.max).length() * 1.5f);
+    }
+
+    deltaEmitters.assign(d->n_emitters, DeltaEmitter());
+    {
+        // AABB::getBSphere (aabb.cpp:44-47) of the kd-tree bounds, DirectionalEmitter::createShape (directional.cpp:88-94)
+        dirCenter = (aabb.max + aabb.min) * 0.5f;
+        dirRadius = (dirCenter - aabb.max).length() * 1.1f;
+    }
+    for (uint32_t e = 0; e < d->n_emitters; ++e) {
+        const orc_emitter &em = emitters[e];
+        if (em.type == 0) continue;
+        DeltaEmitter &de = deltaEmitters[e];
+        const float *M = em.to_world;
+        de.position = Vec3(M[3], M[7], M[11]);
+        de.direction = Vec3(M[2], M[6], M[10]);
+        // linear part of the inverse transform (cofactors over the determinant)
+        const double a = M[0], b = M[1], c = M[2], dd = M[4], ee = M[5], ff = M[6], g = M[8], h = M[9], i = M[10];
+        const double det = a * (ee * i - ff * h) - b * (dd * i - ff * g) + c * (dd * h - ee * g);
+        if (det == 0) return "singular emitter transform";
+        const double inv[9] = { (ee * i - ff * h), (c * h - b * i), (b * ff - c * ee),
+                                (ff * g - dd * i), (a * i - c * g), (c * dd - a * ff),
+                                (dd * h - ee * g), (b * g - a * h), (a * ee - b * dd) };
+        for (int k = 0; k < 9; ++k) de.toLocal[k] = (float) (inv[k] / det);
+        if (em.type == 2) {     // SpotEmitter (spot.cpp:70-74,89-94)
+            const float cutoff = em.cutoff_angle * (M_PI_F / 180.0f), beam = em.beam_width * (M_PI_F / 180.0f);
+            if (!(cutoff >= beam)) return "spot emitter: the cutoff angle must not be smaller than the beam width";
+            de.cutoffAngle = cutoff;
+            de.cosBeam = std::cos(beam);
+            de.cosCutoff = std::cos(cutoff);
+            de.invTransitionWidth = 1.0f / (cutoff - beam);
+        }
     }
 
     // Camera (perspective.cpp:126-157)
@@ -238,6 +274,7 @@ struct DirectSample {
     Vec3 p, n, d;
     float dist = 0, pdf = 0;
     int emitter = -1;
+    bool delta = false;     // discrete measure: the emitter cannot be reached by BSDF sampling
 };
 
 // Scene::sampleEmitterDirect sans visibility (scene.cpp:828-852), AreaLight::sampleDirect
@@ -248,6 +285,46 @@ static Spectrum sampleEmitterDirect(const Scene &sc, const Vec3 &ref, const Vec3
     float emPdf;
     size_t index = sc.emitterPDF.sampleReuse(sample.x, emPdf);
     const orc_emitter &em = sc.emitters[index];
+    if (em.type != 0) {
+        // PointEmitter::sampleDirect (point.cpp:131-147), SpotEmitter::sampleDirect (spot.cpp:184-200),
+        // DirectionalEmitter::sampleDirect (directional.cpp:159-180): one position or direction, discrete measure
+        const Scene::DeltaEmitter &de = sc.deltaEmitters[index];
+        Spectrum value(em.radiance[0], em.radiance[1], em.radiance[2]);
+        dRec.pdf = 0.0f;
+        if (em.type == 3) {
+            const Vec3 d = de.direction;
+            const Vec3 diskCenter = sc.dirCenter - d * sc.dirRadius;
+            const float distance = dot(ref - diskCenter, d);
+            if (distance < 0) return Spectrum(0.0f);
+            dRec.p = ref - d * distance;
+            dRec.d = -d;
+            dRec.n = d;
+            dRec.dist = distance;
+        } else {
+            dRec.p = de.position;
+            dRec.d = dRec.p - ref;
+            dRec.dist = dRec.d.length();
+            const float invDist = 1.0f / dRec.dist;
+            dRec.d *= invDist;
+            dRec.n = Vec3(0.0f);
+            if (em.type == 2) {     // SpotEmitter::falloffCurve (spot.cpp:105-125), constant texture
+                const Vec3 w = -dRec.d;
+                const float *T = de.toLocal;
+                const float cosTheta = T[6] * w.x + T[7] * w.y + T[8] * w.z;
+                float falloff = 1.0f;
+                if (cosTheta <= de.cosCutoff) falloff = 0.0f;
+                else if (cosTheta < de.cosBeam) falloff = (de.cutoffAngle - std::acos(cosTheta)) * de.invTransitionWidth;
+                value *= falloff;
+            }
+            value *= invDist * invDist;
+        }
+        dRec.pdf = 1.0f;
+        dRec.delta = true;
+        dRec.emitter = (int) index;
+        dRec.pdf *= emPdf;
+        value /= emPdf;
+        return value;
+    }
     if (em.shape < 0) {     // ConstantBackgroundEmitter::sampleDirect (constant.cpp:178-216)
         Vec3 d;
         float pdf;
@@ -381,7 +458,8 @@ static Spectrum Li(const Scene &sc, const Ray &r, Pcg32 &rng, float &alpha, RayC
                 Vec3 wo = its.toLocal(dRec.d);
                 const Spectrum bsdfVal = bsdfEval(bsdf, its.wi, wo);
                 if (!bsdfVal.isZero() && (!ig.strict_normals || dot(its.geoFrame.n, dRec.d) * Frame::cosTheta(wo) > 0)) {
-                    float bsdfPdf_ = bsdfPdf(bsdf, its.wi, wo);   // area lights: on surface, solid angle
+                    // path.cpp:192-193: only emitters with a surface, sampled in the solid-angle measure, compete with BSDF sampling
+                    float bsdfPdf_ = dRec.delta ? 0.0f : bsdfPdf(bsdf, its.wi, wo);
                     float weight = miWeight(dRec.pdf, bsdfPdf_);
                     Li += throughput * value * bsdfVal * weight;
                 }

@@ -105,6 +105,17 @@ struct Scene {
     int envEmitter = -1;
     Vec3 envCenter;
     float envRadius = 0;
+    // Emitters without a surface (point.cpp, spot.cpp, directional.cpp), indexed like `emitters`
+    struct DeltaEmitter {
+        Vec3 position;              // point, spot: trafo.transformAffine(Point(0))
+        Vec3 direction;             // directional: trafo(Vector(0, 0, 1))
+        float toLocal[9];           // spot: linear part of trafo.inverse(), row-major
+        float cosCutoff = 0, cosBeam = 0, cutoffAngle = 0, invTransitionWidth = 0;    // SpotEmitter::configure (spot.cpp:89-94)
+    };
+    std::vector<DeltaEmitter> deltaEmitters;
+    // sphere a directional emitter starts from: 1.1 x the bounding sphere of the kd-tree bounds (directional.cpp:88-94)
+    Vec3 dirCenter;
+    float dirRadius = 0;
 
     // kd-tree
     std::vector<TriAccel> triAccel;

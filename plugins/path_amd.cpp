@@ -197,6 +197,7 @@ private:
 		std::vector<std::vector<float> > tables;
 		tables.reserve(meshes.size());
 		std::map<const BSDF *, int> bsdfIds;
+		std::map<const Emitter *, int32_t> emitterShape;
 		bool anyN = false, anyUV = false;
 		for (size_t i = 0; i < meshes.size(); ++i) { anyN |= meshes[i]->hasVertexNormals(); anyUV |= meshes[i]->hasVertexTexcoords(); }
 
@@ -226,32 +227,51 @@ private:
 			}
 			s.material = bsdfIds[bsdf];
 			s.emitter = -1;
-			if (mesh->isEmitter()) {
-				const Emitter *e = mesh->getEmitter();
-				if (e->getProperties().getPluginName() != "area") { Log(EWarn, "path_amd: only area emitters are supported"); return false; }
-				mtsamd_emitter me;
-				me.shape = (int32_t) i;
-				rgb(e->getProperties().getSpectrum("radiance", Spectrum::getD65()), me.radiance);
-				me.sampling_weight = e->getSamplingWeight();
-				s.emitter = (int32_t) emitters.size();
-				emitters.push_back(me);
-			}
+			if (mesh->isEmitter()) emitterShape[mesh->getEmitter()] = (int32_t) i;
 			shapes.push_back(s);
 		}
-		/* the constant environment emitter (src/emitters/constant.cpp) travels as an emitter record without a shape */
-		if (const Emitter *env = scene->getEnvironmentEmitter()) {
-			if (env->getProperties().getPluginName() != "constant") {
-				Log(EWarn, "path_amd: environment emitter \"%s\" is not on the GPU path", env->getProperties().getPluginName().c_str());
+		/* emitter records in the order of Scene::getEmitters(), which is the order of the emitter choice
+		   (src/librender/scene.cpp:375-380): area lights point at their mesh, the constant environment
+		   (src/emitters/constant.cpp) has no shape, point / spot / directional lights carry their transform */
+		const ref_vector<Emitter> &sceneEmitters = scene->getEmitters();
+		for (size_t k = 0; k < sceneEmitters.size(); ++k) {
+			const Emitter *e = sceneEmitters[k].get();
+			const Properties &ep = e->getProperties();
+			const std::string kind = ep.getPluginName();
+			mtsamd_emitter me;
+			memset(&me, 0, sizeof(me));
+			me.shape = -1;
+			me.sampling_weight = e->getSamplingWeight();
+			const Matrix4x4 &M = e->getWorldTransform()->eval(0).getMatrix();
+			for (int r = 0; r < 4; ++r)
+				for (int c = 0; c < 4; ++c)
+					me.to_world[4 * r + c] = (float) M(r, c);
+			if (kind == "area") {
+				std::map<const Emitter *, int32_t>::const_iterator it = emitterShape.find(e);
+				if (it == emitterShape.end()) { Log(EWarn, "path_amd: area emitter without a triangle mesh"); return false; }
+				me.shape = it->second;
+				shapes[me.shape].emitter = (int32_t) emitters.size();
+				rgb(ep.getSpectrum("radiance", Spectrum::getD65()), me.radiance);
+			} else if (kind == "constant") {
+				rgb(ep.getSpectrum("radiance", Spectrum::getD65()), me.radiance);
+			} else if (kind == "point") {
+				me.type = MTSAMD_EMITTER_POINT;
+				rgb(ep.getSpectrum("intensity", Spectrum::getD65()), me.radiance);
+			} else if (kind == "spot") {
+				me.type = MTSAMD_EMITTER_SPOT;
+				if (!ep.hasProperty("texture") || ep.getType("texture") == Properties::ESpectrum) {
+					rgb(ep.getSpectrum("intensity", Spectrum(1.0f)) * ep.getSpectrum("texture", Spectrum::getD65()), me.radiance);
+				} else { Log(EWarn, "path_amd: textured spot emitters are not on the GPU path"); return false; }
+				me.cutoff_angle = (float) ep.getFloat("cutoffAngle", 20);
+				me.beam_width = (float) ep.getFloat("beamWidth", me.cutoff_angle * 3.0f / 4.0f);
+			} else if (kind == "directional") {
+				me.type = MTSAMD_EMITTER_DIRECTIONAL;
+				rgb(ep.getSpectrum("irradiance", Spectrum::getD65()), me.radiance);
+			} else {
+				Log(EWarn, "path_amd: emitter \"%s\" is not on the GPU path", kind.c_str());
 				return false;
 			}
-			mtsamd_emitter me;
-			me.shape = -1;
-			rgb(env->getProperties().getSpectrum("radiance", Spectrum::getD65()), me.radiance);
-			me.sampling_weight = env->getSamplingWeight();
 			emitters.push_back(me);
-		}
-		if (emitters.size() != scene->getEmitters().size()) {
-			Log(EWarn, "path_amd: delta emitters and image-based environments are not supported"); return false;
 		}
 
 		mtsamd_scene_desc d;

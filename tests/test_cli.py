@@ -220,12 +220,48 @@ def test_cli_constant_emitter(scene_dir, tmp_path):
     assert sd.emitters[1]["shape"] == -1 and sd.emitters[1]["radiance"] == (0.5, 0.75, 1.25) and sd.emitters[1]["sampling_weight"] == 2.0
 
 
+def test_cli_point_spot_directional_emitters(scene_dir, tmp_path):
+    """point.cpp:58-69, spot.cpp:67-78, directional.cpp:56-73: both loaders hand over the same records."""
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    f = tmp_path / "lamps.xml"
+    f.write_text(SCENE % """
+      <emitter type="point"><point name="position" x="1" y="-2" z="3"/><rgb name="intensity" value="10, 20, 30"/></emitter>
+      <emitter type="point"><transform name="toWorld"><translate x="-1" y="0.5" z="2"/></transform></emitter>
+      <emitter type="spot"><transform name="toWorld"><lookat origin="2, -3, 4" target="0, 0, 0.5" up="0, 0, 1"/></transform>
+        <rgb name="intensity" value="100, 100, 50"/><float name="cutoffAngle" value="30"/><float name="samplingWeight" value="3"/></emitter>
+      <emitter type="spot"><float name="beamWidth" value="5"/></emitter>
+      <emitter type="directional"><vector name="direction" x="0.2" y="0.3" z="-1"/><spectrum name="irradiance" value="2"/></emitter>
+      <emitter type="directional"><transform name="toWorld"><rotate x="1" angle="150"/></transform></emitter>""")
+    d = _describe(f)
+    sd, _ = loader.load_xml(str(f))
+    assert d["emitters"] == len(sd.emitters) == 7
+    assert [e["type"] for e in d["emitter_records"]] == [0, 1, 1, 2, 2, 3, 3] == [e.get("type", 0) for e in sd.emitters]
+    for a, b in zip(d["emitter_records"][1:], sd.emitters[1:]):
+        assert np.allclose(a["radiance"], b["radiance"]) and a["sampling_weight"] == b["sampling_weight"]
+        assert np.allclose(a["to_world"], np.asarray(b["to_world"]).ravel(), atol=1e-6)
+        if a["type"] == 2:
+            assert (a["cutoff_angle"], a["beam_width"]) == (b["cutoff_angle"], b["beam_width"])
+    r = d["emitter_records"]
+    assert r[1]["to_world"][3::4][:3] == [1, -2, 3] and r[1]["radiance"] == [10, 20, 30] and r[2]["radiance"] == [1, 1, 1]
+    assert (r[3]["cutoff_angle"], r[3]["beam_width"], r[3]["sampling_weight"]) == (30, 22.5, 3) and (r[4]["cutoff_angle"], r[4]["beam_width"]) == (20, 5)
+    want = np.float32([0.2, 0.3, -1]) / np.linalg.norm(np.float32([0.2, 0.3, -1]))
+    assert np.allclose(r[5]["to_world"][2::4][:3], want, atol=1e-6) and r[5]["radiance"] == [2, 2, 2]
+    for body, needle in (('<emitter type="point"><point name="position" x="1"/><transform name="toWorld"><translate x="1"/></transform></emitter>', "Only one of the parameters"),
+                         ('<emitter type="spot"><float name="cutoffAngle" value="10"/><float name="beamWidth" value="20"/></emitter>', "cutoff angle")):
+        bad = tmp_path / "bad_lamp.xml"
+        bad.write_text(SCENE % body)
+        out = subprocess.run([CLI, str(bad), "--describe"], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 1 and needle in out.stderr, out.stderr
+        with pytest.raises((loader.SceneFormatError, ValueError), match=needle):
+            loader.load_xml(str(bad))
+
+
 def test_cli_rejects_unsupported_content(scene_dir, tmp_path):
     for body, needle in (('<shape type="sphere"/>', "not supported"),
                          ('<shape type="cube"><bsdf type="coating"/></shape>', "outside the path hot path"),
                          ('<shape type="cube"><bsdf type="twosided"><bsdf type="dielectric"/></bsdf></shape>', "transmission component"),
                          ('<shape type="cube"><bsdf type="twosided"/></shape>', "nested one-sided material is required"),
-                         ('<emitter type="envmap"/>', "only area emitters and the constant environment emitter"),
+                         ('<emitter type="envmap"/>', "emitter type 'envmap' is not supported"),
                          ('<shape type="cube"><bsdf type="roughconductor"><string name="material" value="Au"/></bsdf></shape>', "spectral data")):
         f = tmp_path / "bad.xml"
         f.write_text(SCENE % body)
