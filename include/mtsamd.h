@@ -223,6 +223,22 @@ void mtsamd_cancel(mtsamd_scene *scene);
 /* HDRFilm::develop weight division (src/libcore/fmtconv.cpp:978-990): film (w*h*5) -> rgba (w*h*4), host */
 int mtsamd_film_develop(const mtsamd_scene *scene, const float *film_host, float *rgba_host);
 
+/* LDRFilm::develop (src/films/ldrfilm.cpp:300-321): weight division, tone mapping (exposure + gamma, or Reinhard's
+   operator, src/libcore/bitmap.cpp:1707-1854), gamma curve and 8-bit quantisation (src/libcore/fmtconv.cpp:1104-1160).
+   film (width*height*5) -> out (width*height*channels bytes; 1, 2, 3 or 4 channels by pixel format), host memory;
+   needs no scene and no device. The banner the reference
+   stamps into the corner (ldrfilm.cpp:323-336) is not drawn. */
+enum { MTSAMD_PIXEL_LUMINANCE = 0, MTSAMD_PIXEL_LUMINANCE_ALPHA = 1, MTSAMD_PIXEL_RGB = 2, MTSAMD_PIXEL_RGBA = 3 };
+enum { MTSAMD_TONEMAP_GAMMA = 0, MTSAMD_TONEMAP_REINHARD = 1 };
+typedef struct {
+    int32_t pixel_format;   /* ldrfilm.cpp:159-170, default rgb */
+    int32_t tonemap;        /* ldrfilm.cpp:150-157, default gamma */
+    float gamma;            /* -1 = sRGB curve (default) */
+    float exposure;         /* f-stops, gamma method (default 0) */
+    float key, burn;        /* Reinhard (defaults 0.18, 0) */
+} mtsamd_ldr_opts;
+int mtsamd_film_develop_ldr(const float *film_host, int32_t width, int32_t height, const mtsamd_ldr_opts *opts, uint8_t *out_host);
+
 /* ---- batch entry points (host arrays in, host arrays out) used by the parity harness --------------- */
 
 /* Scene::rayIntersect(ray, its) (include/mitsuba/render/scene.h:187-189): rays = n*8 floats

@@ -36,6 +36,11 @@ class Emitter(C.Structure):
                 ("to_world", C.c_float * 16), ("cutoff_angle", C.c_float), ("beam_width", C.c_float)]
 
 
+class LdrOpts(C.Structure):
+    _fields_ = [("pixel_format", C.c_int32), ("tonemap", C.c_int32), ("gamma", C.c_float), ("exposure", C.c_float),
+                ("key", C.c_float), ("burn", C.c_float)]
+
+
 class Camera(C.Structure):
     _fields_ = [("to_world", C.c_float * 16), ("x_fov", C.c_float), ("near_clip", C.c_float), ("far_clip", C.c_float)]
 
@@ -89,7 +94,7 @@ ISECT_DTYPE = np.dtype([("t", "f4"), ("u", "f4"), ("v", "f4"), ("shape", "u4"), 
 EXPORTS = ["mtsamd_last_error", "mtsamd_init", "mtsamd_scene_create", "mtsamd_scene_destroy", "mtsamd_scene_bvh_info",
            "mtsamd_render", "mtsamd_render_device", "mtsamd_cancel", "mtsamd_scene_set_counting", "mtsamd_film_develop", "mtsamd_trace", "mtsamd_trace_device", "mtsamd_occluded_device",
            "mtsamd_occluded", "mtsamd_intersect", "mtsamd_bsdf_eval", "mtsamd_bsdf_pdf", "mtsamd_bsdf_sample",
-           "mtsamd_sample_emitter_direct", "mtsamd_camera_rays", "mtsamd_li", "mtsamd_film_put", "mtsamd_rng_stream",
+           "mtsamd_sample_emitter_direct", "mtsamd_camera_rays", "mtsamd_li", "mtsamd_film_put", "mtsamd_film_develop_ldr", "mtsamd_rng_stream",
            "mtsamd_rtrans_reduce", "mtsamd_filter_gaussian", "mtsamd_filter_box"]
 
 _lib = None
@@ -190,6 +195,17 @@ def fill_desc(sd):
     return d, keep
 
 
+def develop_ldr(film, pixel_format="rgb", tonemap="gamma", gamma=-1.0, exposure=0.0, key=0.18, burn=0.0):
+    """LDRFilm::develop (src/films/ldrfilm.cpp:300-321): film (h, w, 5) float32 -> (h, w, channels) uint8. Host work."""
+    film = np.ascontiguousarray(film, np.float32)
+    h, w = film.shape[:2]
+    fmt = ("luminance", "luminancealpha", "rgb", "rgba").index(pixel_format.lower())
+    o = LdrOpts(fmt, ("gamma", "reinhard").index(tonemap.lower()), gamma, exposure, key, burn)
+    out = np.zeros((h, w, fmt + 1), np.uint8)
+    _check(lib().mtsamd_film_develop_ldr(_fp(film), C.c_int32(w), C.c_int32(h), C.byref(o), out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
 class Scene:
     """An uploaded scene (mtsamd_scene handle)."""
 
@@ -249,6 +265,9 @@ class Scene:
         out = np.zeros((self.hgt, self.w, 4), np.float32)
         _check(self.L.mtsamd_film_develop(self.h, _fp(film), _fp(out)))
         return out
+
+    def develop_ldr(self, film, **kw):
+        return develop_ldr(film, **kw)
 
     def cancel(self):
         self.L.mtsamd_cancel(self.h)

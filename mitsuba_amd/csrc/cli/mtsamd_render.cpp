@@ -2,7 +2,7 @@
 // renders it with the `path` integrator on one MI355X and writes a PFM or OpenEXR image, the role `mitsuba scene.xml -o out`
 // plays for the reference (src/mitsuba/mitsuba.cpp:129-397, film output src/films/hdrfilm.cpp:481-537).
 //
-//   mtsamd-render scene.xml -o out.pfm|out.exr [--spp N] [--size W H] [--seed S] [--device D] [--data-dir DIR]
+//   mtsamd-render scene.xml -o out.pfm|out.exr|out.png [--spp N] [--size W H] [--seed S] [--device D] [--data-dir DIR]
 //                 [--max-depth N] [--describe] [--film out.raw] [-D name=value ...]
 //
 // --describe prints a JSON summary of the loaded scene and exits without touching the GPU.
@@ -19,7 +19,7 @@
 using namespace mtsamd_host;
 
 static int usage() {
-    fprintf(stderr, "usage: mtsamd-render scene.xml -o out.pfm|out.exr [--spp N] [--size W H] [--seed S] [--device D] [--data-dir DIR] "
+    fprintf(stderr, "usage: mtsamd-render scene.xml -o out.pfm|out.exr|out.png [--spp N] [--size W H] [--seed S] [--device D] [--data-dir DIR] "
                     "[--max-depth N] [--describe] [--film out.raw] [-D name=value ...]\n");
     return 2;
 }
@@ -115,11 +115,19 @@ int main(int argc, char **argv) {
     mtsamd_stats st;
     if (mtsamd_render(handle, &ro, film.data(), &st) != MTSAMD_OK) { fprintf(stderr, "mtsamd-render: %s\n", mtsamd_last_error()); return 1; }
     mtsamd_film_develop(handle, film.data(), rgba.data());
+    // the extension picks the container: .png -> LDRFilm's tone-mapped 8-bit image (with the scene's ldrfilm parameters, or
+    // its defaults), .exr -> OpenEXR, anything else -> PFM
+    auto endsWith = [&](const char *ext) { return outPath.size() >= 4 && outPath.compare(outPath.size() - 4, 4, ext) == 0; };
+    std::string werr;
+    if (endsWith(".png")) {
+        const int channels[4] = { 1, 2, 3, 4 };
+        std::vector<uint8_t> ldr((size_t) W * H * 4);
+        if (mtsamd_film_develop_ldr(film.data(), W, H, &scene.ldr, ldr.data()) != MTSAMD_OK) { fprintf(stderr, "mtsamd-render: %s\n", mtsamd_last_error()); return 1; }
+        werr = writePng(outPath, ldr.data(), W, H, channels[scene.ldr.pixel_format]);
+    } else {
+        werr = endsWith(".exr") ? writeExr(outPath, rgba.data(), W, H) : writePfm(outPath, rgba.data(), W, H);
+    }
     mtsamd_scene_destroy(handle);
-
-    // the extension picks the container, like HDRFilm's fileFormat: .exr -> OpenEXR, anything else -> PFM
-    const bool exr = outPath.size() >= 4 && outPath.compare(outPath.size() - 4, 4, ".exr") == 0;
-    const std::string werr = exr ? writeExr(outPath, rgba.data(), W, H) : writePfm(outPath, rgba.data(), W, H);
     if (!werr.empty()) { fprintf(stderr, "mtsamd-render: %s\n", werr.c_str()); return 1; }
     if (!filmPath.empty()) {
         FILE *f = fopen(filmPath.c_str(), "wb");

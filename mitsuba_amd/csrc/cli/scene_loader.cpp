@@ -696,6 +696,46 @@ std::string writePfm(const std::string &path, const float *rgba, int width, int 
     return "";
 }
 
+// PNG: signature, IHDR, one IDAT holding the zlib stream of the unfiltered rows, IEND
+std::string writePng(const std::string &path, const uint8_t *pixels, int width, int height, int channels) {
+    if (channels < 1 || channels > 4) return "PNG output needs 1 to 4 channels";
+    const size_t row = (size_t) width * channels;
+    std::vector<uint8_t> raw((row + 1) * (size_t) height);
+    for (int y = 0; y < height; ++y) {
+        raw[(row + 1) * y] = 0;     // filter type "none"
+        memcpy(&raw[(row + 1) * y + 1], pixels + row * y, row);
+    }
+    uLongf zlen = compressBound((uLong) raw.size());
+    std::vector<uint8_t> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong) raw.size(), 6) != Z_OK) return "zlib compression failed";
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return "cannot write " + path;
+    auto be32 = [](uint8_t *p, uint32_t v) { p[0] = (uint8_t) (v >> 24); p[1] = (uint8_t) (v >> 16); p[2] = (uint8_t) (v >> 8); p[3] = (uint8_t) v; };
+    auto chunk = [&](const char *type, const uint8_t *data, size_t n) {
+        uint8_t head[8], tail[4];
+        be32(head, (uint32_t) n);
+        memcpy(head + 4, type, 4);
+        uLong crc = crc32(0L, head + 4, 4);
+        if (n) crc = crc32(crc, data, (uInt) n);
+        be32(tail, (uint32_t) crc);
+        fwrite(head, 1, 8, f);
+        if (n) fwrite(data, 1, n, f);
+        fwrite(tail, 1, 4, f);
+    };
+    const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+    fwrite(sig, 1, 8, f);
+    uint8_t ihdr[13];
+    be32(ihdr, (uint32_t) width); be32(ihdr + 4, (uint32_t) height);
+    const uint8_t colourType[5] = { 0, 0, 4, 2, 6 };    // grey, grey + alpha, RGB, RGBA
+    ihdr[8] = 8; ihdr[9] = colourType[channels]; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", z.data(), zlen);
+    chunk("IEND", nullptr, 0);
+    const bool ok = !ferror(f);
+    fclose(f);
+    return ok ? "" : "cannot write " + path;
+}
+
 // OpenEXR, the format HDRFilm writes by default (src/films/hdrfilm.cpp:213-223, Bitmap::writeOpenEXR in
 // src/libcore/bitmap.cpp): here a single-part scan-line file, version 2, three 32-bit float channels (B, G, R in the
 // file's alphabetical order), no compression, rows top to bottom. Any OpenEXR reader opens it; the reference's
@@ -983,6 +1023,25 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
                         fw = (int) getF(fp, "width", 768); fh = (int) getF(fp, "height", 576);
                         if (fp.count("cropOffsetX") || fp.count("cropWidth")) return "film crop windows are set through the C ABI, not the scene file";
                         for (const auto &r : c->children) if (r->tag == "rfilter") rf = r.get();
+                        out.filmType = c->get("type");
+                        if (out.filmType == "ldrfilm") {    // src/films/ldrfilm.cpp:131-183
+                            const std::string fileFormat = lower(getS(fp, "fileFormat", "png"));
+                            if (fileFormat == "jpg" || fileFormat == "jpeg") return "ldrfilm: JPEG output is not supported (use fileFormat=png)";
+                            if (fileFormat != "png") return "The \"fileFormat\" parameter must either be equal to \"png\" or \"jpeg\"!";
+                            const std::string pf = lower(getS(fp, "pixelFormat", "rgb")), tm = lower(getS(fp, "tonemapMethod", "gamma"));
+                            if (pf == "luminance") out.ldr.pixel_format = MTSAMD_PIXEL_LUMINANCE;
+                            else if (pf == "luminancealpha") out.ldr.pixel_format = MTSAMD_PIXEL_LUMINANCE_ALPHA;
+                            else if (pf == "rgb") out.ldr.pixel_format = MTSAMD_PIXEL_RGB;
+                            else if (pf == "rgba") out.ldr.pixel_format = MTSAMD_PIXEL_RGBA;
+                            else return "The \"pixelFormat\" parameter must either be equal to \"luminance\", \"luminanceAlpha\", \"rgb\", or \"rgba\"!";
+                            if (tm == "gamma") out.ldr.tonemap = MTSAMD_TONEMAP_GAMMA;
+                            else if (tm == "reinhard") out.ldr.tonemap = MTSAMD_TONEMAP_REINHARD;
+                            else return "The \"tonemapMethod\" parameter must either be equal to \"gamma\" or \"reinhard\"!";
+                            out.ldr.gamma = (float) getF(fp, "gamma", -1);
+                            out.ldr.exposure = (float) getF(fp, "exposure", 0.0);
+                            out.ldr.key = (float) getF(fp, "key", 0.18);
+                            out.ldr.burn = (float) getF(fp, "burn", 0.0);
+                        }
                     } else if (c->tag == "sampler") {
                         out.sampleCount = (int) getF(parseProps(*c), "sampleCount", 4);
                     }

@@ -34,6 +34,8 @@ struct LoadedScene {
     bool anyNormals = false, anyTexcoords = false;
     int sampleCount = 4;
     std::string integratorType;
+    std::string filmType;               // "hdrfilm", "ldrfilm", ... as the scene file names it
+    mtsamd_ldr_opts ldr = { MTSAMD_PIXEL_RGB, MTSAMD_TONEMAP_GAMMA, -1.0f, 0.0f, 0.18f, 0.0f };     // LDRFilm parameters (src/films/ldrfilm.cpp:131-183)
 
     // The returned description points into this object; keep it alive until mtsamd_scene_create has returned.
     mtsamd_scene_desc desc() const;
@@ -57,5 +59,7 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
 std::string writePfm(const std::string &path, const float *rgba, int width, int height);
 // OpenEXR (HDRFilm's default container): RGB, 32-bit float, uncompressed scan lines, top row first.
 std::string writeExr(const std::string &path, const float *rgba, int width, int height);
+// PNG, LDRFilm's default container (src/films/ldrfilm.cpp:141-142): 8 bits per channel, 1-4 channels, top row first.
+std::string writePng(const std::string &path, const uint8_t *pixels, int width, int height, int channels);
 
 }  // namespace mtsamd_host

@@ -574,6 +574,16 @@ extern "C" int mtsamd_film_develop(const mtsamd_scene *scene, const float *film,
     return MTSAMD_OK;
 }
 
+namespace mtsamd_host { const char *developLdr(const float *film, size_t pixels, const mtsamd_ldr_opts &o, uint8_t *out); }
+
+extern "C" int mtsamd_film_develop_ldr(const float *film, int32_t width, int32_t height, const mtsamd_ldr_opts *opts, uint8_t *out) {
+    if (!film || !opts || !out) return fail(MTSAMD_EINVAL, "null argument");
+    if (width < 0 || height < 0) return fail(MTSAMD_EINVAL, "negative image size");
+    const char *err = mtsamd_host::developLdr(film, (size_t) width * (size_t) height, *opts, out);
+    if (err && *err) return fail(MTSAMD_EINVAL, "%s", err);
+    return MTSAMD_OK;
+}
+
 // ---- batch entry points ---------------------------------------------------------------------------------------------------
 namespace {
 

@@ -263,6 +263,75 @@ class OracleScene:
 
 
 # ---- scene-free helpers -------------------------------------------------------------------------------
+def develop_ldr(film, pixel_format="rgb", tonemap="gamma", gamma=-1.0, exposure=0.0, key=0.18, burn=0.0):
+    """LDRFilm::develop (src/films/ldrfilm.cpp:300-321) restated in numpy, single precision: the weight division of
+    Bitmap::convert (src/libcore/fmtconv.cpp:955-1005), tonemapReinhard (src/libcore/bitmap.cpp:1707-1854) or the
+    exposure multiplier, applyGamma and the 8-bit rounding of convertScalar (fmtconv.cpp:1104-1160).
+    film: (h, w, 5) float32 -> (h, w, channels) uint8."""
+    f32 = np.float32
+    film = np.asarray(film, f32)
+    h, w = film.shape[:2]
+    px = film.reshape(-1, 5)
+    wgt = px[:, 4]
+    with np.errstate(all="ignore"):
+        inv = np.where(wgt != 0, f32(1) / wgt, wgt).astype(f32)
+        colour = pixel_format.lower() in ("rgb", "rgba")
+        alpha = pixel_format.lower() in ("luminancealpha", "rgba")
+        lum_w = (f32(0.212671), f32(0.715160), f32(0.072169))
+
+        def luminance(c):
+            return (c[:, 0] * lum_w[0] + c[:, 1] * lum_w[1]) + c[:, 2] * lum_w[2]
+
+        img = (px[:, :3] * inv[:, None]) if colour else (luminance(px) * inv)[:, None]
+        img = img.astype(f32)
+        multiplier = f32(1)
+        if tonemap.lower() == "reinhard":
+            lum = luminance(img) if colour else img[:, 0]
+            # the running maximum restarts at a pixel whose luminance is exactly 1024 (bitmap.cpp:1745-1746)
+            restart = np.nonzero(lum == 1024)[0]
+            max_lum = f32(max(0.0, lum[restart[-1]:].max() if len(restart) else lum.max())) if lum.size else f32(0)
+            if not max_lum >= 0:
+                max_lum = f32(0)
+            log_avg = np.exp(np.cumsum(np.log(f32(1e-3) + lum), dtype=f32)[-1] / f32(lum.size), dtype=f32)
+            if max_lum != 0:
+                b = f32(min(1.0, max(1e-8, 1 - burn)))
+                scale = f32(key) / log_avg
+                l_white = max_lum * scale
+                inv_wp2 = f32(1) / (l_white * l_white * np.power(b, f32(4)))
+                if colour:
+                    X = (img[:, 0] * f32(0.412453) + img[:, 1] * f32(0.357580)) + img[:, 2] * f32(0.180423)
+                    Y = (img[:, 0] * f32(0.212671) + img[:, 1] * f32(0.715160)) + img[:, 2] * f32(0.072169)
+                    Z = (img[:, 0] * f32(0.019334) + img[:, 1] * f32(0.119193)) + img[:, 2] * f32(0.950227)
+                    norm = f32(1) / (X + Y + Z)
+                    x, y, Lp = X * norm, Y * norm, Y * scale
+                    Y = Lp * (f32(1) + Lp * inv_wp2) / (f32(1) + Lp)
+                    ratio = Y / y
+                    X, Z = ratio * x, ratio * (f32(1) - x - y)
+                    img = np.stack([(f32(3.240479) * X + f32(-1.537150) * Y) + f32(-0.498535) * Z,
+                                    (f32(-0.969256) * X + f32(1.875991) * Y) + f32(0.041556) * Z,
+                                    (f32(0.055648) * X + f32(-0.204043) * Y) + f32(1.057311) * Z], 1).astype(f32)
+                else:
+                    Lp = img[:, 0] * scale
+                    img = (Lp * (f32(1) + Lp * inv_wp2) / (f32(1) + Lp))[:, None].astype(f32)
+        else:
+            multiplier = np.power(f32(2), f32(exposure))
+
+        def quantise(v, mult, inv_gamma):
+            v = (v * mult).astype(f32)
+            if inv_gamma == -1:
+                v = np.where(v <= f32(0.0031308), f32(12.92) * v, f32(1.055) * np.power(v, f32(1.0 / 2.4)) - f32(0.055)).astype(f32)
+            elif inv_gamma != 1:
+                v = np.power(v, f32(inv_gamma)).astype(f32)
+            s = v * f32(255) + f32(0.5)
+            s = np.where(s > 0, s, f32(0))          # std::max(0, NaN) is 0
+            return np.minimum(f32(255), s).astype(np.uint8)
+
+        out = [quantise(img, multiplier, f32(1) / f32(gamma))]
+        if alpha:
+            out.append(quantise((px[:, 3] * inv)[:, None], f32(1), f32(1)))
+    return np.concatenate(out, 1).reshape(h, w, -1)
+
+
 def clipped_aabb(v, box):
     v, box = np.ascontiguousarray(v, np.float32), np.ascontiguousarray(box, np.float32)
     out = np.zeros(6, np.float32)

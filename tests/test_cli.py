@@ -302,6 +302,54 @@ def test_cli_render_matches_binding(scene_dir, tmp_path):
     assert np.allclose(_read_exr(str(exr)), img, rtol=1e-6, atol=0)
 
 
+def _read_png(path):
+    """Minimal reader for 8-bit, non-interlaced PNG files whose rows use filter type 0."""
+    b = open(path, "rb").read()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, head = 8, b"", None
+    while pos < len(b):
+        n, = struct.unpack_from(">I", b, pos)
+        typ, data = b[pos + 4:pos + 8], b[pos + 8:pos + 8 + n]
+        assert struct.unpack_from(">I", b, pos + 8 + n)[0] == zlib.crc32(typ + data)
+        if typ == b"IHDR":
+            head = struct.unpack(">IIBBBBB", data)
+        elif typ == b"IDAT":
+            idat += data
+        pos += 12 + n
+    w, h, depth, colour, comp, flt, interlace = head
+    assert (depth, comp, flt, interlace) == (8, 0, 0, 0)
+    ch = {0: 1, 4: 2, 2: 3, 6: 4}[colour]
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * ch)
+    assert np.all(raw[:, 0] == 0)
+    return raw[:, 1:].reshape(h, w, ch)
+
+
+@pytest.mark.gpu
+def test_cli_ldrfilm_png(scene_dir, tmp_path):
+    """<film type="ldrfilm"> (src/films/ldrfilm.cpp:131-183) and a .png output name: the tone-mapped 8-bit image."""
+    from mitsuba_amd import capi
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    text = (scene_dir / "scene.xml").read_text()
+    for film_xml, kw in (('<film type="ldrfilm">', dict()),
+                         ('<film type="ldrfilm"><string name="pixelFormat" value="rgba"/><string name="tonemapMethod" value="reinhard"/>'
+                          '<float name="key" value="0.3"/><float name="burn" value="0.2"/><float name="gamma" value="2.2"/>',
+                          dict(pixel_format="rgba", tonemap="reinhard", key=0.3, burn=0.2, gamma=2.2)),
+                         ('<film type="ldrfilm"><string name="pixelFormat" value="luminance"/><float name="exposure" value="1.5"/>',
+                          dict(pixel_format="luminance", exposure=1.5))):
+        f = tmp_path / "ldr.xml"
+        f.write_text(text.replace('<film type="hdrfilm">', film_xml))
+        png, raw = tmp_path / "out.png", tmp_path / "film.raw"
+        out = subprocess.run([CLI, str(f), "-o", str(png), "--film", str(raw), "--spp", "4", "--seed", "2"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        film = np.fromfile(str(raw), np.float32).reshape(48, 64, 5)
+        img = _read_png(str(png))
+        assert np.array_equal(img, capi.develop_ldr(film, **kw))
+        assert img[..., 0].std() > 5
+    f.write_text(text.replace('<film type="hdrfilm">', '<film type="ldrfilm"><string name="fileFormat" value="jpeg"/>'))
+    out = subprocess.run([CLI, str(f), "--describe"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "JPEG" in out.stderr
+
+
 def _read_exr(path):
     """Minimal reader for uncompressed single-part scan-line OpenEXR files with 32-bit float channels."""
     b = open(path, "rb").read()
