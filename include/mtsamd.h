@@ -35,7 +35,7 @@ enum {
    type of its own: it is the two_sided / back_material pair of the record of the BRDF it wraps. */
 enum { MTSAMD_BSDF_DIFFUSE = 0, MTSAMD_BSDF_ROUGHCONDUCTOR = 1, MTSAMD_BSDF_ROUGHPLASTIC = 2,
        MTSAMD_BSDF_DIELECTRIC = 3, MTSAMD_BSDF_WARD = 4, MTSAMD_BSDF_CONDUCTOR = 5, MTSAMD_BSDF_PLASTIC = 6,
-       MTSAMD_BSDF_ROUGHDIELECTRIC = 7 };
+       MTSAMD_BSDF_ROUGHDIELECTRIC = 7, MTSAMD_BSDF_MIXTURE = 8 };
 /* MicrofacetDistribution::EType (src/bsdfs/microfacet.h:48-57); Phong is not supported */
 enum { MTSAMD_DISTR_BECKMANN = 0, MTSAMD_DISTR_GGX = 1 };
 enum { MTSAMD_SHAPE_HAS_NORMALS = 1, MTSAMD_SHAPE_HAS_TEXCOORDS = 2 };
@@ -83,6 +83,12 @@ typedef struct {
        -1 = the same record on both sides. Only reflection-only BRDFs may be nested (twosided.cpp:103-105). */
     int32_t two_sided;
     int32_t back_material;
+    /* MixtureBSDF (src/bsdfs/mixturebsdf.cpp:66-85,115-172), type MTSAMD_BSDF_MIXTURE: the records of up to four nested
+       BSDFs and their linear weights (rescaled when they sum to more than one and ensure_energy_conservation is set).
+       Nested records must be one-sided diffuse, roughconductor, roughplastic or ward models. */
+    int32_t mix_count;
+    int32_t mix_material[4];
+    float mix_weight[4];
 } mtsamd_material;
 
 /* Emitter record. type MTSAMD_EMITTER_SURFACE: an AreaLight attached to a mesh (src/emitters/area.cpp; the shape's

@@ -28,7 +28,8 @@ class Material(C.Structure):
                 ("specular_transmittance", C.c_float * 3), ("eta", C.c_float * 3), ("k", C.c_float * 3),
                 ("ext_eta", C.c_float), ("ensure_energy_conservation", C.c_int32),
                 ("rtrans", _f32p), ("rtrans_n", C.c_uint32), ("rtrans_diffuse_ext", C.c_float),
-                ("rtrans_diffuse_int", C.c_float), ("two_sided", C.c_int32), ("back_material", C.c_int32)]
+                ("rtrans_diffuse_int", C.c_float), ("two_sided", C.c_int32), ("back_material", C.c_int32),
+                ("mix_count", C.c_int32), ("mix_material", C.c_int32 * 4), ("mix_weight", C.c_float * 4)]
 
 
 class Emitter(C.Structure):
@@ -168,6 +169,10 @@ def fill_desc(sd):
             setattr(c, k, m[k])
         for k in ("diffuse_reflectance", "specular_reflectance", "specular_transmittance", "eta", "k"):
             setattr(c, k, (C.c_float * 3)(*[float(x) for x in m[k]]))
+        mix = m.get("mix", ())
+        c.mix_count = len(mix)
+        for j, (child, weight) in enumerate(mix[:4]):
+            c.mix_material[j], c.mix_weight[j] = int(child), float(weight)
         if m.get("rtrans") is not None:
             t = np.ascontiguousarray(m["rtrans"], np.float32)
             keep.append(t)

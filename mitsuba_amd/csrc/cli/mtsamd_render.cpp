@@ -45,6 +45,18 @@ static void describe(const LoadedScene &s) {
     for (size_t i = 0; i < s.materials.size(); ++i) printf("%s%d", i ? ", " : "", s.materials[i].two_sided);
     printf("], \"back_materials\": [");
     for (size_t i = 0; i < s.materials.size(); ++i) printf("%s%d", i ? ", " : "", s.materials[i].back_material);
+    printf("], \"mixtures\": [");
+    bool firstMix = true;
+    for (size_t i = 0; i < s.materials.size(); ++i) {
+        const mtsamd_material &m = s.materials[i];
+        if (m.type != MTSAMD_BSDF_MIXTURE) continue;
+        printf("%s{\"material\": %zu, \"children\": [", firstMix ? "" : ", ", i);
+        for (int k = 0; k < m.mix_count; ++k) printf("%s%d", k ? ", " : "", m.mix_material[k]);
+        printf("], \"weights\": [");
+        for (int k = 0; k < m.mix_count; ++k) printf("%s%.9g", k ? ", " : "", m.mix_weight[k]);
+        printf("]}");
+        firstMix = false;
+    }
     printf("], \"shape_triangles\": [");
     for (size_t i = 0; i < s.shapes.size(); ++i) printf("%s%u", i ? ", " : "", s.shapes[i].n_triangles);
     printf("], \"emitter_records\": [");

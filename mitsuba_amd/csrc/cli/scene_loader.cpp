@@ -283,6 +283,48 @@ mtsamd_material makeBsdf(const Element &node, const LoadOptions &opts, LoadedSce
         m.back_material = back;
         return m;
     }
+    if (type == "mixturebsdf") {                // src/bsdfs/mixturebsdf.cpp:66-85,279-287
+        const Props mp = parseProps(node);
+        std::vector<double> weights;
+        {
+            std::string text = getS(mp, "weights", "");
+            for (char &ch : text) if (ch == ',') ch = ' ';
+            std::istringstream in(text);
+            std::string tok;
+            while (in >> tok) {
+                char *end = nullptr;
+                const double w = strtod(tok.c_str(), &end);
+                if (*end != '\0') throw Fail("Could not parse the BSDF weights!");
+                if (w < 0) throw Fail("Invalid BSDF weight!");
+                weights.push_back(w);
+            }
+        }
+        std::vector<int32_t> children;
+        for (const auto &c : node.children) {
+            if (c->tag == "bsdf") {
+                children.push_back((int32_t) addMaterial(out, makeBsdf(*c, opts, out, named)));
+            } else if (c->tag == "ref") {
+                if (!named || !named->count(c->get("id"))) throw Fail("reference to unknown bsdf '" + c->get("id") + "'");
+                children.push_back((int32_t) addMaterial(out, copyMaterial(out, named->at(c->get("id")))));
+            }
+        }
+        for (int32_t c : children) {
+            const mtsamd_material &cm = out.materials[(size_t) c];
+            if (cm.two_sided || !(cm.type == MTSAMD_BSDF_DIFFUSE || cm.type == MTSAMD_BSDF_ROUGHCONDUCTOR || cm.type == MTSAMD_BSDF_ROUGHPLASTIC || cm.type == MTSAMD_BSDF_WARD))
+                throw Fail("mixturebsdf: only diffuse, roughconductor, roughplastic and ward can be nested");
+        }
+        if (children.size() != weights.size())
+            throw Fail("BSDF count mismatch: " + std::to_string(children.size()) + " bsdfs, but specified " + std::to_string(weights.size()) + " weights");
+        if (children.empty() || children.size() > 4) throw Fail("mixturebsdf: between one and four nested BSDFs are supported");
+        mtsamd_material m;
+        memset(&m, 0, sizeof(m));
+        m.type = MTSAMD_BSDF_MIXTURE;
+        m.ensure_energy_conservation = getB(mp, "ensureEnergyConservation", true) ? 1 : 0;
+        m.back_material = -1;
+        m.mix_count = (int32_t) children.size();
+        for (size_t i = 0; i < children.size(); ++i) { m.mix_material[i] = children[i]; m.mix_weight[i] = (float) weights[i]; }
+        return m;
+    }
     for (const auto &c : node.children)
         if (c->tag == "texture" || c->tag == "bsdf")
             throw Fail("nested <" + c->tag + "> inside <bsdf type=\"" + type + "\"> is not supported");

@@ -707,6 +707,87 @@ MTS_DEV uint32_t cdfSampleReuse(const float *cdf, uint32_t n /* entries */, floa
     return index;
 }
 
+// ---- MixtureBSDF (src/bsdfs/mixturebsdf.cpp:174-277), all components requested ---------------------------------
+// A mixture record keeps its count in `variant`, its weights in diffuse[0..2] + rtransOffset, the upper ends of the
+// normalised choice intervals in specular[0..2] + rtransN and the nested records' indices in condEta[0..2] + condK[0].
+// Nested records are diffuse, roughconductor, roughplastic or ward models: solid-angle lobes only, nothing taken
+// from the sampler. Fields are picked with selects, not indexed, so that they stay in registers.
+MTS_DEV float mixWeight(const DevMaterial &m, int i) {
+    return i == 0 ? m.diffuse[0] : i == 1 ? m.diffuse[1] : i == 2 ? m.diffuse[2] : __uint_as_float(m.rtransOffset);
+}
+MTS_DEV float mixCdf(const DevMaterial &m, int i) {      // cdf[0] = 0, cdf[count] = 1
+    return i <= 0 ? 0.0f : i == 1 ? m.specular[0] : i == 2 ? m.specular[1] : i == 3 ? m.specular[2] : __uint_as_float(m.rtransN);
+}
+MTS_DEV uint32_t mixChild(const DevMaterial &m, int i) {
+    return __float_as_uint(i == 0 ? m.condEta[0] : i == 1 ? m.condEta[1] : i == 2 ? m.condEta[2] : m.condK[0]);
+}
+
+MTS_DEV V3 mixEval(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
+    V3 result = mk(0.0f);
+#pragma unroll 1
+    for (int i = 0; i < m.variant; ++i) {
+        DevMaterial c;
+        loadMaterial(sc, mixChild(m, i), c);
+        result = result + bsdfEval<false>(sc, c, wi, wo) * mixWeight(m, i);
+    }
+    return result;
+}
+
+MTS_DEV float mixPdf(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
+    float result = 0.0f;
+#pragma unroll 1
+    for (int i = 0; i < m.variant; ++i) {
+        DevMaterial c;
+        loadMaterial(sc, mixChild(m, i), c);
+        result += bsdfPdf<false>(sc, c, wi, wo) * (mixCdf(m, i + 1) - mixCdf(m, i));
+    }
+    return result;
+}
+
+MTS_DEV V3 mixSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, V3 &wo, float &pdf, float &eta, uint32_t &sampledType) {
+    const int n = m.variant;
+    // DiscreteDistribution::sampleReuse (include/mitsuba/core/pmf.h:124-188) over the five-entry table
+    int lo = 0;
+#pragma unroll
+    for (int k = 0; k <= 4; ++k) lo += (k <= n && mixCdf(m, k) < sx) ? 1 : 0;
+    int entry = lo - 1 < 0 ? 0 : lo - 1;
+    entry = entry < n - 1 ? entry : n - 1;
+    while (mixCdf(m, entry + 1) - mixCdf(m, entry) == 0 && entry < n) ++entry;
+    const float lower = mixCdf(m, entry), width = mixCdf(m, entry + 1) - lower;
+    sx = (sx - lower) / width;
+    DevMaterial c;
+    loadMaterial(sc, mixChild(m, entry), c);
+    V3 result = bsdfSample<false>(sc, c, wi, sx, sy, 0.0f, wo, pdf, eta, sampledType);
+    if (isZero(result)) return result;      // sampling failed
+    result = result * (mixWeight(m, entry) * pdf);
+    pdf *= width;
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) {
+        if (i == entry) continue;
+        loadMaterial(sc, mixChild(m, i), c);
+        pdf += bsdfPdf<false>(sc, c, wi, wo) * (mixCdf(m, i + 1) - mixCdf(m, i));
+        result = result + bsdfEval<false>(sc, c, wi, wo) * mixWeight(m, i);
+    }
+    return result / pdf;
+}
+
+// What the integrator calls on the record that answers for this side: a mixture (only compiled in with MIX) or a plain model
+template <bool RD = true, bool MIX = true>
+MTS_DEV V3 bsdfEvalAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
+    if (MIX && m.type == 8) return mixEval(sc, m, wi, wo);
+    return bsdfEval<RD>(sc, m, wi, wo);
+}
+template <bool RD = true, bool MIX = true>
+MTS_DEV float bsdfPdfAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
+    if (MIX && m.type == 8) return mixPdf(sc, m, wi, wo);
+    return bsdfPdf<RD>(sc, m, wi, wo);
+}
+template <bool RD = true, bool MIX = true>
+MTS_DEV V3 bsdfSampleAny(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, float su, V3 &wo, float &pdf, float &eta, uint32_t &sampledType) {
+    if (MIX && m.type == 8) return mixSample(sc, m, wi, sx, sy, wo, pdf, eta, sampledType);
+    return bsdfSample<RD>(sc, m, wi, sx, sy, su, wo, pdf, eta, sampledType);
+}
+
 struct DirectRec { V3 d; float dist, pdf; bool delta; };
 
 // warp::squareToUniformSphere (src/libcore/warp.cpp:25-31)

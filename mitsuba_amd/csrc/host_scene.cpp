@@ -226,6 +226,8 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
                 dm.typeFlags = EDeltaReflection | EDiffuseReflection | EFrontSide;
                 break;
             }
+            case MTSAMD_BSDF_MIXTURE:           // filled in below, once the nested records are known
+                break;
             default:
                 return "unsupported BSDF type";
         }
@@ -234,6 +236,45 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         dm.twoSided = m.two_sided != 0;
         dm.backMaterial = (int32_t) i;
         hs.materials[i] = dm;
+    }
+    // MixtureBSDF::configure (mixturebsdf.cpp:115-172). The record keeps the count in `variant`, the weights in
+    // diffuse[0..2] + rtransOffset, the upper ends of the normalised choice intervals in specular[0..2] + rtransN and
+    // the nested records' indices in condEta[0..2] + condK[0] (the last of each group as raw bits).
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const mtsamd_material &m = d->materials[i];
+        if (m.type != MTSAMD_BSDF_MIXTURE) continue;
+        DevMaterial &dm = hs.materials[i];
+        const int n = m.mix_count;
+        if (n < 1 || n > 4) return "mixturebsdf: between one and four nested BSDFs are supported";
+        float total = 0;
+        for (int k = 0; k < n; ++k) {
+            if (m.mix_weight[k] < 0) return "Invalid BSDF weight!";
+            total += m.mix_weight[k];
+        }
+        if (total <= 0) return "The weights must sum to a value greater than zero!";
+        const float scale = (m.ensure_energy_conservation && total > 1) ? 1.0f / total : 1.0f;
+        float w[4] = { 0, 0, 0, 0 }, cdf[5] = { 0, 0, 0, 0, 0 };
+        int32_t child[4] = { 0, 0, 0, 0 };
+        unsigned flags = 0;
+        for (int k = 0; k < n; ++k) {
+            const int32_t c = m.mix_material[k];
+            if (c < 0 || c >= (int32_t) d->n_materials) return "mixturebsdf: nested material index out of range";
+            const int t = d->materials[c].type;
+            if (d->materials[c].two_sided || !(t == MTSAMD_BSDF_DIFFUSE || t == MTSAMD_BSDF_ROUGHCONDUCTOR || t == MTSAMD_BSDF_ROUGHPLASTIC || t == MTSAMD_BSDF_WARD))
+                return "mixturebsdf: only diffuse, roughconductor, roughplastic and ward can be nested";
+            child[k] = c;
+            w[k] = scale != 1.0f ? m.mix_weight[k] * scale : m.mix_weight[k];
+            cdf[k + 1] = cdf[k] + w[k];
+            flags |= hs.materials[c].ownFlags;
+        }
+        normalizeCdf(cdf, (size_t) n, nullptr);
+        for (int k = n + 1; k <= 4; ++k) cdf[k] = cdf[n];
+        dm.variant = n;
+        memcpy(dm.diffuse, w, 12); memcpy(&dm.rtransOffset, &w[3], 4);
+        memcpy(dm.specular, &cdf[1], 12); memcpy(&dm.rtransN, &cdf[4], 4);
+        memcpy(dm.condEta, child, 12); memcpy(&dm.condK[0], &child[3], 4);
+        dm.typeFlags = dm.ownFlags = flags;
+        hs.mixture = true;
     }
     // TwoSidedBRDF::configure (twosided.cpp:84-106): the adapter shows the front BRDF's components on the front side
     // and the back BRDF's on the back side
@@ -441,7 +482,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         }
     }
     if (d->n_materials >= (1u << 24)) return "too many materials";
-    for (TriRecord &r : hs.bvh.tris) r.pad = (uint32_t) hs.materials[hs.shapes[hs.triShape[r.tri]].material].type << 28;
+    for (TriRecord &r : hs.bvh.tris) r.pad = (uint32_t) std::min(hs.materials[hs.shapes[hs.triShape[r.tri]].material].type, 7) << 28;
 
     // ---- scalar parameters -------------------------------------------------------------------------------------
     DevScene &p = hs.params;

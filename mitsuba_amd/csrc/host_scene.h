@@ -23,6 +23,7 @@ struct HostScene {
     bool hasNormals = false, hasTexcoords = false;
     int32_t envEmitter = -1;    // index of the constant environment emitter in `emitters`, if any
     std::vector<DevDeltaEmitter> deltaEmitters;     // point, spot and directional emitters
+    bool mixture = false;       // some material is a mixturebsdf (selects the kernels that know it)
     bool extEmitters = false;   // some emitter is not an area light (selects the kernels that know the other kinds)
 };
 

@@ -90,7 +90,7 @@ struct HeldPath {
 
 // One vertex of MIPathTracer::Li (src/integrators/path/path.cpp:135-287) for the path `in` whose ray produced `hit`.
 // Radiance gathered at this vertex goes to sampleL[slot] directly; the rest comes back in `o`.
-template <bool ENV, bool RD, typename Path>
+template <bool ENV, bool RD, bool MIX, typename Path>
 MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &in, const float4 hit, float4 *sampleL, ShadeOut &o) {
     const uint32_t triWord = __float_as_uint(hit.w);
     if (triWord != kMiss) {
@@ -186,10 +186,10 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                     V3 c = mk(0.0f);
                     const V3 wo = toLocal(its.sh, dRec.d);
                     const V3 woSide = flipped ? mirrorZ(wo) : wo;
-                    const V3 bsdfVal = bsdfEval<RD>(sc, bsdf, wiLocal, woSide);
+                    const V3 bsdfVal = bsdfEvalAny<RD, MIX>(sc, bsdf, wiLocal, woSide);
                     if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
                         // path.cpp:192-193: only emitters with a surface, sampled in the solid-angle measure, compete with BSDF sampling
-                        const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdf<RD>(sc, bsdf, wiLocal, woSide);
+                        const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX>(sc, bsdf, wiLocal, woSide);
                         c = throughput * value * bsdfVal * miWeight(dRec.pdf, bPdf);
                     }
                     o.wantShadow = true;
@@ -203,7 +203,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             const float bx = rng.next1D(), by = rng.next1D();
             V3 woLocal; float bPdf, bEta; uint32_t sampledType;
             const float bu = RD && bsdfUsesSampler(bsdf) ? rng.next1D() : 0.0f;     // bRec.sampler->next1D() inside BSDF::sample
-            const V3 bsdfWeight = bsdfSample<RD>(sc, bsdf, wiLocal, bx, by, bu, woLocal, bPdf, bEta, sampledType);
+            const V3 bsdfWeight = bsdfSampleAny<RD, MIX>(sc, bsdf, wiLocal, bx, by, bu, woLocal, bPdf, bEta, sampledType);
             if (flipped && !isZero(bsdfWeight) && bPdf != 0) woLocal.z = -woLocal.z;      // twosided.cpp:172-181
             if (!isZero(bsdfWeight)) {
                 if (sampledType != ENull) flags |= PF_SCATTERED;
@@ -275,7 +275,7 @@ static constexpr int kShadeBlock = MTS_SHADE_BLOCK;
 // ENV: the scene has emitters other than area lights: an environment emitter (rays that leave the scene are shaded
 // too, one more queue stream), point, spot or directional lights.
 // RD: the scene has a rough dielectric material.
-template <int ROUNDS, bool ENV, bool RD>
+template <int ROUNDS, bool ENV, bool RD, bool MIX>
 __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out,
                                                        ShadowQueue sq, float4 *sampleL, uint32_t *counters, uint32_t n) {
     constexpr int kWaves = kShadeBlock / 64, kKeys = 9, kCells = kKeys * ROUNDS * kWaves;   // BSDF models 0..7, misses
@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
     asm volatile("" : "+v"(tidS));
     const uint32_t i = first + sOrder[round * kShadeBlock + tidS];
     ShadeOut o;
-    if (i < n) shadeVertex<ENV, RD>(sc, pp, QueuedPath{ in, i }, hits[i], sampleL, o);
+    if (i < n) shadeVertex<ENV, RD, MIX>(sc, pp, QueuedPath{ in, i }, hits[i], sampleL, o);
     const bool alive = o.alive, wantShadow = o.wantShadow;
     uint32_t tidL = threadIdx.x;
     asm volatile("" : "+v"(tidL));
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
 // functions as the wavefront kernels, hence the same results. counts[0] / counts[1] receive the closest-hit and
 // shadow rays traced (the reference's two ray counters).
 static constexpr int kTailBlock = 64;
-template <bool ENV, bool RD>
+template <bool ENV, bool RD, bool MIX>
 __global__ void __launch_bounds__(kTailBlock) k_tail(DevScene sc, PassParams pp, PathQueue in, float4 *sampleL, uint32_t n,
                                                      uint32_t triShare, unsigned long long *counts) {
     __shared__ uint2 sStack[kLdsStack * kTailBlock];
@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(kTailBlock) k_tail(DevScene sc, PassParams pp,
         traceHeldRays<false>(sc, r, busy, ldsStack, triShare);
         // shade
         ShadeOut o;
-        if (active) shadeVertex<ENV, RD>(sc, pp, path, make_float4(r.hit.t, r.hit.u, r.hit.v, __uint_as_float(r.hit.tri)), sampleL, o);
+        if (active) shadeVertex<ENV, RD, MIX>(sc, pp, path, make_float4(r.hit.t, r.hit.u, r.hit.v, __uint_as_float(r.hit.tri)), sampleL, o);
         // shadow ray of the emitter sample (scene.cpp:839-843), then path.cpp:196-198
         const bool wantShadow = active && o.wantShadow;
         busy = false;
@@ -558,7 +558,8 @@ __global__ void k_tag_triangle_records(float4 *tris, uint32_t triStride, uint32_
     float4 *rec = tris + (size_t) triStride * i;
     const uint32_t tri = __float_as_uint(rec[2].z);
     const uint32_t mat = __float_as_uint(shadeTris[6 * (size_t) tri].w) & 0xffffffu;
-    rec[2].w = __uint_as_float((uint32_t) materials[mat].type << 28);
+    const int type = materials[mat].type;
+    rec[2].w = __uint_as_float((uint32_t) (type < 7 ? type : 7) << 28);      // mixtures share the last sorting key
 }
 
 // ---- batch kernels behind the parity entry points -------------------------------------------------------------------------
@@ -607,8 +608,8 @@ __global__ void k_bsdf_evalpdf(DevScene sc, int material, int mode, uint32_t n, 
     loadMaterial(sc, (uint32_t) material, m);
     V3 a = ld3(wi, i), b = ld3(wo, i);
     if (resolveTwoSided(sc, (uint32_t) material, a.z, m)) { a = mirrorZ(a); b = mirrorZ(b); }
-    if (mode == 0) { const V3 r = bsdfEval(sc, m, a, b); out[3 * (size_t) i] = r.x; out[3 * (size_t) i + 1] = r.y; out[3 * (size_t) i + 2] = r.z; }
-    else out[i] = bsdfPdf(sc, m, a, b);
+    if (mode == 0) { const V3 r = bsdfEvalAny(sc, m, a, b); out[3 * (size_t) i] = r.x; out[3 * (size_t) i + 1] = r.y; out[3 * (size_t) i + 2] = r.z; }
+    else out[i] = bsdfPdfAny(sc, m, a, b);
 }
 
 __global__ void k_bsdf_sample(DevScene sc, int material, uint32_t n, const float *wi, const float *sample, const float *sampler1D,
@@ -621,7 +622,7 @@ __global__ void k_bsdf_sample(DevScene sc, int material, uint32_t n, const float
     const bool flipped = resolveTwoSided(sc, (uint32_t) material, a.z, m);
     if (flipped) a = mirrorZ(a);
     V3 o; float p, e; uint32_t t;
-    const V3 w = bsdfSample(sc, m, a, sample[2 * (size_t) i], sample[2 * (size_t) i + 1], sampler1D ? sampler1D[i] : 0.5f, o, p, e, t);
+    const V3 w = bsdfSampleAny(sc, m, a, sample[2 * (size_t) i], sample[2 * (size_t) i + 1], sampler1D ? sampler1D[i] : 0.5f, o, p, e, t);
     if (flipped && !isZero(w) && p != 0) o.z = -o.z;
     wo[3 * (size_t) i] = o.x; wo[3 * (size_t) i + 1] = o.y; wo[3 * (size_t) i + 2] = o.z;
     weight[3 * (size_t) i] = w.x; weight[3 * (size_t) i + 1] = w.y; weight[3 * (size_t) i + 2] = w.z;

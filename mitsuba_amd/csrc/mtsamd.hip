@@ -102,7 +102,7 @@ struct mtsamd_scene {
         PathQueue q;
         q.rayO = qbuf[i][0].as<float4>(); q.rayD = qbuf[i][1].as<float4>(); q.thr = qbuf[i][2].as<float4>();
         q.misc = qbuf[i][3].as<uint4>(); q.bsdfPdf = qbuf[i][4].as<float>();
-        q.refCos = host.extEmitters ? qbuf[i][5].as<float>() : nullptr;
+        q.refCos = (host.extEmitters || host.mixture) ? qbuf[i][5].as<float>() : nullptr;
         return q;
     }
     ShadowQueue shadowQueue() const {
@@ -117,7 +117,7 @@ struct mtsamd_scene {
         for (int i = 0; i < 2; ++i) {
             for (int j = 0; j < 4; ++j) HIP_TRY(qbuf[i][j].ensure(n * 16));
             HIP_TRY(qbuf[i][4].ensure(n * 4));
-            if (host.extEmitters) HIP_TRY(qbuf[i][5].ensure(n * 4));
+            if (host.extEmitters || host.mixture) HIP_TRY(qbuf[i][5].ensure(n * 4));
         }
         HIP_TRY(hits.ensure(n * 16));
         for (int j = 0; j < 3; ++j) HIP_TRY(sbuf[j].ensure(n * 16));
@@ -368,9 +368,11 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
             unsigned long long *tailCounts = cnt64 + CNT64_TAIL_NORMAL;
             HIP_TRY(hipMemsetAsync(tailCounts, 0, 2 * sizeof(unsigned long long), st));
             timer.begin(T_TAIL);
-#define MTS_LAUNCH_TAIL(E, R) hipLaunchKernelGGL((k_tail<E, R>), dim3(blocksFor(n, kTailBlock)), dim3(kTailBlock), 0, st, sc, pp, s->queue(cur), sampleL, n, s->triShare, tailCounts)
-            if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_TAIL(true, true); else MTS_LAUNCH_TAIL(true, false); }
-            else { if (s->roughDielectric) MTS_LAUNCH_TAIL(false, true); else MTS_LAUNCH_TAIL(false, false); }
+#define MTS_LAUNCH_TAIL(E, R, M) hipLaunchKernelGGL((k_tail<E, R, M>), dim3(blocksFor(n, kTailBlock)), dim3(kTailBlock), 0, st, sc, pp, s->queue(cur), sampleL, n, s->triShare, tailCounts)
+            // scenes with a mixturebsdf run the variant that knows every feature
+            if (s->host.mixture) MTS_LAUNCH_TAIL(true, true, true);
+            else if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_TAIL(true, true, false); else MTS_LAUNCH_TAIL(true, false, false); }
+            else { if (s->roughDielectric) MTS_LAUNCH_TAIL(false, true, false); else MTS_LAUNCH_TAIL(false, false, false); }
 #undef MTS_LAUNCH_TAIL
             timer.end(T_TAIL);
             HIP_TRY(hipMemcpyAsync(s->hostTail, tailCounts, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -398,10 +400,11 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         timer.begin(T_SHADE);
         // large queues: several sweeps per workgroup (purer wavefronts); small ones: one, to keep every CU busy
         const int rounds = n >= s->shadeRoundsAbove ? s->shadeRounds : 1;
-#define MTS_LAUNCH_SHADE_AS(R, E, D) hipLaunchKernelGGL((k_shade<R, E, D>), dim3(blocksFor(n, kShadeBlock * R)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, cnt, n)
+#define MTS_LAUNCH_SHADE_AS(R, E, D, M) hipLaunchKernelGGL((k_shade<R, E, D, M>), dim3(blocksFor(n, kShadeBlock * R)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, cnt, n)
 #define MTS_LAUNCH_SHADE(R) do { \
-            if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true); else MTS_LAUNCH_SHADE_AS(R, true, false); } \
-            else { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, false, true); else MTS_LAUNCH_SHADE_AS(R, false, false); } } while (0)
+            if (s->host.mixture) MTS_LAUNCH_SHADE_AS(R, true, true, true); \
+            else if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true, false); else MTS_LAUNCH_SHADE_AS(R, true, false, false); } \
+            else { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, false, true, false); else MTS_LAUNCH_SHADE_AS(R, false, false, false); } } while (0)
         // (sweeps per workgroup: 8 for large queues, 1 for small ones; MTSAMD_SHADE_ROUNDS=1 switches the sweeps off)
         if (rounds >= 2) MTS_LAUNCH_SHADE(8);
         else MTS_LAUNCH_SHADE(1);

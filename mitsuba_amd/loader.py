@@ -226,6 +226,33 @@ def _make_bsdf(node, data_dir: Optional[str], add_material=None, named: Optional
                 raise SceneFormatError("twosided with two nested BRDFs needs a material list to add the second one to")
             back = add_material(nested[1])
         return S.twosided(nested[0], back)
+    if t == "mixturebsdf":  # src/bsdfs/mixturebsdf.cpp:66-85,279-287
+        try:
+            weights = [float(w) for w in p.get("weights", "").replace(",", " ").split()]
+        except ValueError:
+            raise SceneFormatError("Could not parse the BSDF weights!")
+        if any(w < 0 for w in weights):
+            raise SceneFormatError("Invalid BSDF weight!")
+        if add_material is None:
+            raise SceneFormatError("mixturebsdf needs a material list to add the nested BSDFs to")
+        children = []
+
+        def nest(rec):
+            if rec["two_sided"] or rec["type"] not in (S.BSDF_DIFFUSE, S.BSDF_ROUGHCONDUCTOR, S.BSDF_ROUGHPLASTIC, S.BSDF_WARD):
+                raise SceneFormatError("mixturebsdf: only diffuse, roughconductor, roughplastic and ward can be nested")
+            children.append(add_material(rec))
+
+        for c in node:
+            if c.tag == "bsdf":
+                nest(_make_bsdf(c, data_dir, add_material, named))
+            elif c.tag == "ref":
+                if named is None or c.get("id") not in named:
+                    raise SceneFormatError("reference to unknown bsdf '%s'" % c.get("id"))
+                nest(dict(named[c.get("id")]))
+        try:
+            return S.mixture(children, weights, p.get("ensureEnergyConservation", True))
+        except ValueError as e:
+            raise SceneFormatError(str(e))
     for c in node:
         if c.tag in ("texture", "bsdf"):
             raise SceneFormatError("nested <%s> inside a <bsdf type=\"%s\"> is not supported" % (c.tag, t))

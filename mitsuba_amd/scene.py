@@ -16,7 +16,7 @@ from typing import Dict, List, Optional
 import numpy as np
 
 BSDF_DIFFUSE, BSDF_ROUGHCONDUCTOR, BSDF_ROUGHPLASTIC, BSDF_DIELECTRIC, BSDF_WARD, BSDF_CONDUCTOR, BSDF_PLASTIC, \
-    BSDF_ROUGHDIELECTRIC = range(8)
+    BSDF_ROUGHDIELECTRIC, BSDF_MIXTURE = range(9)
 DISTR_BECKMANN, DISTR_GGX = 0, 1
 SHAPE_HAS_NORMALS, SHAPE_HAS_TEXCOORDS = 1, 2
 EMITTER_SURFACE, EMITTER_POINT, EMITTER_SPOT, EMITTER_DIRECTIONAL = range(4)
@@ -198,6 +198,17 @@ def twosided(front: Dict, back_material: int = -1) -> Dict:
     m = dict(front)
     m["two_sided"], m["back_material"] = 1, int(back_material)
     return m
+
+
+def mixture(children, weights, ensure_energy_conservation=True) -> Dict:
+    """src/bsdfs/mixturebsdf.cpp:66-85,115-172: `children` are the indices of the nested BSDFs' records (at most four),
+    `weights` their linear weights."""
+    if len(children) != len(weights):
+        raise ValueError("BSDF count mismatch: %d bsdfs, but specified %d weights" % (len(children), len(weights)))
+    if not 1 <= len(children) <= 4:
+        raise ValueError("mixturebsdf: between one and four nested BSDFs are supported")
+    return _mat(type=BSDF_MIXTURE, mix=[(int(c), float(w)) for c, w in zip(children, weights)],
+                ensure_energy_conservation=int(ensure_energy_conservation))
 
 
 def _distr(name) -> int:
@@ -556,9 +567,11 @@ def config5(width=3840, height=2160) -> SceneData:
                             max_depth=16, emitters_grid=32)
 
 
-def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_weight=1.0, hide_emitters=0, lamps=False, area_lights=True) -> SceneData:
+def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_weight=1.0, hide_emitters=0, lamps=False, area_lights=True,
+                     blend=False) -> SceneData:
     """A few hundred triangles with every BSDF type present; used by the parity tests. `sky` adds a constant
-    environment emitter of that radiance next to the two area lights; `lamps` adds a point, a spot and a directional light."""
+    environment emitter of that radiance next to the two area lights; `lamps` adds a point, a spot and a directional light;
+    `blend` makes the ground and two of the blobs mixtures of the other materials."""
     rng = np.random.default_rng(7)
     b = SceneBuilder()
     mats = [b.add_material(diffuse((0.6, 0.5, 0.4))),
@@ -569,6 +582,11 @@ def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_
             b.add_material(roughconductor(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), alpha=0.3, distribution="beckmann")),
             b.add_material(roughplastic(alpha=0.3, distribution="beckmann", int_ior=1.49, diffuse_reflectance=(0.2, 0.4, 0.6)))]
     m_ground = b.add_material(diffuse((0.5, 0.5, 0.5)))
+    m_light = m_ground
+    if blend:
+        m_ground = b.add_material(twosided(mixture([m_ground, mats[1]], [0.75, 0.25])))
+        mats[0] = b.add_material(mixture([mats[0], mats[2], mats[4]], [0.6, 0.5, 0.4]))      # weights above one: rescaled
+        mats[5] = b.add_material(mixture([mats[5], mats[6], mats[1], m_light], [0.3, 0.2, 0.0, 0.4]))
     for k, m in enumerate(mats):
         p, f, n = blob(subdiv, rng, radius=0.8)
         c = np.array([(k % 4) * 2.2 - 3.3, (k // 4) * 2.4 - 1.2, 1.0], np.float32)
@@ -576,8 +594,8 @@ def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_
         b.add_mesh(p + c, f, m, normals=n if k != 0 else None, texcoords=uv)
     gp, gf = grid(6, 6, (-7, -6), (7, 6), 0.0)
     b.add_mesh(gp, gf, m_ground)
-    b.add_quad([-2, -2, 6], [-2, 2, 6], [2, 2, 6], [2, -2, 6], m_ground, radiance=(15, 14, 12) if area_lights else None)
-    b.add_quad([4, -1, 3.5], [4, 1, 3.5], [5, 1, 4.5], [5, -1, 4.5], m_ground, radiance=(6, 9, 12) if area_lights else None, sampling_weight=0.5)
+    b.add_quad([-2, -2, 6], [-2, 2, 6], [2, 2, 6], [2, -2, 6], m_light, radiance=(15, 14, 12) if area_lights else None)
+    b.add_quad([4, -1, 3.5], [4, 1, 3.5], [5, 1, 4.5], [5, -1, 4.5], m_light, radiance=(6, 9, 12) if area_lights else None, sampling_weight=0.5)
     if sky is not None:
         b.add_constant_emitter(sky, sky_weight)
     if lamps:

@@ -472,6 +472,43 @@ void Material::configure() {
     back = nullptr;
 }
 
+// MixtureBSDF::configure (src/bsdfs/mixturebsdf.cpp:115-172): weights rescaled when they sum to more than one, the
+// discrete choice proportional to them, the type the union of the nested BSDFs' components. Nested BSDFs are
+// restricted to one-sided models whose lobes all live in the solid-angle measure and that draw nothing from the
+// sampler themselves (diffuse, roughconductor, roughplastic, ward).
+const char *linkMixtures(std::vector<Material> &materials) {
+    for (Material &mat : materials) {
+        if (mat.m.type != ORC_BSDF_MIXTURE) continue;
+        const int n = mat.m.mix_count;
+        if (n < 1 || n > 4) return "mixturebsdf: between one and four nested BSDFs are supported";
+        float total = 0;
+        for (int i = 0; i < n; ++i) {
+            if (mat.m.mix_weight[i] < 0) return "Invalid BSDF weight!";
+            total += mat.m.mix_weight[i];
+        }
+        if (total <= 0) return "The weights must sum to a value greater than zero!";
+        const float scale = (mat.m.ensure_energy_conservation && total > 1) ? 1.0f / total : 1.0f;
+        mat.mixChildren.clear(); mat.mixWeights.clear();
+        mat.mixPdf = DiscreteDistribution();
+        mat.own_flags = 0;
+        for (int i = 0; i < n; ++i) {
+            const int c = mat.m.mix_material[i];
+            if (c < 0 || c >= (int) materials.size()) return "mixturebsdf: nested material index out of range";
+            const Material &child = materials[c];
+            const int t = child.m.type;
+            if (child.m.two_sided || !(t == ORC_BSDF_DIFFUSE || t == ORC_BSDF_ROUGHCONDUCTOR || t == ORC_BSDF_ROUGHPLASTIC || t == ORC_BSDF_WARD))
+                return "mixturebsdf: only diffuse, roughconductor, roughplastic and ward can be nested";
+            mat.mixChildren.push_back(&child);
+            mat.mixWeights.push_back(scale != 1.0f ? mat.m.mix_weight[i] * scale : mat.m.mix_weight[i]);
+            mat.mixPdf.append(mat.mixWeights.back());
+            mat.own_flags |= child.own_flags;
+        }
+        mat.mixPdf.normalize();
+        mat.type_flags = mat.own_flags;
+    }
+    return nullptr;
+}
+
 // TwoSidedBRDF::configure (src/bsdfs/twosided.cpp:84-106): the adapter's components are the front BRDF's on the
 // front side and the back BRDF's on the back side; nesting a transmissive BSDF is an error.
 const char *linkTwoSided(std::vector<Material> &materials) {
@@ -872,21 +909,54 @@ static Spectrum sampleOneSided(const Material &mat, const Vec3 &wi, const Vec2 &
     return Spectrum(0.0f);
 }
 
-// ---- the entry points the integrator calls: the BRDF itself, or the same through the twosided adapter
+// ---- MixtureBSDF::eval / pdf / sample (src/bsdfs/mixturebsdf.cpp:174-277), all components requested -------------
+static Spectrum evalPlain(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
+    if (mat.m.type != ORC_BSDF_MIXTURE) return evalOneSided(mat, wi, wo);
+    Spectrum result(0.0f);
+    for (size_t i = 0; i < mat.mixChildren.size(); ++i)
+        result += evalOneSided(*mat.mixChildren[i], wi, wo) * mat.mixWeights[i];
+    return result;
+}
+
+static float pdfPlain(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
+    if (mat.m.type != ORC_BSDF_MIXTURE) return pdfOneSided(mat, wi, wo);
+    float result = 0.0f;
+    for (size_t i = 0; i < mat.mixChildren.size(); ++i)
+        result += pdfOneSided(*mat.mixChildren[i], wi, wo) * mat.mixPdf[i];
+    return result;
+}
+
+static Spectrum samplePlain(const Material &mat, const Vec3 &wi, const Vec2 &sample_, BSDFSample &out, float &pdf, Sampler1D *sampler1D) {
+    if (mat.m.type != ORC_BSDF_MIXTURE) return sampleOneSided(mat, wi, sample_, out, pdf, sampler1D);
+    Vec2 sample(sample_);
+    const size_t entry = mat.mixPdf.sampleReuse(sample.x);
+    Spectrum result = sampleOneSided(*mat.mixChildren[entry], wi, sample, out, pdf, sampler1D);
+    if (result.isZero()) return result;     // sampling failed
+    result *= mat.mixWeights[entry] * pdf;
+    pdf *= mat.mixPdf[entry];
+    for (size_t i = 0; i < mat.mixChildren.size(); ++i) {
+        if (i == entry) continue;
+        pdf += pdfOneSided(*mat.mixChildren[i], wi, out.wo) * mat.mixPdf[i];
+        result += evalOneSided(*mat.mixChildren[i], wi, out.wo) * mat.mixWeights[i];
+    }
+    return result / pdf;
+}
+
+// ---- the entry points the integrator calls: the BSDF itself, or the same through the twosided adapter
 // (src/bsdfs/twosided.cpp:108-183: seen from behind, wi and wo are mirrored and the back BRDF answers) ----------
 Spectrum bsdfEval(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
-    if (!mat.m.two_sided || Frame::cosTheta(wi) > 0) return evalOneSided(mat, wi, wo);
-    return evalOneSided(*mat.back, Vec3(wi.x, wi.y, -wi.z), Vec3(wo.x, wo.y, -wo.z));
+    if (!mat.m.two_sided || Frame::cosTheta(wi) > 0) return evalPlain(mat, wi, wo);
+    return evalPlain(*mat.back, Vec3(wi.x, wi.y, -wi.z), Vec3(wo.x, wo.y, -wo.z));
 }
 
 float bsdfPdf(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
-    if (!mat.m.two_sided || wi.z > 0) return pdfOneSided(mat, wi, wo);
-    return pdfOneSided(*mat.back, Vec3(wi.x, wi.y, -wi.z), Vec3(wo.x, wo.y, -wo.z));
+    if (!mat.m.two_sided || wi.z > 0) return pdfPlain(mat, wi, wo);
+    return pdfPlain(*mat.back, Vec3(wi.x, wi.y, -wi.z), Vec3(wo.x, wo.y, -wo.z));
 }
 
 Spectrum bsdfSample(const Material &mat, const Vec3 &wi, const Vec2 &sample, BSDFSample &out, float &pdf, Sampler1D *sampler1D) {
-    if (!mat.m.two_sided || !(Frame::cosTheta(wi) < 0)) return sampleOneSided(mat, wi, sample, out, pdf, sampler1D);
-    Spectrum result = sampleOneSided(*mat.back, Vec3(wi.x, wi.y, -wi.z), sample, out, pdf, sampler1D);
+    if (!mat.m.two_sided || !(Frame::cosTheta(wi) < 0)) return samplePlain(mat, wi, sample, out, pdf, sampler1D);
+    Spectrum result = samplePlain(*mat.back, Vec3(wi.x, wi.y, -wi.z), sample, out, pdf, sampler1D);
     if (!result.isZero() && pdf != 0) out.wo.z *= -1;
     return result;
 }

@@ -66,6 +66,7 @@ struct Sampler1D { virtual float next1D() = 0; virtual ~Sampler1D() {} };
 Spectrum bsdfSample(const Material &m, const Vec3 &wi, const Vec2 &sample, BSDFSample &out, float &pdf, Sampler1D *sampler1D = nullptr);
 
 // TwoSidedBRDF::configure over the whole material list; returns an error message or nullptr
+const char *linkMixtures(std::vector<Material> &materials);
 const char *linkTwoSided(std::vector<Material> &materials);
 
 }  // namespace orc

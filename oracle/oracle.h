@@ -13,7 +13,7 @@ extern "C" {
 
 enum { ORC_BSDF_DIFFUSE = 0, ORC_BSDF_ROUGHCONDUCTOR = 1, ORC_BSDF_ROUGHPLASTIC = 2,
        ORC_BSDF_DIELECTRIC = 3, ORC_BSDF_WARD = 4, ORC_BSDF_CONDUCTOR = 5, ORC_BSDF_PLASTIC = 6,
-       ORC_BSDF_ROUGHDIELECTRIC = 7 };
+       ORC_BSDF_ROUGHDIELECTRIC = 7, ORC_BSDF_MIXTURE = 8 };
 enum { ORC_DISTR_BECKMANN = 0, ORC_DISTR_GGX = 1 };
 enum { ORC_SHAPE_HAS_NORMALS = 1, ORC_SHAPE_HAS_TEXCOORDS = 2 };
 
@@ -44,6 +44,10 @@ typedef struct {
     float rtrans_diffuse_int;
     int32_t two_sided;          /* nested in a twosided adapter (src/bsdfs/twosided.cpp) */
     int32_t back_material;      /* record seen from behind, -1 = the same one */
+    /* MixtureBSDF (src/bsdfs/mixturebsdf.cpp), type ORC_BSDF_MIXTURE: up to four nested BSDF records and their weights */
+    int32_t mix_count;
+    int32_t mix_material[4];
+    float mix_weight[4];
 } orc_material;
 
 /* type 0: attached to `shape` (area light) or, with shape = -1, the constant environment emitter;

@@ -106,6 +106,7 @@ std::string Scene::build(const orc_scene_desc *d) {
     emitters.assign(d->emitters, d->emitters + d->n_emitters);
     materials.resize(d->n_materials);
     for (uint32_t i = 0; i < d->n_materials; ++i) { materials[i].m = d->materials[i]; materials[i].configure(); }
+    if (const char *err = linkMixtures(materials)) return err;
     if (const char *err = linkTwoSided(materials)) return err;
 
     triShape.assign(d->n_triangles, 0xFFFFFFFFu);

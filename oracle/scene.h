@@ -56,6 +56,10 @@ struct Material {
     unsigned own_flags = 0;                      // BSDF::EBSDFType combined over this BRDF's own components
     unsigned type_flags = 0;                     // what the integrator sees: own_flags, or the twosided adapter's
     const Material *back = nullptr;              // twosided: BRDF seen from behind (may be this one)
+    // MixtureBSDF (src/bsdfs/mixturebsdf.cpp:115-172): nested BSDFs, weights after the energy rescale, normalised choice
+    std::vector<const Material *> mixChildren;
+    std::vector<float> mixWeights;
+    DiscreteDistribution mixPdf;
     void configure();
 };
 

@@ -176,7 +176,9 @@ private:
 		} else {
 			/* "twosided": the library takes it as two_sided / back_material on the nested BRDF's record, but
 			   TwoSidedBRDF keeps its nested BRDFs private (src/bsdfs/twosided.cpp:231-232); with a getter added there,
-			   fill the record from getNestedBRDF(0) and append the record of getNestedBRDF(1) for back_material. */
+			   fill the record from getNestedBRDF(0) and append the record of getNestedBRDF(1) for back_material.
+			   "mixturebsdf" likewise: the library takes mix_count / mix_material / mix_weight, but MixtureBSDF keeps
+			   m_bsdfs and m_weights private (src/bsdfs/mixturebsdf.cpp:317-322). */
 			Log(EWarn, "path_amd: BSDF plugin \"%s\" is not on the GPU path", type.c_str());
 			return false;
 		}

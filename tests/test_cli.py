@@ -220,6 +220,40 @@ def test_cli_constant_emitter(scene_dir, tmp_path):
     assert sd.emitters[1]["shape"] == -1 and sd.emitters[1]["radiance"] == (0.5, 0.75, 1.25) and sd.emitters[1]["sampling_weight"] == 2.0
 
 
+def test_cli_mixturebsdf(scene_dir, tmp_path):
+    """mixturebsdf.cpp:66-85,279-287: nested BSDFs are appended before the mixture's own record, by both loaders alike."""
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    f = tmp_path / "blend.xml"
+    f.write_text(SCENE % """
+      <bsdf type="mixturebsdf" id="blend"><string name="weights" value="0.7, 0.2,0.3"/>
+        <bsdf type="diffuse"><rgb name="reflectance" value="0.2, 0.4, 0.6"/></bsdf>
+        <ref id="metal"/>
+        <bsdf type="ward"><float name="alphaU" value="0.2"/><float name="alphaV" value="0.3"/></bsdf></bsdf>
+      <shape type="serialized"><string name="filename" value="meshes.serialized"/><integer name="shapeIndex" value="1"/><ref id="blend"/></shape>
+      <shape type="serialized"><string name="filename" value="meshes.serialized"/><integer name="shapeIndex" value="1"/><transform name="toWorld"><translate x="3"/></transform>
+        <bsdf type="twosided"><bsdf type="mixturebsdf"><string name="weights" value="1"/><boolean name="ensureEnergyConservation" value="false"/>
+          <ref id="grey"/></bsdf></bsdf></shape>""")
+    d = _describe(f)
+    sd, _ = loader.load_xml(str(f))
+    assert d["material_types"] == [m["type"] for m in sd.materials]
+    assert d["two_sided"] == [m["two_sided"] for m in sd.materials]
+    mixes = [(i, m) for i, m in enumerate(sd.materials) if m["type"] == 8]
+    assert len(mixes) == len(d["mixtures"]) == 2
+    for rec, (i, m) in zip(d["mixtures"], mixes):
+        assert rec["material"] == i and rec["children"] == [c for c, _ in m["mix"]]
+        assert np.allclose(rec["weights"], [w for _, w in m["mix"]])
+    assert d["mixtures"][0]["weights"] == pytest.approx([0.7, 0.2, 0.3]) and [sd.materials[c]["type"] for c in d["mixtures"][0]["children"]] == [0, 1, 4]
+    for body, needle in (('<bsdf type="mixturebsdf"><string name="weights" value="0.5"/></bsdf>', "BSDF count mismatch"),
+                         ('<bsdf type="mixturebsdf"><string name="weights" value="0.5, x"/><ref id="grey"/><ref id="grey"/></bsdf>', "Could not parse the BSDF weights"),
+                         ('<shape type="cube"><bsdf type="mixturebsdf"><string name="weights" value="1"/><bsdf type="dielectric"/></bsdf></shape>', "can be nested")):
+        bad = tmp_path / "bad_blend.xml"
+        bad.write_text(SCENE % body)
+        out = subprocess.run([CLI, str(bad), "--describe"], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 1 and needle in out.stderr, out.stderr
+        with pytest.raises(loader.SceneFormatError, match=needle):
+            loader.load_xml(str(bad))
+
+
 def test_cli_point_spot_directional_emitters(scene_dir, tmp_path):
     """point.cpp:58-69, spot.cpp:67-78, directional.cpp:56-73: both loaders hand over the same records."""
     (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())

@@ -17,7 +17,8 @@ def _scenes():
     return {"small": S.small_test_scene(), "cornell": S.cornell_box(96, 96), "veach": S.veach_bidir(128, 96),
             "mixed": S.cornell_mixed(96, 96), "sky": S.small_test_scene(sky=(0.6, 0.8, 1.2), sky_weight=2.0),
             "sky_hidden": S.small_test_scene(sky=(0.6, 0.8, 1.2), hide_emitters=1),
-            "lamps": S.small_test_scene(lamps=True), "lamps_only": S.small_test_scene(lamps=True, area_lights=False)}
+            "lamps": S.small_test_scene(lamps=True), "lamps_only": S.small_test_scene(lamps=True, area_lights=False),
+            "blend": S.small_test_scene(blend=True)}
 
 
 @pytest.fixture(scope="module")
@@ -136,7 +137,12 @@ def material_pair(gpu, oracle_mod):
             S.twosided(S.plastic(int_ior=1.49), 0),
             S.roughdielectric(alpha=0.2, distribution="ggx", int_ior=1.5, ext_ior=1.0),
             S.roughdielectric(alpha=0.3, distribution="beckmann", sample_visible=False, specular_transmittance=(0.9, 0.8, 0.7)),
-            S.roughdielectric(alpha=0.1, alpha_v=0.25, distribution="beckmann", int_ior=S.IOR["water"])]
+            S.roughdielectric(alpha=0.1, alpha_v=0.25, distribution="beckmann", int_ior=S.IOR["water"]),
+            S.mixture([0, 2, 6], [0.5, 0.3, 0.4]),          # weights above one: rescaled
+            S.mixture([0, 10], [0.25, 0.5]),
+            S.twosided(S.mixture([5, 11, 12, 13], [0.1, 0.2, 0.3, 0.2])),
+            S.mixture([0, 2, 7], [0.0, 1.0, 0.0], ensure_energy_conservation=False),     # entries that are never chosen
+            S.twosided(S.mixture([1], [2.5], ensure_energy_conservation=False), 23)]
     b = S.SceneBuilder()
     for m in mats:
         b.add_material(m)
@@ -179,7 +185,7 @@ def test_bsdf_sample_parity(material_pair):
         assert same_type.mean() > 0.9999, mi          # a lobe choice can flip when a sample sits on the threshold
         ok = same_type
         # the Beckmann visible-normal sampler is an iterative root find: allow 1e-3 there, 1e-4 elsewhere
-        tol = 1e-3 if (mats[mi]["distribution"] == 0 and mats[mi]["type"] in (1, 2, 7)) else 1e-4
+        tol = 1e-3 if ((mats[mi]["distribution"] == 0 and mats[mi]["type"] in (1, 2, 7)) or mats[mi]["type"] == S.BSDF_MIXTURE) else 1e-4
         assert np.mean(np.all(_close(a[0][ok], b[0][ok], tol, 1e-5), axis=1)) > 0.999, ("wo", mi)
         assert np.mean(np.all(_close(a[1][ok], b[1][ok], 10 * tol, 1e-5), axis=1)) > 0.998, ("weight", mi)
         assert np.mean(_close(a[2][ok], b[2][ok], 10 * tol, 1e-5)) > 0.998, ("pdf", mi)
@@ -206,7 +212,7 @@ def test_emitter_sampling_parity(pairs):
                 assert np.allclose(x, y, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["small", "cornell", "veach", "mixed", "sky", "sky_hidden", "lamps", "lamps_only"])
+@pytest.mark.parametrize("name", ["small", "cornell", "veach", "mixed", "sky", "sky_hidden", "lamps", "lamps_only", "blend"])
 def test_per_sample_radiance_parity(pairs, name):
     """MIPathTracer::Li per camera sample with the shared sample stream: same ray counts, same radiance."""
     sd, g, o = pairs[name]
@@ -221,7 +227,7 @@ def test_per_sample_radiance_parity(pairs, name):
     assert abs(Lg[..., :3].mean() - Lo[..., :3].mean()) < 2e-3 * Lo[..., :3].mean() + 1e-6
 
 
-@pytest.mark.parametrize("name", ["small", "mixed", "sky", "lamps"])
+@pytest.mark.parametrize("name", ["small", "mixed", "sky", "lamps", "blend"])
 def test_pass_finishing_kernel_matches_wavefront_loop(gpu, name, monkeypatch):
     """Below MTSAMD_TAIL_BELOW live paths one launch follows each path to its end; above, every bounce is an extend /
     shade / shadow round of launches. Both run the same shading and traversal code: identical radiance and ray counts."""
@@ -273,7 +279,7 @@ def test_film_put_parity(pairs):
     assert np.allclose(fg, fo, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["small", "cornell", "mixed", "sky", "lamps"])
+@pytest.mark.parametrize("name", ["small", "cornell", "mixed", "sky", "lamps", "blend"])
 def test_render_film_parity(pairs, name):
     sd, g, o = pairs[name]
     fg, sg = g.render(4, seed=9)
