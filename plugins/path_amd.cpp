@@ -20,6 +20,7 @@
 #include <mitsuba/core/fstream.h>
 #include <mitsuba/core/statistics.h>
 #include <mtsamd.h>
+#include <algorithm>
 #include <map>
 
 MTS_NAMESPACE_BEGIN
@@ -32,17 +33,20 @@ public:
 	PathTracerAMD(const Properties &props) : MonteCarloIntegrator(props), m_handle(NULL) {
 		m_device = props.getInteger("device", 0);
 		m_seed = (uint32_t) props.getInteger("seed", 1);
+		m_refreshSamples = props.getInteger("refreshSamples", 0);
 	}
 
 	PathTracerAMD(Stream *stream, InstanceManager *manager) : MonteCarloIntegrator(stream, manager), m_handle(NULL) {
 		m_device = stream->readInt();
 		m_seed = stream->readUInt();
+		m_refreshSamples = stream->readInt();
 	}
 
 	void serialize(Stream *stream, InstanceManager *manager) const {
 		MonteCarloIntegrator::serialize(stream, manager);
 		stream->writeInt(m_device);
 		stream->writeUInt(m_seed);
+		stream->writeInt(m_refreshSamples);
 	}
 
 	virtual ~PathTracerAMD() { if (m_handle) mtsamd_scene_destroy(m_handle); }
@@ -65,24 +69,35 @@ public:
 		ref<Bitmap> accum = new Bitmap(Bitmap::EMultiChannel, Bitmap::EFloat32, size, 5);
 		accum->clear();
 
-		mtsamd_render_opts opts;
-		memset(&opts, 0, sizeof(opts));
-		opts.spp = opts.spp_total = (int32_t) spp;
-		opts.seed = m_seed;
-		mtsamd_stats st;
-		int rv = mtsamd_render(m_handle, &opts, accum->getFloat32Data(), &st);
-		if (rv == MTSAMD_ECANCELLED)
-			return false;
-		if (rv != MTSAMD_OK)
-			Log(EError, "%s", mtsamd_last_error());
-		amdNormalRays += st.normal_rays;
-		amdShadowRays += st.shadow_rays;
-
-		/* (R,G,B,alpha,weight) is HDRFilm's ESpectrumAlphaWeight storage when Spectrum is RGB
-		   (src/films/hdrfilm.cpp:351-356); setBitmap stores it and develop() divides by the weight. */
+		/* "refreshSamples" > 0: render that many samples per pixel at a time and hand the film over after each
+		   chunk, so that mtsgui shows the image converging (RenderQueue::signalRefresh, src/librender/renderqueue.cpp;
+		   the CPU integrators refresh per image block, RenderQueue::signalWorkEnd, renderqueue.cpp:119-123).
+		   The chunks use disjoint sample indices of the same stream: the final film equals the one-call film. */
+		const int32_t chunk = m_refreshSamples > 0 ? (int32_t) std::min<size_t>((size_t) m_refreshSamples, spp) : (int32_t) spp;
 		ref<Bitmap> storage = new Bitmap(Bitmap::ESpectrumAlphaWeight, Bitmap::EFloat32, size);
-		memcpy(storage->getFloat32Data(), accum->getFloat32Data(), (size_t) size.x * size.y * 5 * sizeof(float));
-		film->setBitmap(storage);
+		for (int32_t offset = 0; offset < (int32_t) spp; offset += chunk) {
+			mtsamd_render_opts opts;
+			memset(&opts, 0, sizeof(opts));
+			opts.spp = std::min<int32_t>(chunk, (int32_t) spp - offset);
+			opts.spp_total = (int32_t) spp;
+			opts.sample_offset = offset;
+			opts.seed = m_seed;
+			mtsamd_stats st;
+			int rv = mtsamd_render(m_handle, &opts, accum->getFloat32Data(), &st);
+			if (rv == MTSAMD_ECANCELLED)
+				return false;
+			if (rv != MTSAMD_OK)
+				Log(EError, "%s", mtsamd_last_error());
+			amdNormalRays += st.normal_rays;
+			amdShadowRays += st.shadow_rays;
+
+			/* (R,G,B,alpha,weight) is HDRFilm's ESpectrumAlphaWeight storage when Spectrum is RGB
+			   (src/films/hdrfilm.cpp:351-356); setBitmap stores it and develop() divides by the weight. */
+			memcpy(storage->getFloat32Data(), accum->getFloat32Data(), (size_t) size.x * size.y * 5 * sizeof(float));
+			film->setBitmap(storage);
+			if (offset + chunk < (int32_t) spp)
+				queue->signalRefresh(job);
+		}
 		queue->signalRefresh(job);
 		return true;
 	}
@@ -309,6 +324,7 @@ private:
 	mtsamd_scene *m_handle;
 	int m_device;
 	uint32_t m_seed;
+	int m_refreshSamples;
 };
 
 MTS_IMPLEMENT_CLASS_S(PathTracerAMD, false, MonteCarloIntegrator)
