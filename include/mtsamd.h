@@ -125,9 +125,13 @@ typedef struct {
     float filter_values[32];
 } mtsamd_film;
 
-/* MonteCarloIntegrator parameters (src/librender/integrator.cpp:190-225) */
+/* MonteCarloIntegrator parameters (src/librender/integrator.cpp:190-225). type MTSAMD_INTEGRATOR_PATH is the `path`
+   integrator (src/integrators/path/path.cpp); MTSAMD_INTEGRATOR_DIRECT is `direct` (src/integrators/direct/direct.cpp:
+   emitter_samples / bsdf_samples per camera sample, not both zero; max_depth and rr_depth are not used by it). */
+enum { MTSAMD_INTEGRATOR_PATH = 0, MTSAMD_INTEGRATOR_DIRECT = 1 };
 typedef struct {
     int32_t max_depth, rr_depth, strict_normals, hide_emitters;
+    int32_t type, emitter_samples, bsdf_samples;
 } mtsamd_integrator;
 
 typedef struct {

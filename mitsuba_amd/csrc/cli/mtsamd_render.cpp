@@ -34,10 +34,11 @@ static void describe(const LoadedScene &s) {
     printf("{\"vertices\": %zu, \"triangles\": %zu, \"shapes\": %zu, \"materials\": %zu, \"emitters\": %zu, \"has_normals\": %s, "
            "\"has_texcoords\": %s, \"sum_positions\": %.9g, \"sum_normals\": %.9g, \"sum_texcoords\": %.9g, \"sum_indices\": %llu, "
            "\"width\": %d, \"height\": %d, \"x_fov\": %.9g, \"filter_radius\": %.9g, \"max_depth\": %d, \"rr_depth\": %d, "
-           "\"sample_count\": %d, \"integrator\": \"%s\", \"to_world\": [",
+           "\"sample_count\": %d, \"integrator\": \"%s\", \"emitter_samples\": %d, \"bsdf_samples\": %d, \"to_world\": [",
            s.positions.size() / 3, s.indices.size() / 3, s.shapes.size(), s.materials.size(), s.emitters.size(),
            s.anyNormals ? "true" : "false", s.anyTexcoords ? "true" : "false", sp, sn, st, si, s.film.width, s.film.height,
-           s.camera.x_fov, s.film.filter_radius, s.integrator.max_depth, s.integrator.rr_depth, s.sampleCount, s.integratorType.c_str());
+           s.camera.x_fov, s.film.filter_radius, s.integrator.max_depth, s.integrator.rr_depth, s.sampleCount, s.integratorType.c_str(),
+           s.integrator.emitter_samples, s.integrator.bsdf_samples);
     for (int i = 0; i < 16; ++i) printf("%s%.9g", i ? ", " : "", s.camera.to_world[i]);
     printf("], \"material_types\": [");
     for (size_t i = 0; i < s.materials.size(); ++i) printf("%s%d", i ? ", " : "", s.materials[i].type);
@@ -106,7 +107,7 @@ int main(int argc, char **argv) {
     LoadedScene scene;
     const std::string err = loadSceneXml(scenePath, opts, scene);
     if (!err.empty()) { fprintf(stderr, "mtsamd-render: %s\n", err.c_str()); return 1; }
-    if (!scene.integratorType.empty() && scene.integratorType != "path")
+    if (!scene.integratorType.empty() && scene.integratorType != "path" && scene.integratorType != "direct")
         fprintf(stderr, "mtsamd-render: the scene asks for integrator '%s'; rendering with 'path'\n", scene.integratorType.c_str());
     if (describeOnly) { describe(scene); return 0; }
     if (spp <= 0) spp = scene.sampleCount;

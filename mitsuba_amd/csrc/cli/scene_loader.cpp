@@ -1027,7 +1027,9 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
         std::map<std::string, uint32_t> namedBsdfs;
         int defaultBsdf = -1;
         bool haveSensor = false;
-        out.integrator.max_depth = -1; out.integrator.rr_depth = 5; out.integrator.strict_normals = 0; out.integrator.hide_emitters = 0;
+        memset(&out.integrator, 0, sizeof(out.integrator));
+        out.integrator.max_depth = -1; out.integrator.rr_depth = 5;
+        out.integrator.emitter_samples = out.integrator.bsdf_samples = 1;
 
         auto bsdfIndex = [&](const Element &el) {
             const mtsamd_material made = makeBsdf(el, opts, out, &namedBsdfs);
@@ -1054,6 +1056,14 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
                 out.integrator.rr_depth = (int32_t) getF(p, "rrDepth", 5);
                 out.integrator.strict_normals = getB(p, "strictNormals", false) ? 1 : 0;
                 out.integrator.hide_emitters = getB(p, "hideEmitters", false) ? 1 : 0;
+                out.integrator.type = MTSAMD_INTEGRATOR_PATH;
+                out.integrator.emitter_samples = out.integrator.bsdf_samples = 1;
+                if (out.integratorType == "direct") {       // src/integrators/direct/direct.cpp:93-107
+                    out.integrator.type = MTSAMD_INTEGRATOR_DIRECT;
+                    const int shading = (int) getF(p, "shadingSamples", 1);
+                    out.integrator.emitter_samples = (int32_t) getF(p, "emitterSamples", shading);
+                    out.integrator.bsdf_samples = (int32_t) getF(p, "bsdfSamples", shading);
+                }
             } else if (el.tag == "sensor") {
                 if (el.get("type") != "perspective") return "only the perspective sensor is supported";
                 const Props p = parseProps(el);

@@ -351,6 +351,14 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         }
     }
 
+    if (d->integrator.type == MTSAMD_INTEGRATOR_DIRECT) {   // direct.cpp:96-107
+        if (d->integrator.emitter_samples < 0 || d->integrator.bsdf_samples < 0 || d->integrator.emitter_samples + d->integrator.bsdf_samples <= 0)
+            return "direct: the numbers of emitter and BSDF samples must not be negative and not both zero";
+        if (d->integrator.emitter_samples > 1024 || d->integrator.bsdf_samples > 1024) return "direct: at most 1024 emitter and BSDF samples";
+    } else if (d->integrator.type != MTSAMD_INTEGRATOR_PATH) {
+        return "unknown integrator type";
+    }
+
     // ---- emitters: per-mesh area CDF (TriMesh::prepareSamplingTable, trimesh.cpp:388-403) and the scene's
     //      emitter CDF (scene.cpp:375-380) ------------------------------------------------------------------
     hs.emitters.resize(d->n_emitters);

@@ -444,6 +444,174 @@ __global__ void __launch_bounds__(256) k_shadow_accumulate(uint32_t n, const uin
     sampleL[slot] = L;
 }
 
+// ---- MIDirectIntegrator::Li (src/integrators/direct/direct.cpp:146-309) in two kernels around the traversals -------
+// k_direct_shade: one thread per camera sample. It shades the camera vertex, writes `nEmitter` shadow rays to
+// entries [i * nEmitter, (i + 1) * nEmitter) of the shadow queue and `nBsdf` BSDF-sampled rays to entries
+// [i * nBsdf, ...) of the output queue. Entries keep their place whether or not they carry a ray (an idle entry has an
+// empty ray interval), so that k_direct_gather can add a sample's contributions in a fixed order without atomics.
+// Sample order per camera sample: the emitter samples' 2-D numbers, then per BSDF sample its 2-D number followed by
+// what the BSDF itself takes from the sampler. counts[0] += BSDF rays, counts[1] += shadow rays that the reference traces.
+static constexpr uint32_t PF_IDLE = 0x8000u;
+
+__global__ void __launch_bounds__(256) k_direct_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out, ShadowQueue sq,
+                                                     float4 *sampleL, unsigned long long *counts, uint32_t n, int nEmitter, int nBsdf) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t nNormal = 0, nShadow = 0;
+    if (i < n) {
+        const float4 idleO = make_float4(0.0f, 0.0f, 0.0f, 1.0f), idleD = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+        const float4 hit = hits[i], rd = in.rayD[i];
+        const uint4 misc = in.misc[i];
+        const uint32_t slot = misc.x, triWord = __float_as_uint(hit.w);
+        const V3 rayD = mk(rd.x, rd.y, rd.z);
+        bool shade = false;
+        float4 L = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        Isect its;
+        DevMaterial bsdf;
+        Rng rng;
+        if (triWord == kMiss) {
+            // direct.cpp:156-163: the environment seen directly, alpha 0
+            if (sc.envEmitter >= 0 && !sc.hideEmitters) { L.x = sc.envRadiance[0]; L.y = sc.envRadiance[1]; L.z = sc.envRadiance[2]; }
+        } else {
+            int px, py, sIdx;
+            const uint64_t key = sampleKey(sc, pp, slot, px, py, sIdx);
+            rng.inc = (key << 1) | 1u;
+            rng.state = (uint64_t) misc.z | ((uint64_t) misc.w << 32);
+            fillIntersection(sc, triWord & kTriIndexMask, hit.y, hit.z, rayD, its);
+            loadMaterial(sc, its.material, bsdf);
+            L.w = 1.0f;
+            if (its.emitter >= 0 && !sc.hideEmitters && dot(its.sh.n, -rayD) > 0) {    // direct.cpp:166-167
+                const V3 e = ld3(sc.emitters[its.emitter].radiance);
+                L.x = e.x; L.y = e.y; L.z = e.z;
+            }
+            shade = !(sc.strictNormals && dot(rayD, its.geoN) * its.wi.z >= 0);         // direct.cpp:175-187
+        }
+        sampleL[slot] = L;
+
+        uint32_t bsdfType = 0;
+        bool flipped = false;
+        V3 wiLocal = mk(0.0f), refN = mk(0.0f);
+        if (shade) {
+            bsdfType = bsdf.typeFlags;
+            flipped = resolveTwoSided(sc, its.material, its.wi.z, bsdf);
+            wiLocal = flipped ? mirrorZ(its.wi) : its.wi;
+            if ((bsdfType & (ETransmission | EBackSide)) == 0) refN = its.sh.n;
+        }
+        // MIDirectIntegrator::configure (direct.cpp:128-136)
+        const float weightLum = 1 / (float) nEmitter;
+        const float fracBSDF = nBsdf / (float) (nEmitter + nBsdf), fracLum = nEmitter / (float) (nEmitter + nBsdf);
+
+        // emitter sampling (direct.cpp:210-245)
+        for (int k = 0; k < nEmitter; ++k) {
+            const size_t e = (size_t) i * nEmitter + k;
+            float4 sO = idleO, sD = idleD, sC = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(slot));
+            if (shade) {
+                const float sx = rng.next1D(), sy = rng.next1D();
+                if (bsdfType & ESmooth) {
+                    DirectRec dRec;
+                    const V3 value = sampleEmitterDirect<true>(sc, its.p, refN, sx, sy, dRec);
+                    if (dRec.pdf != 0) {
+                        V3 c = mk(0.0f);
+                        const V3 wo = toLocal(its.sh, dRec.d);
+                        const V3 woSide = flipped ? mirrorZ(wo) : wo;
+                        const V3 bsdfVal = bsdfEvalAny(sc, bsdf, wiLocal, woSide);
+                        if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
+                            const float bPdf = dRec.delta ? 0.0f : bsdfPdfAny(sc, bsdf, wiLocal, woSide);
+                            c = value * bsdfVal * (miWeight(dRec.pdf * fracLum, bPdf * fracBSDF) * weightLum);
+                        }
+                        ++nShadow;
+                        sO = make_float4(its.p.x, its.p.y, its.p.z, kEpsilon);
+                        sD = make_float4(dRec.d.x, dRec.d.y, dRec.d.z, dRec.dist * (1 - kShadowEpsilon));
+                        sC = make_float4(c.x, c.y, c.z, __uint_as_float(slot));
+                    }
+                }
+            }
+            sq.rayO[e] = sO; sq.rayD[e] = sD; sq.contrib[e] = sC;
+        }
+
+        // BSDF sampling (direct.cpp:251-275): the ray; what it finds is weighted in k_direct_gather
+        for (int k = 0; k < nBsdf; ++k) {
+            const size_t e = (size_t) i * nBsdf + k;
+            float4 oO = idleO, oD = idleD, oT = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            uint32_t flags = PF_IDLE;
+            float oPdf = 0.0f, oRefCos = -2.0f;
+            if (shade) {
+                const float bx = rng.next1D(), by = rng.next1D();
+                const float bu = bsdfUsesSampler(bsdf) ? rng.next1D() : 0.0f;
+                V3 woLocal; float bPdf, bEta; uint32_t sampledType;
+                const V3 bsdfVal = bsdfSampleAny(sc, bsdf, wiLocal, bx, by, bu, woLocal, bPdf, bEta, sampledType);
+                if (flipped && !isZero(bsdfVal) && bPdf != 0) woLocal.z = -woLocal.z;
+                if (!isZero(bsdfVal)) {
+                    const V3 wo = toWorld(its.sh, woLocal);
+                    if (!(sc.strictNormals && dot(its.geoN, wo) * woLocal.z <= 0)) {
+                        flags = 0;
+                        if (sampledType & EDelta) flags |= PF_PREV_DELTA;
+                        if (dot(wo, refN) >= 0) flags |= PF_REFN_OK;
+                        oO = make_float4(its.p.x, its.p.y, its.p.z, kEpsilon);
+                        oD = make_float4(wo.x, wo.y, wo.z, kInf);
+                        oT = make_float4(bsdfVal.x, bsdfVal.y, bsdfVal.z, 1.0f);
+                        oPdf = bPdf;
+                        oRefCos = isZero(refN) ? -2.0f : dot(wo, refN);
+                        ++nNormal;
+                    }
+                }
+            }
+            out.rayO[e] = oO; out.rayD[e] = oD; out.thr[e] = oT; out.bsdfPdf[e] = oPdf; out.refCos[e] = oRefCos;
+            out.misc[e] = make_uint4(slot, 1u | (flags << 16), 0u, 0u);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { nNormal += __shfl_down(nNormal, off); nShadow += __shfl_down(nShadow, off); }
+    if ((threadIdx.x & 63) == 0 && (nNormal | nShadow)) { atomicAdd(&counts[0], (unsigned long long) nNormal); atomicAdd(&counts[1], (unsigned long long) nShadow); }
+}
+
+// k_direct_gather: one thread per camera sample adds, in entry order, the unoccluded emitter samples and what the
+// BSDF-sampled rays found (direct.cpp:276-305), weighted against the emitter-sampling density.
+__global__ void __launch_bounds__(256) k_direct_gather(DevScene sc, PathQueue in, PathQueue rays, const float4 *hits, ShadowQueue sq, const uint8_t *occluded,
+                                                      float4 *sampleL, uint32_t n, int nEmitter, int nBsdf) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = in.misc[i].x;
+    float4 L = sampleL[slot];
+    for (int k = 0; k < nEmitter; ++k) {
+        const size_t e = (size_t) i * nEmitter + k;
+        if (occluded[e]) continue;
+        const float4 c = sq.contrib[e];
+        L.x += c.x; L.y += c.y; L.z += c.z;
+    }
+    const float weightBSDF = 1 / (float) nBsdf;
+    const float fracBSDF = nBsdf / (float) (nEmitter + nBsdf), fracLum = nEmitter / (float) (nEmitter + nBsdf);
+    for (int k = 0; k < nBsdf; ++k) {
+        const size_t e = (size_t) i * nBsdf + k;
+        const uint32_t flags = rays.misc[e].y >> 16;
+        if (flags & PF_IDLE) continue;
+        const float4 hit = hits[e], rd = rays.rayD[e], th = rays.thr[e];
+        const V3 rayD = mk(rd.x, rd.y, rd.z);
+        const uint32_t triWord = __float_as_uint(hit.w);
+        V3 value;
+        float lumPdf = 0.0f;
+        if (triWord != kMiss) {
+            Isect its;
+            fillIntersection(sc, triWord & kTriIndexMask, hit.y, hit.z, rayD, its);
+            if (its.emitter < 0) continue;
+            const DevEmitter em = sc.emitters[its.emitter];
+            value = dot(its.sh.n, -rayD) > 0 ? ld3(em.radiance) : mk(0.0f);
+            if (!(flags & PF_PREV_DELTA)) {     // pdfEmitterDirect (scene.cpp:949-952), as in the path integrator
+                if ((flags & PF_REFN_OK) && dot(rayD, its.sh.n) < 0) lumPdf = em.invArea * (hit.x * hit.x) / fabsf(dot(rayD, its.sh.n));
+                lumPdf *= em.pdfDiscrete;
+            }
+        } else {
+            if (sc.envEmitter < 0) continue;    // hideEmitters only hides what a null interaction would show (direct.cpp:288)
+            const float4 ro = rays.rayO[e];
+            float farT;
+            if (!environmentExit(sc, mk(ro.x, ro.y, ro.z), rayD, farT)) continue;
+            value = ld3(sc.envRadiance);
+            if (!(flags & PF_PREV_DELTA)) lumPdf = environmentPdfDirect(sc, rays.refCos[e]);
+        }
+        const V3 c = value * mk(th.x, th.y, th.z) * (miWeight(rays.bsdfPdf[e] * fracBSDF, lumPdf * fracLum) * weightBSDF);
+        L.x += c.x; L.y += c.y; L.z += c.z;
+    }
+    sampleL[slot] = L;
+}
+
 // ---- K6 film: ImageBlock::put in gather form (include/mitsuba/render/imageblock.h:144-189). One thread per film
 // pixel of the pass rectangle grown by the filter border; it visits the samples of the pixels whose footprint can
 // reach it, in a fixed order, so the accumulation is deterministic and needs no atomics. A sample with a

@@ -102,7 +102,7 @@ struct mtsamd_scene {
         PathQueue q;
         q.rayO = qbuf[i][0].as<float4>(); q.rayD = qbuf[i][1].as<float4>(); q.thr = qbuf[i][2].as<float4>();
         q.misc = qbuf[i][3].as<uint4>(); q.bsdfPdf = qbuf[i][4].as<float>();
-        q.refCos = (host.extEmitters || host.mixture) ? qbuf[i][5].as<float>() : nullptr;
+        q.refCos = (host.extEmitters || host.mixture || host.desc.integrator.type == MTSAMD_INTEGRATOR_DIRECT) ? qbuf[i][5].as<float>() : nullptr;
         return q;
     }
     ShadowQueue shadowQueue() const {
@@ -110,14 +110,20 @@ struct mtsamd_scene {
         s.rayO = sbuf[0].as<float4>(); s.rayD = sbuf[1].as<float4>(); s.contrib = sbuf[2].as<float4>();
         return s;
     }
-    int ensureWork(size_t n) {
+    // entries of the ray queues per camera sample: 1 for `path`, the larger sample count for `direct`
+    size_t raysPerSample() const {
+        const mtsamd_integrator &ig = host.desc.integrator;
+        return ig.type == MTSAMD_INTEGRATOR_DIRECT ? (size_t) std::max(1, std::max(ig.emitter_samples, ig.bsdf_samples)) : 1;
+    }
+    int ensureWork(size_t nSamples) {
+        const size_t n = nSamples * raysPerSample();
         if (n <= capacity) return MTSAMD_OK;
         // a failed growth leaves some buffers released: forget the old capacity so that the next call rebuilds all of them
         capacity = 0;
         for (int i = 0; i < 2; ++i) {
             for (int j = 0; j < 4; ++j) HIP_TRY(qbuf[i][j].ensure(n * 16));
             HIP_TRY(qbuf[i][4].ensure(n * 4));
-            if (host.extEmitters || host.mixture) HIP_TRY(qbuf[i][5].ensure(n * 4));
+            if (host.extEmitters || host.mixture || host.desc.integrator.type == MTSAMD_INTEGRATOR_DIRECT) HIP_TRY(qbuf[i][5].ensure(n * 4));
         }
         HIP_TRY(hits.ensure(n * 16));
         for (int j = 0; j < 3; ++j) HIP_TRY(sbuf[j].ensure(n * 16));
@@ -337,7 +343,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
                mtsamd_stats *stats, EventTimer &timer) {
     const DevScene &sc = s->dev;
     const size_t nPaths = (size_t) pp.w * pp.h * pp.spp;
-    if (nPaths >= (1ull << 31)) return fail(MTSAMD_EINVAL, "pass too large");
+    if (nPaths * s->raysPerSample() >= (1ull << 31)) return fail(MTSAMD_EINVAL, "pass too large");
     int rc = s->ensureWork(nPaths);
     if (rc != MTSAMD_OK) return rc;
     hipStream_t st = s->stream;
@@ -359,6 +365,48 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
     bool tailLaunch = false;
     bool shadowPending = false;
     const bool traceIters = getenv("MTSAMD_TRACE_ITERS") != nullptr;
+    const mtsamd_integrator &ig = s->host.desc.integrator;
+    if (ig.type == MTSAMD_INTEGRATOR_DIRECT) {
+        // camera rays -> shade the camera vertex into nEmitter shadow rays and nBsdf BSDF-sampled rays per sample -> both
+        // traversals -> gather. The queues keep a fixed place for every ray of a sample.
+        const int nE = ig.emitter_samples, nB = ig.bsdf_samples;
+        PathQueue qin = s->queue(0), qout = s->queue(1);
+        TraceArgs ta;
+        memset(&ta, 0, sizeof(ta));
+        ta.rayO = qin.rayO; ta.rayD = qin.rayD; ta.stride = 1; ta.n = n;
+        ta.hits = hits; ta.stats = cnt64 + CNT64_EXT_NODES;
+        timer.begin(T_EXTEND);
+        launchTrace<TRACE_CLOSEST>(s, ta, st);
+        timer.end(T_EXTEND);
+        unsigned long long *counts = cnt64 + CNT64_TAIL_NORMAL;
+        HIP_TRY(hipMemsetAsync(counts, 0, 2 * sizeof(unsigned long long), st));
+        timer.begin(T_SHADE);
+        hipLaunchKernelGGL(k_direct_shade, dim3(blocksFor(n, 256)), dim3(256), 0, st, sc, pp, qin, hits, qout, sq, sampleL, counts, n, nE, nB);
+        timer.end(T_SHADE);
+        if (nE > 0) {
+            TraceArgs sa;
+            memset(&sa, 0, sizeof(sa));
+            sa.rayO = sq.rayO; sa.rayD = sq.rayD; sa.stride = 1; sa.n = n * (uint32_t) nE;
+            sa.occluded = s->shadowFlags.as<uint8_t>(); sa.stats = cnt64 + CNT64_SHD_NODES;
+            timer.begin(T_SHADOW);
+            launchTrace<TRACE_OCCLUDED>(s, sa, st);
+            timer.end(T_SHADOW);
+        }
+        if (nB > 0) {
+            ta.rayO = qout.rayO; ta.rayD = qout.rayD; ta.n = n * (uint32_t) nB;
+            timer.begin(T_EXTEND);
+            launchTrace<TRACE_CLOSEST>(s, ta, st);
+            timer.end(T_EXTEND);
+        }
+        timer.begin(T_SHADE);
+        hipLaunchKernelGGL(k_direct_gather, dim3(blocksFor(n, 256)), dim3(256), 0, st, sc, qin, qout, hits, sq, s->shadowFlags.as<uint8_t>(), sampleL, n, nE, nB);
+        timer.end(T_SHADE);
+        HIP_TRY(hipMemcpyAsync(s->hostTail, counts, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        normalRays += n + s->hostTail[0]; shadowRays += s->hostTail[1];
+        iterations = 2;
+        n = 0;
+    }
     while (n > 0) {
         // Few paths left: one launch takes them through all their remaining bounces. (The tail of a pass is a
         // long run of bounces on a handful of paths inside dielectrics; three launches and a host round trip for
@@ -486,7 +534,7 @@ int renderCommon(mtsamd_scene *s, const mtsamd_render_opts *opts, float *filmDev
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = (size_t) 16 << 30;
         const size_t byMemory = std::max<size_t>(freeB / 2 / 224, (size_t) 1 << 20);
-        const size_t target = std::min<size_t>((size_t) 512 << 20, byMemory + s->capacity);
+        const size_t target = std::min<size_t>((size_t) 512 << 20, byMemory + s->capacity) / s->raysPerSample();
         sppPass = (int) std::max<size_t>(1, std::min<size_t>((size_t) o.spp, target / ((size_t) w * h)));
     }
     sppPass = std::min(sppPass, o.spp);

@@ -360,6 +360,9 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
             info["integrator_type"] = el.get("type")
             integ.update(max_depth=p.get("maxDepth", -1), rr_depth=p.get("rrDepth", 5),
                          strict_normals=int(p.get("strictNormals", False)), hide_emitters=int(p.get("hideEmitters", False)))
+            if el.get("type") == "direct":      # src/integrators/direct/direct.cpp:93-107
+                shading = p.get("shadingSamples", 1)
+                integ.update(type="direct", emitter_samples=p.get("emitterSamples", shading), bsdf_samples=p.get("bsdfSamples", shading))
         elif el.tag == "sensor":
             if el.get("type") != "perspective":
                 raise SceneFormatError("only the perspective sensor is supported")

@@ -75,8 +75,11 @@ typedef struct {
     float filter_values[32];    /* ReconstructionFilter::m_values */
 } orc_film;
 
+/* type 0: `path` (src/integrators/path/path.cpp); 1: `direct` (src/integrators/direct/direct.cpp) with its numbers
+   of emitter and BSDF samples per camera sample (max_depth and rr_depth are not used by it) */
 typedef struct {
     int32_t max_depth, rr_depth, strict_normals, hide_emitters;
+    int32_t type, emitter_samples, bsdf_samples;
 } orc_integrator;
 
 typedef struct {

@@ -47,7 +47,7 @@ class Film(C.Structure):
 
 class Integrator(C.Structure):
     _fields_ = [("max_depth", C.c_int32), ("rr_depth", C.c_int32), ("strict_normals", C.c_int32),
-                ("hide_emitters", C.c_int32)]
+                ("hide_emitters", C.c_int32), ("type", C.c_int32), ("emitter_samples", C.c_int32), ("bsdf_samples", C.c_int32)]
 
 
 class SceneDesc(C.Structure):
@@ -137,6 +137,9 @@ def fill_desc(sd, desc_cls=SceneDesc, shape_cls=Shape, mat_cls=Material, em_cls=
     d.film.filter_values = (C.c_float * 32)(*np.asarray(f["filter_values"], np.float32))
     for k in ("max_depth", "rr_depth", "strict_normals", "hide_emitters"):
         setattr(d.integrator, k, sd.integrator[k])
+    d.integrator.type = {"path": 0, "direct": 1}[sd.integrator.get("type", "path")]
+    d.integrator.emitter_samples = sd.integrator.get("emitter_samples", 1)
+    d.integrator.bsdf_samples = sd.integrator.get("bsdf_samples", 1)
     return d, keep
 
 

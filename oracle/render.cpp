@@ -189,6 +189,12 @@ std::string Scene::build(const orc_scene_desc *d) {
         envRadius = std::max(Epsilon, (envCenter - box.max).length() * 1.5f);
     }
 
+    if (d->integrator.type == 1) {      // MIDirectIntegrator (direct.cpp:96-107)
+        if (d->integrator.emitter_samples < 0 || d->integrator.bsdf_samples < 0 || d->integrator.emitter_samples + d->integrator.bsdf_samples <= 0)
+            return "direct: the numbers of emitter and BSDF samples must not be negative and not both zero";
+    } else if (d->integrator.type != 0) {
+        return "unknown integrator type";
+    }
     deltaEmitters.assign(d->n_emitters, DeltaEmitter());
     {
         // AABB::getBSphere (aabb.cpp:44-47) of the kd-tree bounds, DirectionalEmitter::createShape (directional.cpp:88-94)
@@ -532,6 +538,101 @@ static Spectrum Li(const Scene &sc, const Ray &r, Pcg32 &rng, float &alpha, RayC
     return Li;
 }
 
+// ---- MIDirectIntegrator::Li (src/integrators/direct/direct.cpp:146-309) -----------------------------------
+// Sample order per camera sample: the emitter samples' 2-D numbers, then for every BSDF sample its 2-D number
+// followed by what the BSDF itself takes from the sampler.
+static Spectrum LiDirect(const Scene &sc, const Ray &r, Pcg32 &rng, float &alpha, RayCounters &cnt) {
+    const orc_integrator &ig = sc.desc.integrator;
+    Intersection its;
+    Ray ray(r);
+    Spectrum Li(0.0f);
+    cnt.normal++;
+    const bool hit = sc.rayIntersect(ray, its, &cnt.trav);
+    alpha = hit ? 1.0f : 0.0f;
+    if (!hit) {     // direct.cpp:156-163
+        if (sc.envEmitter >= 0 && !ig.hide_emitters) {
+            const orc_emitter &em = sc.emitters[sc.envEmitter];
+            return Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]);
+        }
+        return Spectrum(0.0f);
+    }
+    const orc_shape &shape = sc.shapes[its.shape];
+    const Material &bsdf = sc.materials[shape.material];
+    if (shape.emitter >= 0 && !ig.hide_emitters) {      // direct.cpp:166-167, AreaLight::eval (area.cpp:104-109)
+        const orc_emitter &em = sc.emitters[shape.emitter];
+        if (dot(its.shFrame.n, -ray.d) > 0) Li += Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]);
+    }
+    if (ig.strict_normals && dot(ray.d, its.geoFrame.n) * Frame::cosTheta(its.wi) >= 0) return Li;      // direct.cpp:175-187
+
+    const int nDirect = ig.emitter_samples, nBsdf = ig.bsdf_samples;
+    const int sum = nDirect + nBsdf;
+    // MIDirectIntegrator::configure (direct.cpp:128-136)
+    const float weightBSDF = 1 / (float) nBsdf, weightLum = 1 / (float) nDirect;
+    const float fracBSDF = nBsdf / (float) sum, fracLum = nDirect / (float) sum;
+
+    Vec3 refN(0.0f);    // DirectSamplingRecord(its) (records.inl:160-164)
+    if ((bsdf.type_flags & (ETransmission | EBackSide)) == 0) refN = its.shFrame.n;
+
+    // emitter sampling (direct.cpp:210-245); the numbers are drawn whether or not the BSDF is smooth
+    for (int i = 0; i < nDirect; ++i) {
+        const Vec2 s = rng.next2D();
+        if (!(bsdf.type_flags & ESmooth)) continue;
+        DirectSample dRec;
+        Spectrum value = sampleEmitterDirect(sc, its.p, refN, s, dRec);
+        if (dRec.pdf != 0) {
+            cnt.shadow++;
+            Ray shadowRay(its.p, dRec.d, Epsilon, dRec.dist * (1 - ShadowEpsilon));
+            if (sc.rayIntersectShadow(shadowRay, &cnt.trav)) value = Spectrum(0.0f);
+        }
+        if (value.isZero()) continue;
+        const Vec3 wo = its.toLocal(dRec.d);
+        const Spectrum bsdfVal = bsdfEval(bsdf, its.wi, wo);
+        if (!bsdfVal.isZero() && (!ig.strict_normals || dot(its.geoFrame.n, dRec.d) * Frame::cosTheta(wo) > 0)) {
+            const float bsdfPdf_ = dRec.delta ? 0.0f : bsdfPdf(bsdf, its.wi, wo);      // emitter->isOnSurface()
+            const float weight = miWeight(dRec.pdf * fracLum, bsdfPdf_ * fracBSDF) * weightLum;
+            Li += value * bsdfVal * weight;
+        }
+    }
+
+    // BSDF sampling (direct.cpp:251-306)
+    struct StreamTap : Sampler1D { Pcg32 &r; explicit StreamTap(Pcg32 &r_) : r(r_) {} float next1D() override { return r.next1D(); } } tap(rng);
+    for (int i = 0; i < nBsdf; ++i) {
+        float bsdfPdf_;
+        BSDFSample bs;
+        const Vec2 s = rng.next2D();
+        const Spectrum bsdfVal = bsdfSample(bsdf, its.wi, s, bs, bsdfPdf_, &tap);
+        if (bsdfVal.isZero()) continue;
+        const Vec3 wo = its.toWorld(bs.wo);
+        if (ig.strict_normals && dot(its.geoFrame.n, wo) * Frame::cosTheta(bs.wo) <= 0) continue;
+        Ray bsdfRay(its.p, wo);
+        Intersection bsdfIts;
+        Spectrum value;
+        float lumPdf = 0;
+        cnt.normal++;
+        if (sc.rayIntersect(bsdfRay, bsdfIts, &cnt.trav)) {
+            const orc_shape &hs = sc.shapes[bsdfIts.shape];
+            if (hs.emitter < 0) continue;
+            const orc_emitter &em = sc.emitters[hs.emitter];
+            value = dot(bsdfIts.shFrame.n, -bsdfRay.d) > 0 ? Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]) : Spectrum(0.0f);
+            if (!(bs.sampledType & EDelta)) {   // pdfEmitterDirect (scene.cpp:949-952), as in the path integrator
+                if (dot(bsdfRay.d, refN) >= 0 && dot(bsdfRay.d, bsdfIts.shFrame.n) < 0)
+                    lumPdf = sc.invSurfaceArea[bsdfIts.shape] * (bsdfIts.t * bsdfIts.t) / absDot(bsdfRay.d, bsdfIts.shFrame.n);
+                lumPdf *= em.sampling_weight * sc.emitterPDF.normalization;
+            }
+        } else {
+            if (sc.envEmitter < 0) continue;    // (hideEmitters only hides what a null interaction would show, direct.cpp:288)
+            const orc_emitter &em = sc.emitters[sc.envEmitter];
+            value = Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]);
+            float nearT, farT;
+            if (!sphereIntersect(sc.envCenter, sc.envRadius, bsdfRay.o, bsdfRay.d, nearT, farT) || nearT > 0 || farT < 0) continue;
+            if (!(bs.sampledType & EDelta)) lumPdf = envPdfDirect(sc, bsdfRay.d, refN);
+        }
+        const float weight = miWeight(bsdfPdf_ * fracBSDF, lumPdf * fracLum) * weightBSDF;
+        Li += value * bsdfVal * weight;
+    }
+    return Li;
+}
+
 // ---- PerspectiveCameraImpl::sampleRayDifferential (perspective.cpp:271-298), ray part ---------------------
 static Ray cameraRay(const Scene &sc, float px, float py) {
     const float *M = sc.sampleToCamera;
@@ -721,7 +822,7 @@ static inline void renderSample(const Scene &sc, const orc_render_opts *o, int x
     pos[0] = (float) x + j.x; pos[1] = (float) y + j.y;
     Ray ray = cameraRay(sc, pos[0], pos[1]);
     float alpha;
-    Spectrum L = Li(sc, ray, rng, alpha, cnt);
+    Spectrum L = sc.desc.integrator.type == 1 ? LiDirect(sc, ray, rng, alpha, cnt) : Li(sc, ray, rng, alpha, cnt);
     rgba[0] = L.x; rgba[1] = L.y; rgba[2] = L.z; rgba[3] = alpha;
 }
 

@@ -34,12 +34,20 @@ public:
 		m_device = props.getInteger("device", 0);
 		m_seed = (uint32_t) props.getInteger("seed", 1);
 		m_refreshSamples = props.getInteger("refreshSamples", 0);
+		/* "direct" = true: MIDirectIntegrator's estimator (src/integrators/direct/direct.cpp) with its sample counts */
+		m_direct = props.getBoolean("direct", false);
+		int shadingSamples = props.getInteger("shadingSamples", 1);
+		m_emitterSamples = props.getInteger("emitterSamples", shadingSamples);
+		m_bsdfSamples = props.getInteger("bsdfSamples", shadingSamples);
 	}
 
 	PathTracerAMD(Stream *stream, InstanceManager *manager) : MonteCarloIntegrator(stream, manager), m_handle(NULL) {
 		m_device = stream->readInt();
 		m_seed = stream->readUInt();
 		m_refreshSamples = stream->readInt();
+		m_direct = stream->readBool();
+		m_emitterSamples = stream->readInt();
+		m_bsdfSamples = stream->readInt();
 	}
 
 	void serialize(Stream *stream, InstanceManager *manager) const {
@@ -47,6 +55,9 @@ public:
 		stream->writeInt(m_device);
 		stream->writeUInt(m_seed);
 		stream->writeInt(m_refreshSamples);
+		stream->writeBool(m_direct);
+		stream->writeInt(m_emitterSamples);
+		stream->writeInt(m_bsdfSamples);
 	}
 
 	virtual ~PathTracerAMD() { if (m_handle) mtsamd_scene_destroy(m_handle); }
@@ -315,6 +326,8 @@ private:
 
 		d.integrator.max_depth = m_maxDepth; d.integrator.rr_depth = m_rrDepth;
 		d.integrator.strict_normals = m_strictNormals; d.integrator.hide_emitters = m_hideEmitters;
+		d.integrator.type = m_direct ? MTSAMD_INTEGRATOR_DIRECT : MTSAMD_INTEGRATOR_PATH;
+		d.integrator.emitter_samples = m_emitterSamples; d.integrator.bsdf_samples = m_bsdfSamples;
 
 		if (mtsamd_scene_create(&d, &m_handle) != MTSAMD_OK)
 			Log(EError, "%s", mtsamd_last_error());
@@ -325,6 +338,8 @@ private:
 	int m_device;
 	uint32_t m_seed;
 	int m_refreshSamples;
+	bool m_direct;
+	int m_emitterSamples, m_bsdfSamples;
 };
 
 MTS_IMPLEMENT_CLASS_S(PathTracerAMD, false, MonteCarloIntegrator)

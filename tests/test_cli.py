@@ -220,6 +220,23 @@ def test_cli_constant_emitter(scene_dir, tmp_path):
     assert sd.emitters[1]["shape"] == -1 and sd.emitters[1]["radiance"] == (0.5, 0.75, 1.25) and sd.emitters[1]["sampling_weight"] == 2.0
 
 
+def test_cli_direct_integrator(scene_dir, tmp_path):
+    """<integrator type="direct"> (direct.cpp:93-107): shadingSamples sets both counts, the finer ones override it."""
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    text = (scene_dir / "scene.xml").read_text()
+    head = text[text.index("<integrator"):text.index("</integrator>") + len("</integrator>")]
+    for xml, want in (('<integrator type="direct"/>', (1, 1)),
+                      ('<integrator type="direct"><integer name="shadingSamples" value="4"/></integrator>', (4, 4)),
+                      ('<integrator type="direct"><integer name="shadingSamples" value="4"/><integer name="bsdfSamples" value="0"/>'
+                       '<boolean name="hideEmitters" value="true"/></integrator>', (4, 0))):
+        f = tmp_path / "direct.xml"
+        f.write_text(text.replace(head, xml))
+        d = _describe(f)
+        sd, info = loader.load_xml(str(f))
+        assert d["integrator"] == info["integrator_type"] == "direct" and sd.integrator["type"] == "direct"
+        assert (d["emitter_samples"], d["bsdf_samples"]) == want == (sd.integrator["emitter_samples"], sd.integrator["bsdf_samples"])
+
+
 def test_cli_mixturebsdf(scene_dir, tmp_path):
     """mixturebsdf.cpp:66-85,279-287: nested BSDFs are appended before the mixture's own record, by both loaders alike."""
     (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
