@@ -453,6 +453,77 @@ void applyToWorld(Mesh &mesh, const Mat4 &md) {
         for (size_t t = 0; t + 2 < mesh.indices.size(); t += 3) std::swap(mesh.indices[t], mesh.indices[t + 1]);
 }
 
+// TriMesh::rebuildTopology (src/librender/trimesh.cpp:468-606): vertex normals are dropped and the vertices re-made so
+// that, around every distinct (position, uv), the faces whose normals lie within maxAngle of the first unassigned
+// face's normal share a vertex (greedy, in the order the faces name the vertex). Corners sharper than that are split.
+void rebuildTopology(Mesh &mesh, float maxAngleDeg) {
+    const size_t nt = mesh.indices.size() / 3;
+    const bool hasUV = !mesh.texcoords.empty();
+    const float dpThresh = std::cos(maxAngleDeg * (3.14159265358979323846f / 180.0f));
+    struct Entry { float key[5]; uint32_t tri; bool clustered; };
+    std::vector<Entry> entries;
+    entries.reserve(nt * 3);
+    std::vector<float> faceNormals(nt * 3);
+    const float *P = mesh.positions.data();
+    for (size_t t = 0; t < nt; ++t) {
+        const uint32_t *idx = &mesh.indices[3 * t];
+        for (int j = 0; j < 3; ++j) {
+            Entry e;
+            for (int k = 0; k < 3; ++k) e.key[k] = P[3 * (size_t) idx[j] + k];
+            e.key[3] = hasUV ? mesh.texcoords[2 * (size_t) idx[j]] : 0.0f;
+            e.key[4] = hasUV ? mesh.texcoords[2 * (size_t) idx[j] + 1] : 0.0f;
+            e.tri = (uint32_t) t; e.clustered = false;
+            entries.push_back(e);
+        }
+        const float *v0 = P + 3 * (size_t) idx[0], *v1 = P + 3 * (size_t) idx[1], *v2 = P + 3 * (size_t) idx[2];
+        const float a[3] = { v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2] }, b[3] = { v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2] };
+        float n[3] = { a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0] };
+        const float l = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        if (l > 2.93873587705571876e-39f) { n[0] /= l; n[1] /= l; n[2] /= l; } else { n[0] = n[1] = n[2] = 0.0f; }     // degenerate triangle
+        memcpy(&faceNormals[3 * t], n, 12);
+    }
+    // the order of a multimap keyed by (position, uv): ascending keys, equal keys in insertion order
+    auto less = [](const Entry &x, const Entry &y) {
+        for (int k = 0; k < 5; ++k) { if (x.key[k] < y.key[k]) return true; if (x.key[k] > y.key[k]) return false; }
+        return false;
+    };
+    std::stable_sort(entries.begin(), entries.end(), less);
+    std::vector<float> newPositions, newTexcoords;
+    std::vector<uint32_t> newIndices(nt * 3, 0xFFFFFFFFu);
+    for (size_t start = 0; start < entries.size();) {
+        size_t end = start + 1;
+        while (end < entries.size() && !less(entries[start], entries[end])) ++end;
+        for (size_t i2 = start; i2 < end; ++i2) {
+            if (entries[i2].clustered) continue;
+            const float *n1 = &faceNormals[3 * (size_t) entries[i2].tri];
+            const uint32_t vertexIdx = (uint32_t) (newPositions.size() / 3);
+            newPositions.insert(newPositions.end(), entries[i2].key, entries[i2].key + 3);
+            if (hasUV) newTexcoords.insert(newTexcoords.end(), entries[i2].key + 3, entries[i2].key + 5);
+            for (size_t i3 = i2; i3 < end; ++i3) {
+                Entry &t2 = entries[i3];
+                if (t2.clustered) continue;
+                const float *n2 = &faceNormals[3 * (size_t) t2.tri];
+                const bool same = n1[0] == n2[0] && n1[1] == n2[1] && n1[2] == n2[2];
+                if (same || n1[0] * n2[0] + n1[1] * n2[1] + n1[2] * n2[2] > dpThresh) {
+                    const uint32_t *idx = &mesh.indices[3 * (size_t) t2.tri];
+                    for (int k = 0; k < 3; ++k) {
+                        const float *q = P + 3 * (size_t) idx[k];
+                        if (q[0] == entries[i2].key[0] && q[1] == entries[i2].key[1] && q[2] == entries[i2].key[2])
+                            newIndices[3 * (size_t) t2.tri + k] = vertexIdx;
+                    }
+                    t2.clustered = true;
+                }
+            }
+        }
+        start = end;
+    }
+    for (uint32_t v : newIndices) if (v == 0xFFFFFFFFu) throw Fail("rebuildTopology: a triangle corner was left without a vertex");
+    mesh.indices.swap(newIndices);
+    mesh.positions.swap(newPositions);
+    if (hasUV) mesh.texcoords.swap(newTexcoords);
+    mesh.normals.clear();
+}
+
 // TriMesh::computeNormals (src/librender/trimesh.cpp:636-672): angle-weighted face normals
 void computeNormals(Mesh &mesh, bool flip) {
     const size_t nv = mesh.positions.size() / 3, nt = mesh.indices.size() / 3;
@@ -1155,11 +1226,14 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
                 else if (type == "cube") makeCube(mesh);
                 else return "shape type '" + type + "' is not supported (triangle meshes only)";
                 if (!err.empty()) return err;
-                if (p.count("maxSmoothAngle")) return "maxSmoothAngle (TriMesh::rebuildTopology) is not supported";
                 const bool faceNormals = getB(p, "faceNormals", false) || mesh.faceNormals;
                 const bool flipNormals = getB(p, "flipNormals", false);
                 if (faceNormals) mesh.normals.clear();
                 applyToWorld(mesh, p.count("toWorld") ? p.at("toWorld").t : Mat4::identity());
+                if (p.count("maxSmoothAngle")) {        // serialized.cpp:204-209, ply.cpp:124-129, obj.cpp
+                    if (faceNormals) return "The properties 'maxSmoothAngle' and 'faceNormals' can't be specified at the same time!";
+                    rebuildTopology(mesh, (float) getF(p, "maxSmoothAngle", 0));
+                }
                 // TriMesh::computeNormals (src/librender/trimesh.cpp:606-672): flipNormals swaps the winding of a
                 // face-normal mesh, negates given vertex normals, and negates computed ones
                 if (faceNormals) {

@@ -79,6 +79,60 @@ def serialized_mesh_count(data: bytes) -> int:
     return struct.unpack_from("<I", data, len(data) - 4)[0]
 
 
+def rebuild_topology(mesh: Dict, max_angle: float) -> Dict:
+    """TriMesh::rebuildTopology (src/librender/trimesh.cpp:468-606): vertex normals are dropped and the vertices re-made so
+    that, around every distinct (position, uv), the faces whose normals lie within max_angle of the first unassigned
+    face's normal share a vertex (greedy, in the order the faces name the vertex)."""
+    f32 = np.float32
+    P = np.asarray(mesh["positions"], f32)
+    I = np.asarray(mesh["indices"], np.int64).reshape(-1, 3)
+    UV = mesh.get("texcoords")
+    dp_thresh = f32(np.cos(f32(max_angle) * f32(np.pi / 180.0), dtype=f32))
+    a, b = P[I[:, 1]] - P[I[:, 0]], P[I[:, 2]] - P[I[:, 0]]
+    n = np.cross(a, b).astype(f32)
+    l = np.sqrt((n[:, 0] * n[:, 0] + n[:, 1] * n[:, 1]) + n[:, 2] * n[:, 2], dtype=f32)
+    ok = l > f32(2.93873587705571876e-39)
+    n = np.where(ok[:, None], n / np.where(ok, l, 1)[:, None], 0).astype(f32)
+    entries = []
+    for t in range(I.shape[0]):
+        for j in range(3):
+            v = int(I[t, j])
+            key = tuple(P[v]) + (tuple(UV[v]) if UV is not None else (0.0, 0.0))
+            entries.append((key, t))
+    order = sorted(range(len(entries)), key=lambda e: entries[e][0])      # stable: equal keys stay in insertion order
+    new_p, new_uv = [], []
+    new_i = np.full(I.shape, -1, np.int64)
+    k = 0
+    while k < len(order):
+        end = k
+        while end < len(order) and entries[order[end]][0] == entries[order[k]][0]:
+            end += 1
+        group = [entries[e] for e in order[k:end]]
+        clustered = [False] * len(group)
+        for i2, (key, t1) in enumerate(group):
+            if clustered[i2]:
+                continue
+            idx = len(new_p)
+            new_p.append(key[:3])
+            new_uv.append(key[3:])
+            for i3 in range(i2, len(group)):
+                if clustered[i3]:
+                    continue
+                t2 = group[i3][1]
+                dot = (n[t1, 0] * n[t2, 0] + n[t1, 1] * n[t2, 1]) + n[t1, 2] * n[t2, 2]
+                if np.array_equal(n[t1], n[t2]) or dot > dp_thresh:
+                    for c in range(3):
+                        if tuple(P[I[t2, c]]) == key[:3]:
+                            new_i[t2, c] = idx
+                    clustered[i3] = True
+        k = end
+    assert (new_i >= 0).all()
+    out = dict(mesh, positions=np.asarray(new_p, f32).reshape(-1, 3), indices=new_i.astype(np.uint32), normals=None)
+    if UV is not None:
+        out["texcoords"] = np.asarray(new_uv, f32).reshape(-1, 2)
+    return out
+
+
 def apply_to_world(mesh: Dict, m: np.ndarray) -> Dict:
     """SerializedMesh constructor (src/shapes/serialized.cpp:184-202): positions by the matrix, normals by the
     inverse transpose followed by normalisation, winding swapped when the determinant is negative."""
@@ -437,6 +491,10 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
             if p.get("flipNormals", False):
                 raise SceneFormatError("flipNormals is not supported")
             mesh = apply_to_world(mesh, p.get("toWorld", np.eye(4, dtype=np.float32)))
+            if "maxSmoothAngle" in p:       # serialized.cpp:204-209
+                if p.get("faceNormals", False) or mesh.get("face_normals"):
+                    raise SceneFormatError("The properties 'maxSmoothAngle' and 'faceNormals' can't be specified at the same time!")
+                mesh = rebuild_topology(mesh, p["maxSmoothAngle"])
             normals = mesh.get("normals")
             if normals is None and not (p.get("faceNormals", False) or mesh.get("face_normals")):
                 normals = S.vertex_normals(mesh["positions"], mesh["indices"].astype(np.int64))

@@ -56,6 +56,10 @@ def _write_serialized(path):
     meshes.append(((bp + np.float32([0, 0, 1.2])).astype(np.float32), bn, bf.astype(np.uint32)))
     p, idx = _quad(4.0, 1.0, flip=True)                         # light facing down
     meshes.append((p, None, idx))
+    _serialize(path, meshes)
+
+
+def _serialize(path, meshes):
     blob, offsets = b"", []
     for k, (p, n, idx) in enumerate(meshes):
         flags = 0x1000 | (0x1 if n is not None else 0)
@@ -218,6 +222,43 @@ def test_cli_constant_emitter(scene_dir, tmp_path):
     sd, _ = loader.load_xml(str(f))
     assert d["emitters"] == len(sd.emitters) == 2
     assert sd.emitters[1]["shape"] == -1 and sd.emitters[1]["radiance"] == (0.5, 0.75, 1.25) and sd.emitters[1]["sampling_weight"] == 2.0
+
+
+def test_cli_max_smooth_angle(scene_dir, tmp_path):
+    """maxSmoothAngle -> TriMesh::rebuildTopology (trimesh.cpp:468-606): a box with eight shared vertices gets a vertex
+    per face corner (24) and flat normals; a finely tessellated blob keeps its vertex count; both loaders agree."""
+    from mitsuba_amd import scene as S
+    corners = np.array([[x, y, z] for z in (0, 1) for y in (0, 1) for x in (0, 1)], np.float32)
+    quads = [(0, 2, 3, 1), (4, 5, 7, 6), (0, 1, 5, 4), (2, 6, 7, 3), (0, 4, 6, 2), (1, 3, 7, 5)]
+    tris = np.array([t for a, b, c, d in quads for t in ((a, b, c), (a, c, d))], np.uint32)
+    smooth = (corners - 0.5) / np.linalg.norm(corners - 0.5, axis=1, keepdims=True)
+    bp, bf, bn = S.blob(2, np.random.default_rng(3), radius=1.0)
+    _serialize(str(tmp_path / "meshes.serialized"), [(corners, smooth.astype(np.float32), tris), (bp.astype(np.float32), bn, bf.astype(np.uint32)),
+                                                      (_quad(4.0, 1.0, flip=True)[0], None, _quad(4.0, 1.0, flip=True)[1])])
+    text = (scene_dir / "scene.xml").read_text()
+    shape0 = '<integer name="shapeIndex" value="0"/>'
+    shape1 = '<integer name="shapeIndex" value="1"/>'
+    f = tmp_path / "smooth.xml"
+    f.write_text(text.replace(shape0, shape0 + '<float name="maxSmoothAngle" value="30"/>')
+                 .replace(shape1, shape1 + '<float name="maxSmoothAngle" value="60"/>'))
+    d = _describe(f)
+    sd, _ = loader.load_xml(str(f))
+    assert d["vertices"] == sd.positions.shape[0] == 24 + bp.shape[0] + 4 and d["triangles"] == sd.n_triangles
+    assert d["sum_indices"] == int(sd.indices.astype(np.uint64).sum())
+    assert abs(d["sum_positions"] - float(sd.positions.astype(np.float64).sum())) < 1e-4
+    assert abs(d["sum_normals"] - float(sd.normals.astype(np.float64).sum())) < 1e-3
+    # every box vertex now carries the normal of its face
+    box_n, box_p, box_i = sd.normals[:24], sd.positions[:24], sd.indices[:12].astype(np.int64)
+    fn = np.cross(box_p[box_i[:, 1]] - box_p[box_i[:, 0]], box_p[box_i[:, 2]] - box_p[box_i[:, 0]])
+    fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+    for k in range(3):
+        assert np.allclose(box_n[box_i[:, k]], fn, atol=1e-6)
+    # a wide angle leaves the box smooth: eight vertices again
+    f.write_text(text.replace(shape0, shape0 + '<float name="maxSmoothAngle" value="100"/>'))
+    assert _describe(f)["vertices"] == loader.load_xml(str(f))[0].positions.shape[0] == 8 + bp.shape[0] + 4
+    f.write_text(text.replace(shape0, shape0 + '<float name="maxSmoothAngle" value="30"/><boolean name="faceNormals" value="true"/>'))
+    out = subprocess.run([CLI, str(f), "--describe"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "can't be specified at the same time" in out.stderr
 
 
 def test_cli_direct_integrator(scene_dir, tmp_path):
