@@ -203,6 +203,16 @@ typedef struct mtsamd_scene mtsamd_scene;
 
 const char *mtsamd_last_error(void);
 
+/* The records of this header change between versions of the library (fields are added at the end of a record, records
+   are never reordered). A caller compiled against another version must not pass them in: compare MTSAMD_ABI_VERSION with
+   mtsamd_abi_version(), and where records are mirrored by hand (FFI bindings) their sizes with mtsamd_sizeof(). No
+   counterpart in the reference, whose plugins are compiled against its own headers. */
+#define MTSAMD_ABI_VERSION 6
+enum { MTSAMD_SIZEOF_SCENE_DESC = 0, MTSAMD_SIZEOF_MATERIAL = 1, MTSAMD_SIZEOF_EMITTER = 2, MTSAMD_SIZEOF_SHAPE = 3,
+       MTSAMD_SIZEOF_RENDER_OPTS = 4, MTSAMD_SIZEOF_STATS = 5, MTSAMD_SIZEOF_LDR_OPTS = 6 };
+int mtsamd_abi_version(void);
+int64_t mtsamd_sizeof(int record);      /* -1 for an unknown record */
+
 /* Select the HIP device used by subsequent calls on this thread (one process per GPU: pass LOCAL_RANK).
    Replaces nothing in the reference (it has no device notion); mirrors Scheduler worker registration
    in src/mitsuba/mitsuba.cpp:278-329. */

@@ -95,10 +95,11 @@ ISECT_DTYPE = np.dtype([("t", "f4"), ("u", "f4"), ("v", "f4"), ("shape", "u4"), 
 EXPORTS = ["mtsamd_last_error", "mtsamd_init", "mtsamd_scene_create", "mtsamd_scene_destroy", "mtsamd_scene_bvh_info",
            "mtsamd_render", "mtsamd_render_device", "mtsamd_cancel", "mtsamd_scene_set_counting", "mtsamd_film_develop", "mtsamd_trace", "mtsamd_trace_device", "mtsamd_occluded_device",
            "mtsamd_occluded", "mtsamd_intersect", "mtsamd_bsdf_eval", "mtsamd_bsdf_pdf", "mtsamd_bsdf_sample",
-           "mtsamd_sample_emitter_direct", "mtsamd_camera_rays", "mtsamd_li", "mtsamd_film_put", "mtsamd_film_develop_ldr", "mtsamd_rng_stream",
+           "mtsamd_sample_emitter_direct", "mtsamd_camera_rays", "mtsamd_li", "mtsamd_film_put", "mtsamd_film_develop_ldr", "mtsamd_abi_version", "mtsamd_sizeof", "mtsamd_rng_stream",
            "mtsamd_rtrans_reduce", "mtsamd_filter_gaussian", "mtsamd_filter_box"]
 
 _lib = None
+ABI_VERSION = 6     # MTSAMD_ABI_VERSION of include/mtsamd.h
 
 
 class MtsamdError(RuntimeError):
@@ -119,6 +120,15 @@ def lib():
             pass
         L = C.CDLL(_LIB_PATH)
         L.mtsamd_last_error.restype = C.c_char_p
+        # the records above are mirrored by hand: refuse a library built from another version of the header
+        L.mtsamd_sizeof.restype = C.c_int64
+        if L.mtsamd_abi_version() != ABI_VERSION:
+            raise MtsamdError("%s implements ABI version %d, this binding %d: rebuild with `make -C mitsuba_amd/csrc`"
+                              % (_LIB_PATH, L.mtsamd_abi_version(), ABI_VERSION))
+        for record, cls in enumerate((SceneDesc, Material, Emitter, Shape, RenderOpts, Stats, LdrOpts)):
+            if L.mtsamd_sizeof(record) != C.sizeof(cls):
+                raise MtsamdError("record %s is %d bytes in %s and %d bytes in this binding"
+                                  % (cls.__name__, L.mtsamd_sizeof(record), _LIB_PATH, C.sizeof(cls)))
         L.mtsamd_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
         L.mtsamd_scene_destroy.argtypes = [C.c_void_p]
         L.mtsamd_cancel.argtypes = [C.c_void_p]

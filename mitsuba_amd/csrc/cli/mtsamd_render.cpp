@@ -112,6 +112,10 @@ int main(int argc, char **argv) {
     if (describeOnly) { describe(scene); return 0; }
     if (spp <= 0) spp = scene.sampleCount;
 
+    if (mtsamd_abi_version() != MTSAMD_ABI_VERSION) {
+        fprintf(stderr, "mtsamd-render: built against version %d of mtsamd.h, libmtsamd implements version %d\n", MTSAMD_ABI_VERSION, mtsamd_abi_version());
+        return 1;
+    }
     if (mtsamd_init(device) != MTSAMD_OK) { fprintf(stderr, "mtsamd-render: %s\n", mtsamd_last_error()); return 1; }
     const mtsamd_scene_desc desc = scene.desc();
     mtsamd_scene *handle = nullptr;

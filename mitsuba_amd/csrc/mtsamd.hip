@@ -580,6 +580,21 @@ int renderCommon(mtsamd_scene *s, const mtsamd_render_opts *opts, float *filmDev
 
 }  // namespace
 
+extern "C" int mtsamd_abi_version(void) { return MTSAMD_ABI_VERSION; }
+
+extern "C" int64_t mtsamd_sizeof(int record) {
+    switch (record) {
+        case MTSAMD_SIZEOF_SCENE_DESC: return (int64_t) sizeof(mtsamd_scene_desc);
+        case MTSAMD_SIZEOF_MATERIAL: return (int64_t) sizeof(mtsamd_material);
+        case MTSAMD_SIZEOF_EMITTER: return (int64_t) sizeof(mtsamd_emitter);
+        case MTSAMD_SIZEOF_SHAPE: return (int64_t) sizeof(mtsamd_shape);
+        case MTSAMD_SIZEOF_RENDER_OPTS: return (int64_t) sizeof(mtsamd_render_opts);
+        case MTSAMD_SIZEOF_STATS: return (int64_t) sizeof(mtsamd_stats);
+        case MTSAMD_SIZEOF_LDR_OPTS: return (int64_t) sizeof(mtsamd_ldr_opts);
+        default: return -1;
+    }
+}
+
 extern "C" int mtsamd_render_device(mtsamd_scene *scene, const mtsamd_render_opts *opts, float *film_device, mtsamd_stats *stats) {
     if (!scene || !film_device) return fail(MTSAMD_EINVAL, "null argument");
     return renderCommon(scene, opts, film_device, nullptr, nullptr, stats);

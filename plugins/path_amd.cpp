@@ -69,6 +69,9 @@ public:
 	}
 
 	bool render(Scene *scene, RenderQueue *queue, const RenderJob *job, int sceneResID, int sensorResID, int samplerResID) {
+		if (mtsamd_abi_version() != MTSAMD_ABI_VERSION)
+			Log(EError, "path_amd was compiled against version %d of mtsamd.h, libmtsamd implements version %d",
+				MTSAMD_ABI_VERSION, mtsamd_abi_version());
 		if (mtsamd_init(m_device) != MTSAMD_OK)
 			Log(EError, "%s", mtsamd_last_error());
 		if (!m_handle && !upload(scene))
