@@ -710,8 +710,8 @@ MTS_DEV uint32_t cdfSampleReuse(const float *cdf, uint32_t n /* entries */, floa
 // ---- MixtureBSDF (src/bsdfs/mixturebsdf.cpp:174-277), all components requested ---------------------------------
 // A mixture record keeps its count in `variant`, its weights in diffuse[0..2] + rtransOffset, the upper ends of the
 // normalised choice intervals in specular[0..2] + rtransN and the nested records' indices in condEta[0..2] + condK[0].
-// Nested records are diffuse, roughconductor, roughplastic or ward models: solid-angle lobes only, nothing taken
-// from the sampler. Fields are picked with selects, not indexed, so that they stay in registers.
+// Nested records are one-sided models that take nothing from the sampler themselves (all but roughdielectric). Fields
+// are picked with selects, not indexed, so that they stay in registers.
 MTS_DEV float mixWeight(const DevMaterial &m, int i) {
     return i == 0 ? m.diffuse[0] : i == 1 ? m.diffuse[1] : i == 2 ? m.diffuse[2] : __uint_as_float(m.rtransOffset);
 }
@@ -720,6 +720,64 @@ MTS_DEV float mixCdf(const DevMaterial &m, int i) {      // cdf[0] = 0, cdf[coun
 }
 MTS_DEV uint32_t mixChild(const DevMaterial &m, int i) {
     return __float_as_uint(i == 0 ? m.condEta[0] : i == 1 ? m.condEta[1] : i == 2 ? m.condEta[2] : m.condK[0]);
+}
+
+// eval / pdf in the discrete measure: the Dirac lobes of dielectric (dielectric.cpp:228-275), conductor
+// (conductor.cpp:221-250) and plastic (plastic.cpp:243-300); every other lobe is zero there. A mixture asks for them
+// after one of its nested BSDFs has sampled such a lobe.
+static constexpr float kDeltaEpsilon = 1e-3f;       // include/mitsuba/core/constants.h:31
+MTS_DEV V3 bsdfEvalDiscrete(const DevMaterial &m, V3 wi, V3 wo) {
+    const V3 wr = mk(-wi.x, -wi.y, wi.z);
+    switch (m.type) {
+        case 3: {
+            float cosThetaT;
+            const float F = fresnelDielectricExt(wi.z, cosThetaT, m.eta);
+            if (wi.z * wo.z >= 0) {
+                if (fabsf(dot(wr, wo) - 1) > kDeltaEpsilon) return mk(0.0f);
+                return ld3(m.specular) * F;
+            }
+            const float scale = -(cosThetaT < 0 ? m.invEta : m.eta);
+            const V3 wt = mk(scale * wi.x, scale * wi.y, cosThetaT);
+            if (fabsf(dot(wt, wo) - 1) > kDeltaEpsilon) return mk(0.0f);
+            const float factor = cosThetaT < 0 ? m.invEta : m.eta;
+            return ld3(m.transmittance) * (factor * factor * (1 - F));
+        }
+        case 5:
+            if (wi.z <= 0 || wo.z <= 0 || fabsf(dot(wr, wo) - 1) > kDeltaEpsilon) return mk(0.0f);
+            return ld3(m.specular) * fresnelConductorExact(wi.z, ld3(m.condEta), ld3(m.condK));
+        case 6: {
+            if (wo.z <= 0 || wi.z <= 0) return mk(0.0f);
+            float cosThetaT;
+            const float Fi = fresnelDielectricExt(wi.z, cosThetaT, m.eta);
+            if (fabsf(dot(wr, wo) - 1) < kDeltaEpsilon) return ld3(m.specular) * Fi;
+            return mk(0.0f);
+        }
+    }
+    return mk(0.0f);
+}
+
+MTS_DEV float bsdfPdfDiscrete(const DevMaterial &m, V3 wi, V3 wo) {
+    const V3 wr = mk(-wi.x, -wi.y, wi.z);
+    switch (m.type) {
+        case 3: {
+            float cosThetaT;
+            const float F = fresnelDielectricExt(wi.z, cosThetaT, m.eta);
+            if (wi.z * wo.z >= 0) return fabsf(dot(wr, wo) - 1) > kDeltaEpsilon ? 0.0f : F;
+            const float scale = -(cosThetaT < 0 ? m.invEta : m.eta);
+            const V3 wt = mk(scale * wi.x, scale * wi.y, cosThetaT);
+            return fabsf(dot(wt, wo) - 1) > kDeltaEpsilon ? 0.0f : 1 - F;
+        }
+        case 5:
+            return (wi.z <= 0 || wo.z <= 0 || fabsf(dot(wr, wo) - 1) > kDeltaEpsilon) ? 0.0f : 1.0f;
+        case 6: {
+            if (wo.z <= 0 || wi.z <= 0) return 0.0f;
+            float cosThetaT;
+            const float Fi = fresnelDielectricExt(wi.z, cosThetaT, m.eta);
+            const float probSpecular = (Fi * m.specSamplingWeight) / (Fi * m.specSamplingWeight + (1 - Fi) * (1 - m.specSamplingWeight));
+            return fabsf(dot(wr, wo) - 1) < kDeltaEpsilon ? probSpecular : 0.0f;
+        }
+    }
+    return 0.0f;
 }
 
 MTS_DEV V3 mixEval(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
@@ -761,12 +819,13 @@ MTS_DEV V3 mixSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, 
     if (isZero(result)) return result;      // sampling failed
     result = result * (mixWeight(m, entry) * pdf);
     pdf *= width;
+    const bool discrete = (sampledType & EDelta) != 0;     // BSDF::getMeasure(bRec.sampledType)
 #pragma unroll 1
     for (int i = 0; i < n; ++i) {
         if (i == entry) continue;
         loadMaterial(sc, mixChild(m, i), c);
-        pdf += bsdfPdf<false>(sc, c, wi, wo) * (mixCdf(m, i + 1) - mixCdf(m, i));
-        result = result + bsdfEval<false>(sc, c, wi, wo) * mixWeight(m, i);
+        pdf += (discrete ? bsdfPdfDiscrete(c, wi, wo) : bsdfPdf<false>(sc, c, wi, wo)) * (mixCdf(m, i + 1) - mixCdf(m, i));
+        result = result + (discrete ? bsdfEvalDiscrete(c, wi, wo) : bsdfEval<false>(sc, c, wi, wo)) * mixWeight(m, i);
     }
     return result / pdf;
 }

@@ -260,8 +260,8 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
             const int32_t c = m.mix_material[k];
             if (c < 0 || c >= (int32_t) d->n_materials) return "mixturebsdf: nested material index out of range";
             const int t = d->materials[c].type;
-            if (d->materials[c].two_sided || !(t == MTSAMD_BSDF_DIFFUSE || t == MTSAMD_BSDF_ROUGHCONDUCTOR || t == MTSAMD_BSDF_ROUGHPLASTIC || t == MTSAMD_BSDF_WARD))
-                return "mixturebsdf: only diffuse, roughconductor, roughplastic and ward can be nested";
+            if (d->materials[c].two_sided || t == MTSAMD_BSDF_ROUGHDIELECTRIC || t == MTSAMD_BSDF_MIXTURE)
+                return "mixturebsdf: twosided, roughdielectric and mixturebsdf cannot be nested";
             child[k] = c;
             w[k] = scale != 1.0f ? m.mix_weight[k] * scale : m.mix_weight[k];
             cdf[k + 1] = cdf[k] + w[k];

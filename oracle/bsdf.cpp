@@ -474,8 +474,7 @@ void Material::configure() {
 
 // MixtureBSDF::configure (src/bsdfs/mixturebsdf.cpp:115-172): weights rescaled when they sum to more than one, the
 // discrete choice proportional to them, the type the union of the nested BSDFs' components. Nested BSDFs are
-// restricted to one-sided models whose lobes all live in the solid-angle measure and that draw nothing from the
-// sampler themselves (diffuse, roughconductor, roughplastic, ward).
+// restricted to one-sided models that draw nothing from the sampler themselves (all but roughdielectric).
 const char *linkMixtures(std::vector<Material> &materials) {
     for (Material &mat : materials) {
         if (mat.m.type != ORC_BSDF_MIXTURE) continue;
@@ -496,8 +495,8 @@ const char *linkMixtures(std::vector<Material> &materials) {
             if (c < 0 || c >= (int) materials.size()) return "mixturebsdf: nested material index out of range";
             const Material &child = materials[c];
             const int t = child.m.type;
-            if (child.m.two_sided || !(t == ORC_BSDF_DIFFUSE || t == ORC_BSDF_ROUGHCONDUCTOR || t == ORC_BSDF_ROUGHPLASTIC || t == ORC_BSDF_WARD))
-                return "mixturebsdf: only diffuse, roughconductor, roughplastic and ward can be nested";
+            if (child.m.two_sided || t == ORC_BSDF_ROUGHDIELECTRIC || t == ORC_BSDF_MIXTURE)
+                return "mixturebsdf: twosided, roughdielectric and mixturebsdf cannot be nested";
             mat.mixChildren.push_back(&child);
             mat.mixWeights.push_back(scale != 1.0f ? mat.m.mix_weight[i] * scale : mat.m.mix_weight[i]);
             mat.mixPdf.append(mat.mixWeights.back());
@@ -909,6 +908,64 @@ static Spectrum sampleOneSided(const Material &mat, const Vec3 &wi, const Vec2 &
     return Spectrum(0.0f);
 }
 
+// ---- eval / pdf in the discrete measure: the Dirac lobes of dielectric (dielectric.cpp:228-275), conductor
+// (conductor.cpp:221-250) and plastic (plastic.cpp:243-300); every other lobe is zero there. A mixture asks for them
+// after one of its nested BSDFs has sampled such a lobe.
+
+static inline Vec3 reflectZ(const Vec3 &wi) { return Vec3(-wi.x, -wi.y, wi.z); }
+
+static Spectrum evalDiscrete(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
+    switch (mat.m.type) {
+        case ORC_BSDF_DIELECTRIC: {
+            float cosThetaT;
+            const float F = fresnelDielectricExt(Frame::cosTheta(wi), cosThetaT, mat.eta);
+            if (Frame::cosTheta(wi) * Frame::cosTheta(wo) >= 0) {
+                if (std::abs(dot(reflectZ(wi), wo) - 1) > DeltaEpsilon) return Spectrum(0.0f);
+                return mat.specular * F;
+            }
+            const float scale = -(cosThetaT < 0 ? mat.invEta : mat.eta);
+            const Vec3 wt(scale * wi.x, scale * wi.y, cosThetaT);
+            if (std::abs(dot(wt, wo) - 1) > DeltaEpsilon) return Spectrum(0.0f);
+            const float factor = cosThetaT < 0 ? mat.invEta : mat.eta;      // ERadiance
+            return mat.transmittance * (factor * factor * (1 - F));
+        }
+        case ORC_BSDF_CONDUCTOR:
+            if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0 || std::abs(dot(reflectZ(wi), wo) - 1) > DeltaEpsilon) return Spectrum(0.0f);
+            return mat.specular * fresnelConductorExact(Frame::cosTheta(wi), mat.condEta, mat.condK);
+        case ORC_BSDF_PLASTIC: {
+            if (Frame::cosTheta(wo) <= 0 || Frame::cosTheta(wi) <= 0) return Spectrum(0.0f);
+            const float Fi = fresnelDielectricExt(Frame::cosTheta(wi), mat.eta);
+            if (std::abs(dot(reflectZ(wi), wo) - 1) < DeltaEpsilon) return mat.specular * Fi;
+            return Spectrum(0.0f);
+        }
+    }
+    return Spectrum(0.0f);
+}
+
+static float pdfDiscrete(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
+    switch (mat.m.type) {
+        case ORC_BSDF_DIELECTRIC: {
+            float cosThetaT;
+            const float F = fresnelDielectricExt(Frame::cosTheta(wi), cosThetaT, mat.eta);
+            if (Frame::cosTheta(wi) * Frame::cosTheta(wo) >= 0)
+                return std::abs(dot(reflectZ(wi), wo) - 1) > DeltaEpsilon ? 0.0f : F;
+            const float scale = -(cosThetaT < 0 ? mat.invEta : mat.eta);
+            const Vec3 wt(scale * wi.x, scale * wi.y, cosThetaT);
+            return std::abs(dot(wt, wo) - 1) > DeltaEpsilon ? 0.0f : 1 - F;
+        }
+        case ORC_BSDF_CONDUCTOR:
+            if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0 || std::abs(dot(reflectZ(wi), wo) - 1) > DeltaEpsilon) return 0.0f;
+            return 1.0f;
+        case ORC_BSDF_PLASTIC: {
+            if (Frame::cosTheta(wo) <= 0 || Frame::cosTheta(wi) <= 0) return 0.0f;
+            const float Fi = fresnelDielectricExt(Frame::cosTheta(wi), mat.eta);
+            const float probSpecular = (Fi * mat.specularSamplingWeight) / (Fi * mat.specularSamplingWeight + (1 - Fi) * (1 - mat.specularSamplingWeight));
+            return std::abs(dot(reflectZ(wi), wo) - 1) < DeltaEpsilon ? probSpecular : 0.0f;
+        }
+    }
+    return 0.0f;
+}
+
 // ---- MixtureBSDF::eval / pdf / sample (src/bsdfs/mixturebsdf.cpp:174-277), all components requested -------------
 static Spectrum evalPlain(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
     if (mat.m.type != ORC_BSDF_MIXTURE) return evalOneSided(mat, wi, wo);
@@ -934,10 +991,12 @@ static Spectrum samplePlain(const Material &mat, const Vec3 &wi, const Vec2 &sam
     if (result.isZero()) return result;     // sampling failed
     result *= mat.mixWeights[entry] * pdf;
     pdf *= mat.mixPdf[entry];
+    const bool discrete = (out.sampledType & EDelta) != 0;      // BSDF::getMeasure(bRec.sampledType)
     for (size_t i = 0; i < mat.mixChildren.size(); ++i) {
         if (i == entry) continue;
-        pdf += pdfOneSided(*mat.mixChildren[i], wi, out.wo) * mat.mixPdf[i];
-        result += evalOneSided(*mat.mixChildren[i], wi, out.wo) * mat.mixWeights[i];
+        const Material &c = *mat.mixChildren[i];
+        pdf += (discrete ? pdfDiscrete(c, wi, out.wo) : pdfOneSided(c, wi, out.wo)) * mat.mixPdf[i];
+        result += (discrete ? evalDiscrete(c, wi, out.wo) : evalOneSided(c, wi, out.wo)) * mat.mixWeights[i];
     }
     return result / pdf;
 }

@@ -142,7 +142,10 @@ def material_pair(gpu, oracle_mod):
             S.mixture([0, 10], [0.25, 0.5]),
             S.twosided(S.mixture([5, 11, 12, 13], [0.1, 0.2, 0.3, 0.2])),
             S.mixture([0, 2, 7], [0.0, 1.0, 0.0], ensure_energy_conservation=False),     # entries that are never chosen
-            S.twosided(S.mixture([1], [2.5], ensure_energy_conservation=False), 23)]
+            S.twosided(S.mixture([1], [2.5], ensure_energy_conservation=False), 23),
+            S.mixture([14, 0], [0.5, 0.5]),             # conductor + diffuse: a Dirac lobe next to a smooth one
+            S.mixture([14, 15, 9], [0.3, 0.3, 0.4]),    # conductor + plastic + dielectric: Dirac lobes that share directions
+            S.mixture([16, 8, 2], [0.2, 0.5, 0.3])]
     b = S.SceneBuilder()
     for m in mats:
         b.add_material(m)
@@ -176,7 +179,7 @@ def test_bsdf_sample_parity(material_pair):
     n = 200000
     for mi in range(len(mats)):
         wi = _wi(n, rng)
-        if mats[mi]["type"] in (S.BSDF_DIELECTRIC, S.BSDF_ROUGHDIELECTRIC) or mats[mi]["two_sided"]:
+        if mats[mi]["type"] in (S.BSDF_DIELECTRIC, S.BSDF_ROUGHDIELECTRIC, S.BSDF_MIXTURE) or mats[mi]["two_sided"]:
             wi[::2, 2] *= -1
         s = rng.uniform(0, 1, (n, 2)).astype(np.float32)
         u = rng.uniform(0, 1, n).astype(np.float32)       # what an EUsesSampler BSDF draws from the sampler itself
