@@ -270,19 +270,13 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
 #endif
 static constexpr int kShadeBlock = MTS_SHADE_BLOCK;
 
-// ROUNDS: a workgroup sorts ROUNDS x kShadeBlock paths at once and shades them in ROUNDS sweeps of one path per
-// thread; the larger sort domain leaves fewer wavefronts that straddle two BSDF models.
-// ENV: the scene has emitters other than area lights: an environment emitter (rays that leave the scene are shaded
-// too, one more queue stream), point, spot or directional lights.
-// RD: the scene has a rough dielectric material.
-template <int ROUNDS, bool ENV, bool RD, bool MIX>
-__global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out,
-                                                       ShadowQueue sq, float4 *sampleL, uint32_t *counters, uint32_t n) {
-    constexpr int kWaves = kShadeBlock / 64, kKeys = 9, kCells = kKeys * ROUNDS * kWaves;   // BSDF models 0..7, misses
-    __shared__ uint32_t sCount[kCells];         // [key][round][wave]: count, then exclusive start
-    __shared__ uint32_t sOrder[kShadeBlock * ROUNDS];
+// The paths [first, first + ROUNDS * kShadeBlock) of a workgroup, ordered by the BSDF type their hit carries (misses
+// last): sOrder[k] is the offset from `first` of the k-th path in that order. sCount is scratch, [key][round][wave].
+static constexpr int kShadeSortKeys = 9;    // BSDF models 0..7, misses
+template <int ROUNDS>
+MTS_DEV void sortByBsdfType(const float4 *hits, uint32_t first, uint32_t n, uint32_t *sCount, uint32_t *sOrder) {
+    constexpr int kWaves = kShadeBlock / 64, kKeys = kShadeSortKeys, kCells = kKeys * ROUNDS * kWaves;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t first = blockIdx.x * (kShadeBlock * ROUNDS);
     {
         uint32_t key[ROUNDS], rank[ROUNDS];
         const unsigned long long below = (1ull << lane) - 1ull;
@@ -323,6 +317,21 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
             sOrder[sCount[(key[r] * ROUNDS + r) * kWaves + wave] + rank[r]] = r * kShadeBlock + tid;
         __syncthreads();
     }
+}
+
+// ROUNDS: a workgroup sorts ROUNDS x kShadeBlock paths at once and shades them in ROUNDS sweeps of one path per
+// thread; the larger sort domain leaves fewer wavefronts that straddle two BSDF models.
+// ENV: the scene has emitters other than area lights: an environment emitter (rays that leave the scene are shaded
+// too, one more queue stream), point, spot or directional lights.
+// RD: the scene has a rough dielectric material.
+template <int ROUNDS, bool ENV, bool RD, bool MIX>
+__global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out,
+                                                       ShadowQueue sq, float4 *sampleL, uint32_t *counters, uint32_t n) {
+    constexpr int kWaves = kShadeBlock / 64;
+    __shared__ uint32_t sCount[kShadeSortKeys * ROUNDS * kWaves];
+    __shared__ uint32_t sOrder[kShadeBlock * ROUNDS];
+    const uint32_t first = blockIdx.x * (kShadeBlock * ROUNDS);
+    sortByBsdfType<ROUNDS>(hits, first, n, sCount, sOrder);
     __shared__ uint32_t sWaveShadow[kWaves], sWaveNext[kWaves], sBase[2];
   for (int round = 0; round < ROUNDS; ++round) {
     // The thread's coordinates are made opaque per sweep so that nothing derived from them is carried in registers
@@ -445,7 +454,8 @@ __global__ void __launch_bounds__(256) k_shadow_accumulate(uint32_t n, const uin
 }
 
 // ---- MIDirectIntegrator::Li (src/integrators/direct/direct.cpp:146-309) in two kernels around the traversals -------
-// k_direct_shade: one thread per camera sample. It shades the camera vertex, writes `nEmitter` shadow rays to
+// k_direct_shade: one thread per camera sample (a workgroup takes 16 x 256 of them, ordered by the BSDF type of their
+// hits). It shades the camera vertex, writes `nEmitter` shadow rays to
 // entries [i * nEmitter, (i + 1) * nEmitter) of the shadow queue and `nBsdf` BSDF-sampled rays to entries
 // [i * nBsdf, ...) of the output queue. Entries keep their place whether or not they carry a ray (an idle entry has an
 // empty ray interval), so that k_direct_gather can add a sample's contributions in a fixed order without atomics.
@@ -453,10 +463,16 @@ __global__ void __launch_bounds__(256) k_shadow_accumulate(uint32_t n, const uin
 // what the BSDF itself takes from the sampler. counts[0] += BSDF rays, counts[1] += shadow rays that the reference traces.
 static constexpr uint32_t PF_IDLE = 0x8000u;
 
-__global__ void __launch_bounds__(256) k_direct_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out, ShadowQueue sq,
-                                                     float4 *sampleL, unsigned long long *counts, uint32_t n, int nEmitter, int nBsdf) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+static constexpr int kDirectRounds = 16;    // sweeps per workgroup, sorted by BSDF type like k_shade
+__global__ void __launch_bounds__(kShadeBlock) k_direct_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out, ShadowQueue sq,
+                                                             float4 *sampleL, unsigned long long *counts, uint32_t n, int nEmitter, int nBsdf) {
+    __shared__ uint32_t sCount[kShadeSortKeys * kDirectRounds * (kShadeBlock / 64)];
+    __shared__ uint32_t sOrder[kShadeBlock * kDirectRounds];
+    const uint32_t first = blockIdx.x * (kShadeBlock * kDirectRounds);
+    sortByBsdfType<kDirectRounds>(hits, first, n, sCount, sOrder);
     uint32_t nNormal = 0, nShadow = 0;
+  for (int round = 0; round < kDirectRounds; ++round) {
+    const uint32_t i = first + sOrder[round * kShadeBlock + threadIdx.x];
     if (i < n) {
         const float4 idleO = make_float4(0.0f, 0.0f, 0.0f, 1.0f), idleD = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
         const float4 hit = hits[i], rd = in.rayD[i];
@@ -559,6 +575,7 @@ __global__ void __launch_bounds__(256) k_direct_shade(DevScene sc, PassParams pp
             out.misc[e] = make_uint4(slot, 1u | (flags << 16), 0u, 0u);
         }
     }
+  }
     for (int off = 32; off > 0; off >>= 1) { nNormal += __shfl_down(nNormal, off); nShadow += __shfl_down(nShadow, off); }
     if ((threadIdx.x & 63) == 0 && (nNormal | nShadow)) { atomicAdd(&counts[0], (unsigned long long) nNormal); atomicAdd(&counts[1], (unsigned long long) nShadow); }
 }
