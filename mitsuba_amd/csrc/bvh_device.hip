@@ -564,6 +564,7 @@ const char *buildWideDevice(const float *positions, uint32_t nVerts, const uint3
                             void **outNodes, void **outTris, BVH &info) {
     auto t0 = std::chrono::steady_clock::now();
     const size_t N = nTris;
+    if (const char *e = getenv("MTSAMD_COST_TRI")) gCostTri = (float) atof(e);
     ClusterTree ct;
     const char *err = clusterOnDevice(positions, nVerts, indices, nTris, gCostNode, gCostTri, ct);
     if (err && *err) return err;
