@@ -383,6 +383,35 @@ def test_empty_scene_renders_black(gpu):
     assert np.all(film[..., :4] == 0) and film[..., 4].min() > 0
 
 
+def test_direct_integrator_edge_cases(gpu, oracle_mod):
+    """`direct` on an empty scene, on a scene without emitters, with only a sky, and with invalid sample counts."""
+    b = S.SceneBuilder()
+    b.add_material(S.diffuse())
+    sd = S.SceneData(positions=np.zeros((0, 3), np.float32), indices=np.zeros((0, 3), np.uint32), shapes=[], materials=b.materials,
+                     emitters=[], camera=S.make_camera([0, 0, 5], [0, 0, 0], [0, 1, 0], 40), film=S.make_film(16, 16))
+    sd.integrator.update(type="direct", emitter_samples=2, bsdf_samples=3)
+    film, st = gpu.Scene(sd).render(2)
+    assert st.normal_rays == 16 * 16 * 2 and st.shadow_rays == 0 and np.all(film[..., :4] == 0) and film[..., 4].min() > 0
+    dark = S.small_test_scene(area_lights=False)
+    dark.integrator.update(type="direct", emitter_samples=2, bsdf_samples=2)
+    g, o = gpu.Scene(dark), oracle_mod.OracleScene(dark)
+    Lg, _, sg = g.li(2, seed=1)
+    Lo, _, so = o.li(2, seed=1)
+    assert np.all(Lg[..., :3] == 0) and np.array_equal(Lg[..., 3], Lo[..., 3])
+    assert (sg.normal_rays, sg.shadow_rays) == (so.normal_rays, so.shadow_rays) and sg.shadow_rays == 0
+    sky = S.small_test_scene(area_lights=False, sky=(1.0, 1.0, 1.0), hide_emitters=1)
+    sky.integrator.update(type="direct", emitter_samples=1, bsdf_samples=1)
+    Lg, _, sg = gpu.Scene(sky).li(2, seed=1)
+    Lo, _, so = oracle_mod.OracleScene(sky).li(2, seed=1)
+    assert (sg.normal_rays, sg.shadow_rays) == (so.normal_rays, so.shadow_rays)
+    assert np.all(Lg[Lg[..., 3] == 0][:, :3] == 0) and Lg[..., :3].mean() > 0.05       # the sky is hidden, its light is not
+    assert np.mean(np.abs(Lg[..., :3] - Lo[..., :3]).max(-1) < 1e-3 * (np.abs(Lo[..., :3]).max(-1) + 1e-3)) > 0.995
+    bad = S.small_test_scene()
+    bad.integrator.update(type="direct", emitter_samples=0, bsdf_samples=0)
+    with pytest.raises(gpu.MtsamdError, match="not both zero"):
+        gpu.Scene(bad)
+
+
 def test_traversal_counters(pairs):
     sd, g, o = pairs["small"]
     g.set_counting(True)
