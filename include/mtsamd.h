@@ -85,7 +85,7 @@ typedef struct {
     int32_t back_material;
     /* MixtureBSDF (src/bsdfs/mixturebsdf.cpp:66-85,115-172), type MTSAMD_BSDF_MIXTURE: the records of up to four nested
        BSDFs and their linear weights (rescaled when they sum to more than one and ensure_energy_conservation is set).
-       Nested records must be one-sided and neither roughdielectric nor mixtures themselves. */
+       Nested records must be one-sided and not mixtures themselves. */
     int32_t mix_count;
     int32_t mix_material[4];
     float mix_weight[4];

@@ -310,8 +310,8 @@ mtsamd_material makeBsdf(const Element &node, const LoadOptions &opts, LoadedSce
         }
         for (int32_t c : children) {
             const mtsamd_material &cm = out.materials[(size_t) c];
-            if (cm.two_sided || cm.type == MTSAMD_BSDF_ROUGHDIELECTRIC || cm.type == MTSAMD_BSDF_MIXTURE)
-                throw Fail("mixturebsdf: twosided, roughdielectric and mixturebsdf cannot be nested");
+            if (cm.two_sided || cm.type == MTSAMD_BSDF_MIXTURE)
+                throw Fail("mixturebsdf: twosided and mixturebsdf cannot be nested");
         }
         if (children.size() != weights.size())
             throw Fail("BSDF count mismatch: " + std::to_string(children.size()) + " bsdfs, but specified " + std::to_string(weights.size()) + " weights");

@@ -710,8 +710,8 @@ MTS_DEV uint32_t cdfSampleReuse(const float *cdf, uint32_t n /* entries */, floa
 // ---- MixtureBSDF (src/bsdfs/mixturebsdf.cpp:174-277), all components requested ---------------------------------
 // A mixture record keeps its count in `variant`, its weights in diffuse[0..2] + rtransOffset, the upper ends of the
 // normalised choice intervals in specular[0..2] + rtransN and the nested records' indices in condEta[0..2] + condK[0].
-// Nested records are one-sided models that take nothing from the sampler themselves (all but roughdielectric). Fields
-// are picked with selects, not indexed, so that they stay in registers.
+// `distribution` holds the nested records' BSDF types, a byte each. Fields are picked with selects, not indexed, so that
+// they stay in registers.
 MTS_DEV float mixWeight(const DevMaterial &m, int i) {
     return i == 0 ? m.diffuse[0] : i == 1 ? m.diffuse[1] : i == 2 ? m.diffuse[2] : __uint_as_float(m.rtransOffset);
 }
@@ -786,7 +786,7 @@ MTS_DEV V3 mixEval(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
     for (int i = 0; i < m.variant; ++i) {
         DevMaterial c;
         loadMaterial(sc, mixChild(m, i), c);
-        result = result + bsdfEval<false>(sc, c, wi, wo) * mixWeight(m, i);
+        result = result + bsdfEval<true>(sc, c, wi, wo) * mixWeight(m, i);
     }
     return result;
 }
@@ -797,25 +797,40 @@ MTS_DEV float mixPdf(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
     for (int i = 0; i < m.variant; ++i) {
         DevMaterial c;
         loadMaterial(sc, mixChild(m, i), c);
-        result += bsdfPdf<false>(sc, c, wi, wo) * (mixCdf(m, i + 1) - mixCdf(m, i));
+        result += bsdfPdf<true>(sc, c, wi, wo) * (mixCdf(m, i + 1) - mixCdf(m, i));
     }
     return result;
 }
 
-MTS_DEV V3 mixSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, V3 &wo, float &pdf, float &eta, uint32_t &sampledType) {
+// DiscreteDistribution::sampleReuse (include/mitsuba/core/pmf.h:124-188) over the five-entry table: the nested BSDF
+// that the first sample coordinate picks
+MTS_DEV int mixEntry(const DevMaterial &m, float sx) {
     const int n = m.variant;
-    // DiscreteDistribution::sampleReuse (include/mitsuba/core/pmf.h:124-188) over the five-entry table
     int lo = 0;
 #pragma unroll
     for (int k = 0; k <= 4; ++k) lo += (k <= n && mixCdf(m, k) < sx) ? 1 : 0;
     int entry = lo - 1 < 0 ? 0 : lo - 1;
     entry = entry < n - 1 ? entry : n - 1;
     while (mixCdf(m, entry + 1) - mixCdf(m, entry) == 0 && entry < n) ++entry;
+    return entry;
+}
+
+// Whether BSDF::sample with first sample coordinate sx takes a number from the sampler itself (roughdielectric does,
+// bRec.sampler->next1D(); a mixture does when the nested BSDF it picks does)
+template <bool MIX = true>
+MTS_DEV bool bsdfDrawsFromSampler(const DevMaterial &m, float sx) {
+    if (MIX && m.type == 8) return (((uint32_t) m.distribution >> (8 * mixEntry(m, sx))) & 0xffu) == 7u;
+    return m.type == 7;
+}
+
+MTS_DEV V3 mixSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, float su, V3 &wo, float &pdf, float &eta, uint32_t &sampledType) {
+    const int n = m.variant;
+    const int entry = mixEntry(m, sx);
     const float lower = mixCdf(m, entry), width = mixCdf(m, entry + 1) - lower;
     sx = (sx - lower) / width;
     DevMaterial c;
     loadMaterial(sc, mixChild(m, entry), c);
-    V3 result = bsdfSample<false>(sc, c, wi, sx, sy, 0.0f, wo, pdf, eta, sampledType);
+    V3 result = bsdfSample<true>(sc, c, wi, sx, sy, su, wo, pdf, eta, sampledType);
     if (isZero(result)) return result;      // sampling failed
     result = result * (mixWeight(m, entry) * pdf);
     pdf *= width;
@@ -824,8 +839,8 @@ MTS_DEV V3 mixSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, 
     for (int i = 0; i < n; ++i) {
         if (i == entry) continue;
         loadMaterial(sc, mixChild(m, i), c);
-        pdf += (discrete ? bsdfPdfDiscrete(c, wi, wo) : bsdfPdf<false>(sc, c, wi, wo)) * (mixCdf(m, i + 1) - mixCdf(m, i));
-        result = result + (discrete ? bsdfEvalDiscrete(c, wi, wo) : bsdfEval<false>(sc, c, wi, wo)) * mixWeight(m, i);
+        pdf += (discrete ? bsdfPdfDiscrete(c, wi, wo) : bsdfPdf<true>(sc, c, wi, wo)) * (mixCdf(m, i + 1) - mixCdf(m, i));
+        result = result + (discrete ? bsdfEvalDiscrete(c, wi, wo) : bsdfEval<true>(sc, c, wi, wo)) * mixWeight(m, i);
     }
     return result / pdf;
 }
@@ -843,7 +858,7 @@ MTS_DEV float bsdfPdfAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo)
 }
 template <bool RD = true, bool MIX = true>
 MTS_DEV V3 bsdfSampleAny(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, float su, V3 &wo, float &pdf, float &eta, uint32_t &sampledType) {
-    if (MIX && m.type == 8) return mixSample(sc, m, wi, sx, sy, wo, pdf, eta, sampledType);
+    if (MIX && m.type == 8) return mixSample(sc, m, wi, sx, sy, su, wo, pdf, eta, sampledType);
     return bsdfSample<RD>(sc, m, wi, sx, sy, su, wo, pdf, eta, sampledType);
 }
 

@@ -239,7 +239,8 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
     }
     // MixtureBSDF::configure (mixturebsdf.cpp:115-172). The record keeps the count in `variant`, the weights in
     // diffuse[0..2] + rtransOffset, the upper ends of the normalised choice intervals in specular[0..2] + rtransN and
-    // the nested records' indices in condEta[0..2] + condK[0] (the last of each group as raw bits).
+    // the nested records' indices in condEta[0..2] + condK[0] (the last of each group as raw bits) and their BSDF types,
+    // a byte each, in `distribution`.
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const mtsamd_material &m = d->materials[i];
         if (m.type != MTSAMD_BSDF_MIXTURE) continue;
@@ -256,12 +257,14 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         float w[4] = { 0, 0, 0, 0 }, cdf[5] = { 0, 0, 0, 0, 0 };
         int32_t child[4] = { 0, 0, 0, 0 };
         unsigned flags = 0;
+        uint32_t childTypes = 0;        // one byte per nested record: its BSDF type
         for (int k = 0; k < n; ++k) {
             const int32_t c = m.mix_material[k];
             if (c < 0 || c >= (int32_t) d->n_materials) return "mixturebsdf: nested material index out of range";
             const int t = d->materials[c].type;
-            if (d->materials[c].two_sided || t == MTSAMD_BSDF_ROUGHDIELECTRIC || t == MTSAMD_BSDF_MIXTURE)
-                return "mixturebsdf: twosided, roughdielectric and mixturebsdf cannot be nested";
+            if (d->materials[c].two_sided || t == MTSAMD_BSDF_MIXTURE)
+                return "mixturebsdf: twosided and mixturebsdf cannot be nested";
+            childTypes |= (uint32_t) t << (8 * k);
             child[k] = c;
             w[k] = scale != 1.0f ? m.mix_weight[k] * scale : m.mix_weight[k];
             cdf[k + 1] = cdf[k] + w[k];
@@ -270,6 +273,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         normalizeCdf(cdf, (size_t) n, nullptr);
         for (int k = n + 1; k <= 4; ++k) cdf[k] = cdf[n];
         dm.variant = n;
+        dm.distribution = (int32_t) childTypes;
         memcpy(dm.diffuse, w, 12); memcpy(&dm.rtransOffset, &w[3], 4);
         memcpy(dm.specular, &cdf[1], 12); memcpy(&dm.rtransN, &cdf[4], 4);
         memcpy(dm.condEta, child, 12); memcpy(&dm.condK[0], &child[3], 4);

@@ -202,7 +202,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             // BSDF sampling (path.cpp:206-226)
             const float bx = rng.next1D(), by = rng.next1D();
             V3 woLocal; float bPdf, bEta; uint32_t sampledType;
-            const float bu = RD && bsdfUsesSampler(bsdf) ? rng.next1D() : 0.0f;     // bRec.sampler->next1D() inside BSDF::sample
+            const float bu = RD && bsdfDrawsFromSampler<MIX>(bsdf, bx) ? rng.next1D() : 0.0f;     // bRec.sampler->next1D() inside BSDF::sample
             const V3 bsdfWeight = bsdfSampleAny<RD, MIX>(sc, bsdf, wiLocal, bx, by, bu, woLocal, bPdf, bEta, sampledType);
             if (flipped && !isZero(bsdfWeight) && bPdf != 0) woLocal.z = -woLocal.z;      // twosided.cpp:172-181
             if (!isZero(bsdfWeight)) {
@@ -552,7 +552,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_direct_shade(DevScene sc, PassP
             float oPdf = 0.0f, oRefCos = -2.0f;
             if (shade) {
                 const float bx = rng.next1D(), by = rng.next1D();
-                const float bu = bsdfUsesSampler(bsdf) ? rng.next1D() : 0.0f;
+                const float bu = bsdfDrawsFromSampler(bsdf, bx) ? rng.next1D() : 0.0f;
                 V3 woLocal; float bPdf, bEta; uint32_t sampledType;
                 const V3 bsdfVal = bsdfSampleAny(sc, bsdf, wiLocal, bx, by, bu, woLocal, bPdf, bEta, sampledType);
                 if (flipped && !isZero(bsdfVal) && bPdf != 0) woLocal.z = -woLocal.z;

@@ -292,8 +292,8 @@ def _make_bsdf(node, data_dir: Optional[str], add_material=None, named: Optional
         children = []
 
         def nest(rec):
-            if rec["two_sided"] or rec["type"] in (S.BSDF_ROUGHDIELECTRIC, S.BSDF_MIXTURE):
-                raise SceneFormatError("mixturebsdf: twosided, roughdielectric and mixturebsdf cannot be nested")
+            if rec["two_sided"] or rec["type"] == S.BSDF_MIXTURE:
+                raise SceneFormatError("mixturebsdf: twosided and mixturebsdf cannot be nested")
             children.append(add_material(rec))
 
         for c in node:

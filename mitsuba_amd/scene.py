@@ -588,7 +588,8 @@ def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_
         mats[0] = b.add_material(mixture([mats[0], mats[2], mats[4]], [0.6, 0.5, 0.4]))      # weights above one: rescaled
         mats[5] = b.add_material(mixture([mats[5], mats[6], mats[1], m_light], [0.3, 0.2, 0.0, 0.4]))
         shiny = b.add_material(plastic(int_ior=1.49, diffuse_reflectance=(0.3, 0.5, 0.2)))
-        mats[3] = b.add_material(mixture([mats[3], shiny], [0.6, 0.4]))       # Dirac lobes: glass and the plastic's coat
+        frosted = b.add_material(roughdielectric(alpha=0.2, distribution="ggx", int_ior=1.5, ext_ior=1.0))
+        mats[3] = b.add_material(mixture([mats[3], shiny, frosted], [0.4, 0.3, 0.3]))    # Dirac lobes next to a rough dielectric
     for k, m in enumerate(mats):
         p, f, n = blob(subdiv, rng, radius=0.8)
         c = np.array([(k % 4) * 2.2 - 3.3, (k // 4) * 2.4 - 1.2, 1.0], np.float32)

@@ -474,7 +474,7 @@ void Material::configure() {
 
 // MixtureBSDF::configure (src/bsdfs/mixturebsdf.cpp:115-172): weights rescaled when they sum to more than one, the
 // discrete choice proportional to them, the type the union of the nested BSDFs' components. Nested BSDFs are
-// restricted to one-sided models that draw nothing from the sampler themselves (all but roughdielectric).
+// restricted to one-sided models other than mixtures.
 const char *linkMixtures(std::vector<Material> &materials) {
     for (Material &mat : materials) {
         if (mat.m.type != ORC_BSDF_MIXTURE) continue;
@@ -495,8 +495,9 @@ const char *linkMixtures(std::vector<Material> &materials) {
             if (c < 0 || c >= (int) materials.size()) return "mixturebsdf: nested material index out of range";
             const Material &child = materials[c];
             const int t = child.m.type;
-            if (child.m.two_sided || t == ORC_BSDF_ROUGHDIELECTRIC || t == ORC_BSDF_MIXTURE)
-                return "mixturebsdf: twosided, roughdielectric and mixturebsdf cannot be nested";
+            (void) t;
+            if (child.m.two_sided || child.m.type == ORC_BSDF_MIXTURE)
+                return "mixturebsdf: twosided and mixturebsdf cannot be nested";
             mat.mixChildren.push_back(&child);
             mat.mixWeights.push_back(scale != 1.0f ? mat.m.mix_weight[i] * scale : mat.m.mix_weight[i]);
             mat.mixPdf.append(mat.mixWeights.back());

@@ -303,7 +303,7 @@ def test_cli_mixturebsdf(scene_dir, tmp_path):
     assert d["mixtures"][0]["weights"] == pytest.approx([0.7, 0.2, 0.3]) and [sd.materials[c]["type"] for c in d["mixtures"][0]["children"]] == [0, 1, 4]
     for body, needle in (('<bsdf type="mixturebsdf"><string name="weights" value="0.5"/></bsdf>', "BSDF count mismatch"),
                          ('<bsdf type="mixturebsdf"><string name="weights" value="0.5, x"/><ref id="grey"/><ref id="grey"/></bsdf>', "Could not parse the BSDF weights"),
-                         ('<shape type="cube"><bsdf type="mixturebsdf"><string name="weights" value="1"/><bsdf type="roughdielectric"/></bsdf></shape>', "cannot be nested")):
+                         ('<shape type="cube"><bsdf type="mixturebsdf"><string name="weights" value="1"/><bsdf type="twosided"><bsdf type="diffuse"/></bsdf></bsdf></shape>', "cannot be nested")):
         bad = tmp_path / "bad_blend.xml"
         bad.write_text(SCENE % body)
         out = subprocess.run([CLI, str(bad), "--describe"], capture_output=True, text=True, timeout=60)

@@ -145,7 +145,8 @@ def material_pair(gpu, oracle_mod):
             S.twosided(S.mixture([1], [2.5], ensure_energy_conservation=False), 23),
             S.mixture([14, 0], [0.5, 0.5]),             # conductor + diffuse: a Dirac lobe next to a smooth one
             S.mixture([14, 15, 9], [0.3, 0.3, 0.4]),    # conductor + plastic + dielectric: Dirac lobes that share directions
-            S.mixture([16, 8, 2], [0.2, 0.5, 0.3])]
+            S.mixture([16, 8, 2], [0.2, 0.5, 0.3]),
+            S.mixture([20, 0, 22], [0.5, 0.2, 0.3])]    # rough dielectrics: the chosen one draws from the sampler itself
     b = S.SceneBuilder()
     for m in mats:
         b.add_material(m)
