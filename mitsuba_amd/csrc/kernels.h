@@ -673,7 +673,10 @@ __global__ void __launch_bounds__(256) k_film(DevScene sc, PassParams pp, const 
 // from memory once per tile that can see it instead of once per film pixel. Dropped samples and source pixels outside
 // the pass rectangle are staged with position +inf, which fails the footprint test.
 static constexpr int kFilmTile = 16;
-static constexpr int kFilmLdsEntries = 2048;
+#ifndef MTS_FILM_LDS_ENTRIES
+#define MTS_FILM_LDS_ENTRIES 2048
+#endif
+static constexpr int kFilmLdsEntries = MTS_FILM_LDS_ENTRIES;
 
 __global__ void __launch_bounds__(256) k_film_tiled(DevScene sc, PassParams pp, const float4 *sampleL, const float2 *samplePos, float *film,
                                                     int border, int gx0, int gy0, int gw, int gh, int tilesX, int chunk) {
