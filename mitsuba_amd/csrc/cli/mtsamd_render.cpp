@@ -142,7 +142,7 @@ int main(int argc, char **argv) {
         if (mtsamd_film_develop_ldr(film.data(), W, H, &scene.ldr, ldr.data()) != MTSAMD_OK) { fprintf(stderr, "mtsamd-render: %s\n", mtsamd_last_error()); return 1; }
         werr = writePng(outPath, ldr.data(), W, H, channels[scene.ldr.pixel_format]);
     } else {
-        werr = endsWith(".exr") ? writeExr(outPath, rgba.data(), W, H) : writePfm(outPath, rgba.data(), W, H);
+        werr = endsWith(".exr") ? writeExr(outPath, rgba.data(), W, H, scene.hdrPixelFormat, scene.hdrHalf) : writePfm(outPath, rgba.data(), W, H);
     }
     mtsamd_scene_destroy(handle);
     if (!werr.empty()) { fprintf(stderr, "mtsamd-render: %s\n", werr.c_str()); return 1; }

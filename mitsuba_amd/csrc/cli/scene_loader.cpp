@@ -853,7 +853,30 @@ std::string writePng(const std::string &path, const uint8_t *pixels, int width, 
 // src/libcore/bitmap.cpp): here a single-part scan-line file, version 2, three 32-bit float channels (B, G, R in the
 // file's alphabetical order), no compression, rows top to bottom. Any OpenEXR reader opens it; the reference's
 // default of half-precision samples with PIZ compression is a storage choice, not a different image.
-std::string writeExr(const std::string &path, const float *rgba, int width, int height) {
+// float -> half, round to nearest even, overflow to infinity (what OpenEXR's half(float) does)
+static uint16_t floatToHalf(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t) (sign | 0x7c00u | (x > 0x7f800000u ? 0x200u | ((x >> 13) & 0x3ffu) : 0u));     // inf, NaN
+    if (x >= 0x477ff000u) return (uint16_t) (sign | 0x7c00u);       // rounds to 65520 or more: infinity
+    if (x < 0x33000001u) return (uint16_t) sign;                     // rounds to zero (at most half the smallest subnormal)
+    if (x < 0x38800000u) {                                           // subnormal half
+        const int shift = 126 - (int) (x >> 23);                     // 14..24
+        const uint32_t mant = (x & 0x7fffffu) | 0x800000u;
+        uint32_t h = mant >> shift;
+        const uint32_t rem = mant & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (h & 1u))) ++h;
+        return (uint16_t) (sign | h);
+    }
+    uint32_t h = (x - 0x38000000u) >> 13;
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+    return (uint16_t) (sign | h);
+}
+
+std::string writeExr(const std::string &path, const float *rgba, int width, int height, int pixelFormat, bool half) {
     FILE *f = fopen(path.c_str(), "wb");
     if (!f) return "cannot write " + path;
     std::vector<uint8_t> h;
@@ -862,9 +885,18 @@ std::string writeExr(const std::string &path, const float *rgba, int width, int 
     auto putI = [&](int32_t v) { put(&v, 4); };
     auto putF = [&](float v) { put(&v, 4); };
     auto attr = [&](const char *name, const char *type, int32_t size) { putStr(name); putStr(type); putI(size); };
+    // channels in the alphabetical order the format wants; source: 0..3 = R, G, B, alpha of the developed image, 4 = luminance
+    struct Channel { const char *name; int source; };
+    std::vector<Channel> channels;
+    const bool colour = pixelFormat == MTSAMD_PIXEL_RGB || pixelFormat == MTSAMD_PIXEL_RGBA;
+    const bool alpha = pixelFormat == MTSAMD_PIXEL_LUMINANCE_ALPHA || pixelFormat == MTSAMD_PIXEL_RGBA;
+    if (alpha) channels.push_back({ "A", 3 });
+    if (colour) { channels.push_back({ "B", 2 }); channels.push_back({ "G", 1 }); channels.push_back({ "R", 0 }); }
+    else channels.push_back({ "Y", 4 });
+    const size_t nc = channels.size(), bpc = half ? 2 : 4;
     putI(20000630); putI(2);
-    attr("channels", "chlist", 3 * 18 + 1);
-    for (const char *c : { "B", "G", "R" }) { putStr(c); putI(2 /* FLOAT */); putI(0); putI(1); putI(1); }
+    attr("channels", "chlist", (int32_t) (nc * 18 + 1));
+    for (const Channel &c : channels) { putStr(c.name); putI(half ? 1 /* HALF */ : 2 /* FLOAT */); putI(0); putI(1); putI(1); }
     h.push_back(0);
     attr("compression", "compression", 1); h.push_back(0);
     attr("dataWindow", "box2i", 16); putI(0); putI(0); putI(width - 1); putI(height - 1);
@@ -874,17 +906,23 @@ std::string writeExr(const std::string &path, const float *rgba, int width, int 
     attr("screenWindowCenter", "v2f", 8); putF(0.0f); putF(0.0f);
     attr("screenWindowWidth", "float", 4); putF(1.0f);
     h.push_back(0);
-    const uint64_t rowBytes = 8 + (uint64_t) width * 12;
+    const uint64_t dataBytes = (uint64_t) width * nc * bpc, rowBytes = 8 + dataBytes;
     uint64_t offset = h.size() + (uint64_t) height * 8;
     for (int y = 0; y < height; ++y, offset += rowBytes) put(&offset, 8);
     fwrite(h.data(), 1, h.size(), f);
-    std::vector<float> row((size_t) width * 3);
+    std::vector<uint8_t> row(dataBytes);
     for (int y = 0; y < height; ++y) {
-        const int32_t head[2] = { y, (int32_t) (width * 12) };
+        const int32_t head[2] = { y, (int32_t) dataBytes };
         fwrite(head, 4, 2, f);
-        for (int c = 0; c < 3; ++c)         // B, G, R planes of the row
-            for (int x = 0; x < width; ++x) row[(size_t) c * width + x] = rgba[4 * ((size_t) y * width + x) + (2 - c)];
-        fwrite(row.data(), sizeof(float), row.size(), f);
+        for (size_t c = 0; c < nc; ++c)         // one plane per channel within the row
+            for (int x = 0; x < width; ++x) {
+                const float *px = rgba + 4 * ((size_t) y * width + x);
+                // Spectrum::getLuminance for RGB (src/libcore/spectrum.cpp)
+                const float v = channels[c].source == 4 ? px[0] * 0.212671f + px[1] * 0.715160f + px[2] * 0.072169f : px[channels[c].source];
+                uint8_t *dst = &row[(c * (size_t) width + x) * bpc];
+                if (half) { const uint16_t hv = floatToHalf(v); memcpy(dst, &hv, 2); } else memcpy(dst, &v, 4);
+            }
+        fwrite(row.data(), 1, row.size(), f);
     }
     fclose(f);
     return "";
@@ -1147,6 +1185,17 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
                         if (fp.count("cropOffsetX") || fp.count("cropWidth")) return "film crop windows are set through the C ABI, not the scene file";
                         for (const auto &r : c->children) if (r->tag == "rfilter") rf = r.get();
                         out.filmType = c->get("type");
+                        if (out.filmType == "hdrfilm") {    // src/films/hdrfilm.cpp:213-260
+                            const std::string pf = lower(getS(fp, "pixelFormat", "rgb")), cf = lower(getS(fp, "componentFormat", "float16"));
+                            if (pf == "luminance") out.hdrPixelFormat = MTSAMD_PIXEL_LUMINANCE;
+                            else if (pf == "luminancealpha") out.hdrPixelFormat = MTSAMD_PIXEL_LUMINANCE_ALPHA;
+                            else if (pf == "rgb") out.hdrPixelFormat = MTSAMD_PIXEL_RGB;
+                            else if (pf == "rgba") out.hdrPixelFormat = MTSAMD_PIXEL_RGBA;
+                            else return "hdrfilm: pixel format '" + pf + "' is not supported (luminance, luminanceAlpha, rgb, rgba)";
+                            if (cf == "float16") out.hdrHalf = true;
+                            else if (cf == "float32") out.hdrHalf = false;
+                            else return "hdrfilm: component format '" + cf + "' is not supported (float16, float32)";
+                        }
                         if (out.filmType == "ldrfilm") {    // src/films/ldrfilm.cpp:131-183
                             const std::string fileFormat = lower(getS(fp, "fileFormat", "png"));
                             if (fileFormat == "jpg" || fileFormat == "jpeg") return "ldrfilm: JPEG output is not supported (use fileFormat=png)";

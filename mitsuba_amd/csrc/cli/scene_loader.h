@@ -35,6 +35,8 @@ struct LoadedScene {
     int sampleCount = 4;
     std::string integratorType;
     std::string filmType;               // "hdrfilm", "ldrfilm", ... as the scene file names it
+    int hdrPixelFormat = MTSAMD_PIXEL_RGB;      // HDRFilm parameters (src/films/hdrfilm.cpp:213-260): channels ...
+    bool hdrHalf = true;                        // ... and component format of the OpenEXR output (float16 is HDRFilm's default)
     mtsamd_ldr_opts ldr = { MTSAMD_PIXEL_RGB, MTSAMD_TONEMAP_GAMMA, -1.0f, 0.0f, 0.18f, 0.0f };     // LDRFilm parameters (src/films/ldrfilm.cpp:131-183)
 
     // The returned description points into this object; keep it alive until mtsamd_scene_create has returned.
@@ -57,8 +59,9 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
 
 // Portable float map, the format HDRFilm writes for ".pfm" (src/films/hdrfilm.cpp:226-227): RGB, bottom row first.
 std::string writePfm(const std::string &path, const float *rgba, int width, int height);
-// OpenEXR (HDRFilm's default container): RGB, 32-bit float, uncompressed scan lines, top row first.
-std::string writeExr(const std::string &path, const float *rgba, int width, int height);
+// OpenEXR (HDRFilm's default container): luminance / luminance-alpha / RGB / RGBA channels (MTSAMD_PIXEL_*), 16- or
+// 32-bit float, uncompressed scan lines, top row first.
+std::string writeExr(const std::string &path, const float *rgba, int width, int height, int pixelFormat, bool half);
 // PNG, LDRFilm's default container (src/films/ldrfilm.cpp:141-142): 8 bits per channel, 1-4 channels, top row first.
 std::string writePng(const std::string &path, const uint8_t *pixels, int width, int height, int channels);
 

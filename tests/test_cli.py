@@ -386,12 +386,28 @@ def test_cli_render_matches_binding(scene_dir, tmp_path):
     w = film_cli[..., 4:5]
     assert np.allclose(img, np.where(w != 0, film_cli[..., :3] / np.where(w != 0, w, 1), 0), rtol=1e-5, atol=1e-6)
     assert img.mean() > 0.01
-    # the same render as OpenEXR: header attributes, offset table and the B, G, R planes of every scan line
-    exr = tmp_path / "out.exr"
-    out = subprocess.run([CLI, str(scene_dir / "scene.xml"), "-o", str(exr), "--spp", "8", "--seed", "3"],
-                         capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr
-    assert np.allclose(_read_exr(str(exr)), img, rtol=1e-6, atol=0)
+    # the same render as OpenEXR: header attributes, offset table and the channel planes of every scan line. HDRFilm's
+    # defaults are RGB in half precision (hdrfilm.cpp:213-221); the scene file can ask for other channels and float32.
+    text = (scene_dir / "scene.xml").read_text()
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    lum = img[..., 0] * np.float32(0.212671) + img[..., 1] * np.float32(0.715160) + img[..., 2] * np.float32(0.072169)
+    alpha = np.where(w[..., 0] != 0, film_cli[..., 3] / np.where(w[..., 0] != 0, w[..., 0], 1), 0)
+    for props, want, dtype in (("", dict(R=img[..., 0], G=img[..., 1], B=img[..., 2]), np.float16),
+                               ('<string name="componentFormat" value="float32"/><string name="pixelFormat" value="rgba"/>',
+                                dict(R=img[..., 0], G=img[..., 1], B=img[..., 2], A=alpha), np.float32),
+                               ('<string name="pixelFormat" value="luminanceAlpha"/>', dict(Y=lum, A=alpha), np.float16)):
+        f = tmp_path / "hdr.xml"
+        f.write_text(text.replace('<film type="hdrfilm">', '<film type="hdrfilm">' + props))
+        exr = tmp_path / "out.exr"
+        out = subprocess.run([CLI, str(f), "-o", str(exr), "--spp", "8", "--seed", "3"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        planes, got = _read_exr(str(exr))
+        assert got == dtype and sorted(planes) == sorted(want)
+        for c, ref in want.items():
+            if dtype == np.float16:     # numpy rounds to nearest even like the writer: the same bits
+                assert np.array_equal(planes[c].view(np.uint16), ref.astype(np.float32).astype(np.float16).view(np.uint16)), c
+            else:
+                assert np.allclose(planes[c], ref, rtol=1e-6, atol=0), c
 
 
 def _read_png(path):
@@ -443,7 +459,8 @@ def test_cli_ldrfilm_png(scene_dir, tmp_path):
 
 
 def _read_exr(path):
-    """Minimal reader for uncompressed single-part scan-line OpenEXR files with 32-bit float channels."""
+    """Minimal reader for uncompressed single-part scan-line OpenEXR files with 16- or 32-bit float channels:
+    returns ({channel name: (h, w) array}, numpy dtype of the stored components)."""
     b = open(path, "rb").read()
     assert struct.unpack_from("<ii", b, 0) == (20000630, 2)
     pos, attrs = 8, {}
@@ -456,18 +473,21 @@ def _read_exr(path):
     assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
     x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
     w, h = x1 - x0 + 1, y1 - y0 + 1
-    chans, p = [], 0
+    chans, kinds, p = [], set(), 0
     cl = attrs["channels"][1]
     while cl[p] != 0:
         e = cl.index(b"\0", p); chans.append(cl[p:e].decode()); p = e + 1
-        assert struct.unpack_from("<i", cl, p)[0] == 2       # FLOAT
+        kinds.add(struct.unpack_from("<i", cl, p)[0])
         p += 16
-    assert chans == ["B", "G", "R"]
+    assert chans == sorted(chans) and len(kinds) == 1
+    dtype = {1: np.float16, 2: np.float32}[kinds.pop()]
+    bpc = np.dtype(dtype).itemsize
     offsets = struct.unpack_from("<%dQ" % h, b, pos)
-    img = np.zeros((h, w, 3), np.float32)
+    planes = {c: np.zeros((h, w), dtype) for c in chans}
     for y in range(h):
         yy, size = struct.unpack_from("<ii", b, offsets[y])
-        assert yy == y and size == w * 12
-        row = np.frombuffer(b, np.float32, 3 * w, offsets[y] + 8).reshape(3, w)
-        img[y] = row[::-1].T
-    return img
+        assert yy == y and size == w * len(chans) * bpc
+        row = np.frombuffer(b, dtype, len(chans) * w, offsets[y] + 8).reshape(len(chans), w)
+        for k, c in enumerate(chans):
+            planes[c][y] = row[k]
+    return planes, dtype
