@@ -33,11 +33,11 @@ static void describe(const LoadedScene &s) {
     for (uint32_t v : s.indices) si += v;
     printf("{\"vertices\": %zu, \"triangles\": %zu, \"shapes\": %zu, \"materials\": %zu, \"emitters\": %zu, \"has_normals\": %s, "
            "\"has_texcoords\": %s, \"sum_positions\": %.9g, \"sum_normals\": %.9g, \"sum_texcoords\": %.9g, \"sum_indices\": %llu, "
-           "\"width\": %d, \"height\": %d, \"x_fov\": %.9g, \"filter_radius\": %.9g, \"max_depth\": %d, \"rr_depth\": %d, "
+           "\"width\": %d, \"height\": %d, \"crop\": [%d, %d, %d, %d], \"x_fov\": %.9g, \"filter_radius\": %.9g, \"max_depth\": %d, \"rr_depth\": %d, "
            "\"sample_count\": %d, \"integrator\": \"%s\", \"emitter_samples\": %d, \"bsdf_samples\": %d, \"to_world\": [",
            s.positions.size() / 3, s.indices.size() / 3, s.shapes.size(), s.materials.size(), s.emitters.size(),
            s.anyNormals ? "true" : "false", s.anyTexcoords ? "true" : "false", sp, sn, st, si, s.film.width, s.film.height,
-           s.camera.x_fov, s.film.filter_radius, s.integrator.max_depth, s.integrator.rr_depth, s.sampleCount, s.integratorType.c_str(),
+           s.film.crop_x, s.film.crop_y, s.film.crop_w, s.film.crop_h, s.camera.x_fov, s.film.filter_radius, s.integrator.max_depth, s.integrator.rr_depth, s.sampleCount, s.integratorType.c_str(),
            s.integrator.emitter_samples, s.integrator.bsdf_samples);
     for (int i = 0; i < 16; ++i) printf("%s%.9g", i ? ", " : "", s.camera.to_world[i]);
     printf("], \"material_types\": [");

@@ -1177,12 +1177,17 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
                 if (el.get("type") != "perspective") return "only the perspective sensor is supported";
                 const Props p = parseProps(el);
                 int fw = 768, fh = 576;         // Film defaults (src/librender/film.cpp:25-55)
+                int cropX = 0, cropY = 0, cropW = fw, cropH = fh;
                 const Element *rf = nullptr;
                 for (const auto &c : el.children) {
                     if (c->tag == "film") {
                         const Props fp = parseProps(*c);
                         fw = (int) getF(fp, "width", 768); fh = (int) getF(fp, "height", 576);
-                        if (fp.count("cropOffsetX") || fp.count("cropWidth")) return "film crop windows are set through the C ABI, not the scene file";
+                        // crop window in pixels, by default the whole film (src/librender/film.cpp:35-48)
+                        cropX = (int) getF(fp, "cropOffsetX", 0); cropY = (int) getF(fp, "cropOffsetY", 0);
+                        cropW = (int) getF(fp, "cropWidth", fw); cropH = (int) getF(fp, "cropHeight", fh);
+                        if (cropX < 0 || cropY < 0 || cropW <= 0 || cropH <= 0 || cropX + cropW > fw || cropY + cropH > fh)
+                            return "Invalid crop window specification!";
                         for (const auto &r : c->children) if (r->tag == "rfilter") rf = r.get();
                         out.filmType = c->get("type");
                         if (out.filmType == "hdrfilm") {    // src/films/hdrfilm.cpp:213-260
@@ -1218,7 +1223,7 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
                         out.sampleCount = (int) getF(parseProps(*c), "sampleCount", 4);
                     }
                 }
-                if (opts.width > 0 && opts.height > 0) { fw = opts.width; fh = opts.height; }
+                if (opts.width > 0 && opts.height > 0) { fw = opts.width; fh = opts.height; cropX = cropY = 0; cropW = fw; cropH = fh; }
                 const double aspect = (double) fw / fh;
                 if (!p.count("fov")) return "sensor needs a 'fov' (focalLength is not supported)";
                 double fov = getF(p, "fov", 0);
@@ -1234,7 +1239,8 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
                 out.camera.x_fov = (float) fov;
                 out.camera.near_clip = (float) getF(p, "nearClip", 1e-2); out.camera.far_clip = (float) getF(p, "farClip", 1e4);
                 memset(&out.film, 0, sizeof(out.film));
-                out.film.width = fw; out.film.height = fh; out.film.crop_w = fw; out.film.crop_h = fh;
+                out.film.width = fw; out.film.height = fh;
+                out.film.crop_x = cropX; out.film.crop_y = cropY; out.film.crop_w = cropW; out.film.crop_h = cropH;
                 makeFilter(rf, out.film);
                 haveSensor = true;
             } else if (el.tag == "shape") {

@@ -421,11 +421,15 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
             if el.get("type") != "perspective":
                 raise SceneFormatError("only the perspective sensor is supported")
             p = _props(el)
-            fw, fh, rf = 768, 576, None      # Film defaults (src/librender/film.cpp:25-55)
+            fw, fh, rf, crop = 768, 576, None, None      # Film defaults (src/librender/film.cpp:25-55)
             for c in el:
                 if c.tag == "film":
                     fp = _props(c)
                     fw, fh = fp.get("width", 768), fp.get("height", 576)
+                    # crop window in pixels, by default the whole film (src/librender/film.cpp:35-48)
+                    crop = (fp.get("cropOffsetX", 0), fp.get("cropOffsetY", 0), fp.get("cropWidth", fw), fp.get("cropHeight", fh))
+                    if crop[0] < 0 or crop[1] < 0 or crop[2] <= 0 or crop[3] <= 0 or crop[0] + crop[2] > fw or crop[1] + crop[3] > fh:
+                        raise SceneFormatError("Invalid crop window specification!")
                     for r in c:
                         if r.tag == "rfilter":
                             rp = _props(r)
@@ -438,7 +442,7 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
                 elif c.tag == "sampler":
                     info["sample_count"] = _props(c).get("sampleCount", 4)
             if width is not None:
-                fw, fh = width, height
+                fw, fh, crop = width, height, None
             aspect = fw / fh
             fov = p.get("fov")
             if fov is None:
@@ -454,7 +458,7 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
                 raise SceneFormatError("fovAxis '%s' is not supported" % axis)
             camera = dict(to_world=p.get("toWorld", np.eye(4, dtype=np.float32)), x_fov=float(fov),
                           near_clip=float(p.get("nearClip", 1e-2)), far_clip=float(p.get("farClip", 1e4)))
-            film = S.make_film(fw, fh, rf)
+            film = S.make_film(fw, fh, rf, crop)
         elif el.tag == "shape":
             p = _props(el)
             mat = None

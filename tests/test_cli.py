@@ -261,6 +261,26 @@ def test_cli_max_smooth_angle(scene_dir, tmp_path):
     assert out.returncode == 1 and "can't be specified at the same time" in out.stderr
 
 
+def test_cli_film_crop_window(scene_dir, tmp_path):
+    """cropOffsetX/Y, cropWidth/Height (film.cpp:35-48) reach the film record; an invalid window is refused."""
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    text = (scene_dir / "scene.xml").read_text()
+    crop = '<integer name="cropOffsetX" value="8"/><integer name="cropOffsetY" value="4"/><integer name="cropWidth" value="40"/><integer name="cropHeight" value="30"/>'
+    f = tmp_path / "crop.xml"
+    f.write_text(text.replace('<film type="hdrfilm">', '<film type="hdrfilm">' + crop))
+    d = _describe(f)
+    sd, _ = loader.load_xml(str(f))
+    assert d["crop"] == [8, 4, 40, 30] == [sd.film[k] for k in ("crop_x", "crop_y", "crop_w", "crop_h")]
+    assert (d["width"], d["height"]) == (64, 48)
+    assert _describe(f, "--size", "32", "16")["crop"] == [0, 0, 32, 16]
+    assert _describe(scene_dir / "scene.xml")["crop"] == [0, 0, 64, 48]
+    f.write_text(text.replace('<film type="hdrfilm">', '<film type="hdrfilm"><integer name="cropOffsetX" value="40"/><integer name="cropWidth" value="40"/>'))
+    out = subprocess.run([CLI, str(f), "--describe"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "Invalid crop window specification" in out.stderr
+    with pytest.raises(loader.SceneFormatError, match="Invalid crop window"):
+        loader.load_xml(str(f))
+
+
 def test_cli_direct_integrator(scene_dir, tmp_path):
     """<integrator type="direct"> (direct.cpp:93-107): shadingSamples sets both counts, the finer ones override it."""
     (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())

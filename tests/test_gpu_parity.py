@@ -384,6 +384,28 @@ def test_empty_scene_renders_black(gpu):
     assert np.all(film[..., :4] == 0) and film[..., 4].min() > 0
 
 
+def test_film_crop_window(gpu, oracle_mod):
+    """A crop window (film.cpp:35-48, perspective.cpp:126-157): the ray through crop pixel (x, y) is the full frame's ray
+    through (x + cropOffsetX, y + cropOffsetY); radiance and film agree with the oracle on the cropped scene."""
+    full = S.small_test_scene(width=64, height=48)
+    crop = S.small_test_scene(width=64, height=48)
+    crop.film.update(crop_x=8, crop_y=4, crop_w=40, crop_h=30)
+    gf, gc, oc = gpu.Scene(full), gpu.Scene(crop), oracle_mod.OracleScene(crop)
+    pos = np.random.default_rng(8).uniform(0, 1, (5000, 2)).astype(np.float32) * np.float32([40, 30])
+    a, b = gc.camera_rays(pos), gf.camera_rays(pos + np.float32([8, 4]))
+    assert np.allclose(a, b, rtol=1e-5, atol=1e-5)
+    assert np.allclose(a, oc.camera_rays(pos), rtol=1e-6, atol=1e-6)
+    Lg, pg, sg = gc.li(4, seed=2)
+    Lo, po_, so = oc.li(4, seed=2)
+    assert Lg.shape[0] == 40 * 30 and np.array_equal(pg, po_)
+    assert (sg.normal_rays, sg.shadow_rays) == (so.normal_rays, so.shadow_rays)
+    rel = np.abs(Lg[..., :3] - Lo[..., :3]).max(-1) / (np.abs(Lo[..., :3]).max(-1) + 1e-3)
+    assert np.mean(rel < 1e-3) > 0.995
+    fg, _ = gc.render(4, seed=2)
+    fo, _ = oc.render(4, seed=2)
+    assert fg.shape == (30, 40, 5) and np.allclose(gc.develop(fg), oc.develop(fo), rtol=2e-3, atol=2e-4)
+
+
 def test_direct_integrator_edge_cases(gpu, oracle_mod):
     """`direct` on an empty scene, on a scene without emitters, with only a sky, and with invalid sample counts."""
     b = S.SceneBuilder()
