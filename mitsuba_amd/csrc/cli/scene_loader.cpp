@@ -1225,14 +1225,33 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
                 }
                 if (opts.width > 0 && opts.height > 0) { fw = opts.width; fh = opts.height; cropX = cropY = 0; cropW = fw; cropH = fh; }
                 const double aspect = (double) fw / fh;
-                if (!p.count("fov")) return "sensor needs a 'fov' (focalLength is not supported)";
+                // PerspectiveCamera::configure (src/librender/sensor.cpp:239-278): fov along an axis, or a focal length on
+                // 35 mm film (36 x 24 mm, diagonal field of view); setYFov / setDiagonalFov (sensor.cpp:296-305)
+                if (p.count("fov") && p.count("focalLength")) return "Please specify either a focal length ('focalLength') or a field of view ('fov')!";
+                const double kPi = 3.14159265358979323846;
                 double fov = getF(p, "fov", 0);
                 std::string axis = lower(getS(p, "fovAxis", "x"));
+                if (!p.count("fov")) {
+                    std::string fl = getS(p, "focalLength", "50mm");
+                    if (fl.size() >= 2 && fl.compare(fl.size() - 2, 2, "mm") == 0) fl = fl.substr(0, fl.size() - 2);
+                    char *end = nullptr;
+                    const double value = strtod(fl.c_str(), &end);
+                    if (*end != '\0') return "Could not parse the focal length (must be of the form <x>mm, where <x> is a positive integer)!";
+                    fov = 2 * 180 / kPi * std::atan(std::sqrt((double) (36 * 36 + 24 * 24)) / (2 * value));
+                    axis = "diagonal";
+                }
                 if (axis == "smaller") axis = aspect > 1 ? "y" : "x";
                 else if (axis == "larger") axis = aspect > 1 ? "x" : "y";
-                if (axis == "y")            // PerspectiveCamera::setYFov (src/librender/sensor.cpp:296-299)
-                    fov = 2 * std::atan(std::tan(0.5 * fov * 3.14159265358979323846 / 180.0) * aspect) * 180.0 / 3.14159265358979323846;
-                else if (axis != "x") return "fovAxis '" + axis + "' is not supported";
+                if (axis == "y") {
+                    fov = 2 * std::atan(std::tan(0.5 * fov * kPi / 180.0) * aspect) * 180.0 / kPi;
+                } else if (axis == "diagonal") {
+                    const double diagonal = 2 * std::tan(0.5 * fov * kPi / 180.0);
+                    const double width = diagonal / std::sqrt(1.0 + 1.0 / (aspect * aspect));
+                    fov = 2 * std::atan(width * 0.5) * 180.0 / kPi;
+                } else if (axis != "x") {
+                    return "The 'fovAxis' parameter must be set to one of 'smaller', 'larger', 'diagonal', 'x', or 'y'!";
+                }
+                if (fov <= 0 || fov >= 180) return "The horizontal field of view must be in the interval (0, 180)!";
                 memset(&out.camera, 0, sizeof(out.camera));
                 Mat4 tw = p.count("toWorld") ? p.at("toWorld").t : Mat4::identity();
                 for (int i = 0; i < 16; ++i) out.camera.to_world[i] = (float) tw.m[i];

@@ -444,18 +444,33 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
             if width is not None:
                 fw, fh, crop = width, height, None
             aspect = fw / fh
+            # PerspectiveCamera::configure (src/librender/sensor.cpp:239-278): fov along an axis, or a focal length on
+            # 35 mm film (diagonal field of view); setYFov / setDiagonalFov (sensor.cpp:296-305)
+            if "fov" in p and "focalLength" in p:
+                raise SceneFormatError("Please specify either a focal length ('focalLength') or a field of view ('fov')!")
             fov = p.get("fov")
-            if fov is None:
-                raise SceneFormatError("sensor needs a 'fov' (focalLength is not supported)")
             axis = p.get("fovAxis", "x").lower()
+            if fov is None:
+                fl = p.get("focalLength", "50mm")
+                try:
+                    value = float(fl[:-2] if fl.endswith("mm") else fl)
+                except ValueError:
+                    raise SceneFormatError("Could not parse the focal length (must be of the form <x>mm, where <x> is a positive integer)!")
+                fov = math.degrees(2 * math.atan(math.sqrt(36 * 36 + 24 * 24) / (2 * value)))
+                axis = "diagonal"
             if axis == "smaller":
                 axis = "y" if aspect > 1 else "x"
             elif axis == "larger":
                 axis = "x" if aspect > 1 else "y"
-            if axis == "y":     # PerspectiveCamera::setYFov (src/librender/sensor.cpp:296-299)
+            if axis == "y":
                 fov = math.degrees(2 * math.atan(math.tan(0.5 * math.radians(fov)) * aspect))
+            elif axis == "diagonal":
+                diagonal = 2 * math.tan(0.5 * math.radians(fov))
+                fov = math.degrees(2 * math.atan(diagonal / math.sqrt(1.0 + 1.0 / (aspect * aspect)) * 0.5))
             elif axis != "x":
-                raise SceneFormatError("fovAxis '%s' is not supported" % axis)
+                raise SceneFormatError("The 'fovAxis' parameter must be set to one of 'smaller', 'larger', 'diagonal', 'x', or 'y'!")
+            if not 0 < fov < 180:
+                raise SceneFormatError("The horizontal field of view must be in the interval (0, 180)!")
             camera = dict(to_world=p.get("toWorld", np.eye(4, dtype=np.float32)), x_fov=float(fov),
                           near_clip=float(p.get("nearClip", 1e-2)), far_clip=float(p.get("farClip", 1e4)))
             film = S.make_film(fw, fh, rf, crop)

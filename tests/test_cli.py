@@ -261,6 +261,30 @@ def test_cli_max_smooth_angle(scene_dir, tmp_path):
     assert out.returncode == 1 and "can't be specified at the same time" in out.stderr
 
 
+def test_cli_focal_length_and_fov_axes(scene_dir, tmp_path):
+    """PerspectiveCamera::configure (sensor.cpp:239-305): focal length on 35 mm film, fov along y / the diagonal."""
+    import math
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    text = (scene_dir / "scene.xml").read_text()
+    fov45 = '<float name="fov" value="45"/>'
+    aspect = 64 / 48
+    for xml, want in (('<string name="focalLength" value="50mm"/>',
+                       math.degrees(2 * math.atan(math.sqrt(36 ** 2 + 24 ** 2) / 100 / math.sqrt(1 + 1 / aspect ** 2)))),
+                      ("", math.degrees(2 * math.atan(math.sqrt(36 ** 2 + 24 ** 2) / 100 / math.sqrt(1 + 1 / aspect ** 2)))),
+                      ('<float name="fov" value="45"/><string name="fovAxis" value="diagonal"/>',
+                       math.degrees(2 * math.atan(math.tan(math.radians(22.5)) / math.sqrt(1 + 1 / aspect ** 2)))),
+                      ('<float name="fov" value="45"/><string name="fovAxis" value="smaller"/>',
+                       math.degrees(2 * math.atan(math.tan(math.radians(22.5)) * aspect)))):
+        f = tmp_path / "cam.xml"
+        f.write_text(text.replace(fov45, xml))
+        d = _describe(f)
+        sd, _ = loader.load_xml(str(f))
+        assert d["x_fov"] == pytest.approx(want, rel=1e-6) and sd.camera["x_fov"] == pytest.approx(want, rel=1e-6)
+    f.write_text(text.replace(fov45, fov45 + '<string name="focalLength" value="35mm"/>'))
+    out = subprocess.run([CLI, str(f), "--describe"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "either a focal length" in out.stderr
+
+
 def test_cli_film_crop_window(scene_dir, tmp_path):
     """cropOffsetX/Y, cropWidth/Height (film.cpp:35-48) reach the film record; an invalid window is refused."""
     (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
