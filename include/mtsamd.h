@@ -207,7 +207,7 @@ const char *mtsamd_last_error(void);
    are never reordered). A caller compiled against another version must not pass them in: compare MTSAMD_ABI_VERSION with
    mtsamd_abi_version(), and where records are mirrored by hand (FFI bindings) their sizes with mtsamd_sizeof(). No
    counterpart in the reference, whose plugins are compiled against its own headers. */
-#define MTSAMD_ABI_VERSION 6
+#define MTSAMD_ABI_VERSION 7
 enum { MTSAMD_SIZEOF_SCENE_DESC = 0, MTSAMD_SIZEOF_MATERIAL = 1, MTSAMD_SIZEOF_EMITTER = 2, MTSAMD_SIZEOF_SHAPE = 3,
        MTSAMD_SIZEOF_RENDER_OPTS = 4, MTSAMD_SIZEOF_STATS = 5, MTSAMD_SIZEOF_LDR_OPTS = 6 };
 int mtsamd_abi_version(void);
@@ -316,6 +316,12 @@ int mtsamd_rtrans_reduce(const void *dat, uint64_t size, float eta, float alpha,
    (src/rfilters/gaussian.cpp:32-57, src/libcore/rfilter.cpp:37-55) */
 int mtsamd_filter_gaussian(float stddev, float *radius, float values[32]);
 int mtsamd_filter_box(float radius_in, float *radius, float values[32]);
+/* Any of the reference's reconstruction filters by kind: gaussian (p0 = stddev), box (p0 = radius), tent
+   (src/rfilters/tent.cpp), mitchell (p0 = B, p1 = C; src/rfilters/mitchell.cpp), catmullrom (src/rfilters/catmullrom.cpp),
+   lanczos (p0 = lobes; src/rfilters/lanczos.cpp) */
+enum { MTSAMD_FILTER_GAUSSIAN = 0, MTSAMD_FILTER_BOX = 1, MTSAMD_FILTER_TENT = 2, MTSAMD_FILTER_MITCHELL = 3,
+       MTSAMD_FILTER_CATMULLROM = 4, MTSAMD_FILTER_LANCZOS = 5 };
+int mtsamd_filter_table(int kind, float p0, float p1, float *radius, float values[32]);
 
 #ifdef __cplusplus
 }

@@ -95,11 +95,11 @@ ISECT_DTYPE = np.dtype([("t", "f4"), ("u", "f4"), ("v", "f4"), ("shape", "u4"), 
 EXPORTS = ["mtsamd_last_error", "mtsamd_init", "mtsamd_scene_create", "mtsamd_scene_destroy", "mtsamd_scene_bvh_info",
            "mtsamd_render", "mtsamd_render_device", "mtsamd_cancel", "mtsamd_scene_set_counting", "mtsamd_film_develop", "mtsamd_trace", "mtsamd_trace_device", "mtsamd_occluded_device",
            "mtsamd_occluded", "mtsamd_intersect", "mtsamd_bsdf_eval", "mtsamd_bsdf_pdf", "mtsamd_bsdf_sample",
-           "mtsamd_sample_emitter_direct", "mtsamd_camera_rays", "mtsamd_li", "mtsamd_film_put", "mtsamd_film_develop_ldr", "mtsamd_abi_version", "mtsamd_sizeof", "mtsamd_rng_stream",
+           "mtsamd_sample_emitter_direct", "mtsamd_camera_rays", "mtsamd_li", "mtsamd_film_put", "mtsamd_film_develop_ldr", "mtsamd_abi_version", "mtsamd_sizeof", "mtsamd_filter_table", "mtsamd_rng_stream",
            "mtsamd_rtrans_reduce", "mtsamd_filter_gaussian", "mtsamd_filter_box"]
 
 _lib = None
-ABI_VERSION = 6     # MTSAMD_ABI_VERSION of include/mtsamd.h
+ABI_VERSION = 7     # MTSAMD_ABI_VERSION of include/mtsamd.h
 
 
 class MtsamdError(RuntimeError):
@@ -396,4 +396,13 @@ def filter_box(radius=0.5):
     r = C.c_float()
     v = (C.c_float * 32)()
     _check(lib().mtsamd_filter_box(C.c_float(radius), C.byref(r), v))
+    return r.value, np.array(v, np.float32)
+
+
+def filter_table(kind, p0=0.0, p1=0.0):
+    """kind: 'gaussian' (p0 = stddev), 'box' (radius), 'tent', 'mitchell' (B, C), 'catmullrom', 'lanczos' (lobes)."""
+    k = ("gaussian", "box", "tent", "mitchell", "catmullrom", "lanczos").index(kind)
+    r = C.c_float()
+    v = (C.c_float * 32)()
+    _check(lib().mtsamd_filter_table(C.c_int(k), C.c_float(p0), C.c_float(p1), C.byref(r), v))
     return r.value, np.array(v, np.float32)

@@ -605,10 +605,19 @@ void makeFilter(const Element *rf, mtsamd_film &film) {
         rc = mtsamd_filter_gaussian(rf ? (float) getF(parseProps(*rf), "stddev", 0.5) : 0.5f, &film.filter_radius, film.filter_values);
     } else if (rf->get("type") == "box") {
         rc = mtsamd_filter_box((float) getF(parseProps(*rf), "radius", 0.5), &film.filter_radius, film.filter_values);
+    } else if (rf->get("type") == "tent") {
+        rc = mtsamd_filter_table(MTSAMD_FILTER_TENT, 0, 0, &film.filter_radius, film.filter_values);
+    } else if (rf->get("type") == "mitchell") {
+        const Props fp = parseProps(*rf);
+        rc = mtsamd_filter_table(MTSAMD_FILTER_MITCHELL, (float) getF(fp, "B", 1.0 / 3.0), (float) getF(fp, "C", 1.0 / 3.0), &film.filter_radius, film.filter_values);
+    } else if (rf->get("type") == "catmullrom") {
+        rc = mtsamd_filter_table(MTSAMD_FILTER_CATMULLROM, 0, 0, &film.filter_radius, film.filter_values);
+    } else if (rf->get("type") == "lanczos") {
+        rc = mtsamd_filter_table(MTSAMD_FILTER_LANCZOS, (float) getF(parseProps(*rf), "lobes", 3), 0, &film.filter_radius, film.filter_values);
     } else {
         throw Fail("reconstruction filter '" + rf->get("type") + "' is not supported");
     }
-    if (rc != MTSAMD_OK) throw Fail(mtsamd_last_error());
+    if (rc != MTSAMD_OK) throw Fail("invalid reconstruction filter parameters");
 }
 
 }  // namespace

@@ -113,7 +113,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
     const mtsamd_film &f = d->film;
     if (f.width <= 0 || f.height <= 0 || f.crop_w <= 0 || f.crop_h <= 0 || f.crop_x < 0 || f.crop_y < 0 ||
         f.crop_x + f.crop_w > f.width || f.crop_y + f.crop_h > f.height) return "invalid film/crop size";
-    if (!(f.filter_radius > 0) || f.filter_radius > 2.5f) return "reconstruction filter radius must be in (0, 2.5]";
+    if (!(f.filter_radius > 0) || f.filter_radius > 8.0f) return "reconstruction filter radius must be in (0, 8]";
     if (d->integrator.rr_depth <= 0) return "'rrDepth' must be set to a value greater than zero!";                 // integrator.cpp:220-221
     if (d->integrator.max_depth <= 0 && d->integrator.max_depth != -1)
         return "'maxDepth' must be set to -1 (infinite) or a value greater than zero!";                            // integrator.cpp:223-224

@@ -162,10 +162,52 @@ extern "C" int mtsamd_filter_gaussian(float stddev, float *radius, float values[
     return MTSAMD_OK;
 }
 
+// The other reconstruction filters of the reference, tabulated the same way (ReconstructionFilter::configure):
+// tent (src/rfilters/tent.cpp:34-44), Mitchell-Netravali (mitchell.cpp:35-68), Catmull-Rom (catmullrom.cpp:32-55),
+// Lanczos sinc (lanczos.cpp:35-55)
+extern "C" int mtsamd_filter_table(int kind, float p0, float p1, float *radius, float values[32]) {
+    if (!radius || !values) return MTSAMD_EINVAL;
+    if (kind == MTSAMD_FILTER_GAUSSIAN) return mtsamd_filter_gaussian(p0, radius, values);
+    if (kind == MTSAMD_FILTER_BOX) return mtsamd_filter_box(p0, radius, values);
+    float r;
+    float B = 0.0f, C = 0.5f;
+    switch (kind) {
+        case MTSAMD_FILTER_TENT: r = 1.0f; break;
+        case MTSAMD_FILTER_MITCHELL: r = 2.0f; B = p0; C = p1; break;
+        case MTSAMD_FILTER_CATMULLROM: r = 2.0f; break;
+        case MTSAMD_FILTER_LANCZOS: r = (float) (int) p0; if (!(r >= 1)) return MTSAMD_EINVAL; break;
+        default: return MTSAMD_EINVAL;
+    }
+    for (int i = 0; i < 31; ++i) {
+        float x = std::fabs((r * (float) i) / 31);
+        float v;
+        if (kind == MTSAMD_FILTER_TENT) {
+            v = std::max(0.0f, 1.0f - std::fabs(x / r));
+        } else if (kind == MTSAMD_FILTER_LANCZOS) {
+            if (x < 1e-4f) v = 1.0f;
+            else if (x > r) v = 0.0f;
+            else {
+                const float x1 = 3.14159265358979323846f * x, x2 = x1 / r;
+                v = (std::sin(x1) * std::sin(x2)) / (x1 * x2);
+            }
+        } else {
+            const float x2 = x * x, x3 = x2 * x;
+            if (x < 1) v = 1.0f / 6.0f * ((12 - 9 * B - 6 * C) * x3 + (-18 + 12 * B + 6 * C) * x2 + (6 - 2 * B));
+            else if (x < 2) v = 1.0f / 6.0f * ((-B - 6 * C) * x3 + (6 * B + 30 * C) * x2 + (-12 * B - 48 * C) * x + (8 * B + 24 * C));
+            else v = 0.0f;
+        }
+        values[i] = v;
+    }
+    normalizeFilter(r, values);
+    *radius = r;
+    return MTSAMD_OK;
+}
+
 extern "C" int mtsamd_filter_box(float radius_in, float *radius, float values[32]) {
     if (!(radius_in > 0) || !radius || !values) return MTSAMD_EINVAL;
+    const float r = radius_in + 1e-5f;      // box.cpp:38
     for (int i = 0; i < 31; ++i) values[i] = 1.0f;
-    normalizeFilter(radius_in, values);
-    *radius = radius_in;
+    normalizeFilter(r, values);
+    *radius = r;
     return MTSAMD_OK;
 }

@@ -437,6 +437,14 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
                                 rf = S.gaussian_filter(rp.get("stddev", 0.5))
                             elif r.get("type") == "box":
                                 rf = S.box_filter(rp.get("radius", 0.5))
+                            elif r.get("type") == "tent":
+                                rf = S.tent_filter()
+                            elif r.get("type") == "mitchell":
+                                rf = S.mitchell_filter(rp.get("B", 1.0 / 3.0), rp.get("C", 1.0 / 3.0))
+                            elif r.get("type") == "catmullrom":
+                                rf = S.catmullrom_filter()
+                            elif r.get("type") == "lanczos":
+                                rf = S.lanczos_filter(rp.get("lobes", 3))
                             else:
                                 raise SceneFormatError("reconstruction filter '%s' is not supported" % r.get("type"))
                 elif c.tag == "sampler":

@@ -82,14 +82,71 @@ def gaussian_filter(stddev: float = 0.5):
 
 
 def box_filter(radius: float = 0.5):
-    """BoxFilter: eval = 1 inside the radius (src/rfilters/box.cpp), same normalisation."""
+    """BoxFilter: eval = 1 inside the radius, which is the given one plus 1e-5 (src/rfilters/box.cpp:38-48), same normalisation."""
     f32 = np.float32
-    radius = f32(radius)
+    radius = f32(f32(radius) + f32(1e-5))
     vals = np.zeros(32, np.float32)
     s = f32(31.0)
     s = f32(s * (f32(2) * radius / f32(31)))
     vals[:31] = f32(1.0) / s
     return float(radius), vals
+
+
+def _tabulate(radius, ev):
+    """ReconstructionFilter::configure (src/libcore/rfilter.cpp:37-55) in single precision."""
+    f32 = np.float32
+    radius = f32(radius)
+    vals = np.zeros(32, np.float32)
+    s = f32(0)
+    for i in range(31):
+        vals[i] = f32(ev(f32(f32(radius * f32(i)) / f32(31))))
+        s = f32(s + vals[i])
+    s = f32(s * (f32(2) * radius / f32(31)))
+    vals[:31] = (vals[:31] * (f32(1.0) / s)).astype(np.float32)
+    return float(radius), vals
+
+
+def tent_filter():
+    """src/rfilters/tent.cpp:34-44"""
+    return _tabulate(1.0, lambda x: max(np.float32(0), np.float32(1) - abs(x / np.float32(1.0))))
+
+
+def mitchell_filter(B=1.0 / 3.0, C=1.0 / 3.0):
+    """src/rfilters/mitchell.cpp:35-68 (B = 0, C = 1/2 is catmullrom.cpp:32-55)"""
+    f32 = np.float32
+    B, C = f32(B), f32(C)
+
+    def ev(x):
+        x = abs(x)
+        x2 = f32(x * x)
+        x3 = f32(x2 * x)
+        if x < 1:
+            return f32(1.0 / 6.0) * ((12 - 9 * B - 6 * C) * x3 + (-18 + 12 * B + 6 * C) * x2 + (6 - 2 * B))
+        if x < 2:
+            return f32(1.0 / 6.0) * ((-B - 6 * C) * x3 + (6 * B + 30 * C) * x2 + (-12 * B - 48 * C) * x + (8 * B + 24 * C))
+        return f32(0)
+    return _tabulate(2.0, ev)
+
+
+def catmullrom_filter():
+    return mitchell_filter(0.0, 0.5)
+
+
+def lanczos_filter(lobes=3):
+    """src/rfilters/lanczos.cpp:35-55"""
+    f32 = np.float32
+    r = f32(int(lobes))
+
+    def ev(x):
+        x = abs(x)
+        if x < 1e-4:
+            return f32(1)
+        if x > r:
+            return f32(0)
+        x1 = f32(f32(np.pi) * x)
+        x2 = f32(x1 / r)
+        return f32(np.sin(x1, dtype=f32) * np.sin(x2, dtype=f32)) / f32(x1 * x2)
+    return _tabulate(r, ev)
 
 
 @dataclass

@@ -36,7 +36,20 @@ def test_filter_tables_match_reference_construction():
     assert r == r2 == 2.0 and np.array_equal(v, v2)
     assert v[31] == 0 and abs(v[:31].sum() * 2 * r / 31 - 1) < 1e-6      # rfilter.cpp:51-54 normalisation
     rb, vb = capi.filter_box(0.5)
-    assert np.array_equal(vb, S.box_filter(0.5)[1])
+    assert np.array_equal(vb, S.box_filter(0.5)[1]) and rb == S.box_filter(0.5)[0] == float(np.float32(0.5) + np.float32(1e-5))
+    # tent.cpp, mitchell.cpp, catmullrom.cpp, lanczos.cpp: radius, unit integral of the table, known values
+    for kind, args, py in (("tent", (), S.tent_filter()), ("mitchell", (1 / 3, 1 / 3), S.mitchell_filter()),
+                           ("mitchell", (0.2, 0.4), S.mitchell_filter(0.2, 0.4)), ("catmullrom", (), S.catmullrom_filter()),
+                           ("lanczos", (3,), S.lanczos_filter(3)), ("lanczos", (2,), S.lanczos_filter(2))):
+        r, v = capi.filter_table(kind, *args)
+        assert r == py[0] == {"tent": 1.0, "mitchell": 2.0, "catmullrom": 2.0, "lanczos": float(args[0]) if args else 0}[kind]
+        assert np.allclose(v, py[1], rtol=2e-6, atol=1e-7) and v[31] == 0
+        assert abs(v[:31].sum() * 2 * r / 31 - 1) < 1e-5
+    r, v = capi.filter_table("tent")
+    assert np.allclose(v[:31] / v[0], 1 - np.arange(31) / 31, atol=1e-6)
+    r, v = capi.filter_table("catmullrom")
+    assert v[15:31].min() < 0 and abs(v[int(round(31 / 2))]) < 0.02 * v[0]       # negative lobe, zero crossing at x = 1
+    assert np.array_equal(capi.filter_table("gaussian", 0.5)[1], capi.filter_gaussian(0.5)[1])
 
 
 def test_rtrans_reduce_product_vs_oracle_and_packaged(oracle_mod):
