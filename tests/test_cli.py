@@ -454,6 +454,28 @@ def test_cli_render_matches_binding(scene_dir, tmp_path):
                 assert np.allclose(planes[c], ref, rtol=1e-6, atol=0), c
 
 
+@pytest.mark.gpu
+def test_cli_direct_render_matches_binding(scene_dir, tmp_path):
+    """The standalone caller with <integrator type="direct">: same film and ray counts as the binding on the same scene."""
+    from mitsuba_amd import capi
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    text = (scene_dir / "scene.xml").read_text()
+    head = text[text.index("<integrator"):text.index("</integrator>") + len("</integrator>")]
+    f = tmp_path / "direct.xml"
+    f.write_text(text.replace(head, '<integrator type="direct"><integer name="emitterSamples" value="3"/><integer name="bsdfSamples" value="2"/></integrator>'))
+    raw = tmp_path / "film.raw"
+    out = subprocess.run([CLI, str(f), "-o", str(tmp_path / "out.pfm"), "--film", str(raw), "--spp", "4", "--seed", "5"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    stats = json.loads(out.stdout)
+    film_cli = np.fromfile(str(raw), np.float32).reshape(48, 64, 5)
+    sd, _ = loader.load_xml(str(f))
+    film_py, st = capi.Scene(sd).render(4, seed=5)
+    assert stats["normal_rays"] == st.normal_rays and stats["shadow_rays"] == st.shadow_rays
+    assert st.shadow_rays > 0 and st.normal_rays > 64 * 48 * 4
+    assert np.allclose(film_cli, film_py, rtol=1e-4, atol=1e-5) and film_cli[..., :3].mean() > 0.01
+
+
 def _read_png(path):
     """Minimal reader for 8-bit, non-interlaced PNG files whose rows use filter type 0."""
     b = open(path, "rb").read()
