@@ -43,7 +43,8 @@ enum { MTSAMD_SHAPE_HAS_NORMALS = 1, MTSAMD_SHAPE_HAS_TEXCOORDS = 2 };
    src/librender/skdtree.cpp:68-110): Morton sort + locally-ordered clustering on the GPU with a SAH sweep over the
    resulting clusters for the top of the tree (default), or a binned-SAH sweep over all triangles on the host cores.
    Selected with the environment variable MTSAMD_BVH_BUILDER=device|host when the scene is created. */
-enum { MTSAMD_BVH_HOST = 0, MTSAMD_BVH_DEVICE = 1 };
+enum { MTSAMD_BVH_HOST = 0, MTSAMD_BVH_DEVICE = 1,
+       MTSAMD_BVH_DEVICE_BINARY = 2 /* MTSAMD_BVH_BUILDER=device-binary: clustering on the GPU, collapse on the host (for comparisons) */ };
 
 /* One TriMesh (include/mitsuba/render/trimesh.h). Its triangles occupy
    [first_triangle, first_triangle + n_triangles) of the global index array; the primitive index the
@@ -181,7 +182,8 @@ typedef struct {
     double build_seconds;       /* whole acceleration-structure build */
     double sah_cost;
     double binary_seconds;      /* of which: the binary tree under the wide BVH (host SAH sweep or device clustering) */
-    int32_t builder;            /* MTSAMD_BVH_HOST or MTSAMD_BVH_DEVICE */
+    int32_t builder;            /* MTSAMD_BVH_*: who built the tree in the end (a scene whose GPU-built tree would be deeper than
+                                   the traversal stack is rebuilt by the host builder, which bounds the depth) */
     int32_t reserved;
 } mtsamd_bvh_info;
 
@@ -311,6 +313,13 @@ int mtsamd_rng_stream(uint32_t seed, uint64_t key, uint32_t n, float *out);
    *theta_samples floats (capacity out_cap). */
 int mtsamd_rtrans_reduce(const void *dat, uint64_t size, float eta, float alpha, float *out_T, uint32_t out_cap,
                          uint32_t *theta_samples, float *diffuse_ext, float *diffuse_int);
+
+/* The host builder of the acceleration structure alone (binned-SAH sweep, collapse to 8-wide nodes, depth bounded to
+   what the traversal stack holds): fills `info`, keeps nothing, needs no device. Counterpart of building a ShapeKDTree and
+   reading its statistics (src/librender/skdtree.cpp:68-110; include/mitsuba/render/gkdtree.h:1213-1263). */
+int mtsamd_bvh_host_info(const float *positions, uint32_t n_vertices, const uint32_t *indices, uint32_t n_triangles, mtsamd_bvh_info *info);
+/* Deepest tree (levels of wide nodes, root = 1) the traversal kernels accept; the builders never return a deeper one */
+int mtsamd_bvh_max_depth(void);
 
 /* GaussianFilter / BoxFilter tables as ReconstructionFilter::configure builds them
    (src/rfilters/gaussian.cpp:32-57, src/libcore/rfilter.cpp:37-55) */

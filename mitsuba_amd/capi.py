@@ -96,7 +96,7 @@ EXPORTS = ["mtsamd_last_error", "mtsamd_init", "mtsamd_scene_create", "mtsamd_sc
            "mtsamd_render", "mtsamd_render_device", "mtsamd_cancel", "mtsamd_scene_set_counting", "mtsamd_film_develop", "mtsamd_trace", "mtsamd_trace_device", "mtsamd_occluded_device",
            "mtsamd_occluded", "mtsamd_intersect", "mtsamd_bsdf_eval", "mtsamd_bsdf_pdf", "mtsamd_bsdf_sample",
            "mtsamd_sample_emitter_direct", "mtsamd_camera_rays", "mtsamd_li", "mtsamd_film_put", "mtsamd_film_develop_ldr", "mtsamd_abi_version", "mtsamd_sizeof", "mtsamd_filter_table", "mtsamd_rng_stream",
-           "mtsamd_rtrans_reduce", "mtsamd_filter_gaussian", "mtsamd_filter_box"]
+           "mtsamd_rtrans_reduce", "mtsamd_filter_gaussian", "mtsamd_filter_box", "mtsamd_bvh_host_info", "mtsamd_bvh_max_depth"]
 
 _lib = None
 ABI_VERSION = 7     # MTSAMD_ABI_VERSION of include/mtsamd.h
@@ -367,6 +367,19 @@ class Scene:
             film = np.zeros((self.hgt, self.w, 5), np.float32)
         _check(self.L.mtsamd_film_put(self.h, C.c_uint64(pos.shape[0]), _fp(pos), _fp(value), _fp(film)))
         return film
+
+
+def bvh_host_info(positions, indices) -> BvhInfo:
+    """The host builder alone (no device): statistics of the wide BVH it makes of these triangles."""
+    pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(indices, np.uint32).reshape(-1, 3)
+    info = BvhInfo()
+    _check(lib().mtsamd_bvh_host_info(_fp(pos), C.c_uint32(pos.shape[0]), idx.ctypes.data_as(_u32p), C.c_uint32(idx.shape[0]), C.byref(info)))
+    return info
+
+
+def bvh_max_depth() -> int:
+    return int(lib().mtsamd_bvh_max_depth())
 
 
 def rng_stream(seed, key, n):

@@ -28,6 +28,7 @@ struct Builder2 {
     std::atomic<uint32_t> nextNode{ 0 };
     std::atomic<int> liveThreads{ 0 };
     int maxThreads = 1;
+    int sahDepthLimit = std::numeric_limits<int>::max();   // below this depth: median splits (a balanced subtree)
 
     uint32_t alloc2() { return nextNode.fetch_add(2); }
 
@@ -43,7 +44,7 @@ struct Builder2 {
         // binned SAH over the centroid bounds
         int bestAxis = -1, bestBin = -1;
         float bestCost = std::numeric_limits<float>::infinity();
-        for (int axis = 0; axis < 3; ++axis) {
+        for (int axis = 0; axis < 3 && depth < sahDepthLimit; ++axis) {
             float lo = cbox.lo[axis], hi = cbox.hi[axis];
             if (!(hi > lo)) continue;
             Box bb[kBins];
@@ -81,7 +82,14 @@ struct Builder2 {
             });
             mid = (uint32_t) (m - prims.data());
         } else {
-            mid = first + count / 2;    // all centroids coincide
+            // all centroids coincide, or the SAH splits have used up their depth allowance: median split along the
+            // widest axis of the centroid bounds, which halves the count whatever the geometry looks like
+            mid = first + count / 2;
+            int axis = 0;
+            for (int a = 1; a < 3; ++a) if (cbox.hi[a] - cbox.lo[a] > cbox.hi[axis] - cbox.lo[axis]) axis = a;
+            if (cbox.hi[axis] > cbox.lo[axis])
+                std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
+                                 [axis](const Prim &a, const Prim &b) { return a.c[axis] < b.c[axis]; });
         }
         if (mid == first || mid == first + count) mid = first + count / 2;
         uint32_t c = alloc2();
@@ -107,8 +115,9 @@ inline float bitsFloat(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 void loadTriRecord(const float *A, const float *B, const float *C, TriRecord &t) { loadTriRecordHD(A, B, C, t); }
 
-const char *buildBinaryTreeHost(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BinaryTree &out) {
+const char *buildBinaryTreeHost(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BinaryTree &out, int sahDepthLimit) {
     Builder2 b2;
+    b2.sahDepthLimit = sahDepthLimit;
     b2.prims.resize(nTris);
     Box sceneBox; sceneBox.reset();
     for (uint32_t t = 0; t < nTris; ++t) {
@@ -176,13 +185,26 @@ const char *buildBVH(const float *positions, uint32_t nVerts, const uint32_t *in
     if (nTris >= (1u << 27)) return "too many triangles";
     if (const char *e = getenv("MTSAMD_COST_TRI")) kCostTri = (float) atof(e);
     setDeviceBuilderCosts(kCostNode, kCostTri);
-    BinaryTree tree;
     out.builder = builder;
-    const char *err = builder == BVH_BUILDER_DEVICE_BINARY ? buildBinaryTreeDevice(positions, nVerts, indices, nTris, tree)
-                                                    : buildBinaryTreeHost(positions, nVerts, indices, nTris, tree);
-    if (err && *err) return err;
-    out.binarySeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    err = collapseToWide(tree, positions, indices, out);
+    // Surface-area splits follow the geometry and can produce a tree deeper than the traversal stack (long chains of
+    // nested or geometrically growing triangles). Such a tree is rebuilt on the host with the surface-area splits
+    // confined to the top levels and median splits below; with no surface-area levels at all the tree is balanced
+    // and fits by construction (kMaxWideDepth).
+    const int kNoLimit = std::numeric_limits<int>::max();
+    const int limits[] = { kNoLimit, 16, 0 };
+    const char *err = "";
+    for (int limit : limits) {
+        BinaryTree tree;
+        const bool onDevice = builder == BVH_BUILDER_DEVICE_BINARY && limit == kNoLimit;
+        err = onDevice ? buildBinaryTreeDevice(positions, nVerts, indices, nTris, tree)
+                       : buildBinaryTreeHost(positions, nVerts, indices, nTris, tree, limit);
+        if (err && *err) return err;
+        if (!onDevice) out.builder = BVH_BUILDER_HOST;
+        out.binarySeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        out.nodes.clear(); out.tris.clear(); out.depth = 0;
+        err = collapseToWide(tree, positions, indices, out);
+        if (!(err && strcmp(err, kTooDeep) == 0)) break;
+    }
     out.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return err;
 }
@@ -225,7 +247,7 @@ const char *collapseToWide(const BinaryTree &tree, const float *positions, const
         }
         const float leafCost = nd.count <= kMaxLeaf ? area * kCostTri * (float) nd.count : kInfCost;
         const float nodeCost = area * kCostNode + dist[8];
-        d.leaf = leafCost <= nodeCost;
+        d.leaf = nd.count <= kMaxLeaf && leafCost <= nodeCost;    // (the count guard matters when the areas overflow)
         d.c[1] = std::min(leafCost, nodeCost);
         d.take = 0;
         for (int j = 2; j <= 7; ++j) {
@@ -374,8 +396,7 @@ const char *collapseToWide(const BinaryTree &tree, const float *positions, const
         }
         (void) nInternal;
     }
-    if (out.nodes.size() >= (1u << 24)) return "BVH has too many nodes for the 24-bit traversal stack entries";
-    if ((int) out.depth > kMaxWideDepth) return "BVH too deep for the traversal stack";
+    if ((int) out.depth > kMaxWideDepth) return kTooDeep;
     out.sahCost = sah;
     out.nodeCount = (uint32_t) out.nodes.size(); out.triCount = (uint32_t) out.tris.size();
     return "";

@@ -92,6 +92,18 @@ MTS_HD inline void loadTriRecordHD(const float *A, const float *B, const float *
 }
 void loadTriRecord(const float *A, const float *B, const float *C, TriRecord &t);
 
-static const int kMaxWideDepth = 23;    // the traversal stack holds one entry per level
+// Per-lane traversal stack of the GPU kernels: kLdsStack entries in LDS, kSpillStack more in scratch memory. A ray
+// pushes at most one entry per level of wide nodes it descends through with siblings still pending, and neither the
+// root (a group of one) nor the deepest level (no internal children) pushes: a tree of depth D (root = 1) needs D - 2
+// entries. The builders refuse deeper trees, so the stack cannot overflow.
+#ifndef MTS_LDS_STACK
+#define MTS_LDS_STACK 4
+#endif
+static constexpr int kLdsStack = MTS_LDS_STACK;
+static constexpr int kSpillStack = 26;
+static constexpr int kMaxWideDepth = kLdsStack + kSpillStack + 2;
+// A binary tree split at the median all the way down is at most 27 levels deep below its root (fewer than 2^27
+// triangles), and collapsing can only remove levels: the builders' last resort always fits.
+static_assert(kMaxWideDepth >= 29, "the traversal stack must hold the tree of a balanced binary build");
 
 }  // namespace mtsamd

@@ -137,7 +137,7 @@ MTS_HD inline void dpInner(const DNode &nd, const DDp &L, const DDp &R, float co
     }
     const float leafCost = nd.count <= kMaxLeafTris ? area * costTri * (float) nd.count : INFINITY;
     const float nodeCost = area * costNode + dist[8];
-    d.leaf = leafCost <= nodeCost;
+    d.leaf = nd.count <= kMaxLeafTris && leafCost <= nodeCost;    // (the count guard matters when the areas overflow)
     d.c[1] = leafCost < nodeCost ? leafCost : nodeCost;
     d.take = 0;
     for (int j = 2; j <= 7; ++j) {
@@ -591,7 +591,7 @@ const char *buildWideDevice(const float *positions, uint32_t nVerts, const uint3
     a.root = ct.root;
     uint32_t start = 0, end = 1, depth = 0;
     while (start < end) {
-        if (++depth > (uint32_t) kMaxWideDepth) return "BVH too deep for the traversal stack";
+        if (++depth > (uint32_t) kMaxWideDepth) return kTooDeep;
         a.levelStart = start; a.levelEnd = end;
         hipLaunchKernelGGL(k_emit_level, dim3((end - start + 63) / 64), dim3(64), 0, 0, a);
         uint32_t c[4];
@@ -603,7 +603,6 @@ const char *buildWideDevice(const float *positions, uint32_t nVerts, const uint3
     uint32_t c[4];
     DEV_TRY(hipMemcpy(c, dCounters.p, 16, hipMemcpyDeviceToHost));
     if (c[1] != nTris) return "device BVH build lost triangles";
-    if (c[0] >= (1u << 24)) return "BVH has too many nodes for the 24-bit traversal stack entries";
     DEV_TRY(hipMemcpy(&info.sahCost, dSah.p, 8, hipMemcpyDeviceToHost));
     // hand over right-sized buffers
     void *nodesOut = nullptr;

@@ -43,8 +43,12 @@ struct BinaryTree {
     Box sceneBox;
 };
 
-// Host builder: multithreaded binned SAH down to single triangles.
-const char *buildBinaryTreeHost(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BinaryTree &out);
+// What a builder returns for a tree deeper than kMaxWideDepth (compared by content)
+static const char *const kTooDeep = "BVH too deep for the traversal stack";
+// Host builder: multithreaded binned SAH down to single triangles. Nodes at depth >= sahDepthLimit are split at the
+// median instead (0: a balanced tree throughout).
+const char *buildBinaryTreeHost(const float *positions, uint32_t nVerts, const uint32_t *indices, uint32_t nTris, BinaryTree &out,
+                                int sahDepthLimit = std::numeric_limits<int>::max());
 // The host sweep over arbitrary boxes; primTri holds the box order.
 const char *buildBinaryOverBoxes(const std::vector<Box> &boxes, BinaryTree &out);
 // Device builder: Morton sort + parallel locally-ordered clustering on the current HIP device.

@@ -7,17 +7,15 @@
 //  include/mitsuba/render/triaccel.h:96-158).
 #pragma once
 #include "device_math.h"
+#include "bvh.h"
 
 namespace mtsamd {
 
 struct HitRec { float t, u, v; uint32_t tri; };     // tri = global triangle index | BSDF type << 28, 0xFFFFFFFF = miss
 static constexpr uint32_t kTriIndexMask = 0x0fffffffu;
 
-#ifndef MTS_LDS_STACK
-#define MTS_LDS_STACK 4
-#endif
-static constexpr int kLdsStack = MTS_LDS_STACK;         // entries per lane kept in LDS
-static constexpr int kSpillStack = 16;      // further entries in scratch
+// kLdsStack entries per lane of the traversal stack live in LDS, kSpillStack more in scratch (bvh.h, next to the depth
+// limit of the builders that they imply)
 static constexpr int kNodeFloat4 = 5;       // a wide node is 5 x float4
 // LDS of a traversal workgroup: a copy of the first `topNodes` nodes of the BVH (nodes are stored breadth first, so
 // these are the top levels every ray walks through), then kLdsStack stack entries per lane,

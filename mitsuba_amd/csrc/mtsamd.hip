@@ -167,21 +167,23 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
     for (const DevMaterial &m : h.materials) s->roughDielectric |= m.type == MTSAMD_BSDF_ROUGHDIELECTRIC;
     if (const char *e = getenv("MTSAMD_NODE_STRIDE")) s->nodeStride = (uint32_t) std::min(16, std::max(5, atoi(e)));
     if (const char *e = getenv("MTSAMD_TRI_STRIDE")) s->triStride = (uint32_t) std::min(16, std::max(3, atoi(e)));
+    // nodes and triangle records as raw float4 streams, each record padded to its stride
+    auto uploadHostBvh = [&]() -> int {
+        auto padded = [&](DeviceBuffer &buf, const void *src, size_t count, size_t recBytes, size_t strideBytes) -> int {
+            std::vector<char> tmp(std::max<size_t>(count, 1) * strideBytes, 0);
+            for (size_t i = 0; i < count; ++i) memcpy(&tmp[i * strideBytes], (const char *) src + i * recBytes, recBytes);
+            HIP_TRY(buf.ensure(tmp.size()));
+            HIP_TRY(hipMemcpy(buf.ptr, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
+            return MTSAMD_OK;
+        };
+        int rc2 = padded(s->nodes, h.bvh.nodes.data(), h.bvh.nodes.size(), sizeof(WideNode), (size_t) s->nodeStride * 16);
+        if (rc2 != MTSAMD_OK) return rc2;
+        return padded(s->tris, h.bvh.tris.data(), h.bvh.tris.size(), sizeof(TriRecord), (size_t) s->triStride * 16);
+    };
     auto up = [&]() -> int {
-        {   // nodes and triangle records as raw float4 streams, each record padded to its stride
-            auto padded = [&](DeviceBuffer &buf, const void *src, size_t count, size_t recBytes, size_t strideBytes) -> int {
-                std::vector<char> tmp(std::max<size_t>(count, 1) * strideBytes, 0);
-                for (size_t i = 0; i < count; ++i) memcpy(&tmp[i * strideBytes], (const char *) src + i * recBytes, recBytes);
-                HIP_TRY(buf.ensure(tmp.size()));
-                HIP_TRY(hipMemcpy(buf.ptr, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
-                return MTSAMD_OK;
-            };
-            if (!(h.bvh.builder == BVH_BUILDER_DEVICE && h.desc.n_triangles > 0)) {
-                int rc2 = padded(s->nodes, h.bvh.nodes.data(), h.bvh.nodes.size(), sizeof(WideNode), (size_t) s->nodeStride * 16);
-                if (rc2 != MTSAMD_OK) return rc2;
-                rc2 = padded(s->tris, h.bvh.tris.data(), h.bvh.tris.size(), sizeof(TriRecord), (size_t) s->triStride * 16);
-                if (rc2 != MTSAMD_OK) return rc2;
-            }
+        if (!(h.bvh.builder == BVH_BUILDER_DEVICE && h.desc.n_triangles > 0)) {
+            int rc2 = uploadHostBvh();
+            if (rc2 != MTSAMD_OK) return rc2;
         }
         HIP_TRY(upload(s->shadeTris, h.shadeTris));
         if (!h.shadeUV.empty()) HIP_TRY(upload(s->shadeUV, h.shadeUV));
@@ -196,9 +198,17 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
             // the acceleration structure is built where it will be used; the records then learn their BSDF types
             void *dn = nullptr, *dt = nullptr;
             const char *err = buildWideDevice(h.positions.data(), h.desc.n_vertices, h.indices.data(), h.desc.n_triangles, s->nodeStride, s->triStride, &dn, &dt, h.bvh);
-            if (err && *err) return fail(MTSAMD_EDEVICE, "%s", err);
-            s->nodes.ptr = dn; s->nodes.bytes = (size_t) h.bvh.nodeCount * s->nodeStride * 16;
-            s->tris.ptr = dt; s->tris.bytes = (size_t) h.bvh.triCount * s->triStride * 16;
+            if (err && strcmp(err, kTooDeep) == 0) {
+                // geometry whose clustering gives a tree deeper than the traversal stack: the host builder bounds the depth
+                err = buildBVH(h.positions.data(), h.desc.n_vertices, h.indices.data(), h.desc.n_triangles, h.bvh, BVH_BUILDER_HOST);
+                if (err && *err) return fail(MTSAMD_EINVAL, "%s", err);
+                int rc2 = uploadHostBvh();
+                if (rc2 != MTSAMD_OK) return rc2;
+            } else {
+                if (err && *err) return fail(MTSAMD_EDEVICE, "%s", err);
+                s->nodes.ptr = dn; s->nodes.bytes = (size_t) h.bvh.nodeCount * s->nodeStride * 16;
+                s->tris.ptr = dt; s->tris.bytes = (size_t) h.bvh.triCount * s->triStride * 16;
+            }
             hipLaunchKernelGGL(k_tag_triangle_records, dim3(blocksFor(h.bvh.triCount, 256)), dim3(256), 0, 0, s->tris.as<float4>(), s->triStride, h.bvh.triCount,
                                s->shadeTris.as<float4>(), s->materials.as<DevMaterial>());
             HIP_TRY(hipDeviceSynchronize());
@@ -272,6 +282,25 @@ extern "C" int mtsamd_scene_bvh_info(const mtsamd_scene *scene, mtsamd_bvh_info 
     info->binary_seconds = b.binarySeconds; info->builder = b.builder; info->reserved = 0;
     return MTSAMD_OK;
 }
+
+extern "C" int mtsamd_bvh_host_info(const float *positions, uint32_t n_vertices, const uint32_t *indices, uint32_t n_triangles, mtsamd_bvh_info *info) {
+    if (!info || (n_triangles && (!positions || !indices))) return fail(MTSAMD_EINVAL, "null argument");
+    BVH b;
+    const char *err = "";
+    try {
+        err = buildBVH(positions, n_vertices, indices, n_triangles, b, BVH_BUILDER_HOST);
+    } catch (const std::exception &ex) {
+        return fail(MTSAMD_EINVAL, "BVH build failed: %s", ex.what());
+    }
+    if (err && *err) return fail(MTSAMD_EINVAL, "%s", err);
+    info->n_nodes = b.nodeCount; info->n_triangles = b.triCount; info->depth = b.depth;
+    info->node_bytes = (uint64_t) b.nodeCount * sizeof(WideNode); info->triangle_bytes = (uint64_t) b.triCount * sizeof(TriRecord);
+    info->build_seconds = b.buildSeconds; info->sah_cost = b.sahCost;
+    info->binary_seconds = b.binarySeconds; info->builder = b.builder; info->reserved = 0;
+    return MTSAMD_OK;
+}
+
+extern "C" int mtsamd_bvh_max_depth(void) { return kMaxWideDepth; }
 
 extern "C" void mtsamd_cancel(mtsamd_scene *scene) { if (scene) scene->cancel.store(1); }
 
@@ -395,6 +424,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
             timer.begin(T_SHADOW);
             launchTrace<TRACE_OCCLUDED>(s, sa, st);
             timer.end(T_SHADOW);
+            if (stats) stats->shadow_launches++;
         }
         if (nB > 0) {
             ta.rayO = qout.rayO; ta.rayD = qout.rayD; ta.n = n * (uint32_t) nB;
@@ -487,6 +517,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
             timer.end(T_SHADOW, sst);
             if (beside) { HIP_TRY(hipEventRecord(s->evShadowed, sst)); shadowPending = true; }
             shadowRays += nShadow;
+            if (stats) stats->shadow_launches++;
         }
         if (traceIters) fprintf(stderr, "iter %llu n=%u shadow=%u next=%u\n", (unsigned long long) iterations, n, nShadow, nNext);
         n = nNext;

@@ -667,6 +667,24 @@ def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_
     return b.finish(cam, make_film(width, height), dict(max_depth=max_depth, hide_emitters=hide_emitters))
 
 
+def nested_slivers(n=420, ratio=1.15, first=1e-12) -> SceneData:
+    """A deliberately deep hierarchy: n thin triangles that all start at the origin, each `ratio` times larger than the
+    one before and slightly higher up. Surface-area splits peel the largest few off at every level, so the tree a
+    builder makes of them is a long chain (depth ~ n / 14 with the host builder); used to test the traversal stack at
+    and beyond its limit. One diffuse material, no emitters."""
+    k = np.arange(n, dtype=np.float64)
+    s = first * ratio ** k
+    z = 1e-3 * s
+    pos = np.zeros((n, 3, 3))
+    pos[:, 0, 2] = z
+    pos[:, 1, 0], pos[:, 1, 1], pos[:, 1, 2] = s, 0.01 * s, z
+    pos[:, 2, 0], pos[:, 2, 1], pos[:, 2, 2] = 0.01 * s, s, z
+    b = SceneBuilder()
+    m = b.add_material(diffuse())
+    b.add_mesh(pos.reshape(-1, 3).astype(np.float32), np.arange(3 * n, dtype=np.uint32).reshape(-1, 3), m)
+    return b.finish(make_camera([0.3, 0.3, 5.0], [0.3, 0.3, 0.0], [0, 1, 0], 30.0), make_film(16, 16))
+
+
 def veach_bidir(width=1024, height=768, max_depth=-1, golden_dir=None) -> SceneData:
     """Config 2: the veach_bidir scene (geometry of testScene/veach_bidir/bidir.serialized, materials, emitters and
     camera of bidir.bak) rendered with the `path` integrator. Geometry and scene description are read from the

@@ -595,3 +595,41 @@ def test_device_built_bvh_gives_the_same_answers(gpu, oracle_mod, monkeypatch):
     fh, sh = host.render(3, seed=8)
     fd, sdv = dev.render(3, seed=8)
     assert np.array_equal(fh, fd) and (sh.normal_rays, sh.shadow_rays) == (sdv.normal_rays, sdv.shadow_rays)
+
+
+@pytest.mark.parametrize("n", [420, 450])
+def test_deep_tree_fills_the_traversal_stack(gpu, oracle_mod, monkeypatch, n):
+    """A chain of nested slivers gives the deepest tree the builders may return (420: the surface-area tree at the depth
+    limit; 450: rebuilt with median splits because it would exceed it). Rays that pass through every level of the chain
+    must find the same hits as an exhaustive search, with both builders."""
+    sd = S.nested_slivers(n)
+    o = oracle_mod.OracleScene(sd)
+    rng = np.random.default_rng(n)
+    m = 60000
+    s = np.exp(rng.uniform(np.log(1e-13), np.log(1e16), m))
+    a = rng.uniform(0.02, 0.98, m)
+    x, y = s * a, s * (1 - a)
+    tilt = rng.normal(0, 0.2, (m, 2))
+    rays = np.zeros((m, 8), np.float32)
+    up = np.arange(m) % 2 == 0
+    rays[:, 0], rays[:, 1] = x, y
+    rays[:, 2] = np.where(up, -(x + y), 10 * (x + y))
+    d = np.stack([tilt[:, 0], tilt[:, 1], np.where(up, 1.0, -1.0)], 1)
+    rays[:, 4:7] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 3], rays[:, 7] = 0.0, np.inf
+    hb = o.trace(rays, brute=True)
+    ob = o.occluded(rays, brute=True)
+    assert (hb["prim"] != MISS).mean() > 0.5
+    limit = gpu.bvh_max_depth()
+    for builder in ("host", "device"):
+        monkeypatch.setenv("MTSAMD_BVH_BUILDER", builder)
+        g = gpu.Scene(sd)
+        info = g.bvh_info()
+        assert info.n_triangles == n and info.depth <= limit
+        if builder == "host" and n == 420:
+            assert info.depth >= limit - 2
+        hg = g.trace(rays)
+        same = (hg["shape"] == hb["shape"]) & (hg["prim"] == hb["prim"])
+        assert (same | (hg["t"] == hb["t"])).all(), (builder, (~same).sum())
+        assert np.array_equal(hg["t"][same], hb["t"][same]) and np.array_equal(hg["u"][same], hb["u"][same])
+        assert np.array_equal(g.occluded(rays), ob)

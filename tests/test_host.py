@@ -172,3 +172,29 @@ def test_two_rank_partition_and_film_reduce_gloo(tmp_path, oracle_mod):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                           "--master-port", "29611", str(script)], capture_output=True, text=True, env=env, timeout=600)
     assert "DIST_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_bvh_depth_never_exceeds_the_traversal_stack():
+    """The host builder on geometry whose surface-area tree is a long chain (mitsuba_amd.scene.nested_slivers): up to
+    the depth limit the chain is kept; beyond it the tree is rebuilt with median splits below the top levels, so the
+    depth the traversal kernels must hold is never exceeded and no triangle is lost."""
+    limit = capi.bvh_max_depth()
+    assert limit >= 29
+    depths = {}
+    for n in (100, 420, 450, 470):
+        sd = S.nested_slivers(n)
+        info = capi.bvh_host_info(sd.positions, sd.indices)
+        assert info.n_triangles == n and 1 <= info.depth <= limit, (n, info.depth)
+        depths[n] = info.depth
+    assert depths[420] >= limit - 2          # the chain reaches the limit ...
+    assert depths[450] < depths[420]         # ... and the longer one was rebuilt shallower
+    # degenerate inputs: nothing, one triangle, coincident triangles, coordinates whose box areas overflow
+    assert capi.bvh_host_info(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.uint32)).n_triangles == 0
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    assert capi.bvh_host_info(tri, [[0, 1, 2]]).depth == 1
+    same = capi.bvh_host_info(tri, [[0, 1, 2]] * 40)
+    assert same.n_triangles == 40 and same.depth <= limit
+    huge = S.nested_slivers(300, ratio=1.25, first=1.0)        # sizes up to 1e29: areas overflow to infinity
+    assert np.isfinite(huge.positions).all()
+    info = capi.bvh_host_info(huge.positions, huge.indices)
+    assert info.n_triangles == 300 and info.depth <= limit

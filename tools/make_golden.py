@@ -7,7 +7,10 @@ checkout (no reference source is copied): run in the build container where /root
                                        ranges + ~100 table entries each) -- used to pin the microfacet / Fresnel code
   tests/golden/veach_bidir_meshes.npz  the 11 meshes of testScene/veach_bidir/bidir.serialized (object space)
   tests/golden/veach_bidir_path.xml    testScene/veach_bidir/bidir.bak with the integrator switched to `path`
-  tests/golden/bidir_ref_lowres.npz    testScene/veach_bidir/bidir.exr (768x576 bdpt render) box-downsampled to 96x72
+  tests/golden/bidir_ref_lowres.npz    testScene/veach_bidir/bidir.exr (768x576) box-downsampled to 96x72
+  tests/golden/bidir_ref_cells.npz     the same image as means over 24-pixel cells, the bounding box of the banner the film
+                                       stamped into it, and the lines of the log embedded in the file that say how its final
+                                       version was rendered
   mitsuba_amd/data/rtrans_slices.json  reduced rough-transmittance tables for the bundled scenes (mtsamd_rtrans_reduce)
 """
 import json
@@ -159,6 +162,29 @@ def bidir_ref():
     print("bidir.exr", rgb.shape, "mean", rgb.mean((0, 1)))
 
 
+def bidir_ref_cells():
+    """Cell means of bidir.exr plus what the file says about itself. The log attribute is the GUI session's whole
+    log up to the moment the file was (over)written; the lines kept are the `Starting render job` / `Writing image`
+    pairs and the integrator configuration, i.e. which integrator produced the pixels that are in the file."""
+    img, chans, attrs = read_exr_zip_half(os.path.join(T, "veach_bidir", "bidir.exr"))
+    rgb = img[..., [chans.index(c) for c in "RGB"]]
+    h, w, _ = rgb.shape
+    c = 24
+    cells = rgb.reshape(h // c, c, w // c, c, 3).mean((1, 3)).astype(np.float32)
+    # the banner is drawn with one saturated value (hdrfilm.cpp:496-506 stamps it 5 pixels from the corner)
+    top = rgb.max()
+    ys, xs = np.nonzero((rgb == top).all(-1))
+    banner = [int(xs.min()), int(ys.min()), int(xs.max()) + 1, int(ys.max()) + 1]
+    log = attrs["log"][1].decode("utf-8", "replace").splitlines()
+    keep = [ln.strip() for ln in log if any(k in ln for k in ("Starting render job", "Writing image to", "did not complete", "Render time",
+                                                              "photon map full", "Maximum path depth", "Mitsuba version", "Loading plugin"))]
+    np.savez_compressed(os.path.join(GOLD, "bidir_ref_cells.npz"), cells=cells, cell=c, full_size=[w, h], banner_box=banner,
+                        banner_value=np.float32(top), log_lines=np.array(keep))
+    print("cells", cells.shape, "banner box", banner, "value", top)
+    for ln in keep[-12:]:
+        print("   ", ln[:150])
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     kd_clip()
@@ -166,4 +192,5 @@ if __name__ == "__main__":
     rtrans_slices()
     veach()
     bidir_ref()
+    bidir_ref_cells()
     print("done")
