@@ -685,21 +685,20 @@ def nested_slivers(n=420, ratio=1.15, first=1e-12) -> SceneData:
     return b.finish(make_camera([0.3, 0.3, 5.0], [0.3, 0.3, 0.0], [0, 1, 0], 30.0), make_film(16, 16))
 
 
-def veach_bidir(width=1024, height=768, max_depth=-1, golden_dir=None) -> SceneData:
+def veach_bidir(width=1024, height=768, max_depth=-1, data_dir=None) -> SceneData:
     """Config 2: the veach_bidir scene (geometry of testScene/veach_bidir/bidir.serialized, materials, emitters and
     camera of bidir.bak) rendered with the `path` integrator. Geometry and scene description are read from the
-    fixtures extracted by tools/make_golden.py."""
+    package data extracted by tools/make_golden.py (data/veach_bidir/)."""
     from . import loader
-    if golden_dir is None:
-        golden_dir = os.path.join(os.path.dirname(_DATA_DIR.rstrip("/")), "..", "tests", "golden")
-    golden_dir = os.path.abspath(golden_dir)
-    z = np.load(os.path.join(golden_dir, "veach_bidir_meshes.npz"))
+    if data_dir is None:
+        data_dir = os.path.join(_DATA_DIR, "veach_bidir")
+    z = np.load(os.path.join(data_dir, "meshes.npz"))
 
     def provider(filename, idx):
         return dict(positions=z["p%d" % idx], indices=z["i%d" % idx],
                     normals=z["n%d" % idx] if "n%d" % idx in z.files else None,
                     texcoords=z["t%d" % idx] if "t%d" % idx in z.files else None, face_normals=False)
 
-    sd, _ = loader.load_xml(os.path.join(golden_dir, "veach_bidir_path.xml"), width=width, height=height,
+    sd, _ = loader.load_xml(os.path.join(data_dir, "scene_path.xml"), width=width, height=height,
                             integrator_override=dict(max_depth=max_depth), mesh_provider=provider)
     return sd

@@ -633,3 +633,25 @@ def test_deep_tree_fills_the_traversal_stack(gpu, oracle_mod, monkeypatch, n):
         assert (same | (hg["t"] == hb["t"])).all(), (builder, (~same).sum())
         assert np.array_equal(hg["t"][same], hb["t"][same]) and np.array_equal(hg["u"][same], hb["u"][same])
         assert np.array_equal(g.occluded(rays), ob)
+
+
+def test_veach_room_against_the_reference_held_image(gpu):
+    """End to end against the one image the reference holds (tests/bidir_pin.py says what that image is): the Veach room
+    at the file's 768x576, 4 096 samples per pixel at unbounded depth and 512 at maxDepth 2, 48-pixel cells. Directly
+    lit cells: reference / (2 direct + indirect) = 0.96 within 5 % in every cell; cells without direct light: within
+    the photon map's bias."""
+    import bidir_pin
+    imgs = {}
+    for md, spp in ((2, 512), (-1, 4096)):
+        g = gpu.Scene(S.veach_bidir(768, 576, max_depth=md))
+        film, st = g.render(spp, seed=3)
+        imgs[md] = g.develop(film)[..., :3]
+        assert np.isfinite(imgs[md]).all()
+    c = bidir_pin.compare(imgs[2], imgs[-1])
+    lit = c["lit"]
+    assert c["lit_mask"].sum() >= 20 and c["unlit_mask"].sum() >= 100
+    assert abs(np.median(lit) - 0.96) < 0.02, np.median(lit)
+    assert np.all(np.abs(lit - 0.96) < 0.05), np.sort(lit)
+    assert 1.55 < np.median(c["lit_plain"]) < 1.85
+    q = np.percentile(c["unlit"], [10, 50, 90])
+    assert 0.65 < q[0] and 0.8 < q[1] < 0.97 and q[2] < 1.1, q

@@ -5,8 +5,8 @@ checkout (no reference source is copied): run in the build container where /root
                                        (src/tests/test_kd.cpp:34-84), transcribed as data
   tests/golden/rtrans_nodes.json       raw grid-node values of data/microfacet/{beckmann,ggx}.dat (header
                                        ranges + ~100 table entries each) -- used to pin the microfacet / Fresnel code
-  tests/golden/veach_bidir_meshes.npz  the 11 meshes of testScene/veach_bidir/bidir.serialized (object space)
-  tests/golden/veach_bidir_path.xml    testScene/veach_bidir/bidir.bak with the integrator switched to `path`
+  mitsuba_amd/data/veach_bidir/meshes.npz      the 11 meshes of testScene/veach_bidir/bidir.serialized (object space)
+  mitsuba_amd/data/veach_bidir/scene_path.xml  testScene/veach_bidir/bidir.bak with the integrator switched to `path`
   tests/golden/bidir_ref_lowres.npz    testScene/veach_bidir/bidir.exr (768x576) box-downsampled to 96x72
   tests/golden/bidir_ref_cells.npz     the same image as means over 24-pixel cells, the bounding box of the banner the film
                                        stamped into it, and the lines of the log embedded in the file that say how its final
@@ -93,10 +93,12 @@ def veach():
             arrs["n%d" % i] = m["normals"]
         if m["texcoords"] is not None:
             arrs["t%d" % i] = m["texcoords"]
-    np.savez_compressed(os.path.join(GOLD, "veach_bidir_meshes.npz"), count=n, **arrs)
+    vdir = os.path.join(ROOT, "mitsuba_amd", "data", "veach_bidir")
+    os.makedirs(vdir, exist_ok=True)
+    np.savez_compressed(os.path.join(vdir, "meshes.npz"), count=n, **arrs)
     xml = open(os.path.join(T, "veach_bidir", "bidir.bak")).read()
     xml = xml.replace('<integrator type="bdpt">', '<integrator type="path">')
-    open(os.path.join(GOLD, "veach_bidir_path.xml"), "w").write(xml)
+    open(os.path.join(vdir, "scene_path.xml"), "w").write(xml)
 
 
 def read_exr_zip_half(path):
