@@ -273,6 +273,15 @@ int mtsamd_occluded(mtsamd_scene *scene, uint64_t n, const float *rays, uint8_t 
    measured with HIP events on the library's stream. */
 int mtsamd_trace_device(mtsamd_scene *scene, uint64_t n, const float *rays_device, mtsamd_hit *hits_device, double *kernel_seconds);
 int mtsamd_occluded_device(mtsamd_scene *scene, uint64_t n, const float *rays_device, uint8_t *occluded_device, double *kernel_seconds);
+/* mtsamd_trace_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+   loops, harnesses that forbid hipMalloc). No counterpart in the reference. Same query, same results; its work
+   memory (ray hand-out counters and the raw hits) is a static device array inside the library instead of buffers
+   allocated per call, so one call takes at most mtsamd_trace_device_static_max() rays (2^20; 16 MiB of device memory
+   per GPU the library runs on, held until the process ends) and fails with MTSAMD_EINVAL beyond that. The call
+   allocates and frees nothing. Every call on a GPU uses that GPU's one array: calls that overlap on the same GPU
+   (other threads, other scenes) race; calls in sequence are independent of each other. */
+int mtsamd_trace_device_static(mtsamd_scene *scene, uint64_t n, const float *rays_device, mtsamd_hit *hits_device);
+uint64_t mtsamd_trace_device_static_max(void);
 /* rayIntersect + fillIntersectionRecord (include/mitsuba/render/skdtree.h:343-428) */
 int mtsamd_intersect(mtsamd_scene *scene, uint64_t n, const float *rays, mtsamd_intersection *its);
 

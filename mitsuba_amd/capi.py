@@ -96,7 +96,8 @@ EXPORTS = ["mtsamd_last_error", "mtsamd_init", "mtsamd_scene_create", "mtsamd_sc
            "mtsamd_render", "mtsamd_render_device", "mtsamd_cancel", "mtsamd_scene_set_counting", "mtsamd_film_develop", "mtsamd_trace", "mtsamd_trace_device", "mtsamd_occluded_device",
            "mtsamd_occluded", "mtsamd_intersect", "mtsamd_bsdf_eval", "mtsamd_bsdf_pdf", "mtsamd_bsdf_sample",
            "mtsamd_sample_emitter_direct", "mtsamd_camera_rays", "mtsamd_li", "mtsamd_film_put", "mtsamd_film_develop_ldr", "mtsamd_abi_version", "mtsamd_sizeof", "mtsamd_filter_table", "mtsamd_rng_stream",
-           "mtsamd_rtrans_reduce", "mtsamd_filter_gaussian", "mtsamd_filter_box", "mtsamd_bvh_host_info", "mtsamd_bvh_max_depth"]
+           "mtsamd_rtrans_reduce", "mtsamd_filter_gaussian", "mtsamd_filter_box", "mtsamd_bvh_host_info", "mtsamd_bvh_max_depth",
+           "mtsamd_trace_device_static", "mtsamd_trace_device_static_max"]
 
 _lib = None
 ABI_VERSION = 7     # MTSAMD_ABI_VERSION of include/mtsamd.h
@@ -312,6 +313,10 @@ class Scene:
         _check(self.L.mtsamd_trace_device(self.h, C.c_uint64(n), C.c_void_p(rays_ptr), C.c_void_p(hits_ptr), C.byref(sec)))
         return sec.value
 
+    def trace_device_static(self, rays_ptr: int, n: int, hits_ptr: int):
+        """mtsamd_trace_device_static: the same query through the library's static device scratch (no allocation)."""
+        _check(self.L.mtsamd_trace_device_static(self.h, C.c_uint64(n), C.c_void_p(rays_ptr), C.c_void_p(hits_ptr)))
+
     def occluded_device(self, rays_ptr: int, n: int, out_ptr: int) -> float:
         sec = C.c_double(0)
         _check(self.L.mtsamd_occluded_device(self.h, C.c_uint64(n), C.c_void_p(rays_ptr), C.c_void_p(out_ptr), C.byref(sec)))
@@ -376,6 +381,12 @@ def bvh_host_info(positions, indices) -> BvhInfo:
     info = BvhInfo()
     _check(lib().mtsamd_bvh_host_info(_fp(pos), C.c_uint32(pos.shape[0]), idx.ctypes.data_as(_u32p), C.c_uint32(idx.shape[0]), C.byref(info)))
     return info
+
+
+def trace_device_static_max() -> int:
+    f = lib().mtsamd_trace_device_static_max
+    f.restype = C.c_uint64
+    return int(f())
 
 
 def bvh_max_depth() -> int:

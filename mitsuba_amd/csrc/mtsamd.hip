@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -59,6 +60,39 @@ template <typename T> hipError_t upload(DeviceBuffer &buf, const std::vector<T> 
 
 inline unsigned blocksFor(size_t n, unsigned bs) { return (unsigned) ((n + bs - 1) / bs); }
 
+}  // namespace
+
+// ---- static device scratch of mtsamd_trace_device_static -----------------------------------------------------------------
+// Callers that may not allocate (code under graph capture, tight serving loops) get a closest-hit query whose work
+// memory -- the ray hand-out counters and the raw (t, u, v, triangle) hits that k_hits_to_records turns into hit
+// records -- lives in this array instead of buffers from hipMalloc. Every GPU holds its own copy at its own address;
+// host code never uses the array's name as an address, only the pointer hipGetSymbolAddress returns for the device
+// that is current (g_scratchPtr, filled once per device).
+static constexpr uint64_t kStaticMaxRays = 1ull << 20;
+static constexpr size_t kStaticHeadsBytes = 768;         // 8 counters 64 bytes apart, rounded up to the array's alignment
+static constexpr size_t kStaticScratchBytes = kStaticHeadsBytes + kStaticMaxRays * 16;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+unsigned char *g_scratchPtr[kMaxDevices] = {};
+std::mutex g_scratchMutex;
+
+// The address of `scratch` on the current device (looked up once per device, with that device current).
+int staticScratch(unsigned char **out) {
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return fail(MTSAMD_EDEVICE, "device index %d beyond the %d this library keeps scratch pointers for", dev, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    if (!g_scratchPtr[dev]) {
+        void *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(MTSAMD_EDEVICE, "hipGetSymbolAddress returned a null address for the static scratch array");
+        g_scratchPtr[dev] = (unsigned char *) p;
+    }
+    *out = g_scratchPtr[dev];
+    return MTSAMD_OK;
+}
 }  // namespace
 
 struct mtsamd_scene {
@@ -143,7 +177,8 @@ extern "C" int mtsamd_init(int device) {
     if (e != hipSuccess || count == 0) return fail(MTSAMD_EDEVICE, "no HIP device available (%s)", hipGetErrorString(e));
     if (device < 0 || device >= count) return fail(MTSAMD_EINVAL, "device %d out of range (%d devices)", device, count);
     HIP_TRY(hipSetDevice(device));
-    return MTSAMD_OK;
+    unsigned char *p = nullptr;
+    return staticScratch(&p);       // the static scratch array's address on this device, looked up once
 }
 
 extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene **out) {
@@ -354,7 +389,7 @@ int checkOpts(const mtsamd_scene *s, const mtsamd_render_opts *o, mtsamd_render_
 
 // Launches the persistent traversal kernel over n rays. The hand-out counter must be zero when the kernel starts.
 template <int MODE>
-void launchTrace(mtsamd_scene *s, TraceArgs a, hipStream_t st) {
+void launchTrace(mtsamd_scene *s, TraceArgs a, hipStream_t st, uint32_t *heads = nullptr) {
     a.refillBelow = s->refillBelow; a.triShare = s->triShare; a.topNodes = s->topNodes;
     const unsigned grid = std::min(s->traceGrid, blocksFor(a.n, s->traceBlock));
     // chunk of rays a wave takes per atomic: large enough to make the counter cheap, small enough to balance the tail
@@ -363,7 +398,7 @@ void launchTrace(mtsamd_scene *s, TraceArgs a, hipStream_t st) {
     // hand-out counters: one range of rays per XCD (MTSAMD_XCD_RANGES=1: a single range)
     a.segments = s->xcdRanges;
     a.segmentLen = (uint32_t) (((uint64_t) a.n + a.segments - 1) / a.segments + 63) / 64 * 64;
-    a.fetchHeads = s->fetchHeads.as<uint32_t>() + (MODE == TRACE_CLOSEST ? 0 : kFetchHeads * kFetchHeadStride);
+    a.fetchHeads = heads ? heads : s->fetchHeads.as<uint32_t>() + (MODE == TRACE_CLOSEST ? 0 : kFetchHeads * kFetchHeadStride);
     (void) hipMemsetAsync(a.fetchHeads, 0, kFetchHeads * kFetchHeadStride * sizeof(uint32_t), st);
     const size_t lds = traceLdsBytes(s->topNodes, s->traceBlock);
     if (s->countTraversal) hipLaunchKernelGGL((k_trace<MODE, true>), dim3(grid), dim3(s->traceBlock), lds, st, s->dev, a);
@@ -717,13 +752,13 @@ int finish(hipStream_t st) {
 
 // Batch query over host-layout rays (8 floats each: origin, mint, direction, maxt) already on the device.
 template <int MODE>
-int traceBatch(mtsamd_scene *s, const void *raysDev, uint64_t n, float4 *hitsDev, uint8_t *occludedDev) {
+int traceBatch(mtsamd_scene *s, const void *raysDev, uint64_t n, float4 *hitsDev, uint8_t *occludedDev, uint32_t *heads = nullptr) {
     TraceArgs a;
     memset(&a, 0, sizeof(a));
     a.rayO = (const float4 *) raysDev; a.rayD = a.rayO + 1; a.stride = 2; a.n = (uint32_t) n;
     a.hits = hitsDev; a.occluded = occludedDev;
     a.stats = s->counters.as<unsigned long long>() + CNT64_EXT_NODES;
-    launchTrace<MODE>(s, a, s->stream);
+    launchTrace<MODE>(s, a, s->stream, heads);
     return MTSAMD_OK;
 }
 
@@ -791,6 +826,24 @@ extern "C" int mtsamd_trace_device(mtsamd_scene *s, uint64_t n, const float *ray
     hipLaunchKernelGGL(k_hits_to_records, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, (const float4 *) dH, (uint32_t) n, hitsDev);
     return finish(s->stream);
 }
+
+extern "C" int mtsamd_trace_device_static(mtsamd_scene *s, uint64_t n, const float *raysDev, mtsamd_hit *hitsDev) {
+    TRY(checkBatch(s, n));
+    if (n == 0) return MTSAMD_OK;
+    if (!raysDev || !hitsDev) return fail(MTSAMD_EINVAL, "null argument");
+    if (n > kStaticMaxRays) return fail(MTSAMD_EINVAL, "mtsamd_trace_device_static takes at most %llu rays per call (%llu given)",
+                                        (unsigned long long) kStaticMaxRays, (unsigned long long) n);
+    unsigned char *base = nullptr;
+    TRY(staticScratch(&base));
+    // the array keeps the previous call's contents: the hand-out counters are cleared by launchTrace, the raw hits
+    // of all n rays are overwritten by the traversal before k_hits_to_records reads them
+    float4 *rawHits = (float4 *) (base + kStaticHeadsBytes);
+    TRY(traceBatch<TRACE_CLOSEST>(s, raysDev, n, rawHits, nullptr, (uint32_t *) base));
+    hipLaunchKernelGGL(k_hits_to_records, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, (const float4 *) rawHits, (uint32_t) n, hitsDev);
+    return finish(s->stream);
+}
+
+extern "C" uint64_t mtsamd_trace_device_static_max(void) { return kStaticMaxRays; }
 
 extern "C" int mtsamd_occluded_device(mtsamd_scene *s, uint64_t n, const float *raysDev, uint8_t *occludedDev, double *kernelSeconds) {
     TRY(checkBatch(s, n));
