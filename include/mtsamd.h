@@ -157,6 +157,12 @@ typedef struct {
     int32_t x0, y0, x1, y1; /* pixel rectangle [x0,x1) x [y0,y1) of the crop window rendered by this call
                                (the unit a multi-GPU driver deals out); all zero = whole crop window */
     int32_t spp_per_pass;   /* samples per pixel traced together in one wavefront pass; 0 = automatic */
+    /* Interleaved tile partition (one GPU's share of the frame, the counterpart of the blocks one worker gets from
+       BlockedImageProcess, src/librender/imageproc.cpp:43-78): with band_rows = h > 0 the call renders, of the
+       rectangle, only the rows y0 + k * band_period + j, j < h, i.e. full-width tiles of h rows, every
+       (band_period / h)-th of them, in ONE wavefront pass. GPU r of n passes y0 = r * h, band_period = n * h.
+       band_rows = 0: the whole rectangle. */
+    int32_t band_rows, band_period;
 } mtsamd_render_opts;
 
 /* Counters matching the reference's statistics: "Normal rays traced" / "Shadow rays traced"
@@ -209,7 +215,7 @@ const char *mtsamd_last_error(void);
    are never reordered). A caller compiled against another version must not pass them in: compare MTSAMD_ABI_VERSION with
    mtsamd_abi_version(), and where records are mirrored by hand (FFI bindings) their sizes with mtsamd_sizeof(). No
    counterpart in the reference, whose plugins are compiled against its own headers. */
-#define MTSAMD_ABI_VERSION 7
+#define MTSAMD_ABI_VERSION 8
 enum { MTSAMD_SIZEOF_SCENE_DESC = 0, MTSAMD_SIZEOF_MATERIAL = 1, MTSAMD_SIZEOF_EMITTER = 2, MTSAMD_SIZEOF_SHAPE = 3,
        MTSAMD_SIZEOF_RENDER_OPTS = 4, MTSAMD_SIZEOF_STATS = 5, MTSAMD_SIZEOF_LDR_OPTS = 6 };
 int mtsamd_abi_version(void);
@@ -233,6 +239,15 @@ int mtsamd_scene_bvh_info(const mtsamd_scene *scene, mtsamd_bvh_info *info);
    device pointer on the current HIP device (e.g. a torch tensor that is then reduced over RCCL). */
 int mtsamd_render(mtsamd_scene *scene, const mtsamd_render_opts *opts, float *film_host, mtsamd_stats *stats);
 int mtsamd_render_device(mtsamd_scene *scene, const mtsamd_render_opts *opts, float *film_device, mtsamd_stats *stats);
+
+/* The same job over several GPUs of one node (the role of the Scheduler's workers, src/librender/integrator.cpp:95-129
+   and src/librender/renderproc.cpp:142-149): scenes[i] is the same description created on device i (mtsamd_init(i)
+   followed by mtsamd_scene_create, per device). The rectangle of opts is cut into full-width tiles of band_rows rows
+   (0 = 16); GPU i renders tiles i, i + n, i + 2n, ... on a host thread of its own, and the n films are added into
+   film_host (host memory, ACCUMULATED like mtsamd_render) in device order. stats, if not NULL, has n_scenes entries,
+   one per GPU (their `seconds` show the balance of the partition). opts->band_rows / band_period must be zero. */
+int mtsamd_render_multi(mtsamd_scene *const *scenes, int32_t n_scenes, const mtsamd_render_opts *opts, int32_t band_rows,
+                        float *film_host, mtsamd_stats *stats);
 
 /* Per-ray traversal statistics, the counterpart of rayIntersectHavranCollectStatistics
    (include/mitsuba/render/sahkdtree3.h:330-429): when enabled, renders run instrumented traversal kernels and

@@ -67,7 +67,8 @@ class SceneDesc(C.Structure):
 
 class RenderOpts(C.Structure):
     _fields_ = [("spp", C.c_int32), ("spp_total", C.c_int32), ("sample_offset", C.c_int32), ("seed", C.c_uint32),
-                ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32), ("spp_per_pass", C.c_int32)]
+                ("x0", C.c_int32), ("y0", C.c_int32), ("x1", C.c_int32), ("y1", C.c_int32), ("spp_per_pass", C.c_int32),
+                ("band_rows", C.c_int32), ("band_period", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -97,10 +98,10 @@ EXPORTS = ["mtsamd_last_error", "mtsamd_init", "mtsamd_scene_create", "mtsamd_sc
            "mtsamd_occluded", "mtsamd_intersect", "mtsamd_bsdf_eval", "mtsamd_bsdf_pdf", "mtsamd_bsdf_sample",
            "mtsamd_sample_emitter_direct", "mtsamd_camera_rays", "mtsamd_li", "mtsamd_film_put", "mtsamd_film_develop_ldr", "mtsamd_abi_version", "mtsamd_sizeof", "mtsamd_filter_table", "mtsamd_rng_stream",
            "mtsamd_rtrans_reduce", "mtsamd_filter_gaussian", "mtsamd_filter_box", "mtsamd_bvh_host_info", "mtsamd_bvh_max_depth",
-           "mtsamd_trace_device_static", "mtsamd_trace_device_static_max"]
+           "mtsamd_trace_device_static", "mtsamd_trace_device_static_max", "mtsamd_render_multi"]
 
 _lib = None
-ABI_VERSION = 7     # MTSAMD_ABI_VERSION of include/mtsamd.h
+ABI_VERSION = 8     # MTSAMD_ABI_VERSION of include/mtsamd.h
 
 
 class MtsamdError(RuntimeError):
@@ -250,10 +251,13 @@ class Scene:
         _check(self.L.mtsamd_scene_bvh_info(self.h, C.byref(info)))
         return info
 
-    def _opts(self, spp, spp_total=None, sample_offset=0, seed=1, rect=None, spp_per_pass=0):
+    def _opts(self, spp, spp_total=None, sample_offset=0, seed=1, rect=None, spp_per_pass=0, bands=None):
+        """bands = (rows per band, period in rows): render only every (period / rows)-th full-width band of the
+        rectangle, starting at its first row (one GPU's share of an interleaved tile partition)."""
         x0, y0, x1, y1 = rect if rect is not None else (0, 0, self.w, self.hgt)
+        band_rows, band_period = bands if bands is not None else (0, 0)
         return RenderOpts(spp, spp_total if spp_total is not None else sample_offset + spp, sample_offset, seed,
-                          x0, y0, x1, y1, spp_per_pass)
+                          x0, y0, x1, y1, spp_per_pass, band_rows, band_period)
 
     def render(self, spp, film=None, **kw):
         o = self._opts(spp, **kw)
@@ -372,6 +376,18 @@ class Scene:
             film = np.zeros((self.hgt, self.w, 5), np.float32)
         _check(self.L.mtsamd_film_put(self.h, C.c_uint64(pos.shape[0]), _fp(pos), _fp(value), _fp(film)))
         return film
+
+
+def render_multi(scenes, spp, film=None, band_rows=0, **kw):
+    """mtsamd_render_multi: one job over the devices the scenes were created on; returns (film, [Stats per device])."""
+    first = scenes[0]
+    o = first._opts(spp, **kw)
+    if film is None:
+        film = np.zeros((first.hgt, first.w, 5), np.float32)
+    handles = (C.c_void_p * len(scenes))(*[s.h for s in scenes])
+    stats = (Stats * len(scenes))()
+    _check(lib().mtsamd_render_multi(handles, C.c_int32(len(scenes)), C.byref(o), C.c_int32(band_rows), _fp(film), stats))
+    return film, list(stats)
 
 
 def bvh_host_info(positions, indices) -> BvhInfo:

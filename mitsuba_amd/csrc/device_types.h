@@ -114,6 +114,10 @@ struct PassParams {
     int32_t sppTotal, sampleBase;
     uint32_t seed;
     uint32_t sppMagic, wMagic;  // ceil(2^32 / spp), ceil(2^32 / w) (0 for a divisor of 1): see divideBy
+    // Interleaved bands (the share of one GPU in a tile partition): the h rows of the pass are rows
+    // y0 + (r / bandRows) * bandPeriod + r % bandRows of the frame, r = 0 .. h-1. bandRows == 0: h consecutive rows.
+    int32_t bandRows, bandPeriod;
+    uint32_t bandMagic;         // ceil(2^32 / bandRows)
 };
 
 // n / d for 32-bit n through one multiply-high: with m = ceil(2^32 / d) the product's high word is the quotient or

@@ -12,6 +12,10 @@ MTS_DEV uint64_t sampleKey(const DevScene &sc, const PassParams &pp, uint32_t sl
     s = (int) (slot - pix * (uint32_t) pp.spp);
     const uint32_t row = divideBy(pix, (uint32_t) pp.w, pp.wMagic);
     py = pp.y0 + (int) row;
+    if (pp.bandRows) {      // interleaved bands: the pass's rows are every bandPeriod-th group of bandRows frame rows
+        const uint32_t band = divideBy(row, (uint32_t) pp.bandRows, pp.bandMagic);
+        py += (int) (band * (uint32_t) (pp.bandPeriod - pp.bandRows));
+    }
     px = pp.x0 + (int) (pix - row * (uint32_t) pp.w);
     const uint64_t pixelIndex = (uint64_t) py * (uint64_t) sc.cropW + (uint64_t) px;
     return pixelIndex * (uint64_t) pp.sppTotal + (uint64_t) (pp.sampleBase + s);

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace mtsamd;
@@ -384,7 +385,16 @@ int checkOpts(const mtsamd_scene *s, const mtsamd_render_opts *o, mtsamd_render_
     if (r.spp <= 0) return fail(MTSAMD_EINVAL, "spp must be positive");
     if (r.spp_total <= 0) r.spp_total = r.sample_offset + r.spp;
     if (r.sample_offset < 0 || r.sample_offset + r.spp > r.spp_total) return fail(MTSAMD_EINVAL, "sample_offset + spp exceeds spp_total");
+    if (r.band_rows < 0 || (r.band_rows > 0 && r.band_period < r.band_rows)) return fail(MTSAMD_EINVAL, "band_period must be at least band_rows");
+    if (r.band_rows == 0) r.band_period = 0;
     return MTSAMD_OK;
+}
+
+// Rows of the rectangle [y0, y1) that belong to the interleaved bands starting at y0 (all of them without bands)
+int bandedRows(int y0, int y1, int bandRows, int bandPeriod) {
+    if (bandRows <= 0) return y1 - y0;
+    const int span = y1 - y0, full = span / bandPeriod, rest = span - full * bandPeriod;
+    return full * bandRows + std::min(rest, bandRows);
 }
 
 // Launches the persistent traversal kernel over n rays. The hand-out counter must be zero when the kernel starts.
@@ -563,19 +573,33 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
     if (liOut) {
         hipLaunchKernelGGL(k_copy_samples, dim3(blocksFor(nPaths, 256)), dim3(256), 0, st, sampleL, samplePos, (uint32_t) nPaths, liOut, liPos, liOffset);
     } else {
+        // ImageBlock::put for every sample of the pass. Interleaved bands are filtered band by band: each is a rectangle
+        // of its own whose samples lie together in the pass's buffers (launches on one stream: bands whose filter borders
+        // meet add to the film one after the other).
         const int border = (int) std::ceil(sc.filterRadius - 0.5f);
-        const int gx0 = std::max(pp.x0 - border, 0), gy0 = std::max(pp.y0 - border, 0);
-        const int gx1 = std::min(pp.x0 + pp.w + border, sc.cropW), gy1 = std::min(pp.y0 + pp.h + border, sc.cropH);
-        const size_t npx = (size_t) (gx1 - gx0) * (gy1 - gy0);
-        const int rw = kFilmTile + 2 * border;
         timer.begin(T_FILM);
-        if (rw * rw <= kFilmLdsEntries) {
-            const int chunk = std::max(1, std::min(pp.spp, kFilmLdsEntries / (rw * rw)));
-            const int tilesX = (gx1 - gx0 + kFilmTile - 1) / kFilmTile, tilesY = (gy1 - gy0 + kFilmTile - 1) / kFilmTile;
-            hipLaunchKernelGGL(k_film_tiled, dim3((unsigned) (tilesX * tilesY)), dim3(256), 0, st, sc, pp, sampleL, samplePos, filmDev,
-                               border, gx0, gy0, gx1 - gx0, gy1 - gy0, tilesX, chunk);
-        } else {    // very wide filters: the staged region would not fit in LDS
-            hipLaunchKernelGGL(k_film, dim3(blocksFor(npx, 256)), dim3(256), 0, st, sc, pp, sampleL, samplePos, filmDev);
+        const int nBands = pp.bandRows ? (pp.h + pp.bandRows - 1) / pp.bandRows : 1;
+        for (int b = 0; b < nBands; ++b) {
+            PassParams bp = pp;
+            bp.bandRows = bp.bandPeriod = 0; bp.bandMagic = 0;
+            size_t first = 0;
+            if (pp.bandRows) {
+                bp.y0 = pp.y0 + b * pp.bandPeriod;
+                bp.h = std::min(pp.bandRows, pp.h - b * pp.bandRows);
+                first = (size_t) b * pp.bandRows * pp.w * pp.spp;
+            }
+            const int gx0 = std::max(bp.x0 - border, 0), gy0 = std::max(bp.y0 - border, 0);
+            const int gx1 = std::min(bp.x0 + bp.w + border, sc.cropW), gy1 = std::min(bp.y0 + bp.h + border, sc.cropH);
+            const size_t npx = (size_t) (gx1 - gx0) * (gy1 - gy0);
+            const int rw = kFilmTile + 2 * border;
+            if (rw * rw <= kFilmLdsEntries) {
+                const int chunk = std::max(1, std::min(bp.spp, kFilmLdsEntries / (rw * rw)));
+                const int tilesX = (gx1 - gx0 + kFilmTile - 1) / kFilmTile, tilesY = (gy1 - gy0 + kFilmTile - 1) / kFilmTile;
+                hipLaunchKernelGGL(k_film_tiled, dim3((unsigned) (tilesX * tilesY)), dim3(256), 0, st, sc, bp, sampleL + first, samplePos + first, filmDev,
+                                   border, gx0, gy0, gx1 - gx0, gy1 - gy0, tilesX, chunk);
+            } else {    // very wide filters: the staged region would not fit in LDS
+                hipLaunchKernelGGL(k_film, dim3(blocksFor(npx, 256)), dim3(256), 0, st, sc, bp, sampleL + first, samplePos + first, filmDev);
+            }
         }
         timer.end(T_FILM);
     }
@@ -595,7 +619,8 @@ int renderCommon(mtsamd_scene *s, const mtsamd_render_opts *opts, float *filmDev
     if (stats) memset(stats, 0, sizeof(*stats));
     s->cancel.store(0);
     HIP_TRY(hipSetDevice(s->device));
-    const int w = o.x1 - o.x0, h = o.y1 - o.y0;
+    const int w = o.x1 - o.x0, h = bandedRows(o.y0, o.y1, o.band_rows, o.band_period);
+    if (liOutDev && o.band_rows) return fail(MTSAMD_EINVAL, "per-sample output takes a plain rectangle");
     int sppPass = o.spp_per_pass;
     if (sppPass <= 0) {
         // Paths in flight per pass: large passes keep the later, thinner bounces of the wavefront loop wide enough to
@@ -629,6 +654,7 @@ int renderCommon(mtsamd_scene *s, const mtsamd_render_opts *opts, float *filmDev
         pp.spp = std::min(sppPass, o.spp - done);
         pp.sppTotal = o.spp_total; pp.sampleBase = o.sample_offset + done; pp.seed = o.seed;
         pp.sppMagic = divisionMagic((uint32_t) pp.spp); pp.wMagic = divisionMagic((uint32_t) pp.w);
+        pp.bandRows = o.band_rows; pp.bandPeriod = o.band_period; pp.bandMagic = divisionMagic((uint32_t) std::max(1, o.band_rows));
         rc = renderPass(s, pp, filmDev, liOutDev, liPosDev, 0, stats, timer);
         if (rc != MTSAMD_OK) return rc;
     }
@@ -681,6 +707,79 @@ extern "C" int mtsamd_render(mtsamd_scene *scene, const mtsamd_render_opts *opts
     int rc = renderCommon(scene, opts, film.as<float>(), nullptr, nullptr, stats);
     if (rc != MTSAMD_OK) return rc;
     HIP_TRY(hipMemcpy(film_host, film.ptr, bytes, hipMemcpyDeviceToHost));
+    return MTSAMD_OK;
+}
+
+// One render job dealt out over several GPUs behind the ABI: scenes[i] is the same scene created on device i; GPU i
+// renders the i-th of every n full-width tiles of `band_rows` rows (interleaved, so that expensive parts of the image
+// spread over all GPUs) in passes of its own on a host thread of its own, and the per-GPU films are added into
+// film_host in device order (Film::put(block) under the reference's mutex, renderproc.cpp:142-149; the order is fixed
+// here, so the sum is reproducible).
+extern "C" int mtsamd_render_multi(mtsamd_scene *const *scenes, int32_t n_scenes, const mtsamd_render_opts *opts, int32_t band_rows,
+                                   float *film_host, mtsamd_stats *stats) {
+    if (!scenes || n_scenes <= 0 || !opts || !film_host) return fail(MTSAMD_EINVAL, "null argument");
+    if (n_scenes > 64) return fail(MTSAMD_EINVAL, "at most 64 devices");
+    for (int i = 0; i < n_scenes; ++i) {
+        if (!scenes[i]) return fail(MTSAMD_EINVAL, "null scene handle");
+        if (scenes[i]->dev.cropW != scenes[0]->dev.cropW || scenes[i]->dev.cropH != scenes[0]->dev.cropH || scenes[i]->dev.nTris != scenes[0]->dev.nTris)
+            return fail(MTSAMD_EINVAL, "scene %d is not a replica of scene 0", i);
+        for (int j = 0; j < i; ++j) if (scenes[j] == scenes[i]) return fail(MTSAMD_EINVAL, "scene handle %d given twice", i);
+    }
+    mtsamd_render_opts base;
+    int rc = checkOpts(scenes[0], opts, base);
+    if (rc != MTSAMD_OK) return rc;
+    if (base.band_rows) return fail(MTSAMD_EINVAL, "mtsamd_render_multi deals the bands out itself: leave band_rows / band_period of the options zero");
+    if (band_rows <= 0) band_rows = 16;
+    const size_t floats = (size_t) scenes[0]->dev.cropW * scenes[0]->dev.cropH * 5;
+    std::vector<std::vector<float>> films((size_t) n_scenes);
+    std::vector<int> codes((size_t) n_scenes, MTSAMD_OK);
+    std::vector<std::string> errors((size_t) n_scenes);
+    auto work = [&](int i) {
+        // every error path of this thread leaves its message in the thread's own g_error: carry it to the caller
+        auto run = [&]() -> int {
+            mtsamd_scene *sc = scenes[i];
+            mtsamd_render_opts o = base;
+            o.y0 = base.y0 + i * band_rows;
+            o.band_rows = band_rows; o.band_period = band_rows * n_scenes;
+            if (stats) memset(&stats[i], 0, sizeof(mtsamd_stats));
+            if (o.y0 >= o.y1) return MTSAMD_OK;            // fewer bands than GPUs: nothing for this one
+            HIP_TRY(hipSetDevice(sc->device));
+            DeviceBuffer film;
+            HIP_TRY(film.ensure(floats * sizeof(float)));
+            HIP_TRY(hipMemset(film.ptr, 0, floats * sizeof(float)));
+            int r = renderCommon(sc, &o, film.as<float>(), nullptr, nullptr, stats ? &stats[i] : nullptr);
+            if (r != MTSAMD_OK) return r;
+            films[(size_t) i].resize(floats);
+            HIP_TRY(hipMemcpy(films[(size_t) i].data(), film.ptr, floats * sizeof(float), hipMemcpyDeviceToHost));
+            return MTSAMD_OK;
+        };
+        try { codes[(size_t) i] = run(); } catch (const std::exception &ex) { codes[(size_t) i] = fail(MTSAMD_EDEVICE, "%s", ex.what()); }
+        if (codes[(size_t) i] != MTSAMD_OK) errors[(size_t) i] = g_error;
+    };
+    {
+        std::vector<std::thread> threads;
+        for (int i = 1; i < n_scenes; ++i) threads.emplace_back(work, i);
+        work(0);
+        for (std::thread &t : threads) t.join();
+    }
+    for (int i = 0; i < n_scenes; ++i)
+        if (codes[(size_t) i] != MTSAMD_OK) return fail(codes[(size_t) i], "device %d: %s", scenes[i]->device, errors[(size_t) i].c_str());
+    // film_host += film 0 + film 1 + ... (fixed order per element; the element ranges are summed side by side)
+    {
+        const int nt = std::max(1, std::min(n_scenes, 16));
+        std::vector<std::thread> threads;
+        auto sum = [&](int t) {
+            const size_t a = floats * (size_t) t / nt, b = floats * (size_t) (t + 1) / nt;
+            for (int i = 0; i < n_scenes; ++i) {
+                if (films[(size_t) i].empty()) continue;
+                const float *src = films[(size_t) i].data();
+                for (size_t k = a; k < b; ++k) film_host[k] += src[k];
+            }
+        };
+        for (int t = 1; t < nt; ++t) threads.emplace_back(sum, t);
+        sum(0);
+        for (std::thread &t : threads) t.join();
+    }
     return MTSAMD_OK;
 }
 

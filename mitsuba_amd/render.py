@@ -37,6 +37,29 @@ def band_schedule(width: int, height: int, world_size: int, rank: int, bands_per
     return [(0, edges[i], width, edges[i + 1]) for i in range(n) if i % world_size == rank and edges[i + 1] > edges[i]]
 
 
+def interleaved_bands(height: int, band_rows: int, world_size: int, rank: int):
+    """The tile partition the GPU path uses: full-width tiles of `band_rows` rows dealt round-robin, rank r owning tiles
+    r, r + n, r + 2n, ... -- the counterpart of the reference's blocks (src/librender/imageproc.cpp:43-78), wide
+    instead of square so that one GPU's whole share is ONE wavefront pass (mtsamd_render_opts.band_rows /
+    band_period). Returns (first row, band_rows, period) for the render call, or None when the rank owns no row."""
+    if band_rows <= 0 or world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError("bad band partition arguments")
+    y0 = rank * band_rows
+    if y0 >= height:
+        return None
+    return y0, band_rows, band_rows * world_size
+
+
+def band_rects(width: int, height: int, band_rows: int, world_size: int, rank: int) -> List[Rect]:
+    """The same partition as explicit rectangles (what a renderer without band support is given, e.g. the CPU oracle)."""
+    out = []
+    y = rank * band_rows
+    while y < height:
+        out.append((0, y, width, min(y + band_rows, height)))
+        y += band_rows * world_size
+    return out
+
+
 def render_partitioned(render_rect: Callable[[Rect], None], rects: List[Rect]) -> int:
     """Calls render_rect for every rectangle; returns the number of pixels covered."""
     px = 0

@@ -655,3 +655,132 @@ def test_veach_room_against_the_reference_held_image(gpu):
     assert 1.55 < np.median(c["lit_plain"]) < 1.85
     q = np.percentile(c["unlit"], [10, 50, 90])
     assert 0.65 < q[0] and 0.8 < q[1] < 0.97 and q[2] < 1.1, q
+
+
+def test_interleaved_band_partition_matches_the_whole_frame(gpu, pairs):
+    """One GPU's share of the tile partition (every n-th full-width band of h rows, one wavefront pass) summed over the
+    ranks equals the single render; band heights that do not divide the frame, a sub-rectangle, several passes."""
+    from mitsuba_amd import render
+    sd, g, o = pairs["small"]
+    w, h = sd.film["crop_w"], sd.film["crop_h"]
+    full, sf = g.render(5, seed=2)
+    for rows, world in ((5, 3), (16, 2), (1, 4), (7, 9)):
+        parts = np.zeros_like(full)
+        rays = 0
+        for rank in range(world):
+            b = render.interleaved_bands(h, rows, world, rank)
+            if b is None:
+                continue
+            _, st = g.render(5, film=parts, seed=2, rect=(0, b[0], w, h), bands=(b[1], b[2]), spp_per_pass=2 if rank == 1 else 0)
+            rays += st.normal_rays + st.shadow_rays
+            assert st.paths == 5 * w * sum(r[3] - r[1] for r in render.band_rects(w, h, rows, world, rank))
+        assert rays == sf.normal_rays + sf.shadow_rays, (rows, world)
+        assert np.allclose(parts, full, rtol=1e-5, atol=1e-6), (rows, world)
+    # a sub-rectangle cut into bands
+    sub, _ = g.render(3, seed=4, rect=(8, 6, 50, 41))
+    parts = np.zeros_like(sub)
+    for rank in range(2):
+        g.render(3, film=parts, seed=4, rect=(8, 6 + rank * 4, 50, 41), bands=(4, 8))
+    assert np.allclose(parts, sub, rtol=1e-5, atol=1e-6)
+    with pytest.raises(gpu.MtsamdError):
+        g.render(1, bands=(8, 4))
+    with pytest.raises(gpu.MtsamdError):
+        g.li(1, bands=(4, 8))
+
+
+def test_render_multi_deals_one_job_over_scene_replicas(gpu):
+    """mtsamd_render_multi with two replicas of the scene (both on this box's one GPU, each with a host thread, streams and
+    buffers of its own): the summed film equals the single render, the statistics come back per replica."""
+    sd = S.small_test_scene(width=96, height=80)
+    a, b, c = gpu.Scene(sd), gpu.Scene(sd), gpu.Scene(sd)
+    full, sf = a.render(6, seed=9)
+    for scenes, rows in (((a, b), 16), ((a, b, c), 7), ((b,), 0)):
+        film, stats = gpu.render_multi(list(scenes), 6, seed=9, band_rows=rows)
+        assert np.allclose(film, full, rtol=1e-5, atol=1e-6)
+        assert sum(s.normal_rays + s.shadow_rays for s in stats) == sf.normal_rays + sf.shadow_rays
+        assert sum(s.paths for s in stats) == sf.paths and all(s.paths > 0 for s in stats)
+    acc, _ = gpu.render_multi([a, b], 6, film=full.copy(), seed=9)       # accumulates like mtsamd_render
+    assert np.allclose(acc, 2 * full, rtol=1e-5, atol=1e-6)
+    with pytest.raises(gpu.MtsamdError, match="twice"):
+        gpu.render_multi([a, a], 1)
+    with pytest.raises(gpu.MtsamdError, match="replica"):
+        gpu.render_multi([a, gpu.Scene(S.small_test_scene())], 1)
+
+
+def test_4k_film_weight_and_band_partition(gpu):
+    """The 4K frame of the multi-GPU configuration (3840x2160, the 1M-triangle scene) at 1 sample per pixel: every
+    interior pixel's weight is one sample's filter mass, radiance is finite and non-negative, and the two halves of an
+    interleaved 16-row tile partition add up to the single render with the same ray counts."""
+    from mitsuba_amd import render
+    sd = S.config3(3840, 2160)
+    g = gpu.Scene(sd)
+    film, st = g.render(1, seed=1)
+    assert film.shape == (2160, 3840, 5) and np.isfinite(film).all() and film.min() >= 0
+    assert st.paths == 3840 * 2160 and st.normal_rays > st.paths and st.shadow_rays > 0
+    assert abs(film[8:-8, 8:-8, 4].mean() - 1.0) < 0.01
+    parts = np.zeros_like(film)
+    rays = paths = 0
+    for rank in range(2):
+        y0, rows, period = render.interleaved_bands(2160, 16, 2, rank)
+        _, sr = g.render(1, film=parts, seed=1, rect=(0, y0, 3840, 2160), bands=(rows, period))
+        assert sr.paths == 3840 * 16 * (68 - rank)          # 135 tiles of 16 rows: 68 and 67
+        rays += sr.normal_rays + sr.shadow_rays
+        paths += sr.paths
+    assert rays == st.normal_rays + st.shadow_rays and paths == st.paths
+    assert np.allclose(parts, film, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.timeout(900)
+def test_config5_ten_million_triangles_many_emitters_depth_16(gpu, oracle_mod):
+    """The 10M-triangle, 1 024-emitter, maxDepth-16 scene at full triangle count and a reduced image: structure and
+    film properties, closest-hit and shadow parity against the oracle's kd-tree on a bounded ray sample, emitter sampling
+    through the 1 024-entry distribution (Scene::sampleEmitterDirect, src/librender/scene.cpp:828-852;
+    DiscreteDistribution::sampleReuse, include/mitsuba/core/pmf.h:101-188), per-sample radiance with ray counts."""
+    sd = S.config5(256, 144)
+    assert sd.n_triangles > 10_000_000 and len(sd.emitters) == 1024 and sd.integrator["max_depth"] == 16
+    g, o = gpu.Scene(sd), oracle_mod.OracleScene(sd)
+    info = g.bvh_info()
+    assert info.n_triangles == sd.n_triangles and info.depth <= gpu.bvh_max_depth()
+    # (a) traversal
+    rng = np.random.default_rng(5)
+    cam = g.camera_rays(rng.uniform(0, 1, (40000, 2)) * [256, 144])
+    rays = np.concatenate([random_rays(sd, 40000), cam, surface_rays(sd, o, 40000)])
+    hg, ho = g.trace(rays), o.trace(rays)
+    mism = (hg["shape"] != ho["shape"]) | (hg["prim"] != ho["prim"])
+    hard = np.nonzero(mism & ~(hg["t"] == ho["t"]))[0]
+    assert hard.size <= 3, "%d closest-hit mismatches that are not equal-distance ties" % hard.size
+    same = ~mism
+    assert (hg["prim"] != MISS).mean() > 0.3
+    assert np.array_equal(hg["t"][same], ho["t"][same]) and np.array_equal(hg["u"][same], ho["u"][same]) and np.array_equal(hg["v"][same], ho["v"][same])
+    assert (g.occluded(rays) != o.occluded(rays)).sum() <= 3
+    # (b) emitter sampling: every one of the 1 024 emitters is chosen, probabilities and values agree
+    n = 200000
+    lo, hi = sd.positions.min(0), sd.positions.max(0)
+    ref = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    ref[:, 2] = rng.uniform(0.0, 8.0, n)                   # below the lattice of lights
+    refn = np.tile(np.float32([0, 0, 1]), (n, 1))
+    refn[::3] = 0
+    smp = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+    smp[:2048, 0] = (np.arange(2048) + 0.5) / 2048.0       # walks through the whole distribution
+    a, b = g.sample_emitter_direct(ref, refn, smp), o.sample_emitter_direct(ref, refn, smp)
+    assert np.array_equal(a[2] == 0, b[2] == 0) and (a[2] != 0).mean() > 0.9
+    for x, y in zip(a, b):
+        assert np.allclose(x, y, rtol=1e-5, atol=1e-6)
+    from scipy.spatial import cKDTree
+    centres = np.array([sd.positions[sd.indices[sd.shapes[e["shape"]]["first_triangle"]]].mean(0) for e in sd.emitters])
+    ok = a[2][:2048] != 0
+    hit_point = ref[:2048][ok] + a[0][:2048][ok] * a[1][:2048][ok, None]
+    assert np.unique(cKDTree(centres).query(hit_point)[1]).size >= 1000        # the walk reaches (nearly) every one of the 1 024 lights
+    # (c) radiance per sample at maxDepth 16
+    rect = (96, 60, 144, 84)
+    Lg, pg, sg = g.li(2, seed=3, rect=rect)
+    Lo, po_, so = o.li(2, seed=3, rect=rect)
+    assert np.array_equal(pg, po_)
+    assert abs(sg.normal_rays - so.normal_rays) <= 0.005 * so.normal_rays and abs(sg.shadow_rays - so.shadow_rays) <= 0.005 * so.shadow_rays
+    assert sg.normal_rays <= 16 * sg.paths
+    rel = np.abs(Lg[..., :3] - Lo[..., :3]).max(-1) / (np.abs(Lo[..., :3]).max(-1) + 1e-3)
+    assert np.mean(rel < 1e-3) > 0.99
+    # film properties
+    film, st = g.render(4, seed=1)
+    assert np.isfinite(film).all() and film.min() >= 0 and abs(film[8:-8, 8:-8, 4].mean() - 4.0) < 0.05
+    assert st.bounce_iterations <= 17

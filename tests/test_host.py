@@ -138,6 +138,17 @@ def test_tile_schedules_partition_the_image():
         assert (cover == 1).all()
     with pytest.raises(ValueError):
         render.tile_schedule(10, 10, 0, 1, 0)
+    # the interleaved full-width tiles of the GPU path: the rectangles and the (first row, rows, period) triple agree
+    for w, h, rows, ws in ((3840, 2160, 16, 8), (64, 48, 5, 3), (64, 5, 4, 4), (10, 100, 1, 7)):
+        cover = np.zeros((h, w), int)
+        for r in range(ws):
+            rects = render.band_rects(w, h, rows, ws, r)
+            b = render.interleaved_bands(h, rows, ws, r)
+            assert (b is None) == (not rects)
+            for x0, y0, x1, y1 in rects:
+                cover[y0:y1, x0:x1] += 1
+                assert (y0 - b[0]) % b[2] == 0 and y1 - y0 <= b[1] and (x0, x1) == (0, w)
+        assert (cover == 1).all()
 
 
 _WORKER = r'''
@@ -155,11 +166,17 @@ film = np.zeros((h, w, 5), np.float32)
 px = render.render_partitioned(lambda r: o.render(3, film=film, seed=5, rect=r, n_threads=2), render.tile_schedule(w, h, 16, world, rank))
 t = torch.from_numpy(film)
 render.reduce_film(t, world)
-npx = torch.tensor([px]); dist.all_reduce(npx)
+# the interleaved full-width tiles the multi-GPU benchmark deals out
+film2 = np.zeros((h, w, 5), np.float32)
+px2 = render.render_partitioned(lambda r: o.render(3, film=film2, seed=5, rect=r, n_threads=2), render.band_rects(w, h, 5, world, rank))
+t2 = torch.from_numpy(film2)
+render.reduce_film(t2, world)
+npx = torch.tensor([px, px2]); dist.all_reduce(npx)
 if rank == 0:
     full, _ = o.render(3, seed=5, n_threads=2)
-    assert int(npx) == w * h
+    assert npx.tolist() == [w * h, w * h]
     assert np.allclose(t.numpy(), full, rtol=1e-5, atol=1e-6), np.abs(t.numpy() - full).max()
+    assert np.allclose(t2.numpy(), full, rtol=1e-5, atol=1e-6), np.abs(t2.numpy() - full).max()
     print("DIST_OK")
 dist.destroy_process_group()
 '''
