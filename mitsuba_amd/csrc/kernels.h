@@ -50,13 +50,13 @@ __global__ void __launch_bounds__(256) k_raygen(DevScene sc, PassParams pp, Path
 #ifndef MTS_TRACE_WAVES
 #define MTS_TRACE_WAVES 5
 #endif
-template <int MODE, bool COUNT>
+//   STACK               layout of the per-lane traversal stack (StackLayout): 0 for any tree, N for trees of depth <= N + 2
+template <int MODE, bool COUNT, int STACK>
 __global__ void __attribute__((amdgpu_flat_work_group_size(64, 1024), amdgpu_waves_per_eu(MTS_TRACE_WAVES))) k_trace(DevScene sc, TraceArgs a) {
     extern __shared__ float4 traceLds[];
-    LdsFloat4 *topTree = (LdsFloat4 *) &traceLds[0];
-    LdsUint2 *stacks = (LdsUint2 *) (topTree + a.topNodes * kNodeFloat4);
-    LdsFloat4 *rayBuf = (LdsFloat4 *) (stacks + kLdsStack * blockDim.x);
-    traceLoop<MODE, COUNT>(sc, a, topTree, stacks, rayBuf, (LdsUint *) (rayBuf + 2 * blockDim.x));
+    LdsUint2 *stacks = (LdsUint2 *) &traceLds[0];
+    LdsFloat4 *rayBuf = (LdsFloat4 *) (stacks + StackLayout<STACK>::kLds * a.blockThreads);
+    traceLoop<MODE, COUNT, STACK>(sc, a, stacks, rayBuf, (LdsUint *) (rayBuf + 2 * a.blockThreads));
 }
 
 // What shading one vertex produces: the extension ray with the path state that travels with it, and the shadow ray of
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(kTailBlock) k_tail(DevScene sc, PassParams pp,
                 busy = true;
             }
         }
-        traceHeldRays<false>(sc, r, busy, ldsStack, triShare);
+        traceHeldRays<false>(sc, r, busy, ldsStack, kTailBlock, triShare);
         // shade
         ShadeOut o;
         if (active) shadeVertex<ENV, RD, MIX>(sc, pp, path, make_float4(r.hit.t, r.hit.u, r.hit.v, __uint_as_float(r.hit.tri)), sampleL, o);
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(kTailBlock) k_tail(DevScene sc, PassParams pp,
                 busy = true;
             }
         }
-        traceHeldRays<true>(sc, r, busy, ldsStack, triShare);
+        traceHeldRays<true>(sc, r, busy, ldsStack, kTailBlock, triShare);
         if (wantShadow && !busy && (o.sContrib.x != 0 || o.sContrib.y != 0 || o.sContrib.z != 0)) {
             const uint32_t slot = __float_as_uint(o.sContrib.w);
             float4 L = sampleL[slot];

@@ -115,6 +115,7 @@ struct mtsamd_scene {
     // traversal launch shape: persistent workgroups (as many as fit on the device) and the lane-refill / triangle-phase
     // thresholds of the traversal loop
     unsigned traceGrid = 0, traceBlock = 256;
+    int traceStack = 0;                   // StackLayout of the traversal kernels: 0, 8 or 10 (by the depth of the tree)
     uint32_t nodeStride = 5, triStride = 3;     // record strides in float4 units (padding buys line alignment)
     uint64_t overlapBelow = 8u << 20;     // rays (shadow + next extend) below which the two traversals run side by side
     bool roughDielectric = false;         // some material is a rough dielectric (selects the kernels that know it)
@@ -122,7 +123,7 @@ struct mtsamd_scene {
     uint32_t tailBelow = 1u << 18;        // paths below which one launch finishes the pass (0 = never)
     int shadeRounds = 16;                 // sweeps per shade workgroup: 16, or 1 when set below 2 ...
     uint32_t shadeRoundsAbove = 4u << 20; // ... for queues of at least this many paths
-    uint32_t refillBelow = 56, triShare = 16, topNodes = 73, chunkMax = 512;
+    uint32_t refillBelow = 56, triShare = 16, chunkMax = 512;
 
     ~mtsamd_scene() {
         if (stream) (void) hipStreamDestroy(stream);
@@ -289,19 +290,25 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
         if (const char *e = getenv("MTSAMD_SHADE_ROUNDS")) s->shadeRounds = atoi(e);
         if (const char *e = getenv("MTSAMD_SHADE_ROUNDS_ABOVE")) s->shadeRoundsAbove = (uint32_t) std::max(0ll, atoll(e));
         if (const char *e = getenv("MTSAMD_CHUNK_MAX")) s->chunkMax = (uint32_t) std::min(65536, std::max(64, atoi(e)));
-        if (const char *e = getenv("MTSAMD_TOP_NODES")) s->topNodes = (uint32_t) std::min(1800, std::max(0, atoi(e)));
         if (const char *e = getenv("MTSAMD_TRACE_BLOCK")) s->traceBlock = (unsigned) std::min(1024, std::max(64, atoi(e) / 64 * 64));
-        s->topNodes = std::min<uint32_t>(s->topNodes, h.bvh.nodeCount);
-        const size_t lds = traceLdsBytes(s->topNodes, s->traceBlock);
-        if (lds > (size_t) prop.sharedMemPerBlock) {
-            const void *fns[] = { (const void *) k_trace<TRACE_CLOSEST, false>, (const void *) k_trace<TRACE_CLOSEST, true>,
-                                  (const void *) k_trace<TRACE_OCCLUDED, false>, (const void *) k_trace<TRACE_OCCLUDED, true> };
+        // Traversal stack layout by the depth of the tree that was built: all of it in LDS where that leaves five
+        // workgroups per CU (8 entries: depth <= 10; 10 entries: depth <= 12), else 4 entries in LDS and the rest in scratch.
+        const int need = std::max(1, (int) h.bvh.depth - 2);
+        s->traceStack = need <= 8 ? 8 : need <= 10 ? 10 : 0;
+        if (const char *e = getenv("MTSAMD_TRACE_STACK")) { const int v = atoi(e); if (v == 0 || ((v == 8 || v == 10) && need <= v)) s->traceStack = v; }
+        const size_t lds = traceLdsBytes(s->traceBlock, s->traceStack ? s->traceStack : kLdsStack);
+        const void *fns[] = { (const void *) k_trace<TRACE_CLOSEST, false, 0>, (const void *) k_trace<TRACE_CLOSEST, true, 0>,
+                              (const void *) k_trace<TRACE_OCCLUDED, false, 0>, (const void *) k_trace<TRACE_OCCLUDED, true, 0>,
+                              (const void *) k_trace<TRACE_CLOSEST, false, 8>, (const void *) k_trace<TRACE_CLOSEST, true, 8>,
+                              (const void *) k_trace<TRACE_OCCLUDED, false, 8>, (const void *) k_trace<TRACE_OCCLUDED, true, 8>,
+                              (const void *) k_trace<TRACE_CLOSEST, false, 10>, (const void *) k_trace<TRACE_CLOSEST, true, 10>,
+                              (const void *) k_trace<TRACE_OCCLUDED, false, 10>, (const void *) k_trace<TRACE_OCCLUDED, true, 10> };
+        if (lds > (size_t) prop.sharedMemPerBlock)
             for (const void *f : fns) HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-        }
         int perCu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_trace<TRACE_CLOSEST, false>, (int) s->traceBlock, lds));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, fns[s->traceStack == 8 ? 4 : s->traceStack == 10 ? 8 : 0], (int) s->traceBlock, lds));
         s->traceGrid = (unsigned) std::max(1, perCu) * (unsigned) std::max(1, prop.multiProcessorCount);
-        if (getenv("MTSAMD_VERBOSE")) fprintf(stderr, "mtsamd: trace block %u, %d blocks/CU, %zu B LDS, top %u nodes\n", s->traceBlock, perCu, lds, s->topNodes);
+        if (getenv("MTSAMD_VERBOSE")) fprintf(stderr, "mtsamd: trace block %u, %d blocks/CU, %zu B LDS, stack layout %d (tree depth %u)\n", s->traceBlock, perCu, lds, s->traceStack, h.bvh.depth);
     }
     *out = s;
     return MTSAMD_OK;
@@ -400,7 +407,7 @@ int bandedRows(int y0, int y1, int bandRows, int bandPeriod) {
 // Launches the persistent traversal kernel over n rays. The hand-out counter must be zero when the kernel starts.
 template <int MODE>
 void launchTrace(mtsamd_scene *s, TraceArgs a, hipStream_t st, uint32_t *heads = nullptr) {
-    a.refillBelow = s->refillBelow; a.triShare = s->triShare; a.topNodes = s->topNodes;
+    a.refillBelow = s->refillBelow; a.triShare = s->triShare; a.blockThreads = s->traceBlock;
     const unsigned grid = std::min(s->traceGrid, blocksFor(a.n, s->traceBlock));
     // chunk of rays a wave takes per atomic: large enough to make the counter cheap, small enough to balance the tail
     const uint64_t waves = (uint64_t) grid * (s->traceBlock / 64);
@@ -410,9 +417,14 @@ void launchTrace(mtsamd_scene *s, TraceArgs a, hipStream_t st, uint32_t *heads =
     a.segmentLen = (uint32_t) (((uint64_t) a.n + a.segments - 1) / a.segments + 63) / 64 * 64;
     a.fetchHeads = heads ? heads : s->fetchHeads.as<uint32_t>() + (MODE == TRACE_CLOSEST ? 0 : kFetchHeads * kFetchHeadStride);
     (void) hipMemsetAsync(a.fetchHeads, 0, kFetchHeads * kFetchHeadStride * sizeof(uint32_t), st);
-    const size_t lds = traceLdsBytes(s->topNodes, s->traceBlock);
-    if (s->countTraversal) hipLaunchKernelGGL((k_trace<MODE, true>), dim3(grid), dim3(s->traceBlock), lds, st, s->dev, a);
-    else hipLaunchKernelGGL((k_trace<MODE, false>), dim3(grid), dim3(s->traceBlock), lds, st, s->dev, a);
+    const size_t lds = traceLdsBytes(s->traceBlock, s->traceStack ? s->traceStack : kLdsStack);
+#define MTS_LAUNCH_TRACE(STACK) do { \
+        if (s->countTraversal) hipLaunchKernelGGL((k_trace<MODE, true, STACK>), dim3(grid), dim3(s->traceBlock), lds, st, s->dev, a); \
+        else hipLaunchKernelGGL((k_trace<MODE, false, STACK>), dim3(grid), dim3(s->traceBlock), lds, st, s->dev, a); } while (0)
+    if (s->traceStack == 8) MTS_LAUNCH_TRACE(8);
+    else if (s->traceStack == 10) MTS_LAUNCH_TRACE(10);
+    else MTS_LAUNCH_TRACE(0);
+#undef MTS_LAUNCH_TRACE
 }
 
 // One pass: `pp.spp` samples for every pixel of the rectangle. When liOut is non-null the per-sample radiance is

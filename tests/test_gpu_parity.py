@@ -784,3 +784,21 @@ def test_config5_ten_million_triangles_many_emitters_depth_16(gpu, oracle_mod):
     film, st = g.render(4, seed=1)
     assert np.isfinite(film).all() and film.min() >= 0 and abs(film[8:-8, 8:-8, 4].mean() - 4.0) < 0.05
     assert st.bounce_iterations <= 17
+
+
+def test_traversal_stack_layouts_agree(gpu, monkeypatch):
+    """The traversal kernels keep their stack entirely in LDS when the tree is shallow enough (8 or 10 entries) and
+    otherwise 4 entries in LDS plus scratch: the same hits, shadow answers and film whichever is used."""
+    sd = S.small_test_scene()
+    rays = random_rays(sd, 80000, seed=31)
+    out = {}
+    for layout in ("8", "10", "0"):
+        monkeypatch.setenv("MTSAMD_TRACE_STACK", layout)
+        g = gpu.Scene(sd)
+        out[layout] = (g.trace(rays), g.occluded(rays), g.render(3, seed=6))
+    for layout in ("10", "0"):
+        for k in ("t", "u", "v", "shape", "prim"):
+            assert np.array_equal(out["8"][0][k], out[layout][0][k]), (layout, k)
+        assert np.array_equal(out["8"][1], out[layout][1])
+        assert np.array_equal(out["8"][2][0], out[layout][2][0])
+        assert (out["8"][2][1].normal_rays, out["8"][2][1].shadow_rays) == (out[layout][2][1].normal_rays, out[layout][2][1].shadow_rays)

@@ -4,7 +4,7 @@ set -u
 cd "$(dirname "$0")/.."
 out=gpurun_out/variants_${1:-x}.txt
 : > $out
-for lib in mitsuba_amd/libmtsamd.so variants/lib_*.so; do
+for lib in $(ls variants/*.so | sort); do
   [ -f "$lib" ] || continue
   r=$(MTSAMD_LIB=$PWD/$lib timeout -k 10 120 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline 2>gpurun_out/variants_err.txt | python3 -c "
 import sys, json
