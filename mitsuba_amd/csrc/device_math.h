@@ -14,6 +14,10 @@ static constexpr float kPi = 3.14159265358979323846f;
 static constexpr float kInvPi = 0.31830988618379067154f;
 static constexpr float kInf = __builtin_huge_valf();
 
+// exp / log as the reference computes them: in double precision, rounded to float once
+MTS_DEV float expRef(float x) { return (float) exp((double) x); }
+MTS_DEV float logRef(float x) { return (float) log((double) x); }
+
 struct V3 { float x, y, z; };
 
 MTS_DEV V3 mk(float x, float y, float z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }

@@ -74,9 +74,12 @@ MTS_DEV V3 squareToCosineHemisphere(float sx, float sy) {
     return mk(px, py, z);
 }
 
-// ---- math::erf / erfinv / hypot2 (src/libcore/math.cpp:25-86); fastexp/fastlog are exp/log rounded to float ----
+// ---- math::erf / erfinv / hypot2 (src/libcore/math.cpp:25-86). Exponentials and logarithms go through expRef / logRef:
+//      the reference's fastexp / fastlog are the double-precision functions rounded to float (math.h:185-209), and its
+//      std::exp on a float is glibc's correctly rounded expf; the device's single-precision versions differ from both in
+//      the last bit, which is enough to flip the exit test of the Newton iteration below ----
 MTS_DEV float erfinvM(float x) {
-    float w = -logf((1.0f - x) * (1.0f + x));
+    float w = -logRef((1.0f - x) * (1.0f + x));
     float p;
     if (w < 5.0f) {
         w = w - 2.5f;
@@ -109,7 +112,7 @@ MTS_DEV float erfM(float x) {
     const float sign = copysignf(1.0f, x);
     x = fabsf(x);
     const float t = 1.0f / (1.0f + p * x);
-    const float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * expf(-x * x);
+    const float y = 1.0f - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * expRef(-x * x);
     return sign * y;
 }
 
@@ -193,7 +196,7 @@ struct Microfacet {
         const float beckmannExponent = ((m.x * m.x) / (alphaU * alphaU) + (m.y * m.y) / (alphaV * alphaV)) / cosTheta2;
         float result;
         if (type == 0) {
-            result = expf(-beckmannExponent) / (kPi * alphaU * alphaV * cosTheta2 * cosTheta2);
+            result = expRef(-beckmannExponent) / (kPi * alphaU * alphaV * cosTheta2 * cosTheta2);
         } else {
             const float root = (1.0f + beckmannExponent) * cosTheta2;
             result = 1.0f / (kPi * alphaU * alphaV * root * root);
@@ -246,7 +249,7 @@ struct Microfacet {
             alphaSqr = 1.0f / (cosSc * cosSc + sinSc * sinSc);
         }
         if (type == 0) {
-            const float tanThetaMSqr = alphaSqr * -logf(1.0f - sx);
+            const float tanThetaMSqr = alphaSqr * -logRef(1.0f - sx);
             cosThetaM = 1.0f / sqrtf(1.0f + tanThetaMSqr);
             pdf_ = (1.0f - sx) / (kPi * alphaU * alphaV * cosThetaM * cosThetaM * cosThetaM);
         } else {
@@ -265,7 +268,7 @@ struct Microfacet {
         if (type == 0) {
             if (thetaI < 1e-4f) {
                 float sinPhi, cosPhi;
-                const float r = sqrtf(-logf(1.0f - sx));
+                const float r = sqrtf(-logRef(1.0f - sx));
                 sincosf(2 * kPi * sy, &sinPhi, &cosPhi);
                 slopeX = r * cosPhi; slopeY = r * sinPhi;
                 return;
@@ -276,12 +279,12 @@ struct Microfacet {
             const float sample_x = fmaxf(sx, 1e-6f);
             const float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
             float b = c - (1 + c) * powf(1 - sample_x, fit);
-            const float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * expf(-cotThetaI * cotThetaI));
+            const float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * expRef(-cotThetaI * cotThetaI));
             int it = 0;
             while (++it < 10) {
                 if (!(b >= a && b <= c)) b = 0.5f * (a + c);
                 const float invErf = erfinvM(b);
-                const float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * expf(-invErf * invErf)) - sample_x;
+                const float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * expRef(-invErf * invErf)) - sample_x;
                 const float derivative = normalization * (1 - invErf * tanThetaI);
                 if (fabsf(value) < 1e-5f) break;
                 if (value > 0) c = b; else a = b;
@@ -428,7 +431,7 @@ MTS_DEV V3 bsdfEval(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
             }
             const float factor2 = H.x / m.alphaU, factor3 = H.y / m.alphaV;
             const float exponent = -(factor2 * factor2 + factor3 * factor3) / (H.z * H.z);
-            const float specRef = factor1 * expf(exponent);
+            const float specRef = factor1 * expRef(exponent);
             if (specRef > 1e-10f) result = result + spec * specRef;
             result = result + diff * kInvPi;
             return result * wo.z;
@@ -498,7 +501,7 @@ MTS_DEV float bsdfPdf(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
             const float factor1 = (float) (1.0 / ((double) (4.0f * kPi * m.alphaU * m.alphaV * dot(H, wi)) * (c * c * c)));
             const float factor2 = H.x / m.alphaU, factor3 = H.y / m.alphaV;
             const float exponent = -(factor2 * factor2 + factor3 * factor3) / (H.z * H.z);
-            const float specProb = factor1 * expf(exponent);
+            const float specProb = factor1 * expRef(exponent);
             const float diffuseProb = cosHemiPdf(wo);
             return m.specSamplingWeight * specProb + (1 - m.specSamplingWeight) * diffuseProb;
         }
@@ -651,7 +654,7 @@ MTS_DEV V3 bsdfSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx,
                 if (sy > 0.5f) phiH += kPi;
                 const float cosPhiH = cosf(phiH);
                 const float sinPhiH = safeSqrt(1.0f - cosPhiH * cosPhiH);
-                const float thetaH = atanf(safeSqrt(-logf(sx) /
+                const float thetaH = atanf(safeSqrt(-logRef(sx) /
                     ((cosPhiH * cosPhiH) / (m.alphaU * m.alphaU) + (sinPhiH * sinPhiH) / (m.alphaV * m.alphaV))));
                 float sinTheta, cosTheta, sinPhi, cosPhi;
                 sincosf(thetaH, &sinTheta, &cosTheta);

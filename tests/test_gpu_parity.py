@@ -1,6 +1,7 @@
 """GPU parity tests: every call goes through the C ABI (libmtsamd.so) and is compared with the CPU oracle on
 the same seeded inputs. Bars: hit/miss and (shape, primitive) exact except equal-t ties, t/u/v bit-exact (the
-triangle test reproduces the reference's arithmetic), intersection fields 1e-5 relative, BSDF values 1e-4 relative,
+triangle test reproduces the reference's arithmetic), intersection fields 1e-5 relative, BSDF eval / pdf 1e-4 relative
+(all but 1 in 100 000 inputs) and BSDF samples 1e-4 relative for >= 99.9 % of the inputs,
 per-sample radiance 1e-3 relative for >= 99.5 % of the samples with identical ray counts, film 1e-4 relative."""
 import os
 import numpy as np
@@ -169,8 +170,8 @@ def test_bsdf_eval_pdf_parity(material_pair):
         wi[::11, 2] *= -1
         fg, fo = g.bsdf_eval(mi, wi, wo), o.bsdf_eval(mi, wi, wo)
         pg, po_ = g.bsdf_pdf(mi, wi, wo), o.bsdf_pdf(mi, wi, wo)
-        assert _close(fg, fo).mean() > 0.9995, ("eval", mi, (~_close(fg, fo)).sum())
-        assert _close(pg, po_).mean() > 0.9995, ("pdf", mi)
+        assert _close(fg, fo).mean() > 0.99999, ("eval", mi, (~_close(fg, fo)).sum())
+        assert _close(pg, po_).mean() > 0.99999, ("pdf", mi)
         assert np.array_equal(fg == 0, fo == 0) or (np.mean((fg == 0) != (fo == 0)) < 1e-5)
 
 
@@ -188,11 +189,12 @@ def test_bsdf_sample_parity(material_pair):
         same_type = a[4] == b[4]
         assert same_type.mean() > 0.9999, mi          # a lobe choice can flip when a sample sits on the threshold
         ok = same_type
-        # the Beckmann visible-normal sampler is an iterative root find: allow 1e-3 there, 1e-4 elsewhere
-        tol = 1e-3 if ((mats[mi]["distribution"] == 0 and mats[mi]["type"] in (1, 2, 7)) or mats[mi]["type"] == S.BSDF_MIXTURE) else 1e-4
+        # 1e-4 relative for every model, the Beckmann visible-normal sampler (an iterative root find) and the mixtures
+        # included; the few samples beyond it sit where a last-bit difference of sin / cos / atan is amplified
+        tol = 1e-4
         assert np.mean(np.all(_close(a[0][ok], b[0][ok], tol, 1e-5), axis=1)) > 0.999, ("wo", mi)
-        assert np.mean(np.all(_close(a[1][ok], b[1][ok], 10 * tol, 1e-5), axis=1)) > 0.998, ("weight", mi)
-        assert np.mean(_close(a[2][ok], b[2][ok], 10 * tol, 1e-5)) > 0.998, ("pdf", mi)
+        assert np.mean(np.all(_close(a[1][ok], b[1][ok], tol, 1e-5), axis=1)) > 0.999, ("weight", mi)
+        assert np.mean(_close(a[2][ok], b[2][ok], tol, 1e-5)) > 0.999, ("pdf", mi)
         assert np.array_equal(a[3][ok], b[3][ok])
 
 
