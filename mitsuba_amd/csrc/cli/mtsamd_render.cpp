@@ -2,13 +2,16 @@
 // renders it with the `path` integrator on one MI355X and writes a PFM or OpenEXR image, the role `mitsuba scene.xml -o out`
 // plays for the reference (src/mitsuba/mitsuba.cpp:129-397, film output src/films/hdrfilm.cpp:481-537).
 //
-//   mtsamd-render scene.xml -o out.pfm|out.exr|out.png [--spp N] [--size W H] [--seed S] [--device D] [--data-dir DIR]
-//                 [--max-depth N] [--describe] [--film out.raw] [-D name=value ...]
+//   mtsamd-render scene.xml -o out.pfm|out.exr|out.png [--spp N] [--size W H] [--seed S] [--device D | --devices D0,D1,...]
+//                 [--data-dir DIR] [--max-depth N] [--describe] [--film out.raw] [-D name=value ...]
 //
+// --devices renders one job on several GPUs of the node (mtsamd_render_multi: the scene is created once per GPU, the
+// frame is dealt out as interleaved full-width tiles, the films are summed) -- the role of `mitsuba -p` worker threads.
 // --describe prints a JSON summary of the loaded scene and exits without touching the GPU.
 // --film also stores the unnormalised (R,G,B,alpha,weight) float32 film.
 #include "scene_loader.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -19,7 +22,7 @@
 using namespace mtsamd_host;
 
 static int usage() {
-    fprintf(stderr, "usage: mtsamd-render scene.xml -o out.pfm|out.exr|out.png [--spp N] [--size W H] [--seed S] [--device D] [--data-dir DIR] "
+    fprintf(stderr, "usage: mtsamd-render scene.xml -o out.pfm|out.exr|out.png [--spp N] [--size W H] [--seed S] [--device D | --devices D0,D1,...] [--data-dir DIR] "
                     "[--max-depth N] [--describe] [--film out.raw] [-D name=value ...]\n");
     return 2;
 }
@@ -75,7 +78,8 @@ static void describe(const LoadedScene &s) {
 int main(int argc, char **argv) {
     std::string scenePath, outPath, filmPath;
     LoadOptions opts;
-    int spp = 0, device = 0;
+    int spp = 0;
+    std::vector<int> devices(1, 0);
     unsigned seed = 1;
     bool describeOnly = false;
     for (int i = 1; i < argc; ++i) {
@@ -88,7 +92,20 @@ int main(int argc, char **argv) {
         else if (a == "--spp") spp = atoi(next("--spp"));
         else if (a == "--size") { opts.width = atoi(next("--size")); opts.height = atoi(next("--size")); }
         else if (a == "--seed") seed = (unsigned) strtoul(next("--seed"), nullptr, 10);
-        else if (a == "--device") device = atoi(next("--device"));
+        else if (a == "--device") devices.assign(1, atoi(next("--device")));
+        else if (a == "--devices") {
+            devices.clear();
+            const std::string list = next("--devices");
+            for (size_t p = 0; p < list.size();) {
+                const size_t q = list.find(',', p);
+                const std::string tok = list.substr(p, q == std::string::npos ? std::string::npos : q - p);
+                if (tok.empty() || tok.find_first_not_of("0123456789") != std::string::npos) { fprintf(stderr, "--devices expects a comma-separated list of device numbers\n"); return usage(); }
+                devices.push_back(atoi(tok.c_str()));
+                if (q == std::string::npos) break;
+                p = q + 1;
+            }
+            if (devices.empty()) return usage();
+        }
         else if (a == "--data-dir") opts.dataDir = next("--data-dir");
         else if (a == "--max-depth") opts.maxDepth = atoi(next("--max-depth"));
         else if (a == "--film") filmPath = next("--film");
@@ -116,10 +133,14 @@ int main(int argc, char **argv) {
         fprintf(stderr, "mtsamd-render: built against version %d of mtsamd.h, libmtsamd implements version %d\n", MTSAMD_ABI_VERSION, mtsamd_abi_version());
         return 1;
     }
-    if (mtsamd_init(device) != MTSAMD_OK) { fprintf(stderr, "mtsamd-render: %s\n", mtsamd_last_error()); return 1; }
     const mtsamd_scene_desc desc = scene.desc();
-    mtsamd_scene *handle = nullptr;
-    if (mtsamd_scene_create(&desc, &handle) != MTSAMD_OK) { fprintf(stderr, "mtsamd-render: %s\n", mtsamd_last_error()); return 1; }
+    std::vector<mtsamd_scene *> handles;
+    for (int device : devices) {        // one replica of the scene per GPU
+        mtsamd_scene *h = nullptr;
+        if (mtsamd_init(device) != MTSAMD_OK || mtsamd_scene_create(&desc, &h) != MTSAMD_OK) { fprintf(stderr, "mtsamd-render: %s\n", mtsamd_last_error()); return 1; }
+        handles.push_back(h);
+    }
+    mtsamd_scene *handle = handles[0];
     mtsamd_bvh_info info;
     mtsamd_scene_bvh_info(handle, &info);
 
@@ -130,7 +151,17 @@ int main(int argc, char **argv) {
     ro.spp = ro.spp_total = spp;
     ro.seed = seed;
     mtsamd_stats st;
-    if (mtsamd_render(handle, &ro, film.data(), &st) != MTSAMD_OK) { fprintf(stderr, "mtsamd-render: %s\n", mtsamd_last_error()); return 1; }
+    if (handles.size() == 1) {
+        if (mtsamd_render(handle, &ro, film.data(), &st) != MTSAMD_OK) { fprintf(stderr, "mtsamd-render: %s\n", mtsamd_last_error()); return 1; }
+    } else {
+        std::vector<mtsamd_stats> per(handles.size());
+        if (mtsamd_render_multi(handles.data(), (int32_t) handles.size(), &ro, 0, film.data(), per.data()) != MTSAMD_OK) { fprintf(stderr, "mtsamd-render: %s\n", mtsamd_last_error()); return 1; }
+        memset(&st, 0, sizeof(st));
+        for (const mtsamd_stats &p : per) {     // the job's ray counts; its duration is the slowest GPU's
+            st.normal_rays += p.normal_rays; st.shadow_rays += p.shadow_rays; st.paths += p.paths;
+            st.seconds = std::max(st.seconds, p.seconds);
+        }
+    }
     mtsamd_film_develop(handle, film.data(), rgba.data());
     // the extension picks the container: .png -> LDRFilm's tone-mapped 8-bit image (with the scene's ldrfilm parameters, or
     // its defaults), .exr -> OpenEXR, anything else -> PFM
@@ -144,7 +175,7 @@ int main(int argc, char **argv) {
     } else {
         werr = endsWith(".exr") ? writeExr(outPath, rgba.data(), W, H, scene.hdrPixelFormat, scene.hdrHalf) : writePfm(outPath, rgba.data(), W, H);
     }
-    mtsamd_scene_destroy(handle);
+    for (mtsamd_scene *h : handles) mtsamd_scene_destroy(h);
     if (!werr.empty()) { fprintf(stderr, "mtsamd-render: %s\n", werr.c_str()); return 1; }
     if (!filmPath.empty()) {
         FILE *f = fopen(filmPath.c_str(), "wb");
@@ -154,8 +185,8 @@ int main(int argc, char **argv) {
     }
     const double rays = (double) st.normal_rays + (double) st.shadow_rays;
     printf("{\"width\": %d, \"height\": %d, \"spp\": %d, \"triangles\": %u, \"bvh_nodes\": %u, \"bvh_build_s\": %.3f, \"seconds\": %.4f, "
-           "\"normal_rays\": %llu, \"shadow_rays\": %llu, \"mrays_per_s\": %.1f, \"mpix_spp_per_s\": %.1f}\n",
+           "\"normal_rays\": %llu, \"shadow_rays\": %llu, \"mrays_per_s\": %.1f, \"mpix_spp_per_s\": %.1f, \"devices\": %zu}\n",
            W, H, spp, info.n_triangles, info.n_nodes, info.build_seconds, st.seconds, (unsigned long long) st.normal_rays,
-           (unsigned long long) st.shadow_rays, rays / st.seconds / 1e6, (double) W * H * spp / st.seconds / 1e6);
+           (unsigned long long) st.shadow_rays, rays / st.seconds / 1e6, (double) W * H * spp / st.seconds / 1e6, handles.size());
     return 0;
 }

@@ -22,6 +22,7 @@
 #include <mtsamd.h>
 #include <algorithm>
 #include <map>
+#include "../../bsdfs/ior.h"     /* lookupIOR: the named refractive indices of the BSDF plugins (src/bsdfs/ior.h:39-111) */
 
 MTS_NAMESPACE_BEGIN
 
@@ -30,8 +31,11 @@ static StatsCounter amdShadowRays("MI355X path tracer", "Shadow rays traced");
 
 class PathTracerAMD : public MonteCarloIntegrator {
 public:
-	PathTracerAMD(const Properties &props) : MonteCarloIntegrator(props), m_handle(NULL) {
+	PathTracerAMD(const Properties &props) : MonteCarloIntegrator(props) {
 		m_device = props.getInteger("device", 0);
+		/* "devices" = "0,1,2,3": render on several GPUs of the node (mtsamd_render_multi: the frame is dealt out as
+		   interleaved full-width tiles, one host thread per GPU, films summed); default: the one GPU of "device" */
+		m_deviceList = props.getString("devices", "");
 		m_seed = (uint32_t) props.getInteger("seed", 1);
 		m_refreshSamples = props.getInteger("refreshSamples", 0);
 		/* "direct" = true: MIDirectIntegrator's estimator (src/integrators/direct/direct.cpp) with its sample counts */
@@ -41,8 +45,9 @@ public:
 		m_bsdfSamples = props.getInteger("bsdfSamples", shadingSamples);
 	}
 
-	PathTracerAMD(Stream *stream, InstanceManager *manager) : MonteCarloIntegrator(stream, manager), m_handle(NULL) {
+	PathTracerAMD(Stream *stream, InstanceManager *manager) : MonteCarloIntegrator(stream, manager) {
 		m_device = stream->readInt();
+		m_deviceList = stream->readString();
 		m_seed = stream->readUInt();
 		m_refreshSamples = stream->readInt();
 		m_direct = stream->readBool();
@@ -53,6 +58,7 @@ public:
 	void serialize(Stream *stream, InstanceManager *manager) const {
 		MonteCarloIntegrator::serialize(stream, manager);
 		stream->writeInt(m_device);
+		stream->writeString(m_deviceList);
 		stream->writeUInt(m_seed);
 		stream->writeInt(m_refreshSamples);
 		stream->writeBool(m_direct);
@@ -60,7 +66,9 @@ public:
 		stream->writeInt(m_bsdfSamples);
 	}
 
-	virtual ~PathTracerAMD() { if (m_handle) mtsamd_scene_destroy(m_handle); }
+	virtual ~PathTracerAMD() {
+		for (size_t i = 0; i < m_handles.size(); ++i) mtsamd_scene_destroy(m_handles[i]);
+	}
 
 	/* The CPU path of SamplingIntegrator is not used; Li exists only to satisfy the interface. */
 	Spectrum Li(const RayDifferential &, RadianceQueryRecord &) const {
@@ -72,9 +80,7 @@ public:
 		if (mtsamd_abi_version() != MTSAMD_ABI_VERSION)
 			Log(EError, "path_amd was compiled against version %d of mtsamd.h, libmtsamd implements version %d",
 				MTSAMD_ABI_VERSION, mtsamd_abi_version());
-		if (mtsamd_init(m_device) != MTSAMD_OK)
-			Log(EError, "%s", mtsamd_last_error());
-		if (!m_handle && !upload(scene))
+		if (m_handles.empty() && !upload(scene))
 			return false;
 
 		Film *film = scene->getSensor()->getFilm();
@@ -96,14 +102,17 @@ public:
 			opts.spp_total = (int32_t) spp;
 			opts.sample_offset = offset;
 			opts.seed = m_seed;
-			mtsamd_stats st;
-			int rv = mtsamd_render(m_handle, &opts, accum->getFloat32Data(), &st);
+			std::vector<mtsamd_stats> stats(m_handles.size());
+			int rv = m_handles.size() == 1 ? mtsamd_render(m_handles[0], &opts, accum->getFloat32Data(), &stats[0])
+				: mtsamd_render_multi(&m_handles[0], (int32_t) m_handles.size(), &opts, 0, accum->getFloat32Data(), &stats[0]);
 			if (rv == MTSAMD_ECANCELLED)
 				return false;
 			if (rv != MTSAMD_OK)
 				Log(EError, "%s", mtsamd_last_error());
-			amdNormalRays += st.normal_rays;
-			amdShadowRays += st.shadow_rays;
+			for (size_t i = 0; i < stats.size(); ++i) {
+				amdNormalRays += stats[i].normal_rays;
+				amdShadowRays += stats[i].shadow_rays;
+			}
 
 			/* (R,G,B,alpha,weight) is HDRFilm's ESpectrumAlphaWeight storage when Spectrum is RGB
 			   (src/films/hdrfilm.cpp:351-356); setBitmap stores it and develop() divides by the weight. */
@@ -116,11 +125,31 @@ public:
 		return true;
 	}
 
-	void cancel() { if (m_handle) mtsamd_cancel(m_handle); }
+	void cancel() { for (size_t i = 0; i < m_handles.size(); ++i) mtsamd_cancel(m_handles[i]); }
 
 	MTS_DECLARE_CLASS()
 private:
 	static void rgb(const Spectrum &s, float out[3]) { Float r, g, b; s.toLinearRGB(r, g, b); out[0] = r; out[1] = g; out[2] = b; }
+
+	/* eta and k of `conductor` / `roughconductor` exactly as their constructors derive them (src/bsdfs/roughconductor.cpp:
+	   174-190, src/bsdfs/conductor.cpp:155-176): the `material` preset (default "Cu") is read from data/ior/<name>.eta.spd
+	   and .k.spd through the file resolver and converted to RGB unless it is "none"; explicit `eta` / `k` override the
+	   preset; extEta may be a number or a named medium. The record takes the values BEFORE the division by extEta. */
+	static void conductorConstants(const Properties &p, mtsamd_material &m) {
+		ref<FileResolver> fResolver = Thread::getThread()->getFileResolver();
+		std::string materialName = p.getString("material", "Cu");
+		Spectrum intEta, intK;
+		if (boost::to_lower_copy(materialName) == "none") {
+			intEta = Spectrum(0.0f);
+			intK = Spectrum(1.0f);
+		} else {
+			intEta.fromContinuousSpectrum(InterpolatedSpectrum(fResolver->resolve("data/ior/" + materialName + ".eta.spd")));
+			intK.fromContinuousSpectrum(InterpolatedSpectrum(fResolver->resolve("data/ior/" + materialName + ".k.spd")));
+		}
+		rgb(p.getSpectrum("eta", intEta), m.eta);
+		rgb(p.getSpectrum("k", intK), m.k);
+		m.ext_eta = lookupIOR(p, "extEta", "air");
+	}
 
 	static int distribution(const Properties &p) {
 		std::string d = boost::to_lower_copy(p.getString("distribution", "beckmann"));
@@ -147,14 +176,12 @@ private:
 			Float a = p.getFloat("alpha", 0.1f);
 			m.alpha_u = p.getFloat("alphaU", a); m.alpha_v = p.getFloat("alphaV", a);
 			rgb(p.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular_reflectance);
-			rgb(p.getSpectrum("eta", Spectrum(0.0f)), m.eta);      /* "material" presets: resolve to eta/k first */
-			rgb(p.getSpectrum("k", Spectrum(1.0f)), m.k);
-			m.ext_eta = p.getFloat("extEta", 1.000277f);
+			conductorConstants(p, m);
 		} else if (type == "roughplastic") {
 			m.type = MTSAMD_BSDF_ROUGHPLASTIC;
 			m.distribution = distribution(p);
 			m.alpha_u = m.alpha_v = p.getFloat("alpha", 0.1f);
-			m.int_ior = p.getFloat("intIOR", 1.49f); m.ext_ior = p.getFloat("extIOR", 1.000277f);
+			m.int_ior = lookupIOR(p, "intIOR", "polypropylene"); m.ext_ior = lookupIOR(p, "extIOR", "air");
 			m.variant = p.getBoolean("nonlinear", false) ? 1 : 0;
 			rgb(p.getSpectrum("diffuseReflectance", Spectrum(.5f)), m.diffuse_reflectance);
 			rgb(p.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular_reflectance);
@@ -172,7 +199,7 @@ private:
 			m.rtrans = &tables.back()[0]; m.rtrans_n = n;
 		} else if (type == "dielectric") {
 			m.type = MTSAMD_BSDF_DIELECTRIC;
-			m.int_ior = p.getFloat("intIOR", 1.5046f); m.ext_ior = p.getFloat("extIOR", 1.000277f);
+			m.int_ior = lookupIOR(p, "intIOR", "bk7"); m.ext_ior = lookupIOR(p, "extIOR", "air");
 			rgb(p.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular_reflectance);
 			rgb(p.getSpectrum("specularTransmittance", Spectrum(1.0f)), m.specular_transmittance);
 		} else if (type == "ward") {
@@ -187,18 +214,16 @@ private:
 			m.distribution = distribution(p);
 			Float a = p.getFloat("alpha", 0.1f);
 			m.alpha_u = p.getFloat("alphaU", a); m.alpha_v = p.getFloat("alphaV", a);
-			m.int_ior = p.getFloat("intIOR", 1.5046f); m.ext_ior = p.getFloat("extIOR", 1.000277f);
+			m.int_ior = lookupIOR(p, "intIOR", "bk7"); m.ext_ior = lookupIOR(p, "extIOR", "air");
 			rgb(p.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular_reflectance);
 			rgb(p.getSpectrum("specularTransmittance", Spectrum(1.0f)), m.specular_transmittance);
 		} else if (type == "conductor") {
 			m.type = MTSAMD_BSDF_CONDUCTOR;
 			rgb(p.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular_reflectance);
-			rgb(p.getSpectrum("eta", Spectrum(0.0f)), m.eta);      /* "material" presets: resolve to eta/k first */
-			rgb(p.getSpectrum("k", Spectrum(1.0f)), m.k);
-			m.ext_eta = p.getFloat("extEta", 1.000277f);
+			conductorConstants(p, m);
 		} else if (type == "plastic") {
 			m.type = MTSAMD_BSDF_PLASTIC;
-			m.int_ior = p.getFloat("intIOR", 1.49f); m.ext_ior = p.getFloat("extIOR", 1.000277f);
+			m.int_ior = lookupIOR(p, "intIOR", "polypropylene"); m.ext_ior = lookupIOR(p, "extIOR", "air");
 			m.variant = p.getBoolean("nonlinear", false) ? 1 : 0;
 			rgb(p.getSpectrum("diffuseReflectance", Spectrum(.5f)), m.diffuse_reflectance);
 			rgb(p.getSpectrum("specularReflectance", Spectrum(1.0f)), m.specular_reflectance);
@@ -324,21 +349,38 @@ private:
 		d.film.crop_w = film->getCropSize().x; d.film.crop_h = film->getCropSize().y;
 		const ReconstructionFilter *rf = film->getReconstructionFilter();
 		d.film.filter_radius = rf->getRadius();
-		for (int i = 0; i < 32; ++i)   /* same discretisation as ReconstructionFilter::configure (rfilter.cpp:37-55) */
-			d.film.filter_values[i] = i < 31 ? rf->evalDiscretized(rf->getRadius() * i / 31.0f) : 0.0f;
+		/* The filter's own table (ReconstructionFilter::configure, rfilter.cpp:37-55) read back entry by entry:
+		   evalDiscretized truncates x * 31 / radius to an index (rfilter.h:76-77), so it is asked at the centre of
+		   each cell, where rounding cannot land in the neighbouring entry. */
+		for (int i = 0; i < 32; ++i)
+			d.film.filter_values[i] = i < 31 ? rf->evalDiscretized(rf->getRadius() * (i + 0.5f) / 31.0f) : 0.0f;
 
 		d.integrator.max_depth = m_maxDepth; d.integrator.rr_depth = m_rrDepth;
 		d.integrator.strict_normals = m_strictNormals; d.integrator.hide_emitters = m_hideEmitters;
 		d.integrator.type = m_direct ? MTSAMD_INTEGRATOR_DIRECT : MTSAMD_INTEGRATOR_PATH;
 		d.integrator.emitter_samples = m_emitterSamples; d.integrator.bsdf_samples = m_bsdfSamples;
 
-		if (mtsamd_scene_create(&d, &m_handle) != MTSAMD_OK)
-			Log(EError, "%s", mtsamd_last_error());
+		/* one replica of the scene per GPU (Scene::initialize + kd-tree build happen once per worker node in the
+		   reference's network rendering, src/libcore/sched_remote.cpp; here once per device) */
+		std::vector<int> devices;
+		if (m_deviceList.empty()) {
+			devices.push_back(m_device);
+		} else {
+			std::vector<std::string> tokens = tokenize(m_deviceList, ", ");
+			for (size_t i = 0; i < tokens.size(); ++i) devices.push_back(atoi(tokens[i].c_str()));
+		}
+		for (size_t i = 0; i < devices.size(); ++i) {
+			mtsamd_scene *handle = NULL;
+			if (mtsamd_init(devices[i]) != MTSAMD_OK || mtsamd_scene_create(&d, &handle) != MTSAMD_OK)
+				Log(EError, "%s", mtsamd_last_error());
+			m_handles.push_back(handle);
+		}
 		return true;
 	}
 
-	mtsamd_scene *m_handle;
+	std::vector<mtsamd_scene *> m_handles;     /* one per GPU */
 	int m_device;
+	std::string m_deviceList;
 	uint32_t m_seed;
 	int m_refreshSamples;
 	bool m_direct;

@@ -423,6 +423,14 @@ def test_cli_render_matches_binding(scene_dir, tmp_path):
     film_py, st = capi.Scene(sd).render(8, seed=3)
     assert stats["normal_rays"] == st.normal_rays and stats["shadow_rays"] == st.shadow_rays
     assert np.allclose(film_cli, film_py, rtol=1e-4, atol=1e-5)
+    # the same job dealt out over two replicas of the scene (--devices; both on this box's one GPU): same film, same rays
+    raw2 = tmp_path / "film2.raw"
+    out2 = subprocess.run([CLI, str(scene_dir / "scene.xml"), "-o", str(tmp_path / "out2.pfm"), "--film", str(raw2), "--spp", "8", "--seed", "3",
+                           "--devices", "0,0"], capture_output=True, text=True, timeout=300)
+    assert out2.returncode == 0, out2.stderr
+    stats2 = json.loads(out2.stdout)
+    assert stats2["devices"] == 2 and (stats2["normal_rays"], stats2["shadow_rays"]) == (stats["normal_rays"], stats["shadow_rays"])
+    assert np.allclose(np.fromfile(str(raw2), np.float32).reshape(48, 64, 5), film_cli, rtol=1e-5, atol=1e-6)
     # the PFM holds the developed image bottom row first
     with open(pfm, "rb") as f:
         assert f.readline() == b"PF\n" and f.readline() == b"64 48\n" and f.readline() == b"-1\n"
