@@ -338,6 +338,16 @@ int mtsamd_rng_stream(uint32_t seed, uint64_t key, uint32_t n, float *out);
 int mtsamd_rtrans_reduce(const void *dat, uint64_t size, float eta, float alpha, float *out_T, uint32_t out_cap,
                          uint32_t *theta_samples, float *diffuse_ext, float *diffuse_int);
 
+/* A measured spectrum (n wavelength [nm] / value pairs, wavelengths increasing) to linear Rec. 709 RGB, as the
+   three-sample build of the reference converts the data/ior/<material>.{eta,k}.spd presets: product with the CIE 1931
+   matching functions averaged over 360-830 nm by adaptive Gauss-Lobatto quadrature in 50 nm pieces, in single precision
+   (Spectrum::fromContinuousSpectrum, src/libcore/spectrum.cpp:172-184; ContinuousSpectrum::average, :546-568;
+   InterpolatedSpectrum::eval, :688-714; GaussLobattoIntegrator, src/libcore/quad.cpp:305-409). The file variant
+   reads the text format of InterpolatedSpectrum(path) (spectrum.cpp:575-602). MTSAMD_EINVAL for an unreadable or
+   empty file and for wavelengths that do not increase. */
+int mtsamd_spd_to_rgb(const float *wavelengths, const float *values, uint32_t n, float rgb[3]);
+int mtsamd_spd_file_to_rgb(const char *path, float rgb[3]);
+
 /* The host builder of the acceleration structure alone (binned-SAH sweep, collapse to 8-wide nodes, depth bounded to
    what the traversal stack holds): fills `info`, keeps nothing, needs no device. Counterpart of building a ShapeKDTree and
    reading its statistics (src/librender/skdtree.cpp:68-110; include/mitsuba/render/gkdtree.h:1213-1263). */

@@ -98,7 +98,8 @@ EXPORTS = ["mtsamd_last_error", "mtsamd_init", "mtsamd_scene_create", "mtsamd_sc
            "mtsamd_occluded", "mtsamd_intersect", "mtsamd_bsdf_eval", "mtsamd_bsdf_pdf", "mtsamd_bsdf_sample",
            "mtsamd_sample_emitter_direct", "mtsamd_camera_rays", "mtsamd_li", "mtsamd_film_put", "mtsamd_film_develop_ldr", "mtsamd_abi_version", "mtsamd_sizeof", "mtsamd_filter_table", "mtsamd_rng_stream",
            "mtsamd_rtrans_reduce", "mtsamd_filter_gaussian", "mtsamd_filter_box", "mtsamd_bvh_host_info", "mtsamd_bvh_max_depth",
-           "mtsamd_trace_device_static", "mtsamd_trace_device_static_max", "mtsamd_render_multi"]
+           "mtsamd_trace_device_static", "mtsamd_trace_device_static_max", "mtsamd_render_multi", "mtsamd_spd_to_rgb",
+           "mtsamd_spd_file_to_rgb"]
 
 _lib = None
 ABI_VERSION = 8     # MTSAMD_ABI_VERSION of include/mtsamd.h
@@ -407,6 +408,24 @@ def trace_device_static_max() -> int:
 
 def bvh_max_depth() -> int:
     return int(lib().mtsamd_bvh_max_depth())
+
+
+def spd_to_rgb(wavelengths, values):
+    """Linear RGB of a measured spectrum (see mtsamd_spd_to_rgb); host code only, no device needed."""
+    w = np.ascontiguousarray(wavelengths, np.float32)
+    v = np.ascontiguousarray(values, np.float32)
+    if w.shape != v.shape or w.ndim != 1:
+        raise ValueError("wavelengths and values must be 1-D arrays of one length")
+    out = np.zeros(3, np.float32)
+    _check(lib().mtsamd_spd_to_rgb(_fp(w), _fp(v), C.c_uint32(len(w)), _fp(out)))
+    return out
+
+
+def spd_file_to_rgb(path):
+    out = np.zeros(3, np.float32)
+    if lib().mtsamd_spd_file_to_rgb(os.fsencode(path), _fp(out)) != 0:
+        raise MtsamdError('InterpolatedSpectrum: could not read "%s"' % path)
+    return out
 
 
 def rng_stream(seed, key, n):

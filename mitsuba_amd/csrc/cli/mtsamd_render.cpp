@@ -49,6 +49,11 @@ static void describe(const LoadedScene &s) {
     for (size_t i = 0; i < s.materials.size(); ++i) printf("%s%d", i ? ", " : "", s.materials[i].two_sided);
     printf("], \"back_materials\": [");
     for (size_t i = 0; i < s.materials.size(); ++i) printf("%s%d", i ? ", " : "", s.materials[i].back_material);
+    printf("], \"eta_k\": [");
+    for (size_t i = 0; i < s.materials.size(); ++i) {
+        const mtsamd_material &m = s.materials[i];
+        printf("%s[%.9g, %.9g, %.9g, %.9g, %.9g, %.9g]", i ? ", " : "", m.eta[0], m.eta[1], m.eta[2], m.k[0], m.k[1], m.k[2]);
+    }
     printf("], \"mixtures\": [");
     bool firstMix = true;
     for (size_t i = 0; i < s.materials.size(); ++i) {

@@ -238,6 +238,24 @@ float lookupIor(const Props &p, const char *key, const char *defName) {
     throw Fail("Unable to find an IOR value for \"" + name + "\"!");
 }
 
+// eta and k of the conductor models before the division by extEta (src/bsdfs/roughconductor.cpp:174-190,
+// src/bsdfs/conductor.cpp:153-171): explicit values win, "none" stands for (0, 1), anything else names the measured
+// spectra data/ior/<material>.{eta,k}.spd (default copper)
+void conductorConstants(const Props &p, const LoadOptions &opts, mtsamd_material &m) {
+    const std::string material = getS(p, "material", "Cu");
+    const bool none = lower(material) == "none";
+    struct { const char *key; float noneValue; float *out; } parts[2] = { { "eta", 0.0f, m.eta }, { "k", 1.0f, m.k } };
+    for (auto &part : parts) {
+        if (p.count(part.key) || none) { getRgb(p, part.key, part.noneValue, part.noneValue, part.noneValue, part.out); continue; }
+        if (opts.dataDir.empty())
+            throw Fail("conductor material preset '" + material + "' needs the measured spectra: pass the directory that holds ior/"
+                       + material + "." + part.key + ".spd");
+        const std::string path = opts.dataDir + "/ior/" + material + "." + part.key + ".spd";
+        if (mtsamd_spd_file_to_rgb(path.c_str(), part.out) != MTSAMD_OK)
+            throw Fail("InterpolatedSpectrum: could not read \"" + path + "\"");
+    }
+}
+
 // ---- BSDFs -------------------------------------------------------------------------------------------------------------------
 uint32_t addMaterial(LoadedScene &out, const mtsamd_material &m);
 
@@ -367,10 +385,7 @@ mtsamd_material makeBsdf(const Element &node, const LoadOptions &opts, LoadedSce
         m.type = MTSAMD_BSDF_ROUGHCONDUCTOR;
         m.distribution = distribution();
         m.alpha_u = (float) alphaU; m.alpha_v = (float) alphaV;
-        const std::string material = getS(p, "material", "Cu");
-        if (p.count("eta") && p.count("k")) { getRgb(p, "eta", 0, 0, 0, m.eta); getRgb(p, "k", 1, 1, 1, m.k); }
-        else if (lower(material) != "none")
-            throw Fail("roughconductor material preset '" + material + "' needs data/ior/*.spd spectral data; give RGB 'eta' and 'k' instead");
+        conductorConstants(p, opts, m);
         m.ext_eta = lookupIor(p, "extEta", "air");
         getRgb(p, "specularReflectance", 1, 1, 1, m.specular_reflectance);
     } else if (type == "roughplastic") {        // src/bsdfs/roughplastic.cpp:197-228,281-299
@@ -400,10 +415,7 @@ mtsamd_material makeBsdf(const Element &node, const LoadOptions &opts, LoadedSce
         getRgb(p, "specularTransmittance", 1, 1, 1, m.specular_transmittance);
     } else if (type == "conductor") {           // src/bsdfs/conductor.cpp:153-176
         m.type = MTSAMD_BSDF_CONDUCTOR;
-        const std::string material = getS(p, "material", "Cu");
-        if (p.count("eta") && p.count("k")) { getRgb(p, "eta", 0, 0, 0, m.eta); getRgb(p, "k", 1, 1, 1, m.k); }
-        else if (lower(material) != "none")
-            throw Fail("conductor material preset '" + material + "' needs data/ior/*.spd spectral data; give RGB 'eta' and 'k' instead");
+        conductorConstants(p, opts, m);
         m.ext_eta = lookupIor(p, "extEta", "air");
         getRgb(p, "specularReflectance", 1, 1, 1, m.specular_reflectance);
     } else if (type == "plastic") {             // src/bsdfs/plastic.cpp:146-166

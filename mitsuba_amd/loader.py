@@ -253,6 +253,29 @@ def _ior(props, key, default):
     return float(v)
 
 
+def _conductor_constants(p: Dict, data_dir: Optional[str]):
+    """eta and k of the conductor models before the division by extEta (src/bsdfs/roughconductor.cpp:174-190,
+    src/bsdfs/conductor.cpp:153-171): explicit RGB values win, "none" stands for (0, 1), anything else names the
+    measured spectra data/ior/<material>.{eta,k}.spd (default copper), converted to RGB by mtsamd_spd_file_to_rgb."""
+    material = p.get("material", "Cu")
+    out = []
+    for key, none_value in (("eta", 0.0), ("k", 1.0)):
+        if key in p:
+            out.append(p[key])
+        elif material.lower() == "none":
+            out.append((none_value,) * 3)
+        else:
+            if data_dir is None:
+                raise SceneFormatError("conductor material preset '%s' needs the measured spectra: pass the directory that "
+                                       "holds ior/%s.%s.spd" % (material, material, key))
+            from . import capi
+            try:
+                out.append(tuple(float(c) for c in capi.spd_file_to_rgb(os.path.join(data_dir, "ior", "%s.%s.spd" % (material, key)))))
+            except capi.MtsamdError as e:
+                raise SceneFormatError(str(e))
+    return out[0], out[1]
+
+
 def _make_bsdf(node, data_dir: Optional[str], add_material=None, named: Optional[Dict] = None) -> Dict:
     t = node.get("type")
     p = _props(node)
@@ -329,14 +352,7 @@ def _make_bsdf(node, data_dir: Optional[str], add_material=None, named: Optional
     elif t == "roughconductor":
         if distr in ("phong", "as"):
             raise SceneFormatError("the Phong/Ashikhmin-Shirley microfacet distribution is not supported")
-        material = p.get("material", "Cu")
-        if "eta" in p and "k" in p:
-            eta, k = p["eta"], p["k"]
-        elif material.lower() == "none":
-            eta, k = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
-        else:
-            raise SceneFormatError("roughconductor material preset '%s' needs data/ior/*.spd spectral data; give RGB "
-                                   "'eta' and 'k' instead" % material)
+        eta, k = _conductor_constants(p, data_dir)
         m = S.roughconductor(eta, k, alpha=au, alpha_v=av, distribution=distr,
                              specular_reflectance=p.get("specularReflectance", (1, 1, 1)), ext_eta=_ior(p, "extEta", "air"),
                              sample_visible=p.get("sampleVisible", True))
@@ -360,14 +376,7 @@ def _make_bsdf(node, data_dir: Optional[str], add_material=None, named: Optional
                               specular_reflectance=p.get("specularReflectance", (1, 1, 1)),
                               specular_transmittance=p.get("specularTransmittance", (1, 1, 1)), sample_visible=p.get("sampleVisible", True))
     elif t == "conductor":
-        material = p.get("material", "Cu")
-        if "eta" in p and "k" in p:
-            eta, k = p["eta"], p["k"]
-        elif material.lower() == "none":
-            eta, k = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
-        else:
-            raise SceneFormatError("conductor material preset '%s' needs data/ior/*.spd spectral data; give RGB "
-                                   "'eta' and 'k' instead" % material)
+        eta, k = _conductor_constants(p, data_dir)
         m = S.conductor(eta, k, specular_reflectance=p.get("specularReflectance", (1, 1, 1)), ext_eta=_ior(p, "extEta", "air"))
     elif t == "plastic":
         m = S.plastic(int_ior=_ior(p, "intIOR", "polypropylene"), ext_ior=_ior(p, "extIOR", "air"),

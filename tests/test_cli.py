@@ -146,6 +146,44 @@ def test_cli_smooth_bsdfs_and_twosided(scene_dir, tmp_path):
     assert sd.materials[back]["variant"] == 1 and abs(sd.materials[back]["int_ior"] - 1.6) < 1e-6
 
 
+def test_cli_conductor_material_presets(scene_dir, tmp_path):
+    """material="..." names measured spectra under <data dir>/ior/: both loaders convert them with the library's
+    mtsamd_spd_file_to_rgb, explicit eta / k override one at a time, "none" is the perfect mirror."""
+    import shutil
+    from mitsuba_amd import capi
+    shape = '<shape type="serialized"><string name="filename" value="meshes.serialized"/><integer name="shapeIndex" value="0"/>%s</shape>'
+    body = "".join(shape % b for b in (
+        '<bsdf type="conductor"/>',
+        '<bsdf type="roughconductor"><string name="material" value="Au"/><float name="alpha" value="0.2"/></bsdf>',
+        '<bsdf type="conductor"><string name="material" value="a-C"/><rgb name="k" value="0.5, 0.25, 0.125"/></bsdf>',
+        '<bsdf type="roughconductor"><string name="material" value="none"/></bsdf>'))
+    f = tmp_path / "presets.xml"
+    f.write_text(SCENE % body)
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    data = tmp_path / "data"
+    shutil.copytree(os.path.join(os.path.dirname(__file__), "golden", "ior_spd"), data / "ior")
+    d = _describe(f, "--data-dir", str(data))
+    sd, _ = loader.load_xml(str(f), data_dir=str(data))
+    mine = [list(m["eta"]) + list(m["k"]) for m in sd.materials]
+    assert np.allclose(d["eta_k"], mine, rtol=0, atol=1e-6)     # explicit values: float in one loader, double in the other
+    rgb = lambda name: list(capi.spd_file_to_rgb(str(data / "ior" / name)))
+    new = mine[-4:]
+    assert np.allclose(new[0], rgb("Cu.eta.spd") + rgb("Cu.k.spd"), atol=1e-7)
+    assert np.allclose(new[1], rgb("Au.eta.spd") + rgb("Au.k.spd"), atol=1e-7)
+    assert np.allclose(new[2], rgb("a-C.eta.spd") + [0.5, 0.25, 0.125], atol=1e-7)
+    assert new[3] == [0, 0, 0, 1, 1, 1]
+    # without the directory, or with a material it does not hold, both loaders say what is missing
+    out = subprocess.run([CLI, str(f), "--describe"], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "ior/Cu.eta.spd" in out.stderr
+    with pytest.raises(loader.SceneFormatError, match="ior/Cu.eta.spd"):
+        loader.load_xml(str(f))
+    f.write_text(SCENE % (shape % '<bsdf type="conductor"><string name="material" value="Xx"/></bsdf>'))
+    out = subprocess.run([CLI, str(f), "--describe", "--data-dir", str(data)], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "Xx.eta.spd" in out.stderr
+    with pytest.raises(loader.SceneFormatError, match="Xx.eta.spd"):
+        loader.load_xml(str(f), data_dir=str(data))
+
+
 def _write_ply(path, fmt, pos, nrm, faces):
     """Vertices with normals, a colour and a list property to skip over; an extra element before the faces."""
     head = ["ply", "format %s 1.0" % fmt, "comment test", "element vertex %d" % len(pos)]
@@ -398,7 +436,7 @@ def test_cli_rejects_unsupported_content(scene_dir, tmp_path):
                          ('<shape type="cube"><bsdf type="twosided"><bsdf type="dielectric"/></bsdf></shape>', "transmission component"),
                          ('<shape type="cube"><bsdf type="twosided"/></shape>', "nested one-sided material is required"),
                          ('<emitter type="envmap"/>', "emitter type 'envmap' is not supported"),
-                         ('<shape type="cube"><bsdf type="roughconductor"><string name="material" value="Au"/></bsdf></shape>', "spectral data")):
+                         ('<shape type="cube"><bsdf type="roughconductor"><string name="material" value="Au"/></bsdf></shape>', "needs the measured spectra")):
         f = tmp_path / "bad.xml"
         f.write_text(SCENE % body)
         (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
