@@ -9,6 +9,14 @@
 
 namespace mtsamd {
 
+// float4s from one triangle's shading record to the next (the record itself is six)
+#ifndef MTS_SHADE_TRI_STRIDE
+#define MTS_SHADE_TRI_STRIDE 6
+#endif
+constexpr int kShadeTriStride = MTS_SHADE_TRI_STRIDE;
+static_assert(kShadeTriStride >= 6, "a shading record is six float4");
+
+
 // 80-byte node. Child boxes are stored on an 8-bit grid local to the node:
 //   lo = p + qlo * 2^e,  hi = p + qhi * 2^e   (rounded outwards, so decoded boxes contain the true ones)
 // Children occupy 8 slots; slot s is visited first by rays whose direction-sign octant equals s, the other

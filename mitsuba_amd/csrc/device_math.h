@@ -14,9 +14,37 @@ static constexpr float kPi = 3.14159265358979323846f;
 static constexpr float kInvPi = 0.31830988618379067154f;
 static constexpr float kInf = __builtin_huge_valf();
 
-// exp / log as the reference computes them: in double precision, rounded to float once
-MTS_DEV float expRef(float x) { return (float) exp((double) x); }
-MTS_DEV float logRef(float x) { return (float) log((double) x); }
+// exp / log as the reference computes them: in double precision, rounded to float once. Real calls, not inlined:
+// each expansion is about a hundred double-precision instructions, and a dozen of them inside the shading kernel
+// cost it registers (spills) and instruction-cache room on paths that never run them.
+#ifndef MTS_REF_NOINLINE
+#define MTS_REF_NOINLINE 1
+#endif
+#if MTS_REF_NOINLINE
+#define MTS_REF_FN __device__ __attribute__((noinline)) inline
+#else
+#define MTS_REF_FN MTS_DEV
+#endif
+MTS_REF_FN float expRef(float x) { return (float) exp((double) x); }
+MTS_REF_FN float logRef(float x) { return (float) log((double) x); }
+// The library's trigonometric and power functions behind real calls for the same reason (sincosf alone brings a
+// large-argument reduction of several hundred instructions to every place it is inlined into).
+#ifndef MTS_MATH_NOINLINE
+#define MTS_MATH_NOINLINE 1
+#endif
+#if MTS_MATH_NOINLINE
+#define MTS_MATH_FN __device__ __attribute__((noinline)) inline
+#else
+#define MTS_MATH_FN MTS_DEV
+#endif
+MTS_MATH_FN float2 sinCosM(float x) { float s, c; sincosf(x, &s, &c); return make_float2(s, c); }
+MTS_DEV void sincosM(float x, float *s, float *c) { const float2 r = sinCosM(x); *s = r.x; *c = r.y; }
+MTS_MATH_FN float cosM(float x) { return cosf(x); }
+MTS_MATH_FN float tanM(float x) { return tanf(x); }
+MTS_MATH_FN float atanM(float x) { return atanf(x); }
+MTS_MATH_FN float atan2M(float y, float x) { return atan2f(y, x); }
+MTS_MATH_FN float acosM(float x) { return acosf(x); }
+MTS_MATH_FN float powM(float x, float y) { return powf(x, y); }
 
 struct V3 { float x, y, z; };
 

@@ -17,7 +17,7 @@ struct Isect {
 // (src/libcore/util.cpp:603-608). tri is the global triangle index; everything comes from the triangle's packed
 // shading record, so the six loads go out together.
 MTS_DEV void fillIntersection(const DevScene &sc, uint32_t tri, float u, float v, V3 rayD, Isect &its) {
-    const float4 *g = sc.shadeTris + 6 * (size_t) tri;
+    const float4 *g = sc.shadeTris + kShadeTriStride * (size_t) tri;
     const float4 g0 = g[0], g1 = g[1], g2 = g[2], h0 = g[3], h1 = g[4], h2 = g[5];
     const float bx = 1 - u - v, by = u, bz = v;
     const V3 p0 = mk(g0.x, g0.y, g0.z), p1 = mk(g1.x, g1.y, g1.z), p2 = mk(g2.x, g2.y, g2.z);
@@ -62,7 +62,7 @@ MTS_DEV void squareToUniformDiskConcentric(float sx, float sy, float &px, float 
     else if (r1 * r1 > r2 * r2) { r = r1; phi = (kPi / 4.0f) * (r2 / r1); }
     else { r = r2; phi = (kPi / 2.0f) - (r1 / r2) * (kPi / 4.0f); }
     float s, c;
-    sincosf(phi, &s, &c);
+    sincosM(phi, &s, &c);
     px = r * c; py = r * s;
 }
 
@@ -172,7 +172,7 @@ MTS_DEV float evalCubicInterp1D01(float x, const float *values, uint32_t size) {
 
 // RoughTransmittance::eval in its fully reduced state (src/bsdfs/rtrans.h:183-194,233)
 MTS_DEV float rtransEval(const DevScene &sc, const DevMaterial &m, float cosTheta) {
-    const float warped = powf(fabsf(cosTheta), 0.25f);
+    const float warped = powM(fabsf(cosTheta), 0.25f);
     if (!(cosTheta >= 0)) return 0.f;
     const float result = evalCubicInterp1D01(warped, sc.rtrans + m.rtransOffset, m.rtransN);
     return fminf(1.0f, fmaxf(0.0f, result));
@@ -240,11 +240,11 @@ struct Microfacet {
     MTS_DEV V3 sampleAll(float sx, float sy, float &pdf_) const {   // :287-395
         float cosThetaM, sinPhiM, cosPhiM, alphaSqr;
         if (isotropic()) {
-            sincosf((2.0f * kPi) * sy, &sinPhiM, &cosPhiM);
+            sincosM((2.0f * kPi) * sy, &sinPhiM, &cosPhiM);
             alphaSqr = alphaU * alphaU;
         } else {
-            const float phiM = atanf(alphaV / alphaU * tanf(kPi + 2 * kPi * sy)) + kPi * floorf(2 * sy + 0.5f);
-            sincosf(phiM, &sinPhiM, &cosPhiM);
+            const float phiM = atanM(alphaV / alphaU * tanM(kPi + 2 * kPi * sy)) + kPi * floorf(2 * sy + 0.5f);
+            sincosM(phiM, &sinPhiM, &cosPhiM);
             const float cosSc = cosPhiM / alphaU, sinSc = sinPhiM / alphaV;
             alphaSqr = 1.0f / (cosSc * cosSc + sinSc * sinSc);
         }
@@ -269,16 +269,16 @@ struct Microfacet {
             if (thetaI < 1e-4f) {
                 float sinPhi, cosPhi;
                 const float r = sqrtf(-logRef(1.0f - sx));
-                sincosf(2 * kPi * sy, &sinPhi, &cosPhi);
+                sincosM(2 * kPi * sy, &sinPhi, &cosPhi);
                 slopeX = r * cosPhi; slopeY = r * sinPhi;
                 return;
             }
-            const float tanThetaI = tanf(thetaI);
+            const float tanThetaI = tanM(thetaI);
             const float cotThetaI = 1 / tanThetaI;
             float a = -1, c = erfM(cotThetaI);
             const float sample_x = fmaxf(sx, 1e-6f);
             const float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
-            float b = c - (1 + c) * powf(1 - sample_x, fit);
+            float b = c - (1 + c) * powM(1 - sample_x, fit);
             const float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * expRef(-cotThetaI * cotThetaI));
             int it = 0;
             while (++it < 10) {
@@ -296,11 +296,11 @@ struct Microfacet {
             if (thetaI < 1e-4f) {
                 float sinPhi, cosPhi;
                 const float r = safeSqrt(sx / (1 - sx));
-                sincosf(2 * kPi * sy, &sinPhi, &cosPhi);
+                sincosM(2 * kPi * sy, &sinPhi, &cosPhi);
                 slopeX = r * cosPhi; slopeY = r * sinPhi;
                 return;
             }
-            const float tanThetaI = tanf(thetaI);
+            const float tanThetaI = tanM(thetaI);
             const float a = 1 / tanThetaI;
             const float G1 = 2.0f / (1.0f + safeSqrt(1.0f + 1.0f / (a * a)));
             float A = 2.0f * sx / G1 - 1.0f;
@@ -323,9 +323,9 @@ struct Microfacet {
     MTS_DEV V3 sampleVisibleN(V3 _wi, float sx, float sy) const {   // :421-459
         const V3 wi = normalize(mk(alphaU * _wi.x, alphaV * _wi.y, _wi.z));
         float theta = 0, phi = 0;
-        if (wi.z < 0.99999f) { theta = acosf(wi.z); phi = atan2f(wi.y, wi.x); }
+        if (wi.z < 0.99999f) { theta = acosM(wi.z); phi = atan2M(wi.y, wi.x); }
         float sinPhi, cosPhi;
-        sincosf(phi, &sinPhi, &cosPhi);
+        sincosM(phi, &sinPhi, &cosPhi);
         float slx, sly;
         sampleVisible11(theta, sx, sy, slx, sly);
         float rx = cosPhi * slx - sinPhi * sly, ry = sinPhi * slx + cosPhi * sly;
@@ -650,15 +650,15 @@ MTS_DEV V3 bsdfSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx,
             if (sx <= m.specSamplingWeight) sx /= m.specSamplingWeight;
             else { sx = (sx - m.specSamplingWeight) / (1 - m.specSamplingWeight); choseSpecular = false; }
             if (choseSpecular) {
-                float phiH = atanf(m.alphaV / m.alphaU * tanf(2.0f * kPi * sy));
+                float phiH = atanM(m.alphaV / m.alphaU * tanM(2.0f * kPi * sy));
                 if (sy > 0.5f) phiH += kPi;
-                const float cosPhiH = cosf(phiH);
+                const float cosPhiH = cosM(phiH);
                 const float sinPhiH = safeSqrt(1.0f - cosPhiH * cosPhiH);
-                const float thetaH = atanf(safeSqrt(-logRef(sx) /
+                const float thetaH = atanM(safeSqrt(-logRef(sx) /
                     ((cosPhiH * cosPhiH) / (m.alphaU * m.alphaU) + (sinPhiH * sinPhiH) / (m.alphaV * m.alphaV))));
                 float sinTheta, cosTheta, sinPhi, cosPhi;
-                sincosf(thetaH, &sinTheta, &cosTheta);
-                sincosf(phiH, &sinPhi, &cosPhi);
+                sincosM(thetaH, &sinTheta, &cosTheta);
+                sincosM(phiH, &sinPhi, &cosPhi);
                 const V3 H = mk(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
                 wo = H * (2.0f * dot(wi, H)) - wi;
                 sampledType = EGlossyReflection;
@@ -693,14 +693,40 @@ MTS_DEV bool resolveTwoSided(const DevScene &sc, uint32_t self, float wiZ, DevMa
 
 MTS_DEV V3 mirrorZ(V3 v) { return mk(v.x, v.y, -v.z); }
 
+#ifndef MTS_KARY
+#define MTS_KARY 1
+#endif
 // ---- DiscreteDistribution::sampleReuse on a device CDF (include/mitsuba/core/pmf.h:124-188) ---------------------
 MTS_DEV uint32_t cdfSampleReuse(const float *cdf, uint32_t n /* entries */, float &sample, float *pdfOut) {
-    // lower_bound over cdf[0..n]
+    // lower_bound over cdf[0..n] = the number of entries below the sample (the entries never decrease). Eight-way
+    // steps: the seven pivots of a step are independent loads, so a search costs log8 instead of log2 memory round trips.
     uint32_t lo = 0, count = n + 1;
+#if MTS_KARY
+    while (count > 8) {
+        uint32_t start = lo, end = lo + count;
+        bool open = true;       // the pivots so far are all below the sample
+#pragma unroll
+        for (uint32_t j = 1; j < 8; ++j) {
+            const uint32_t p = lo + (count * j) / 8;
+            const bool below = cdf[p] < sample;
+            if (open && below) start = p + 1;
+            if (open && !below) { end = p; open = false; }
+        }
+        lo = start; count = end - start;
+    }
+    {
+        uint32_t below = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j)
+            if (j < count && cdf[lo + j] < sample) ++below;
+        lo += below;
+    }
+#else
     while (count > 0) {
         const uint32_t step = count / 2, mid = lo + step;
         if (cdf[mid] < sample) { lo = mid + 1; count -= step + 1; } else count = step;
     }
+#endif
     int idx = (int) lo - 1;
     if (idx < 0) idx = 0;
     uint32_t index = (uint32_t) idx < n - 1 ? (uint32_t) idx : n - 1;
@@ -872,7 +898,7 @@ MTS_DEV V3 squareToUniformSphere(float sx, float sy) {
     const float z = 1.0f - 2.0f * sy;
     const float r = safeSqrt(1.0f - z * z);
     float sinPhi, cosPhi;
-    sincosf(2.0f * kPi * sx, &sinPhi, &cosPhi);
+    sincosM(2.0f * kPi * sx, &sinPhi, &cosPhi);
     return mk(r * cosPhi, r * sinPhi, z);
 }
 
@@ -954,7 +980,7 @@ MTS_DEV V3 sampleDeltaDirect(const DevScene &sc, const DevEmitter &em, V3 ref, f
             const float cosTheta = dot(ld3(de.toLocalZ), -d);
             float falloff = 1.0f;
             if (cosTheta <= de.cosCutoff) falloff = 0.0f;
-            else if (cosTheta < de.cosBeam) falloff = (de.cutoffAngle - acosf(cosTheta)) * de.invTransitionWidth;
+            else if (cosTheta < de.cosBeam) falloff = (de.cutoffAngle - acosM(cosTheta)) * de.invTransitionWidth;
             value = value * falloff;
         }
         value = value * (invDist * invDist);
@@ -979,7 +1005,7 @@ MTS_DEV V3 sampleEmitterDirect(const DevScene &sc, V3 ref, V3 refN, float sx, fl
     if (EXT && em.kind >= 2) return sampleDeltaDirect(sc, em, ref, emPdf, dRec);
     const uint32_t triIdx = cdfSampleReuse(sc.areaCdf + em.cdfOffset, em.nTris, sy, nullptr);
     const uint32_t t = em.firstTri + triIdx;
-    const float4 *g = sc.shadeTris + 6 * (size_t) t;
+    const float4 *g = sc.shadeTris + kShadeTriStride * (size_t) t;
     const float4 g0 = g[0], g1 = g[1], g2 = g[2], h0 = g[3], h1 = g[4], h2 = g[5];
     const V3 p0 = mk(g0.x, g0.y, g0.z), p1 = mk(g1.x, g1.y, g1.z), p2 = mk(g2.x, g2.y, g2.z);
     const float a = safeSqrt(1.0f - sx);                  // squareToUniformTriangle (warp.cpp:84-87)

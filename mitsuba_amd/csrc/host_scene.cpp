@@ -475,11 +475,11 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
     // ---- packed per-triangle shading records; the BVH's triangle records get the BSDF type in their spare word so
     //      that a hit carries it (bits 28..30 of the triangle word of a hit) -----------------------------------------
     if (d->n_triangles >= (1u << 27)) return "too many triangles";
-    hs.shadeTris.assign((size_t) d->n_triangles * 24, 0.0f);
+    hs.shadeTris.assign((size_t) d->n_triangles * 4 * kShadeTriStride, 0.0f);
     if (anyUV) hs.shadeUV.assign((size_t) d->n_triangles * 12, 0.0f);
     for (uint32_t t = 0; t < d->n_triangles; ++t) {
         const DevShape &sh = hs.shapes[hs.triShape[t]];
-        float *g = &hs.shadeTris[(size_t) t * 24];
+        float *g = &hs.shadeTris[(size_t) t * 4 * kShadeTriStride];
         const uint32_t w[3] = { (uint32_t) sh.material | (sh.flags << 24), (uint32_t) sh.emitter, hs.triShape[t] };
         for (int k = 0; k < 3; ++k) {
             const uint32_t vi = hs.indices[3 * (size_t) t + k];

@@ -61,6 +61,20 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 1024), amdgpu_wav
 
 // What shading one vertex produces: the extension ray with the path state that travels with it, and the shadow ray of
 // the emitter sample with the radiance it carries if unoccluded.
+// Shade workgroups: threads, wavefronts per SIMD the register budget is set for, and whether a thread's shadow ray
+// waits in workgroup memory while its BSDF is sampled
+#ifndef MTS_SHADE_WAVES
+#define MTS_SHADE_WAVES 4
+#endif
+#ifndef MTS_SHADE_BLOCK
+#define MTS_SHADE_BLOCK 256
+#endif
+static constexpr int kShadeBlock = MTS_SHADE_BLOCK;
+#ifndef MTS_SHADE_PARK
+#define MTS_SHADE_PARK 1
+#endif
+static constexpr bool kShadePark = MTS_SHADE_PARK != 0;
+
 struct ShadeOut {
     bool alive = false, wantShadow = false;
     float4 oRayO = make_float4(0, 0, 0, 0), oRayD = oRayO, oThr = oRayO, sRayO = oRayO, sRayD = oRayO, sContrib = oRayO;
@@ -94,8 +108,14 @@ struct HeldPath {
 
 // One vertex of MIPathTracer::Li (src/integrators/path/path.cpp:135-287) for the path `in` whose ray produced `hit`.
 // Radiance gathered at this vertex goes to sampleL[slot] directly; the rest comes back in `o`.
-template <bool ENV, bool RD, bool MIX, typename Path>
-MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &in, const float4 hit, float4 *sampleL, ShadeOut &o) {
+#ifndef MTS_ABLATE
+#define MTS_ABLATE 0
+#endif
+// `park` (workgroup memory, two float4 per thread of the workgroup) or nullptr: where the shadow ray's direction and
+// contribution wait while the BSDF is sampled, instead of in eight registers.
+template <bool ENV, bool RD, bool MIX, bool PARK, typename Path>
+MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &in, const float4 hit, float4 *sampleL, ShadeOut &o,
+                         float4 *park = nullptr) {
     const uint32_t triWord = __float_as_uint(hit.w);
     if (triWord != kMiss) {
         const uint32_t tri = triWord & kTriIndexMask;
@@ -116,7 +136,11 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
         float eta = th.w;
 
         Isect its;
+#if (MTS_ABLATE & 1)
+        fillIntersection(sc, tri & 4095u, hit.y, hit.z, rayD, its);
+#else
         fillIntersection(sc, tri, hit.y, hit.z, rayD, its);
+#endif
         // the material record comes in as seven 16-byte loads issued together, not field by field
         DevMaterial bsdf;
         loadMaterial(sc, its.material, bsdf);
@@ -171,6 +195,8 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             if (!(depth <= sc.maxDepth || sc.maxDepth < 0)) terminate = true;
         }
 
+        // written here, not at the end: nothing below adds to it, and L would occupy four registers until then
+        if (Lchanged) sampleL[slot] = L;
         // path.cpp:156-165
         if (!terminate && ((depth >= sc.maxDepth && sc.maxDepth > 0) ||
                            (sc.strictNormals && dot(rayD, its.geoN) * wiZ >= 0)))
@@ -182,7 +208,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             if ((bsdfType & (ETransmission | EBackSide)) == 0) refN = its.sh.n;
 
             // direct illumination sampling (path.cpp:172-200)
-            if (bsdfType & ESmooth) {
+            if ((bsdfType & ESmooth) && !(MTS_ABLATE & 2)) {
                 const float sx = rng.next1D(), sy = rng.next1D();
                 DirectRec dRec;
                 const V3 value = sampleEmitterDirect<ENV>(sc, its.p, refN, sx, sy, dRec);
@@ -190,16 +216,26 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                     V3 c = mk(0.0f);
                     const V3 wo = toLocal(its.sh, dRec.d);
                     const V3 woSide = flipped ? mirrorZ(wo) : wo;
+#if (MTS_ABLATE & 8)
+                    const V3 bsdfVal = mk(fabsf(woSide.z) * 0.3f);
+#else
                     const V3 bsdfVal = bsdfEvalAny<RD, MIX>(sc, bsdf, wiLocal, woSide);
+#endif
                     if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
                         // path.cpp:192-193: only emitters with a surface, sampled in the solid-angle measure, compete with BSDF sampling
+#if (MTS_ABLATE & 8)
+                        const float bPdf = fabsf(woSide.z) * 0.3f;
+#else
                         const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX>(sc, bsdf, wiLocal, woSide);
+#endif
                         c = throughput * value * bsdfVal * miWeight(dRec.pdf, bPdf);
                     }
                     o.wantShadow = true;
                     o.sRayO = make_float4(its.p.x, its.p.y, its.p.z, kEpsilon);
-                    o.sRayD = make_float4(dRec.d.x, dRec.d.y, dRec.d.z, dRec.dist * (1 - kShadowEpsilon));   // scene.cpp:840-841
-                    o.sContrib = make_float4(c.x, c.y, c.z, __uint_as_float(slot));
+                    const float4 sRayD = make_float4(dRec.d.x, dRec.d.y, dRec.d.z, dRec.dist * (1 - kShadowEpsilon));   // scene.cpp:840-841
+                    const float4 sContrib = make_float4(c.x, c.y, c.z, __uint_as_float(slot));
+                    if (PARK) { park[threadIdx.x] = sRayD; park[kShadeBlock + threadIdx.x] = sContrib; }
+                    else { o.sRayD = sRayD; o.sContrib = sContrib; }
                 }
             }
 
@@ -229,7 +265,6 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                 }
             }
         }
-        if (Lchanged) sampleL[slot] = L;
     } else if (ENV && sc.envEmitter >= 0) {
         // the ray left the scene and there is an environment emitter
         const uint4 misc = in.misc();
@@ -266,13 +301,6 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
 // the vertex that spawned the ray (0 for camera rays).
 // A workgroup first sorts its paths by the BSDF type the hit carries (misses last), so that a wavefront mostly
 // evaluates one BSDF model instead of stepping through all of them; whole wavefronts of misses leave at once.
-#ifndef MTS_SHADE_WAVES
-#define MTS_SHADE_WAVES 4
-#endif
-#ifndef MTS_SHADE_BLOCK
-#define MTS_SHADE_BLOCK 256
-#endif
-static constexpr int kShadeBlock = MTS_SHADE_BLOCK;
 
 // The paths [first, first + ROUNDS * kShadeBlock) of a workgroup, ordered by the BSDF type their hit carries (misses
 // last): sOrder[k] is the offset from `first` of the k-th path in that order. sCount is scratch, [key][round][wave].
@@ -292,13 +320,16 @@ MTS_DEV void sortByBsdfType(const float4 *hits, uint32_t first, uint32_t n, uint
                 const uint32_t w = __float_as_uint(hits[i].w);
                 if (w != kMiss) key[r] = w >> 28;
             }
-            rank[r] = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < (uint32_t) kKeys; ++k) {
-                const unsigned long long m = __ballot(key[r] == k);
-                if (key[r] == k) rank[r] = (uint32_t) __popcll(m & below);
-                if (lane == 0) sCount[(k * ROUNDS + r) * kWaves + wave] = (uint32_t) __popcll(m);
-            }
+            // One ballot per key bit instead of one per key: the lanes that hold key k are the intersection of the four
+            // bit masks (or their complements); every lane forms it for its own key (its rank), lane k for key k (the count).
+            static_assert(kKeys <= 16, "keys are four bits");
+            const unsigned long long b0 = __ballot(key[r] & 1u), b1 = __ballot(key[r] & 2u), b2 = __ballot(key[r] & 4u),
+                                     b3 = __ballot(key[r] & 8u);
+            auto lanesWith = [&](uint32_t k) {
+                return ((k & 1u) ? b0 : ~b0) & ((k & 2u) ? b1 : ~b1) & ((k & 4u) ? b2 : ~b2) & ((k & 8u) ? b3 : ~b3);
+            };
+            rank[r] = (uint32_t) __popcll(lanesWith(key[r]) & below);
+            if (lane < (uint32_t) kKeys) sCount[(lane * ROUNDS + r) * kWaves + wave] = (uint32_t) __popcll(lanesWith(lane));
         }
         __syncthreads();
         // exclusive prefix over the cells in key-major order
@@ -337,6 +368,7 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
     const uint32_t first = blockIdx.x * (kShadeBlock * ROUNDS);
     sortByBsdfType<ROUNDS>(hits, first, n, sCount, sOrder);
     __shared__ uint32_t sWaveShadow[kWaves], sWaveNext[kWaves], sBase[2];
+    __shared__ float4 sPark[kShadePark ? 2 * kShadeBlock : 1];
   for (int round = 0; round < ROUNDS; ++round) {
     // The thread's coordinates are made opaque per sweep so that nothing derived from them is carried in registers
     // across the shading code (the register allocator would spill it there).
@@ -344,7 +376,7 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
     asm volatile("" : "+v"(tidS));
     const uint32_t i = first + sOrder[round * kShadeBlock + tidS];
     ShadeOut o;
-    if (i < n) shadeVertex<ENV, RD, MIX>(sc, pp, QueuedPath{ in, i }, hits[i], sampleL, o);
+    if (i < n) shadeVertex<ENV, RD, MIX, kShadePark>(sc, pp, QueuedPath{ in, i }, hits[i], sampleL, o, sPark);
     const bool alive = o.alive, wantShadow = o.wantShadow;
     uint32_t tidL = threadIdx.x;
     asm volatile("" : "+v"(tidL));
@@ -370,7 +402,11 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
     __syncthreads();
     uint32_t si = sBase[0] + (uint32_t) __popcll(mShadow & below), oi = sBase[1] + (uint32_t) __popcll(mNext & below);
     for (uint32_t w = 0; w < waveL; ++w) { si += sWaveShadow[w]; oi += sWaveNext[w]; }
-    if (wantShadow) { sq.rayO[si] = o.sRayO; sq.rayD[si] = o.sRayD; sq.contrib[si] = o.sContrib; }
+    if (wantShadow) {
+        sq.rayO[si] = o.sRayO;
+        if (kShadePark) { sq.rayD[si] = sPark[tidL]; sq.contrib[si] = sPark[kShadeBlock + tidL]; }
+        else { sq.rayD[si] = o.sRayD; sq.contrib[si] = o.sContrib; }
+    }
     if (alive) {
         out.rayO[oi] = o.oRayO; out.rayD[oi] = o.oRayD; out.thr[oi] = o.oThr; out.misc[oi] = o.oMisc; out.bsdfPdf[oi] = o.oPdf;
         if (ENV) out.refCos[oi] = o.oRefCos;
@@ -416,7 +452,7 @@ __global__ void __launch_bounds__(kTailBlock) k_tail(DevScene sc, PassParams pp,
         traceHeldRays<false>(sc, r, busy, ldsStack, kTailBlock, triShare);
         // shade
         ShadeOut o;
-        if (active) shadeVertex<ENV, RD, MIX>(sc, pp, path, make_float4(r.hit.t, r.hit.u, r.hit.v, __uint_as_float(r.hit.tri)), sampleL, o);
+        if (active) shadeVertex<ENV, RD, MIX, false>(sc, pp, path, make_float4(r.hit.t, r.hit.u, r.hit.v, __uint_as_float(r.hit.tri)), sampleL, o);
         // shadow ray of the emitter sample (scene.cpp:839-843), then path.cpp:196-198
         const bool wantShadow = active && o.wantShadow;
         busy = false;
@@ -749,7 +785,7 @@ __global__ void k_tag_triangle_records(float4 *tris, uint32_t triStride, uint32_
     if (i >= n) return;
     float4 *rec = tris + (size_t) triStride * i;
     const uint32_t tri = __float_as_uint(rec[2].z);
-    const uint32_t mat = __float_as_uint(shadeTris[6 * (size_t) tri].w) & 0xffffffu;
+    const uint32_t mat = __float_as_uint(shadeTris[kShadeTriStride * (size_t) tri].w) & 0xffffffu;
     const int type = materials[mat].type;
     rec[2].w = __uint_as_float((uint32_t) (type < 7 ? type : 7) << 28);      // mixtures share the last sorting key
 }
@@ -788,7 +824,7 @@ __global__ void k_hits_to_records(DevScene sc, const float4 *hits, uint32_t n, m
     mtsamd_hit r;
     r.t = h.x; r.u = h.y; r.v = h.z;
     if (tri == kMiss) { r.shape = r.prim = kMiss; }
-    else { r.shape = __float_as_uint(sc.shadeTris[6 * (size_t) tri + 2].w); r.prim = tri - sc.shapes[r.shape].firstTri; }
+    else { r.shape = __float_as_uint(sc.shadeTris[kShadeTriStride * (size_t) tri + 2].w); r.prim = tri - sc.shapes[r.shape].firstTri; }
     out[i] = r;
 }
 
