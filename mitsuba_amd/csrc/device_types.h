@@ -61,7 +61,7 @@ struct DevScene {
     const float4 *nodes;        // 5 x float4 per wide node, nodeStride float4 apart
     const float4 *tris;         // 3 x float4 per triangle record (BVH order), triStride float4 apart
     uint32_t nodeStride, triStride;
-    // Shading record of a triangle, global order, 6 x float4: three vertex positions whose w components carry
+    // Shading record of a triangle, global order, 6 x float4 (kShadeTriStride float4 apart): three vertex positions whose w components carry
     // material | flags << 24, emitter (int, -1 = none) and shape; then three vertex normals (zero without normals).
     const float4 *shadeTris;
     // Only when some mesh has texture coordinates, 3 x float4 per triangle: (uv0, uv1), (uv2, dpdu.xy), (dpdu.z, 0, 0, 0)

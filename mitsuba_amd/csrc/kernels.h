@@ -108,9 +108,6 @@ struct HeldPath {
 
 // One vertex of MIPathTracer::Li (src/integrators/path/path.cpp:135-287) for the path `in` whose ray produced `hit`.
 // Radiance gathered at this vertex goes to sampleL[slot] directly; the rest comes back in `o`.
-#ifndef MTS_ABLATE
-#define MTS_ABLATE 0
-#endif
 // `park` (workgroup memory, two float4 per thread of the workgroup) or nullptr: where the shadow ray's direction and
 // contribution wait while the BSDF is sampled, instead of in eight registers.
 template <bool ENV, bool RD, bool MIX, bool PARK, typename Path>
@@ -136,11 +133,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
         float eta = th.w;
 
         Isect its;
-#if (MTS_ABLATE & 1)
-        fillIntersection(sc, tri & 4095u, hit.y, hit.z, rayD, its);
-#else
         fillIntersection(sc, tri, hit.y, hit.z, rayD, its);
-#endif
         // the material record comes in as seven 16-byte loads issued together, not field by field
         DevMaterial bsdf;
         loadMaterial(sc, its.material, bsdf);
@@ -208,7 +201,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             if ((bsdfType & (ETransmission | EBackSide)) == 0) refN = its.sh.n;
 
             // direct illumination sampling (path.cpp:172-200)
-            if ((bsdfType & ESmooth) && !(MTS_ABLATE & 2)) {
+            if (bsdfType & ESmooth) {
                 const float sx = rng.next1D(), sy = rng.next1D();
                 DirectRec dRec;
                 const V3 value = sampleEmitterDirect<ENV>(sc, its.p, refN, sx, sy, dRec);
@@ -216,18 +209,10 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                     V3 c = mk(0.0f);
                     const V3 wo = toLocal(its.sh, dRec.d);
                     const V3 woSide = flipped ? mirrorZ(wo) : wo;
-#if (MTS_ABLATE & 8)
-                    const V3 bsdfVal = mk(fabsf(woSide.z) * 0.3f);
-#else
                     const V3 bsdfVal = bsdfEvalAny<RD, MIX>(sc, bsdf, wiLocal, woSide);
-#endif
                     if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
                         // path.cpp:192-193: only emitters with a surface, sampled in the solid-angle measure, compete with BSDF sampling
-#if (MTS_ABLATE & 8)
-                        const float bPdf = fabsf(woSide.z) * 0.3f;
-#else
                         const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX>(sc, bsdf, wiLocal, woSide);
-#endif
                         c = throughput * value * bsdfVal * miWeight(dRec.pdf, bPdf);
                     }
                     o.wantShadow = true;
@@ -367,7 +352,9 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
     __shared__ uint32_t sOrder[kShadeBlock * ROUNDS];
     const uint32_t first = blockIdx.x * (kShadeBlock * ROUNDS);
     sortByBsdfType<ROUNDS>(hits, first, n, sCount, sOrder);
-    __shared__ uint32_t sWaveShadow[kWaves], sWaveNext[kWaves], sBase[2];
+    // reservation cells, one set per sweep parity: a sweep's cells are rewritten two sweeps later, by when every wave has
+    // passed the barriers of the sweep in between, so no barrier is needed at the end of a sweep
+    __shared__ uint32_t sWaveShadowB[2][kWaves], sWaveNextB[2][kWaves], sBaseB[2][2];
     __shared__ float4 sPark[kShadePark ? 2 * kShadeBlock : 1];
   for (int round = 0; round < ROUNDS; ++round) {
     // The thread's coordinates are made opaque per sweep so that nothing derived from them is carried in registers
@@ -381,6 +368,7 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
     uint32_t tidL = threadIdx.x;
     asm volatile("" : "+v"(tidL));
     const uint32_t laneL = tidL & 63u, waveL = tidL >> 6;
+    uint32_t *sWaveShadow = sWaveShadowB[round & 1], *sWaveNext = sWaveNextB[round & 1], *sBase = sBaseB[round & 1];
 
     // Queue slots are reserved once per workgroup (two atomics per workgroup, not per wavefront: thousands of
     // wavefronts hammering the same two counters serialise at the L2): wave totals go through LDS, thread 0 reserves
@@ -411,7 +399,6 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
         out.rayO[oi] = o.oRayO; out.rayD[oi] = o.oRayD; out.thr[oi] = o.oThr; out.misc[oi] = o.oMisc; out.bsdfPdf[oi] = o.oPdf;
         if (ENV) out.refCos[oi] = o.oRefCos;
     }
-    if (ROUNDS > 1) __syncthreads();        // the reservation cells are reused by the next sweep
   }
 }
 
