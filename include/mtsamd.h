@@ -90,7 +90,22 @@ typedef struct {
     int32_t mix_count;
     int32_t mix_material[4];
     float mix_weight[4];
+    /* Textures in place of the three constant spectra above (a <texture> child named reflectance / diffuseReflectance,
+       specularReflectance, specularTransmittance): 1-based index into mtsamd_scene_desc.textures, 0 = the constant.
+       The BSDF evaluates them at the intersection's uv like `m_reflectance->eval(bRec.its)` (e.g. diffuse.cpp:110-118). */
+    int32_t diffuse_texture, specular_texture, transmittance_texture;
 } mtsamd_material;
+
+/* Procedural 2-D textures (Texture2D, src/librender/texture.cpp:81-121: uv * (uscale, vscale) + (uoffset, voffset), then
+   src/textures/checkerboard.cpp:66-75 or src/textures/gridtexture.cpp:75-88). */
+enum { MTSAMD_TEX_CHECKERBOARD = 1, MTSAMD_TEX_GRID = 2 };
+typedef struct {
+    int32_t type;
+    float color0[3], color1[3];
+    float line_width;           /* gridtexture (default 0.01) */
+    float u_offset, v_offset, u_scale, v_scale;
+    float scale;                /* factor of a `scale` texture wrapped around it (src/textures/scale.cpp); 1 = none */
+} mtsamd_texture;
 
 /* Emitter record. type MTSAMD_EMITTER_SURFACE: an AreaLight attached to a mesh (src/emitters/area.cpp; the shape's
    `emitter` field must point back at this record) or, with shape = -1, the constant environment emitter
@@ -147,6 +162,8 @@ typedef struct {
     mtsamd_camera camera;
     mtsamd_film film;
     mtsamd_integrator integrator;
+    uint32_t n_textures;
+    const mtsamd_texture *textures;     /* what the materials' *_texture fields index (1-based); NULL if none */
 } mtsamd_scene_desc;
 
 typedef struct {
@@ -215,7 +232,7 @@ const char *mtsamd_last_error(void);
    are never reordered). A caller compiled against another version must not pass them in: compare MTSAMD_ABI_VERSION with
    mtsamd_abi_version(), and where records are mirrored by hand (FFI bindings) their sizes with mtsamd_sizeof(). No
    counterpart in the reference, whose plugins are compiled against its own headers. */
-#define MTSAMD_ABI_VERSION 8
+#define MTSAMD_ABI_VERSION 9
 enum { MTSAMD_SIZEOF_SCENE_DESC = 0, MTSAMD_SIZEOF_MATERIAL = 1, MTSAMD_SIZEOF_EMITTER = 2, MTSAMD_SIZEOF_SHAPE = 3,
        MTSAMD_SIZEOF_RENDER_OPTS = 4, MTSAMD_SIZEOF_STATS = 5, MTSAMD_SIZEOF_LDR_OPTS = 6 };
 int mtsamd_abi_version(void);
@@ -304,6 +321,8 @@ int mtsamd_intersect(mtsamd_scene *scene, uint64_t n, const float *rays, mtsamd_
    wi, wo: n*3; sample: n*2; eval -> n*3 (value includes the cosine factor); sample -> wo n*3, weight n*3,
    pdf n, eta n, sampled_type n (BSDF::EBSDFType bits). sampler_1d (n values, may be NULL = 0.5): the number a BSDF
    flagged EUsesSampler (roughdielectric) takes from the sampler itself, bRec.sampler->next1D() */
+/* Where on the surface (its.uv) the three queries below evaluate a material's textures; (0, 0) until set */
+int mtsamd_bsdf_query_uv(mtsamd_scene *scene, float u, float v);
 int mtsamd_bsdf_eval(mtsamd_scene *scene, int material, uint64_t n, const float *wi, const float *wo, float *out);
 int mtsamd_bsdf_pdf(mtsamd_scene *scene, int material, uint64_t n, const float *wi, const float *wo, float *out);
 int mtsamd_bsdf_sample(mtsamd_scene *scene, int material, uint64_t n, const float *wi, const float *sample,

@@ -29,7 +29,14 @@ class Material(C.Structure):
                 ("ext_eta", C.c_float), ("ensure_energy_conservation", C.c_int32),
                 ("rtrans", _f32p), ("rtrans_n", C.c_uint32), ("rtrans_diffuse_ext", C.c_float),
                 ("rtrans_diffuse_int", C.c_float), ("two_sided", C.c_int32), ("back_material", C.c_int32),
-                ("mix_count", C.c_int32), ("mix_material", C.c_int32 * 4), ("mix_weight", C.c_float * 4)]
+                ("mix_count", C.c_int32), ("mix_material", C.c_int32 * 4), ("mix_weight", C.c_float * 4),
+                ("diffuse_texture", C.c_int32), ("specular_texture", C.c_int32), ("transmittance_texture", C.c_int32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("type", C.c_int32), ("color0", C.c_float * 3), ("color1", C.c_float * 3), ("line_width", C.c_float),
+                ("u_offset", C.c_float), ("v_offset", C.c_float), ("u_scale", C.c_float), ("v_scale", C.c_float),
+                ("scale", C.c_float)]
 
 
 class Emitter(C.Structure):
@@ -62,7 +69,8 @@ class SceneDesc(C.Structure):
                 ("n_materials", C.c_uint32), ("n_emitters", C.c_uint32),
                 ("positions", _f32p), ("normals", _f32p), ("texcoords", _f32p), ("indices", _u32p),
                 ("shapes", C.POINTER(Shape)), ("materials", C.POINTER(Material)), ("emitters", C.POINTER(Emitter)),
-                ("camera", Camera), ("film", Film), ("integrator", Integrator)]
+                ("camera", Camera), ("film", Film), ("integrator", Integrator),
+                ("n_textures", C.c_uint32), ("textures", C.POINTER(Texture))]
 
 
 class RenderOpts(C.Structure):
@@ -99,10 +107,10 @@ EXPORTS = ["mtsamd_last_error", "mtsamd_init", "mtsamd_scene_create", "mtsamd_sc
            "mtsamd_sample_emitter_direct", "mtsamd_camera_rays", "mtsamd_li", "mtsamd_film_put", "mtsamd_film_develop_ldr", "mtsamd_abi_version", "mtsamd_sizeof", "mtsamd_filter_table", "mtsamd_rng_stream",
            "mtsamd_rtrans_reduce", "mtsamd_filter_gaussian", "mtsamd_filter_box", "mtsamd_bvh_host_info", "mtsamd_bvh_max_depth",
            "mtsamd_trace_device_static", "mtsamd_trace_device_static_max", "mtsamd_render_multi", "mtsamd_spd_to_rgb",
-           "mtsamd_spd_file_to_rgb"]
+           "mtsamd_spd_file_to_rgb", "mtsamd_bsdf_query_uv"]
 
 _lib = None
-ABI_VERSION = 8     # MTSAMD_ABI_VERSION of include/mtsamd.h
+ABI_VERSION = 9     # MTSAMD_ABI_VERSION of include/mtsamd.h
 
 
 class MtsamdError(RuntimeError):
@@ -182,6 +190,8 @@ def fill_desc(sd):
             setattr(c, k, m[k])
         for k in ("diffuse_reflectance", "specular_reflectance", "specular_transmittance", "eta", "k"):
             setattr(c, k, (C.c_float * 3)(*[float(x) for x in m[k]]))
+        for k in ("diffuse_texture", "specular_texture", "transmittance_texture"):
+            setattr(c, k, int(m.get(k, 0)))
         mix = m.get("mix", ())
         c.mix_count = len(mix)
         for j, (child, weight) in enumerate(mix[:4]):
@@ -210,6 +220,16 @@ def fill_desc(sd):
     d.film.filter_values = (C.c_float * 32)(*np.asarray(f["filter_values"], np.float32))
     for k in ("max_depth", "rr_depth", "strict_normals", "hide_emitters"):
         setattr(d.integrator, k, sd.integrator[k])
+    tex_list = getattr(sd, "textures", None) or []
+    if tex_list:
+        texs = (Texture * len(tex_list))()
+        for i, t in enumerate(tex_list):
+            texs[i].type = t["type"]
+            texs[i].color0, texs[i].color1 = (C.c_float * 3)(*t["color0"]), (C.c_float * 3)(*t["color1"])
+            for k in ("line_width", "u_offset", "v_offset", "u_scale", "v_scale", "scale"):
+                setattr(texs[i], k, t[k])
+        keep.append(texs)
+        d.n_textures, d.textures = len(tex_list), texs
     d.integrator.type = {"path": 0, "direct": 1}[sd.integrator.get("type", "path")]
     d.integrator.emitter_samples = sd.integrator.get("emitter_samples", 1)
     d.integrator.bsdf_samples = sd.integrator.get("bsdf_samples", 1)
@@ -332,6 +352,10 @@ class Scene:
         its = np.zeros(rays.shape[0], ISECT_DTYPE)
         _check(self.L.mtsamd_intersect(self.h, C.c_uint64(rays.shape[0]), _fp(rays), its.ctypes.data_as(C.c_void_p)))
         return its
+
+    def bsdf_query_uv(self, u, v):
+        """Where on the surface bsdf_eval / bsdf_pdf / bsdf_sample evaluate a material's textures."""
+        _check(self.L.mtsamd_bsdf_query_uv(self.h, C.c_float(u), C.c_float(v)))
 
     def bsdf_eval(self, mat, wi, wo):
         wi, wo = np.ascontiguousarray(wi, np.float32), np.ascontiguousarray(wo, np.float32)

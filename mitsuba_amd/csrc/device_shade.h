@@ -685,10 +685,43 @@ MTS_DEV void loadMaterial(const DevScene &sc, uint32_t index, DevMaterial &m) {
     memcpy(&m, mv, sizeof(DevMaterial));
 }
 
-MTS_DEV bool resolveTwoSided(const DevScene &sc, uint32_t self, float wiZ, DevMaterial &m) {
+// `self` becomes the index of the record that answers
+MTS_DEV bool resolveTwoSided(const DevScene &sc, uint32_t &self, float wiZ, DevMaterial &m) {
     if (!m.twoSided || !(wiZ < 0)) return false;
-    if ((uint32_t) m.backMaterial != self) loadMaterial(sc, (uint32_t) m.backMaterial, m);
+    if ((uint32_t) m.backMaterial != self) { self = (uint32_t) m.backMaterial; loadMaterial(sc, self, m); }
     return true;
+}
+
+// ---- Texture2D::eval(its) (src/librender/texture.cpp:112-121) for the two procedural textures ---------------------
+MTS_DEV V3 textureEval(const DevTexture &t, float u, float v) {
+    const float x = u * t.uScale + t.uOffset, y = v * t.vScale + t.vOffset;
+    bool second;
+    if (t.type == 1) {      // Checkerboard::eval (src/textures/checkerboard.cpp:66-75); math::modulo of a truncated int
+        int xi = (int) (x * 2) % 2, yi = (int) (y * 2) % 2;
+        if (xi < 0) xi += 2;
+        if (yi < 0) yi += 2;
+        second = (2 * xi - 1) * (2 * yi - 1) != 1;
+    } else {                // GridTexture::eval (src/textures/gridtexture.cpp:75-88)
+        float fx = x - (float) (int) floorf(x), fy = y - (float) (int) floorf(y);
+        if (fx > 0.5f) fx -= 1;
+        if (fy > 0.5f) fy -= 1;
+        second = fabsf(fx) < t.lineWidth || fabsf(fy) < t.lineWidth;
+    }
+    return second ? ld3(t.color1) : ld3(t.color0);
+}
+
+// The colours of record `index` that are textured, evaluated at the intersection's uv and written over the constants
+// in m: what m_reflectance->eval(bRec.its) etc. return inside the BSDF (e.g. src/bsdfs/diffuse.cpp:110-118)
+MTS_DEV void applyTextures(const DevScene &sc, uint32_t index, float u, float v, DevMaterial &m) {
+    if (!sc.materialTextures) return;
+    const uint4 b = sc.materialTextures[index];
+    if (b.x) { const V3 c = textureEval(sc.textures[b.x - 1], u, v); m.diffuse[0] = c.x; m.diffuse[1] = c.y; m.diffuse[2] = c.z; }
+    if (b.y) { const V3 c = textureEval(sc.textures[b.y - 1], u, v); m.specular[0] = c.x; m.specular[1] = c.y; m.specular[2] = c.z; }
+    if (b.z) { const V3 c = textureEval(sc.textures[b.z - 1], u, v); m.transmittance[0] = c.x; m.transmittance[1] = c.y; m.transmittance[2] = c.z; }
+}
+MTS_DEV void loadMaterialAt(const DevScene &sc, uint32_t index, float2 uv, DevMaterial &m) {
+    loadMaterial(sc, index, m);
+    applyTextures(sc, index, uv.x, uv.y, m);
 }
 
 MTS_DEV V3 mirrorZ(V3 v) { return mk(v.x, v.y, -v.z); }
@@ -809,23 +842,23 @@ MTS_DEV float bsdfPdfDiscrete(const DevMaterial &m, V3 wi, V3 wo) {
     return 0.0f;
 }
 
-MTS_DEV V3 mixEval(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
+MTS_DEV V3 mixEval(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, float2 uv) {
     V3 result = mk(0.0f);
 #pragma unroll 1
     for (int i = 0; i < m.variant; ++i) {
         DevMaterial c;
-        loadMaterial(sc, mixChild(m, i), c);
+        loadMaterialAt(sc, mixChild(m, i), uv, c);
         result = result + bsdfEval<true>(sc, c, wi, wo) * mixWeight(m, i);
     }
     return result;
 }
 
-MTS_DEV float mixPdf(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
+MTS_DEV float mixPdf(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, float2 uv) {
     float result = 0.0f;
 #pragma unroll 1
     for (int i = 0; i < m.variant; ++i) {
         DevMaterial c;
-        loadMaterial(sc, mixChild(m, i), c);
+        loadMaterialAt(sc, mixChild(m, i), uv, c);
         result += bsdfPdf<true>(sc, c, wi, wo) * (mixCdf(m, i + 1) - mixCdf(m, i));
     }
     return result;
@@ -852,13 +885,13 @@ MTS_DEV bool bsdfDrawsFromSampler(const DevMaterial &m, float sx) {
     return m.type == 7;
 }
 
-MTS_DEV V3 mixSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, float su, V3 &wo, float &pdf, float &eta, uint32_t &sampledType) {
+MTS_DEV V3 mixSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, float su, V3 &wo, float &pdf, float &eta, uint32_t &sampledType, float2 uv) {
     const int n = m.variant;
     const int entry = mixEntry(m, sx);
     const float lower = mixCdf(m, entry), width = mixCdf(m, entry + 1) - lower;
     sx = (sx - lower) / width;
     DevMaterial c;
-    loadMaterial(sc, mixChild(m, entry), c);
+    loadMaterialAt(sc, mixChild(m, entry), uv, c);
     V3 result = bsdfSample<true>(sc, c, wi, sx, sy, su, wo, pdf, eta, sampledType);
     if (isZero(result)) return result;      // sampling failed
     result = result * (mixWeight(m, entry) * pdf);
@@ -867,7 +900,7 @@ MTS_DEV V3 mixSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, 
 #pragma unroll 1
     for (int i = 0; i < n; ++i) {
         if (i == entry) continue;
-        loadMaterial(sc, mixChild(m, i), c);
+        loadMaterialAt(sc, mixChild(m, i), uv, c);
         pdf += (discrete ? bsdfPdfDiscrete(c, wi, wo) : bsdfPdf<true>(sc, c, wi, wo)) * (mixCdf(m, i + 1) - mixCdf(m, i));
         result = result + (discrete ? bsdfEvalDiscrete(c, wi, wo) : bsdfEval<true>(sc, c, wi, wo)) * mixWeight(m, i);
     }
@@ -876,18 +909,19 @@ MTS_DEV V3 mixSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, 
 
 // What the integrator calls on the record that answers for this side: a mixture (only compiled in with MIX) or a plain model
 template <bool RD = true, bool MIX = true>
-MTS_DEV V3 bsdfEvalAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
-    if (MIX && m.type == 8) return mixEval(sc, m, wi, wo);
+MTS_DEV V3 bsdfEvalAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, float2 uv = make_float2(0, 0)) {
+    if (MIX && m.type == 8) return mixEval(sc, m, wi, wo, uv);
     return bsdfEval<RD>(sc, m, wi, wo);
 }
 template <bool RD = true, bool MIX = true>
-MTS_DEV float bsdfPdfAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
-    if (MIX && m.type == 8) return mixPdf(sc, m, wi, wo);
+MTS_DEV float bsdfPdfAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, float2 uv = make_float2(0, 0)) {
+    if (MIX && m.type == 8) return mixPdf(sc, m, wi, wo, uv);
     return bsdfPdf<RD>(sc, m, wi, wo);
 }
 template <bool RD = true, bool MIX = true>
-MTS_DEV V3 bsdfSampleAny(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, float su, V3 &wo, float &pdf, float &eta, uint32_t &sampledType) {
-    if (MIX && m.type == 8) return mixSample(sc, m, wi, sx, sy, su, wo, pdf, eta, sampledType);
+MTS_DEV V3 bsdfSampleAny(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, float su, V3 &wo, float &pdf, float &eta, uint32_t &sampledType,
+                         float2 uv = make_float2(0, 0)) {
+    if (MIX && m.type == 8) return mixSample(sc, m, wi, sx, sy, su, wo, pdf, eta, sampledType, uv);
     return bsdfSample<RD>(sc, m, wi, sx, sy, su, wo, pdf, eta, sampledType);
 }
 

@@ -30,6 +30,14 @@ struct alignas(16) DevMaterial {
     uint32_t ownFlags;          // BSDF type bits of this record's own components
 };
 
+// Two-colour procedural texture (src/textures/checkerboard.cpp, gridtexture.cpp) with the colours as the BSDF sees
+// them (scale textures and the energy-conservation factor applied)
+struct alignas(16) DevTexture {
+    float color0[3]; int32_t type;
+    float color1[3]; float lineWidth;
+    float uOffset, vOffset, uScale, vScale;
+};
+
 struct DevShape {
     uint32_t firstTri, nTris;
     int32_t material, emitter;
@@ -73,6 +81,10 @@ struct DevScene {
     const float *emitterCdf;    // nEmitters + 1
     const float *areaCdf;       // concatenated per-emitter triangle CDFs (nTris + 1 each)
     const float *rtrans;        // concatenated reduced transmittance tables
+    // Only when some material has a texture: per material the 1-based texture of its diffuse, specular and
+    // transmittance colour (0 = the constant in the record), and the textures
+    const uint4 *materialTextures;
+    const DevTexture *textures;
     uint32_t nEmitters, nTris, nShapes, nMaterials;
     float aabbMin[3], aabbMax[3];       // enlarged scene bounds (gkdtree.h:1213-1220)
     float sampleToCamera[16];

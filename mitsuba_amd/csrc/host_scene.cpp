@@ -15,17 +15,57 @@ float luminance(const float *s) { return s[0] * 0.212671f + s[1] * 0.715160f + s
 float max3(const float *s) { return std::max(std::max(s[0], s[1]), s[2]); }
 
 // BSDF::ensureEnergyConservation (src/librender/bsdf.cpp:88-146): a "scale" texture of 0.99 * max / actualMax
-void ensureEnergy(bool on, float *a) {
-    if (!on) return;
-    float actualMax = max3(a);
-    if (actualMax > 1.0f) { float s = 0.99f * (1.0f / actualMax); for (int i = 0; i < 3; ++i) a[i] *= s; }
+// A colour parameter of a BSDF: a constant or a two-colour procedural texture, with the factors the reference wraps
+// around it as `scale` textures (the scene's own, then BSDF::ensureEnergyConservation's, src/librender/bsdf.cpp:88-113)
+struct Colour {
+    const mtsamd_texture *tex = nullptr;
+    float base0[3], base1[3];
+    float userScale = 1.0f, energyScale = 1.0f;
+
+    void value(int which, float out[3]) const {
+        const float *b = which ? base1 : base0;
+        for (int i = 0; i < 3; ++i) out[i] = (b[i] * userScale) * energyScale;
+    }
+    void maximum(float out[3]) const {      // Checkerboard / GridTexture::getMaximum, ScaleTexture::getMaximum
+        for (int i = 0; i < 3; ++i) out[i] = (tex ? std::max(base0[i], base1[i]) : base0[i]) * userScale;
+    }
+    void average(float out[3]) const {      // ::getAverage (checkerboard.cpp:96-98, gridtexture.cpp:113-118, scale.cpp)
+        for (int i = 0; i < 3; ++i) {
+            float a = base0[i];
+            if (tex && tex->type == MTSAMD_TEX_CHECKERBOARD) a = (base0[i] + base1[i]) * 0.5f;
+            else if (tex) {
+                const float interiorWidth = std::max(0.0f, 1 - 2 * tex->line_width), interiorArea = interiorWidth * interiorWidth,
+                            lineArea = 1 - interiorArea;
+                a = base1[i] * lineArea + base0[i] * interiorArea;
+            }
+            out[i] = (a * userScale) * energyScale;
+        }
+    }
+};
+std::string makeColour(const mtsamd_scene_desc *d, const float *constant, int32_t texture, Colour &c) {
+    memcpy(c.base0, constant, 12); memcpy(c.base1, constant, 12);
+    if (texture == 0) return "";
+    if (texture < 0 || (uint32_t) texture > d->n_textures || !d->textures) return "material texture index out of range";
+    c.tex = &d->textures[texture - 1];
+    if (c.tex->type != MTSAMD_TEX_CHECKERBOARD && c.tex->type != MTSAMD_TEX_GRID) return "unsupported texture type";
+    memcpy(c.base0, c.tex->color0, 12); memcpy(c.base1, c.tex->color1, 12);
+    c.userScale = c.tex->scale;
+    return "";
 }
-void ensureEnergy2(bool on, float *a, float *b) {
+void ensureEnergy(bool on, Colour &a) {
     if (!on) return;
-    float sum[3] = { a[0] + b[0], a[1] + b[1], a[2] + b[2] };
-    float actualMax = max3(sum);
-    if (actualMax > 1.0f) { float s = 0.99f * (1.0f / actualMax); for (int i = 0; i < 3; ++i) { a[i] *= s; b[i] *= s; } }
+    float m[3]; a.maximum(m);
+    const float actualMax = max3(m);
+    if (actualMax > 1.0f) a.energyScale = 0.99f * (1.0f / actualMax);
 }
+void ensureEnergy2(bool on, Colour &a, Colour &b) {
+    if (!on) return;
+    float ma[3], mb[3]; a.maximum(ma); b.maximum(mb);
+    const float sum[3] = { ma[0] + mb[0], ma[1] + mb[1], ma[2] + mb[2] };
+    const float actualMax = max3(sum);
+    if (actualMax > 1.0f) a.energyScale = b.energyScale = 0.99f * (1.0f / actualMax);
+}
+float averageLuminance(const Colour &c) { float a[3]; c.average(a); return luminance(a); }
 
 void mul4(const float *a, const float *b, float *out) {
     float r[16];
@@ -140,8 +180,11 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         dm.alphaU = m.alpha_u; dm.alphaV = m.alpha_v;
         dm.eta = 1; dm.invEta = 1; dm.invEta2 = 1;
         const bool ee = m.ensure_energy_conservation != 0;
-        float diff[3], spec[3], trans[3];
-        memcpy(diff, m.diffuse_reflectance, 12); memcpy(spec, m.specular_reflectance, 12); memcpy(trans, m.specular_transmittance, 12);
+        Colour diff, spec, trans;
+        for (const std::string &err : { makeColour(d, m.diffuse_reflectance, m.diffuse_texture, diff),
+                                        makeColour(d, m.specular_reflectance, m.specular_texture, spec),
+                                        makeColour(d, m.specular_transmittance, m.transmittance_texture, trans) })
+            if (!err.empty()) return err;
         const unsigned aniso = m.alpha_u != m.alpha_v ? EAnisotropic : 0u;
         if (m.type == MTSAMD_BSDF_ROUGHCONDUCTOR || m.type == MTSAMD_BSDF_ROUGHPLASTIC || m.type == MTSAMD_BSDF_ROUGHDIELECTRIC) {
             if (m.distribution != MTSAMD_DISTR_BECKMANN && m.distribution != MTSAMD_DISTR_GGX)
@@ -150,7 +193,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         switch (m.type) {
             case MTSAMD_BSDF_DIFFUSE:           // diffuse.cpp:93-104
                 ensureEnergy(ee, diff);
-                dm.typeFlags = max3(diff) > 0 ? (EDiffuseReflection | EFrontSide) : 0u;
+                { float mx[3]; diff.maximum(mx); dm.typeFlags = max3(mx) > 0 ? (EDiffuseReflection | EFrontSide) : 0u; }
                 break;
             case MTSAMD_BSDF_ROUGHCONDUCTOR:    // roughconductor.cpp:187-190,228-250
                 ensureEnergy(ee, spec);
@@ -171,7 +214,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
                 ensureEnergy(ee, diff);
                 dm.eta = m.int_ior / m.ext_ior;
                 dm.invEta2 = 1.0f / (dm.eta * dm.eta);
-                float dAvg = luminance(diff), sAvg = luminance(spec);
+                float dAvg = averageLuminance(diff), sAvg = averageLuminance(spec);
                 dm.specSamplingWeight = sAvg / (dAvg + sAvg);
                 dm.fdrInt = m.rtrans_diffuse_int;
                 dm.rtransOffset = (uint32_t) hs.rtrans.size();
@@ -191,7 +234,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
             case MTSAMD_BSDF_WARD: {            // ward.cpp:139-171
                 if (m.variant < 0 || m.variant > 2) return "Specified an invalid model type, must be \"ward\", \"ward-duer\", or \"balanced\"!";
                 ensureEnergy2(ee, spec, diff);
-                float dAvg = luminance(diff), sAvg = luminance(spec);
+                float dAvg = averageLuminance(diff), sAvg = averageLuminance(spec);
                 dm.specSamplingWeight = sAvg / (dAvg + sAvg);
                 dm.typeFlags = EGlossyReflection | EDiffuseReflection | EFrontSide | aniso;
                 break;
@@ -220,7 +263,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
                 ensureEnergy(ee, diff);
                 dm.eta = m.int_ior / m.ext_ior;
                 dm.fdrInt = fresnelDiffuseReflectance(1 / dm.eta);
-                float dAvg = luminance(diff), sAvg = luminance(spec);
+                float dAvg = averageLuminance(diff), sAvg = averageLuminance(spec);
                 dm.specSamplingWeight = sAvg / (dAvg + sAvg);
                 dm.invEta2 = 1 / (dm.eta * dm.eta);
                 dm.typeFlags = EDeltaReflection | EDiffuseReflection | EFrontSide;
@@ -231,7 +274,22 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
             default:
                 return "unsupported BSDF type";
         }
-        memcpy(dm.diffuse, diff, 12); memcpy(dm.specular, spec, 12); memcpy(dm.transmittance, trans, 12);
+        diff.value(0, dm.diffuse); spec.value(0, dm.specular); trans.value(0, dm.transmittance);
+        if (m.type != MTSAMD_BSDF_MIXTURE && (diff.tex || spec.tex || trans.tex)) {
+            if (hs.materialTextures.empty()) hs.materialTextures.assign((size_t) d->n_materials * 4, 0u);
+            const Colour *slots[3] = { &diff, &spec, &trans };
+            for (int k = 0; k < 3; ++k) {
+                if (!slots[k]->tex) continue;
+                const mtsamd_texture &t = *slots[k]->tex;
+                DevTexture dt;
+                slots[k]->value(0, dt.color0); slots[k]->value(1, dt.color1);
+                dt.type = t.type; dt.lineWidth = t.line_width;
+                dt.uOffset = t.u_offset; dt.vOffset = t.v_offset; dt.uScale = t.u_scale; dt.vScale = t.v_scale;
+                hs.textures.push_back(dt);
+                hs.materialTextures[(size_t) i * 4 + k] = (uint32_t) hs.textures.size();
+            }
+            hs.mixture = true;      // textured scenes run the kernels that know every feature
+        }
         dm.ownFlags = dm.typeFlags;
         dm.twoSided = m.two_sided != 0;
         dm.backMaterial = (int32_t) i;

@@ -17,13 +17,15 @@ struct HostScene {
     std::vector<DevMaterial> materials;
     std::vector<DevEmitter> emitters;
     std::vector<float> emitterCdf, areaCdf, rtrans;
+    std::vector<DevTexture> textures;           // one per (material, colour) that is textured
+    std::vector<uint32_t> materialTextures;     // 4 per material (see DevScene), empty without textures
     BVH bvh;
     DevScene params;        // scalar members filled; pointers left null until upload
     mtsamd_scene_desc desc; // copy of the scalar parts of the description
     bool hasNormals = false, hasTexcoords = false;
     int32_t envEmitter = -1;    // index of the constant environment emitter in `emitters`, if any
     std::vector<DevDeltaEmitter> deltaEmitters;     // point, spot and directional emitters
-    bool mixture = false;       // some material is a mixturebsdf (selects the kernels that know it)
+    bool mixture = false;       // some material is a mixturebsdf or textured (selects the kernels that know every feature)
     bool extEmitters = false;   // some emitter is not an area light (selects the kernels that know the other kinds)
 };
 

@@ -143,6 +143,9 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
         // ... and the BRDF that answers on this side (twosided.cpp:108-183)
         const bool flipped = resolveTwoSided(sc, its.material, wiZ, bsdf);
         const V3 wiLocal = flipped ? mirrorZ(its.wi) : its.wi;
+        // textured colours of the answering record, at this hit (only scenes with textures run the MIX kernels with a table)
+        const float2 uv = make_float2(its.uvx, its.uvy);
+        if (MIX) applyTextures(sc, its.material, uv.x, uv.y, bsdf);
         // The sample's radiance is only fetched where something is added to it: at the camera vertex it still is
         // what k_raygen wrote (zero), later only paths that hit an emitter touch it.
         float4 L = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -209,10 +212,10 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                     V3 c = mk(0.0f);
                     const V3 wo = toLocal(its.sh, dRec.d);
                     const V3 woSide = flipped ? mirrorZ(wo) : wo;
-                    const V3 bsdfVal = bsdfEvalAny<RD, MIX>(sc, bsdf, wiLocal, woSide);
+                    const V3 bsdfVal = bsdfEvalAny<RD, MIX>(sc, bsdf, wiLocal, woSide, uv);
                     if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
                         // path.cpp:192-193: only emitters with a surface, sampled in the solid-angle measure, compete with BSDF sampling
-                        const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX>(sc, bsdf, wiLocal, woSide);
+                        const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX>(sc, bsdf, wiLocal, woSide, uv);
                         c = throughput * value * bsdfVal * miWeight(dRec.pdf, bPdf);
                     }
                     o.wantShadow = true;
@@ -228,7 +231,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             const float bx = rng.next1D(), by = rng.next1D();
             V3 woLocal; float bPdf, bEta; uint32_t sampledType;
             const float bu = RD && bsdfDrawsFromSampler<MIX>(bsdf, bx) ? rng.next1D() : 0.0f;     // bRec.sampler->next1D() inside BSDF::sample
-            const V3 bsdfWeight = bsdfSampleAny<RD, MIX>(sc, bsdf, wiLocal, bx, by, bu, woLocal, bPdf, bEta, sampledType);
+            const V3 bsdfWeight = bsdfSampleAny<RD, MIX>(sc, bsdf, wiLocal, bx, by, bu, woLocal, bPdf, bEta, sampledType, uv);
             if (flipped && !isZero(bsdfWeight) && bPdf != 0) woLocal.z = -woLocal.z;      // twosided.cpp:172-181
             if (!isZero(bsdfWeight)) {
                 if (sampledType != ENull) flags |= PF_SCATTERED;
@@ -537,6 +540,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_direct_shade(DevScene sc, PassP
             bsdfType = bsdf.typeFlags;
             flipped = resolveTwoSided(sc, its.material, its.wi.z, bsdf);
             wiLocal = flipped ? mirrorZ(its.wi) : its.wi;
+            applyTextures(sc, its.material, its.uvx, its.uvy, bsdf);
             if ((bsdfType & (ETransmission | EBackSide)) == 0) refN = its.sh.n;
         }
         // MIDirectIntegrator::configure (direct.cpp:128-136)
@@ -556,9 +560,9 @@ __global__ void __launch_bounds__(kShadeBlock) k_direct_shade(DevScene sc, PassP
                         V3 c = mk(0.0f);
                         const V3 wo = toLocal(its.sh, dRec.d);
                         const V3 woSide = flipped ? mirrorZ(wo) : wo;
-                        const V3 bsdfVal = bsdfEvalAny(sc, bsdf, wiLocal, woSide);
+                        const V3 bsdfVal = bsdfEvalAny(sc, bsdf, wiLocal, woSide, make_float2(its.uvx, its.uvy));
                         if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
-                            const float bPdf = dRec.delta ? 0.0f : bsdfPdfAny(sc, bsdf, wiLocal, woSide);
+                            const float bPdf = dRec.delta ? 0.0f : bsdfPdfAny(sc, bsdf, wiLocal, woSide, make_float2(its.uvx, its.uvy));
                             c = value * bsdfVal * (miWeight(dRec.pdf * fracLum, bPdf * fracBSDF) * weightLum);
                         }
                         ++nShadow;
@@ -581,7 +585,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_direct_shade(DevScene sc, PassP
                 const float bx = rng.next1D(), by = rng.next1D();
                 const float bu = bsdfDrawsFromSampler(bsdf, bx) ? rng.next1D() : 0.0f;
                 V3 woLocal; float bPdf, bEta; uint32_t sampledType;
-                const V3 bsdfVal = bsdfSampleAny(sc, bsdf, wiLocal, bx, by, bu, woLocal, bPdf, bEta, sampledType);
+                const V3 bsdfVal = bsdfSampleAny(sc, bsdf, wiLocal, bx, by, bu, woLocal, bPdf, bEta, sampledType, make_float2(its.uvx, its.uvy));
                 if (flipped && !isZero(bsdfVal) && bPdf != 0) woLocal.z = -woLocal.z;
                 if (!isZero(bsdfVal)) {
                     const V3 wo = toWorld(its.sh, woLocal);
@@ -816,28 +820,32 @@ __global__ void k_hits_to_records(DevScene sc, const float4 *hits, uint32_t n, m
 }
 
 // mode 0: eval -> out[3n]; 1: pdf -> out[n]
-__global__ void k_bsdf_evalpdf(DevScene sc, int material, int mode, uint32_t n, const float *wi, const float *wo, float *out) {
+__global__ void k_bsdf_evalpdf(DevScene sc, int material, float2 uv, int mode, uint32_t n, const float *wi, const float *wo, float *out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     DevMaterial m;
-    loadMaterial(sc, (uint32_t) material, m);
+    uint32_t index = (uint32_t) material;
+    loadMaterial(sc, index, m);
     V3 a = ld3(wi, i), b = ld3(wo, i);
-    if (resolveTwoSided(sc, (uint32_t) material, a.z, m)) { a = mirrorZ(a); b = mirrorZ(b); }
-    if (mode == 0) { const V3 r = bsdfEvalAny(sc, m, a, b); out[3 * (size_t) i] = r.x; out[3 * (size_t) i + 1] = r.y; out[3 * (size_t) i + 2] = r.z; }
-    else out[i] = bsdfPdfAny(sc, m, a, b);
+    if (resolveTwoSided(sc, index, a.z, m)) { a = mirrorZ(a); b = mirrorZ(b); }
+    applyTextures(sc, index, uv.x, uv.y, m);
+    if (mode == 0) { const V3 r = bsdfEvalAny(sc, m, a, b, uv); out[3 * (size_t) i] = r.x; out[3 * (size_t) i + 1] = r.y; out[3 * (size_t) i + 2] = r.z; }
+    else out[i] = bsdfPdfAny(sc, m, a, b, uv);
 }
 
-__global__ void k_bsdf_sample(DevScene sc, int material, uint32_t n, const float *wi, const float *sample, const float *sampler1D,
+__global__ void k_bsdf_sample(DevScene sc, int material, float2 uv, uint32_t n, const float *wi, const float *sample, const float *sampler1D,
                               float *wo, float *weight, float *pdf, float *eta, uint32_t *sampledType) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     DevMaterial m;
-    loadMaterial(sc, (uint32_t) material, m);
+    uint32_t index = (uint32_t) material;
+    loadMaterial(sc, index, m);
     V3 a = ld3(wi, i);
-    const bool flipped = resolveTwoSided(sc, (uint32_t) material, a.z, m);
+    const bool flipped = resolveTwoSided(sc, index, a.z, m);
     if (flipped) a = mirrorZ(a);
+    applyTextures(sc, index, uv.x, uv.y, m);
     V3 o; float p, e; uint32_t t;
-    const V3 w = bsdfSampleAny(sc, m, a, sample[2 * (size_t) i], sample[2 * (size_t) i + 1], sampler1D ? sampler1D[i] : 0.5f, o, p, e, t);
+    const V3 w = bsdfSampleAny(sc, m, a, sample[2 * (size_t) i], sample[2 * (size_t) i + 1], sampler1D ? sampler1D[i] : 0.5f, o, p, e, t, uv);
     if (flipped && !isZero(w) && p != 0) o.z = -o.z;
     wo[3 * (size_t) i] = o.x; wo[3 * (size_t) i + 1] = o.y; wo[3 * (size_t) i + 2] = o.z;
     weight[3 * (size_t) i] = w.x; weight[3 * (size_t) i + 1] = w.y; weight[3 * (size_t) i + 2] = w.z;

@@ -101,7 +101,7 @@ struct mtsamd_scene {
     DevScene dev;
     int device = 0;
     DeviceBuffer nodes, tris, shadeTris, shadeUV, shapes, materials, emitters, deltaEmitters,
-        emitterCdf, areaCdf, rtrans;
+        emitterCdf, areaCdf, rtrans, textures, materialTextures;
     // work buffers of the wavefront loop
     DeviceBuffer fetchHeads, qbuf[2][6], hits, sbuf[3], sampleL, samplePos, shadowFlags, counters, scratch[8];
     size_t capacity = 0;
@@ -118,6 +118,7 @@ struct mtsamd_scene {
     int traceStack = 0;                   // StackLayout of the traversal kernels: 0, 8 or 10 (by the depth of the tree)
     uint32_t nodeStride = 5, triStride = 3;     // record strides in float4 units (padding buys line alignment)
     uint64_t overlapBelow = 8u << 20;     // rays (shadow + next extend) below which the two traversals run side by side
+    float2 queryUv = make_float2(0.0f, 0.0f);     // where mtsamd_bsdf_eval / pdf / sample evaluate textures
     bool roughDielectric = false;         // some material is a rough dielectric (selects the kernels that know it)
     uint32_t xcdRanges = 8;               // ranges of rays with a hand-out counter each (8 = one per XCD, 1 = one for all)
     uint32_t tailBelow = 1u << 18;        // paths below which one launch finishes the pass (0 = never)
@@ -230,6 +231,7 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
         HIP_TRY(upload(s->deltaEmitters, h.deltaEmitters));
         HIP_TRY(upload(s->emitterCdf, h.emitterCdf));
         HIP_TRY(upload(s->areaCdf, h.areaCdf));
+        if (!h.textures.empty()) { HIP_TRY(upload(s->textures, h.textures)); HIP_TRY(upload(s->materialTextures, h.materialTextures)); }
         HIP_TRY(upload(s->rtrans, h.rtrans));
         if (h.bvh.builder == BVH_BUILDER_DEVICE && h.desc.n_triangles > 0) {
             // the acceleration structure is built where it will be used; the records then learn their BSDF types
@@ -272,6 +274,8 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
     d.shapes = s->shapes.as<DevShape>(); d.materials = s->materials.as<DevMaterial>(); d.emitters = s->emitters.as<DevEmitter>();
     d.deltaEmitters = s->deltaEmitters.as<DevDeltaEmitter>();
     d.emitterCdf = s->emitterCdf.as<float>(); d.areaCdf = s->areaCdf.as<float>(); d.rtrans = s->rtrans.as<float>();
+    d.textures = h.textures.empty() ? nullptr : s->textures.as<DevTexture>();
+    d.materialTextures = h.textures.empty() ? nullptr : s->materialTextures.as<uint4>();
     s->dev = d;
     const char *ct = getenv("MTSAMD_COUNT_TRAVERSAL");
     s->countTraversal = ct && *ct == '1';
@@ -691,6 +695,12 @@ int renderCommon(mtsamd_scene *s, const mtsamd_render_opts *opts, float *filmDev
 
 extern "C" int mtsamd_abi_version(void) { return MTSAMD_ABI_VERSION; }
 
+extern "C" int mtsamd_bsdf_query_uv(mtsamd_scene *s, float u, float v) {
+    if (!s) return fail(MTSAMD_EINVAL, "null scene");
+    s->queryUv = make_float2(u, v);
+    return MTSAMD_OK;
+}
+
 extern "C" int64_t mtsamd_sizeof(int record) {
     switch (record) {
         case MTSAMD_SIZEOF_SCENE_DESC: return (int64_t) sizeof(mtsamd_scene_desc);
@@ -990,7 +1000,7 @@ static int bsdfEvalPdf(mtsamd_scene *s, int material, int mode, uint64_t n, cons
     Staging sg; void *dI, *dW, *dO;
     const size_t ob = mode == 0 ? n * 12 : n * 4;
     TRY(sg.in(wi, n * 12, &dI)); TRY(sg.in(wo, n * 12, &dW)); TRY(sg.out(ob, &dO));
-    hipLaunchKernelGGL(k_bsdf_evalpdf, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, material, mode, (uint32_t) n, (const float *) dI, (const float *) dW, (float *) dO);
+    hipLaunchKernelGGL(k_bsdf_evalpdf, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, material, s->queryUv, mode, (uint32_t) n, (const float *) dI, (const float *) dW, (float *) dO);
     TRY(finish(s->stream));
     HIP_TRY(hipMemcpy(out, dO, ob, hipMemcpyDeviceToHost));
     return MTSAMD_OK;
@@ -1014,7 +1024,7 @@ extern "C" int mtsamd_bsdf_sample(mtsamd_scene *s, int material, uint64_t n, con
     TRY(sg.in(wi, n * 12, &dI)); TRY(sg.in(sample, n * 8, &dS));
     if (sampler_1d) TRY(sg.in(sampler_1d, n * 4, &dU));
     TRY(sg.out(n * 12, &dWo)); TRY(sg.out(n * 12, &dW)); TRY(sg.out(n * 4, &dP)); TRY(sg.out(n * 4, &dE)); TRY(sg.out(n * 4, &dT));
-    hipLaunchKernelGGL(k_bsdf_sample, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, material, (uint32_t) n, (const float *) dI,
+    hipLaunchKernelGGL(k_bsdf_sample, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, material, s->queryUv, (uint32_t) n, (const float *) dI,
                        (const float *) dS, (const float *) dU, (float *) dWo, (float *) dW, (float *) dP, (float *) dE, (uint32_t *) dT);
     TRY(finish(s->stream));
     HIP_TRY(hipMemcpy(wo, dWo, n * 12, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(weight, dW, n * 12, hipMemcpyDeviceToHost));

@@ -161,6 +161,7 @@ class SceneData:
     camera: Dict = field(default_factory=dict)
     film: Dict = field(default_factory=dict)
     integrator: Dict = field(default_factory=lambda: dict(max_depth=-1, rr_depth=5, strict_normals=0, hide_emitters=0))
+    textures: List[Dict] = field(default_factory=list)      # what the materials' *_texture fields index, 1-based
 
     @property
     def n_triangles(self) -> int:
@@ -176,9 +177,30 @@ def _mat(**kw) -> Dict:
              diffuse_reflectance=(0.5, 0.5, 0.5), specular_reflectance=(1.0, 1.0, 1.0),
              specular_transmittance=(1.0, 1.0, 1.0), eta=(0.0, 0.0, 0.0), k=(1.0, 1.0, 1.0),
              ext_eta=1.000277, ensure_energy_conservation=1,
-             rtrans=None, rtrans_diffuse_ext=0.0, rtrans_diffuse_int=0.0, two_sided=0, back_material=-1)
+             rtrans=None, rtrans_diffuse_ext=0.0, rtrans_diffuse_int=0.0, two_sided=0, back_material=-1,
+             diffuse_texture=0, specular_texture=0, transmittance_texture=0)
     m.update(kw)
     return m
+
+
+TEX_CHECKERBOARD, TEX_GRID = 1, 2
+
+
+def _tex(kind, color0, color1, line_width, uoffset, voffset, uscale, vscale, scale) -> Dict:
+    return dict(type=kind, color0=tuple(float(x) for x in color0), color1=tuple(float(x) for x in color1), line_width=float(line_width),
+                u_offset=float(uoffset), v_offset=float(voffset), u_scale=float(uscale), v_scale=float(vscale), scale=float(scale))
+
+
+def checkerboard(color0=(0.4, 0.4, 0.4), color1=(0.2, 0.2, 0.2), uoffset=0.0, voffset=0.0, uscale=1.0, vscale=1.0, scale=1.0) -> Dict:
+    """src/textures/checkerboard.cpp:48-51 (defaults) on top of Texture2D (src/librender/texture.cpp:81-95); `scale` is the
+    factor of a `scale` texture around it (src/textures/scale.cpp)."""
+    return _tex(TEX_CHECKERBOARD, color0, color1, 0.0, uoffset, voffset, uscale, vscale, scale)
+
+
+def gridtexture(color0=(0.2, 0.2, 0.2), color1=(0.4, 0.4, 0.4), line_width=0.01, uoffset=0.0, voffset=0.0, uscale=1.0, vscale=1.0,
+                scale=1.0) -> Dict:
+    """src/textures/gridtexture.cpp:55-59"""
+    return _tex(TEX_GRID, color0, color1, line_width, uoffset, voffset, uscale, vscale, scale)
 
 
 def diffuse(reflectance=(0.5, 0.5, 0.5)) -> Dict:
@@ -303,7 +325,7 @@ def load_rtrans_slice(distribution, eta, alpha):
 class SceneBuilder:
     def __init__(self):
         self.P, self.N, self.UV, self.I = [], [], [], []
-        self.shapes, self.materials, self.emitters = [], [], []
+        self.shapes, self.materials, self.emitters, self.textures = [], [], [], []
         self.nv = 0
         self.nt = 0
         self.any_normals = False
@@ -312,6 +334,11 @@ class SceneBuilder:
     def add_material(self, m: Dict) -> int:
         self.materials.append(m)
         return len(self.materials) - 1
+
+    def add_texture(self, t: Dict) -> int:
+        """Returns what goes into a material's diffuse_texture / specular_texture / transmittance_texture (1-based)."""
+        self.textures.append(t)
+        return len(self.textures)
 
     def add_constant_emitter(self, radiance=(1.0, 1.0, 1.0), sampling_weight=1.0) -> int:
         """Constant environment emitter (src/emitters/constant.cpp): an emitter record without a shape."""
@@ -404,7 +431,7 @@ class SceneBuilder:
             indices=np.ascontiguousarray(np.concatenate(self.I), np.uint32),
             normals=np.ascontiguousarray(np.concatenate(self.N), np.float32) if self.any_normals else None,
             texcoords=np.ascontiguousarray(np.concatenate(self.UV), np.float32) if self.any_uvs else None,
-            shapes=self.shapes, materials=self.materials, emitters=self.emitters, camera=camera, film=film)
+            shapes=self.shapes, materials=self.materials, emitters=self.emitters, camera=camera, film=film, textures=self.textures)
         if integrator:
             sd.integrator.update(integrator)
         return sd
@@ -625,10 +652,12 @@ def config5(width=3840, height=2160) -> SceneData:
 
 
 def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_weight=1.0, hide_emitters=0, lamps=False, area_lights=True,
-                     blend=False) -> SceneData:
+                     blend=False, textured=False) -> SceneData:
     """A few hundred triangles with every BSDF type present; used by the parity tests. `sky` adds a constant
     environment emitter of that radiance next to the two area lights; `lamps` adds a point, a spot and a directional light;
-    `blend` makes the ground and two of the blobs mixtures of the other materials."""
+    `blend` makes the ground and two of the blobs mixtures of the other materials; `textured` puts checkerboard and grid
+    textures on colours of most materials (meshes with and without texture coordinates, colours above one, a scale
+    texture, two textures in one energy check)."""
     rng = np.random.default_rng(7)
     b = SceneBuilder()
     mats = [b.add_material(diffuse((0.6, 0.5, 0.4))),
@@ -640,6 +669,17 @@ def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_
             b.add_material(roughplastic(alpha=0.3, distribution="beckmann", int_ior=1.49, diffuse_reflectance=(0.2, 0.4, 0.6)))]
     m_ground = b.add_material(diffuse((0.5, 0.5, 0.5)))
     m_light = m_ground
+    if textured:
+        M = b.materials
+        m_ground = b.add_material(diffuse())
+        M[m_ground]["diffuse_texture"] = b.add_texture(checkerboard((0.7, 0.7, 0.6), (0.15, 0.2, 0.3), uscale=7.0, vscale=6.0, uoffset=0.25))
+        M[mats[0]]["diffuse_texture"] = b.add_texture(gridtexture((0.3, 0.5, 0.2), (1.5, 0.3, 0.3), line_width=0.1))       # barycentric uv, > 1
+        M[mats[1]]["specular_texture"] = b.add_texture(checkerboard((1.0, 0.9, 0.8), (0.5, 0.5, 1.0), uscale=3.0, vscale=3.0, scale=0.8))
+        M[mats[2]]["diffuse_texture"] = b.add_texture(checkerboard((0.5, 0.2, 0.2), (0.1, 0.3, 0.6), uscale=2.0, vscale=4.0))
+        M[mats[2]]["specular_texture"] = b.add_texture(gridtexture((1.0, 1.0, 1.0), (0.2, 0.2, 0.2), line_width=0.2, voffset=0.3))
+        M[mats[3]]["transmittance_texture"] = b.add_texture(checkerboard((1.0, 0.6, 0.6), (0.6, 1.0, 0.7), uscale=2.0, vscale=2.0))
+        M[mats[4]]["diffuse_texture"] = b.add_texture(checkerboard((0.6, 0.5, 0.1), (0.1, 0.1, 0.5), uscale=4.0, vscale=4.0))
+        M[mats[4]]["specular_texture"] = b.add_texture(gridtexture((0.7, 0.6, 0.5), (0.2, 0.9, 0.2), line_width=0.15, uscale=3.0, vscale=3.0))
     if blend:
         m_ground = b.add_material(twosided(mixture([m_ground, mats[1]], [0.75, 0.25])))
         mats[0] = b.add_material(mixture([mats[0], mats[2], mats[4]], [0.6, 0.5, 0.4]))      # weights above one: rescaled
@@ -653,7 +693,7 @@ def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_
         uv = (p[:, :2] * 0.5 + 0.5).astype(np.float32) if k == 4 else None
         b.add_mesh(p + c, f, m, normals=n if k != 0 else None, texcoords=uv)
     gp, gf = grid(6, 6, (-7, -6), (7, 6), 0.0)
-    b.add_mesh(gp, gf, m_ground)
+    b.add_mesh(gp, gf, m_ground, texcoords=((gp[:, :2] + np.float32([7, 6])) / np.float32([14, 12])).astype(np.float32) if textured else None)
     b.add_quad([-2, -2, 6], [-2, 2, 6], [2, 2, 6], [2, -2, 6], m_light, radiance=(15, 14, 12) if area_lights else None)
     b.add_quad([4, -1, 3.5], [4, 1, 3.5], [5, 1, 4.5], [5, -1, 4.5], m_light, radiance=(6, 9, 12) if area_lights else None, sampling_weight=0.5)
     if sky is not None:

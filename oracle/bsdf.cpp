@@ -1,5 +1,6 @@
 // TEST INFRASTRUCTURE ONLY -- CPU oracle: BSDF models of the `path` hot path.
 #include "bsdf.h"
+#include <stdexcept>
 
 namespace orc {
 
@@ -376,16 +377,73 @@ Vec2 MicrofacetDistribution::sampleVisible11(float thetaI, Vec2 sample) const {
 // ---- Material configuration ----------------------------------------------------------------------
 static Spectrum toSpec(const float *v) { return Spectrum(v[0], v[1], v[2]); }
 
-// BSDF::ensureEnergyConservation (src/librender/bsdf.cpp:88-146)
-static void ensureEnergy(bool enabled, Spectrum &a) {
-    if (!enabled) return;
-    float actualMax = a.max();
-    if (actualMax > 1.0f) a *= 0.99f * (1.0f / actualMax);
+thread_local Vec2 g_textureUV{ 0, 0 };
+
+static int modulo(int a, int b) { int r = a % b; return r < 0 ? r + b : r; }     // math::modulo
+
+Spectrum Texture::eval(const Vec2 &its_uv) const {
+    Spectrum value = color0;
+    if (type != 0) {
+        // Texture2D::eval(its) (texture.cpp:112-121), no uv partials in the path integrators' BSDF queries after the first hit
+        // and no filtering in either texture
+        const Vec2 uv{ its_uv.x * uvScale.x + uvOffset.x, its_uv.y * uvScale.y + uvOffset.y };
+        if (type == 1) {        // checkerboard.cpp:66-75
+            const int x = 2 * modulo((int) (uv.x * 2), 2) - 1, y = 2 * modulo((int) (uv.y * 2), 2) - 1;
+            value = x * y == 1 ? color0 : color1;
+        } else {                // gridtexture.cpp:75-88
+            float x = uv.x - (float) (int) std::floor(uv.x), y = uv.y - (float) (int) std::floor(uv.y);
+            if (x > .5) x -= 1;
+            if (y > .5) y -= 1;
+            value = (std::abs(x) < lineWidth || std::abs(y) < lineWidth) ? color1 : color0;
+        }
+    }
+    for (float sc : scales) value *= sc;      // ScaleTexture::eval
+    return value;
 }
-static void ensureEnergy2(bool enabled, Spectrum &a, Spectrum &b) {
+
+Spectrum Texture::getMaximum() const {
+    Spectrum m = color0;
+    if (type != 0) m = Spectrum(std::max(color0.x, color1.x), std::max(color0.y, color1.y), std::max(color0.z, color1.z));
+    for (float sc : scales) m *= sc;
+    return m;
+}
+
+Spectrum Texture::getAverage() const {
+    Spectrum a = color0;
+    if (type == 1) a = (color0 + color1) * 0.5f;
+    else if (type == 2) {
+        const float interiorWidth = std::max(0.0f, 1 - 2 * lineWidth), interiorArea = interiorWidth * interiorWidth, lineArea = 1 - interiorArea;
+        a = color1 * lineArea + color0 * interiorArea;
+    }
+    for (float sc : scales) a *= sc;
+    return a;
+}
+
+static const char *makeTexture(const float *constant, int32_t index, const orc_texture *textures, uint32_t n, Texture &out) {
+    out = Texture();
+    out.color0 = out.color1 = toSpec(constant);
+    if (index == 0) return nullptr;
+    if (index < 0 || (uint32_t) index > n || !textures) return "material texture index out of range";
+    const orc_texture &t = textures[index - 1];
+    if (t.type != 1 && t.type != 2) return "unsupported texture type";
+    out.type = t.type;
+    out.color0 = toSpec(t.color0); out.color1 = toSpec(t.color1);
+    out.lineWidth = t.line_width;
+    out.uvOffset = Vec2{ t.u_offset, t.v_offset }; out.uvScale = Vec2{ t.u_scale, t.v_scale };
+    if (t.scale != 1.0f) out.scales.push_back(t.scale);
+    return nullptr;
+}
+
+// BSDF::ensureEnergyConservation (src/librender/bsdf.cpp:88-146): a ScaleTexture around the texture
+static void ensureEnergy(bool enabled, Texture &a) {
     if (!enabled) return;
-    float actualMax = (a + b).max();
-    if (actualMax > 1.0f) { float scale = 0.99f * (1.0f / actualMax); a *= scale; b *= scale; }
+    float actualMax = a.getMaximum().max();
+    if (actualMax > 1.0f) a.scales.push_back(0.99f * (1.0f / actualMax));
+}
+static void ensureEnergy2(bool enabled, Texture &a, Texture &b) {
+    if (!enabled) return;
+    float actualMax = (a.getMaximum() + b.getMaximum()).max();
+    if (actualMax > 1.0f) { float scale = 0.99f * (1.0f / actualMax); a.scales.push_back(scale); b.scales.push_back(scale); }
 }
 
 // fresnelDiffuseReflectance(eta, fast = false) (src/libcore/util.cpp:806-859): the integral over [0,1] of
@@ -401,16 +459,18 @@ static float fresnelDiffuseReflectance(float eta) {
     return (float) (sum / n);
 }
 
-void Material::configure() {
+void Material::configure(const orc_texture *textures, uint32_t nTextures) {
     bool ee = m.ensure_energy_conservation != 0;
-    diffuse = toSpec(m.diffuse_reflectance);
-    specular = toSpec(m.specular_reflectance);
-    transmittance = toSpec(m.specular_transmittance);
+    Texture &diffuse = diffuseTex, &specular = specularTex, &transmittance = transmittanceTex;
+    for (const char *err : { makeTexture(m.diffuse_reflectance, m.diffuse_texture, textures, nTextures, diffuse),
+                             makeTexture(m.specular_reflectance, m.specular_texture, textures, nTextures, specular),
+                             makeTexture(m.specular_transmittance, m.transmittance_texture, textures, nTextures, transmittance) })
+        if (err) throw std::runtime_error(err);
     unsigned aniso = (m.alpha_u != m.alpha_v) ? EAnisotropic : 0;
     switch (m.type) {
         case ORC_BSDF_DIFFUSE:   // src/bsdfs/diffuse.cpp:93-104
             ensureEnergy(ee, diffuse);
-            type_flags = diffuse.max() > 0 ? (EDiffuseReflection | EFrontSide) : 0;
+            type_flags = diffuse.getMaximum().max() > 0 ? (EDiffuseReflection | EFrontSide) : 0;
             break;
         case ORC_BSDF_ROUGHCONDUCTOR:   // src/bsdfs/roughconductor.cpp:187-190,228-250
             ensureEnergy(ee, specular);
@@ -423,7 +483,7 @@ void Material::configure() {
             ensureEnergy(ee, diffuse);
             eta = m.int_ior / m.ext_ior;
             invEta2 = 1.0f / (eta * eta);
-            float dAvg = luminance(diffuse), sAvg = luminance(specular);
+            float dAvg = luminance(diffuse.getAverage()), sAvg = luminance(specular.getAverage());
             specularSamplingWeight = sAvg / (dAvg + sAvg);
             if (m.rtrans && m.rtrans_n) rtrans.assign(m.rtrans, m.rtrans + m.rtrans_n);
             type_flags = EGlossyReflection | EDiffuseReflection | EFrontSide;
@@ -438,7 +498,7 @@ void Material::configure() {
             break;
         case ORC_BSDF_WARD: {   // src/bsdfs/ward.cpp:139-171
             ensureEnergy2(ee, specular, diffuse);
-            float dAvg = luminance(diffuse), sAvg = luminance(specular);
+            float dAvg = luminance(diffuse.getAverage()), sAvg = luminance(specular.getAverage());
             specularSamplingWeight = sAvg / (dAvg + sAvg);
             type_flags = EGlossyReflection | EDiffuseReflection | EFrontSide | aniso;
             break;
@@ -461,7 +521,7 @@ void Material::configure() {
             ensureEnergy(ee, diffuse);
             eta = m.int_ior / m.ext_ior;
             fdrInt = fresnelDiffuseReflectance(1 / eta);
-            float dAvg = luminance(diffuse), sAvg = luminance(specular);
+            float dAvg = luminance(diffuse.getAverage()), sAvg = luminance(specular.getAverage());
             specularSamplingWeight = sAvg / (dAvg + sAvg);
             invEta2 = 1 / (eta * eta);
             type_flags = EDeltaReflection | EDiffuseReflection | EFrontSide;
@@ -549,7 +609,7 @@ static Spectrum evalOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo
         case ORC_BSDF_DIFFUSE: {   // diffuse.cpp:110-118
             if (!(mat.own_flags & EDiffuseReflection)) return Spectrum(0.0f);
             if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0) return Spectrum(0.0f);
-            return mat.diffuse * (INV_PI_F * Frame::cosTheta(wo));
+            return mat.D() * (INV_PI_F * Frame::cosTheta(wo));
         }
         case ORC_BSDF_ROUGHCONDUCTOR: {   // roughconductor.cpp:257-294
             if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0) return Spectrum(0.0f);
@@ -557,7 +617,7 @@ static Spectrum evalOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo
             MicrofacetDistribution distr(m.distribution, m.alpha_u, m.alpha_v, m.sample_visible != 0);
             const float D = distr.eval(H);
             if (D == 0) return Spectrum(0.0f);
-            const Spectrum F = fresnelConductorExact(dot(wi, H), mat.condEta, mat.condK) * mat.specular;
+            const Spectrum F = fresnelConductorExact(dot(wi, H), mat.condEta, mat.condK) * mat.S();
             const float G = distr.G(wi, wo, H);
             float model = D * G / (4.0f * Frame::cosTheta(wi));
             return F * model;
@@ -572,10 +632,10 @@ static Spectrum evalOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo
                 const float F = fresnelDielectricExt(dot(wi, H), mat.eta);
                 const float G = distr.G(wi, wo, H);
                 float value = F * D * G / (4.0f * Frame::cosTheta(wi));
-                result += mat.specular * value;
+                result += mat.S() * value;
             }
             {
-                Spectrum diff = mat.diffuse;
+                Spectrum diff = mat.D();
                 float T12 = rtransEval(mat, Frame::cosTheta(wi));
                 float T21 = rtransEval(mat, Frame::cosTheta(wo));
                 float Fdr = 1 - m.rtrans_diffuse_int;
@@ -602,8 +662,8 @@ static Spectrum evalOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo
             float factor2 = H.x / alphaU, factor3 = H.y / alphaV;
             float exponent = -(factor2 * factor2 + factor3 * factor3) / (H.z * H.z);
             float specRef = factor1 * fastexp(exponent);
-            if (specRef > 1e-10f) result += mat.specular * specRef;
-            result += mat.diffuse * INV_PI_F;
+            if (specRef > 1e-10f) result += mat.S() * specRef;
+            result += mat.D() * INV_PI_F;
             return result * Frame::cosTheta(wo);
         }
         case ORC_BSDF_ROUGHDIELECTRIC: {   // roughdielectric.cpp:276-346
@@ -624,13 +684,13 @@ static Spectrum evalOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo
             const float G = distr.G(wi, wo, H);
             if (reflect_) {
                 float value = F * D * G / (4.0f * std::abs(Frame::cosTheta(wi)));
-                return mat.specular * value;
+                return mat.S() * value;
             } else {
                 float eta_ = Frame::cosTheta(wi) > 0.0f ? mat.eta : mat.invEta;
                 float sqrtDenom = dot(wi, H) + eta_ * dot(wo, H);
                 float value = ((1 - F) * D * G * eta_ * eta_ * dot(wi, H) * dot(wo, H)) / (Frame::cosTheta(wi) * sqrtDenom * sqrtDenom);
                 float factor = Frame::cosTheta(wi) > 0 ? mat.invEta : mat.eta;     // ERadiance
-                return mat.transmittance * std::abs(value * factor * factor);
+                return mat.T() * std::abs(value * factor * factor);
             }
         }
         case ORC_BSDF_CONDUCTOR:   // conductor.cpp:225-239: a delta lobe only, zero for the solid-angle measure
@@ -639,7 +699,7 @@ static Spectrum evalOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo
             if (Frame::cosTheta(wo) <= 0 || Frame::cosTheta(wi) <= 0) return Spectrum(0.0f);
             float Fi = fresnelDielectricExt(Frame::cosTheta(wi), mat.eta);
             float Fo = fresnelDielectricExt(Frame::cosTheta(wo), mat.eta);
-            Spectrum diff = mat.diffuse;
+            Spectrum diff = mat.D();
             if (m.variant) diff = diff / (Spectrum(1.0f) - diff * mat.fdrInt);
             else diff /= 1 - mat.fdrInt;
             return diff * (squareToCosineHemispherePdf(wo) * mat.invEta2 * (1 - Fi) * (1 - Fo));
@@ -739,7 +799,7 @@ static Spectrum sampleOneSided(const Material &mat, const Vec3 &wi, const Vec2 &
             out.eta = 1.0f;
             out.sampledType = EDiffuseReflection;
             pdf = squareToCosineHemispherePdf(out.wo);
-            return mat.diffuse;
+            return mat.D();
         }
         case ORC_BSDF_ROUGHCONDUCTOR: {   // roughconductor.cpp:369-415
             if (Frame::cosTheta(wi) < 0) return Spectrum(0.0f);
@@ -750,7 +810,7 @@ static Spectrum sampleOneSided(const Material &mat, const Vec3 &wi, const Vec2 &
             out.eta = 1.0f;
             out.sampledType = EGlossyReflection;
             if (Frame::cosTheta(out.wo) <= 0) return Spectrum(0.0f);
-            Spectrum F = fresnelConductorExact(dot(wi, mm), mat.condEta, mat.condK) * mat.specular;
+            Spectrum F = fresnelConductorExact(dot(wi, mm), mat.condEta, mat.condK) * mat.S();
             float weight;
             if (distr.sampleVisible) weight = distr.smithG1(out.wo, mm);
             else weight = distr.eval(mm) * distr.G(wi, out.wo, mm) * dot(wi, mm) / (pdf * Frame::cosTheta(wi));
@@ -793,7 +853,7 @@ static Spectrum sampleOneSided(const Material &mat, const Vec3 &wi, const Vec2 &
                 out.wo = Vec3(-wi.x, -wi.y, wi.z);
                 out.eta = 1.0f;
                 pdf = F;
-                return mat.specular;
+                return mat.S();
             } else {
                 out.sampledType = EDeltaTransmission;
                 float scale = -(cosThetaT < 0 ? mat.invEta : mat.eta);
@@ -801,7 +861,7 @@ static Spectrum sampleOneSided(const Material &mat, const Vec3 &wi, const Vec2 &
                 out.eta = cosThetaT < 0 ? mat.eta : mat.invEta;
                 pdf = 1 - F;
                 float factor = cosThetaT < 0 ? mat.invEta : mat.eta;
-                return mat.transmittance * (factor * factor);
+                return mat.T() * (factor * factor);
             }
         }
         case ORC_BSDF_WARD: {   // ward.cpp:266-326
@@ -854,7 +914,7 @@ static Spectrum sampleOneSided(const Material &mat, const Vec3 &wi, const Vec2 &
                 out.eta = 1.0f;
                 out.sampledType = EGlossyReflection;
                 if (Frame::cosTheta(wi) * Frame::cosTheta(out.wo) <= 0) return Spectrum(0.0f);
-                weight *= mat.specular;
+                weight *= mat.S();
                 dwh_dwo = 1.0f / (4.0f * dot(out.wo, mm));
             } else {
                 if (cosThetaT == 0) return Spectrum(0.0f);
@@ -866,7 +926,7 @@ static Spectrum sampleOneSided(const Material &mat, const Vec3 &wi, const Vec2 &
                 out.sampledType = EGlossyTransmission;
                 if (Frame::cosTheta(wi) * Frame::cosTheta(out.wo) >= 0) return Spectrum(0.0f);
                 float factor = cosThetaT < 0 ? mat.invEta : mat.eta;
-                weight *= mat.transmittance * (factor * factor);
+                weight *= mat.T() * (factor * factor);
                 float sqrtDenom = dot(wi, mm) + out.eta * dot(out.wo, mm);
                 dwh_dwo = (out.eta * out.eta * dot(out.wo, mm)) / (sqrtDenom * sqrtDenom);
             }
@@ -881,7 +941,7 @@ static Spectrum sampleOneSided(const Material &mat, const Vec3 &wi, const Vec2 &
             out.wo = Vec3(-wi.x, -wi.y, wi.z);
             out.eta = 1.0f;
             pdf = 1;
-            return mat.specular * fresnelConductorExact(Frame::cosTheta(wi), mat.condEta, mat.condK);
+            return mat.S() * fresnelConductorExact(Frame::cosTheta(wi), mat.condEta, mat.condK);
         }
         case ORC_BSDF_PLASTIC: {   // plastic.cpp:373-440 (both lobes enabled)
             if (Frame::cosTheta(wi) <= 0) return Spectrum(0.0f);
@@ -893,12 +953,12 @@ static Spectrum sampleOneSided(const Material &mat, const Vec3 &wi, const Vec2 &
                 out.sampledType = EDeltaReflection;
                 out.wo = Vec3(-wi.x, -wi.y, wi.z);
                 pdf = probSpecular;
-                return mat.specular * Fi / probSpecular;
+                return mat.S() * Fi / probSpecular;
             } else {
                 out.sampledType = EDiffuseReflection;
                 out.wo = squareToCosineHemisphere(Vec2{ (_sample.x - probSpecular) / (1 - probSpecular), _sample.y });
                 float Fo = fresnelDielectricExt(Frame::cosTheta(out.wo), mat.eta);
-                Spectrum diff = mat.diffuse;
+                Spectrum diff = mat.D();
                 if (m.variant) diff = diff / (Spectrum(1.0f) - diff * mat.fdrInt);
                 else diff /= 1 - mat.fdrInt;
                 pdf = (1 - probSpecular) * squareToCosineHemispherePdf(out.wo);
@@ -922,21 +982,21 @@ static Spectrum evalDiscrete(const Material &mat, const Vec3 &wi, const Vec3 &wo
             const float F = fresnelDielectricExt(Frame::cosTheta(wi), cosThetaT, mat.eta);
             if (Frame::cosTheta(wi) * Frame::cosTheta(wo) >= 0) {
                 if (std::abs(dot(reflectZ(wi), wo) - 1) > DeltaEpsilon) return Spectrum(0.0f);
-                return mat.specular * F;
+                return mat.S() * F;
             }
             const float scale = -(cosThetaT < 0 ? mat.invEta : mat.eta);
             const Vec3 wt(scale * wi.x, scale * wi.y, cosThetaT);
             if (std::abs(dot(wt, wo) - 1) > DeltaEpsilon) return Spectrum(0.0f);
             const float factor = cosThetaT < 0 ? mat.invEta : mat.eta;      // ERadiance
-            return mat.transmittance * (factor * factor * (1 - F));
+            return mat.T() * (factor * factor * (1 - F));
         }
         case ORC_BSDF_CONDUCTOR:
             if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0 || std::abs(dot(reflectZ(wi), wo) - 1) > DeltaEpsilon) return Spectrum(0.0f);
-            return mat.specular * fresnelConductorExact(Frame::cosTheta(wi), mat.condEta, mat.condK);
+            return mat.S() * fresnelConductorExact(Frame::cosTheta(wi), mat.condEta, mat.condK);
         case ORC_BSDF_PLASTIC: {
             if (Frame::cosTheta(wo) <= 0 || Frame::cosTheta(wi) <= 0) return Spectrum(0.0f);
             const float Fi = fresnelDielectricExt(Frame::cosTheta(wi), mat.eta);
-            if (std::abs(dot(reflectZ(wi), wo) - 1) < DeltaEpsilon) return mat.specular * Fi;
+            if (std::abs(dot(reflectZ(wi), wo) - 1) < DeltaEpsilon) return mat.S() * Fi;
             return Spectrum(0.0f);
         }
     }

@@ -48,7 +48,19 @@ typedef struct {
     int32_t mix_count;
     int32_t mix_material[4];
     float mix_weight[4];
+    /* a <texture> in place of the constant colours above: 1-based index into orc_scene_desc.textures, 0 = none */
+    int32_t diffuse_texture, specular_texture, transmittance_texture;
 } orc_material;
+
+/* type 1: checkerboard (src/textures/checkerboard.cpp), 2: gridtexture (src/textures/gridtexture.cpp); uv offset and
+   scale of Texture2D (src/librender/texture.cpp:81-95); `scale`: factor of a ScaleTexture around it (src/textures/scale.cpp) */
+typedef struct {
+    int32_t type;
+    float color0[3], color1[3];
+    float line_width;
+    float u_offset, v_offset, u_scale, v_scale;
+    float scale;
+} orc_texture;
 
 /* type 0: attached to `shape` (area light) or, with shape = -1, the constant environment emitter;
    1: point (src/emitters/point.cpp), 2: spot (src/emitters/spot.cpp), 3: directional (src/emitters/directional.cpp).
@@ -94,6 +106,8 @@ typedef struct {
     orc_camera camera;
     orc_film film;
     orc_integrator integrator;
+    uint32_t n_textures;
+    const orc_texture *textures;
 } orc_scene_desc;
 
 typedef struct {
@@ -131,6 +145,8 @@ int orc_occluded(const orc_scene *s, uint64_t n, const float *rays, uint8_t *out
 
 /* BSDF batch queries in the local shading frame. wi/wo: n*3, sample: n*2.
    eval -> out[n*3] (f*cos), pdf -> out[n], sample -> wo[n*3], weight[n*3], pdf[n], eta[n], type[n] */
+/* its.uv for the three BSDF queries below (where a material's textures are evaluated); (0, 0) until set */
+void orc_bsdf_query_uv(float u, float v);
 int orc_bsdf_eval(const orc_scene *s, int material, uint64_t n, const float *wi, const float *wo, float *out);
 int orc_bsdf_pdf(const orc_scene *s, int material, uint64_t n, const float *wi, const float *wo, float *out);
 /* sampler_1d (n values, may be NULL = 0.5): the number a BSDF flagged EUsesSampler takes from the sampler itself */

@@ -27,7 +27,14 @@ class Material(C.Structure):
                 ("ext_eta", C.c_float), ("ensure_energy_conservation", C.c_int32),
                 ("rtrans", _f32p), ("rtrans_n", C.c_uint32), ("rtrans_diffuse_ext", C.c_float),
                 ("rtrans_diffuse_int", C.c_float), ("two_sided", C.c_int32), ("back_material", C.c_int32),
-                ("mix_count", C.c_int32), ("mix_material", C.c_int32 * 4), ("mix_weight", C.c_float * 4)]
+                ("mix_count", C.c_int32), ("mix_material", C.c_int32 * 4), ("mix_weight", C.c_float * 4),
+                ("diffuse_texture", C.c_int32), ("specular_texture", C.c_int32), ("transmittance_texture", C.c_int32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("type", C.c_int32), ("color0", C.c_float * 3), ("color1", C.c_float * 3), ("line_width", C.c_float),
+                ("u_offset", C.c_float), ("v_offset", C.c_float), ("u_scale", C.c_float), ("v_scale", C.c_float),
+                ("scale", C.c_float)]
 
 
 class Emitter(C.Structure):
@@ -55,7 +62,8 @@ class SceneDesc(C.Structure):
                 ("n_materials", C.c_uint32), ("n_emitters", C.c_uint32),
                 ("positions", _f32p), ("normals", _f32p), ("texcoords", _f32p), ("indices", _u32p),
                 ("shapes", C.POINTER(Shape)), ("materials", C.POINTER(Material)), ("emitters", C.POINTER(Emitter)),
-                ("camera", Camera), ("film", Film), ("integrator", Integrator)]
+                ("camera", Camera), ("film", Film), ("integrator", Integrator),
+                ("n_textures", C.c_uint32), ("textures", C.POINTER(Texture))]
 
 
 class RenderOpts(C.Structure):
@@ -78,7 +86,7 @@ def _fp(a):
     return a.ctypes.data_as(_f32p)
 
 
-def fill_desc(sd, desc_cls=SceneDesc, shape_cls=Shape, mat_cls=Material, em_cls=Emitter):
+def fill_desc(sd, desc_cls=SceneDesc, shape_cls=Shape, mat_cls=Material, em_cls=Emitter, tex_cls=Texture):
     """SceneData -> (ctypes desc, keep-alive list). Shared by the oracle and (via subclass layout
     equality) usable for any library that takes the same struct layout."""
     keep = []
@@ -109,6 +117,8 @@ def fill_desc(sd, desc_cls=SceneDesc, shape_cls=Shape, mat_cls=Material, em_cls=
             setattr(c, k, m[k])
         for k in ("diffuse_reflectance", "specular_reflectance", "specular_transmittance", "eta", "k"):
             setattr(c, k, (C.c_float * 3)(*[float(x) for x in m[k]]))
+        for k in ("diffuse_texture", "specular_texture", "transmittance_texture"):
+            setattr(c, k, int(m.get(k, 0)))
         mix = m.get("mix", ())
         c.mix_count = len(mix)
         for j, (child, weight) in enumerate(mix[:4]):
@@ -137,6 +147,16 @@ def fill_desc(sd, desc_cls=SceneDesc, shape_cls=Shape, mat_cls=Material, em_cls=
     d.film.filter_values = (C.c_float * 32)(*np.asarray(f["filter_values"], np.float32))
     for k in ("max_depth", "rr_depth", "strict_normals", "hide_emitters"):
         setattr(d.integrator, k, sd.integrator[k])
+    tex_list = getattr(sd, "textures", None) or []
+    if tex_list:
+        texs = (tex_cls * len(tex_list))()
+        for i, t in enumerate(tex_list):
+            texs[i].type = t["type"]
+            texs[i].color0, texs[i].color1 = (C.c_float * 3)(*t["color0"]), (C.c_float * 3)(*t["color1"])
+            for k in ("line_width", "u_offset", "v_offset", "u_scale", "v_scale", "scale"):
+                setattr(texs[i], k, t[k])
+        keep.append(texs)
+        d.n_textures, d.textures = len(tex_list), texs
     d.integrator.type = {"path": 0, "direct": 1}[sd.integrator.get("type", "path")]
     d.integrator.emitter_samples = sd.integrator.get("emitter_samples", 1)
     d.integrator.bsdf_samples = sd.integrator.get("bsdf_samples", 1)
@@ -197,6 +217,9 @@ class OracleScene:
         out = np.zeros(rays.shape[0], np.uint8)
         self.L.orc_occluded(C.c_void_p(self.h), C.c_uint64(rays.shape[0]), _fp(rays), out.ctypes.data_as(C.c_void_p), int(brute))
         return out
+
+    def bsdf_query_uv(self, u, v):
+        self.L.orc_bsdf_query_uv(C.c_float(u), C.c_float(v))
 
     def bsdf_eval(self, mat, wi, wo):
         wi, wo = np.ascontiguousarray(wi, np.float32), np.ascontiguousarray(wo, np.float32)

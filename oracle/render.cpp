@@ -105,7 +105,13 @@ std::string Scene::build(const orc_scene_desc *d) {
     shapes.assign(d->shapes, d->shapes + d->n_shapes);
     emitters.assign(d->emitters, d->emitters + d->n_emitters);
     materials.resize(d->n_materials);
-    for (uint32_t i = 0; i < d->n_materials; ++i) { materials[i].m = d->materials[i]; materials[i].configure(); }
+    try {
+        for (uint32_t i = 0; i < d->n_materials; ++i) { materials[i].m = d->materials[i]; materials[i].configure(d->textures, d->n_textures); }
+    } catch (const std::runtime_error &e) {
+        static thread_local std::string message;
+        message = e.what();
+        return message.c_str();
+    }
     if (const char *err = linkMixtures(materials)) return err;
     if (const char *err = linkTwoSided(materials)) return err;
 
@@ -436,6 +442,7 @@ static Spectrum Li(const Scene &sc, const Ray &r, Pcg32 &rng, float &alpha, RayC
         }
         const orc_shape &shape = sc.shapes[its.shape];
         const Material &bsdf = sc.materials[shape.material];
+        g_textureUV = its.uv;       // the intersection the BSDF queries of this vertex refer to
 
         if (shape.emitter >= 0 && emittedRadiance && (!ig.hide_emitters || scattered)) {
             // AreaLight::eval (area.cpp:104-109)
@@ -558,6 +565,7 @@ static Spectrum LiDirect(const Scene &sc, const Ray &r, Pcg32 &rng, float &alpha
     }
     const orc_shape &shape = sc.shapes[its.shape];
     const Material &bsdf = sc.materials[shape.material];
+    g_textureUV = its.uv;
     if (shape.emitter >= 0 && !ig.hide_emitters) {      // direct.cpp:166-167, AreaLight::eval (area.cpp:104-109)
         const orc_emitter &em = sc.emitters[shape.emitter];
         if (dot(its.shFrame.n, -ray.d) > 0) Li += Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]);
@@ -749,9 +757,13 @@ extern "C" int orc_occluded(const orc_scene *s, uint64_t n, const float *rays, u
     return 0;
 }
 
+static Vec2 g_queryUV{ 0, 0 };
+extern "C" void orc_bsdf_query_uv(float u, float v) { g_queryUV = Vec2{ u, v }; }
+
 extern "C" int orc_bsdf_eval(const orc_scene *s, int material, uint64_t n, const float *wi, const float *wo, float *out) {
     if (material < 0 || (size_t) material >= s->s.materials.size()) return -1;
     const Material &m = s->s.materials[material];
+    g_textureUV = g_queryUV;
     for (uint64_t i = 0; i < n; ++i) {
         Spectrum r = bsdfEval(m, Vec3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), Vec3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]));
         out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
@@ -762,6 +774,7 @@ extern "C" int orc_bsdf_eval(const orc_scene *s, int material, uint64_t n, const
 extern "C" int orc_bsdf_pdf(const orc_scene *s, int material, uint64_t n, const float *wi, const float *wo, float *out) {
     if (material < 0 || (size_t) material >= s->s.materials.size()) return -1;
     const Material &m = s->s.materials[material];
+    g_textureUV = g_queryUV;
     for (uint64_t i = 0; i < n; ++i)
         out[i] = bsdfPdf(m, Vec3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), Vec3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]));
     return 0;
@@ -771,6 +784,7 @@ extern "C" int orc_bsdf_sample(const orc_scene *s, int material, uint64_t n, con
                                float *wo, float *weight, float *pdf, float *eta, uint32_t *sampled_type, const float *sampler_1d) {
     if (material < 0 || (size_t) material >= s->s.materials.size()) return -1;
     const Material &m = s->s.materials[material];
+    g_textureUV = g_queryUV;
     struct Fixed : Sampler1D { float v = 0.5f; float next1D() override { return v; } } fixed;
     for (uint64_t i = 0; i < n; ++i) {
         BSDFSample bs;

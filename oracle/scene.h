@@ -44,10 +44,30 @@ struct DiscreteDistribution {
     size_t sampleReuse(float &v, float &pdf) const;
 };
 
+// A colour parameter of a BSDF as the reference holds it: a Texture. ConstantSpectrumTexture (type 0), Checkerboard
+// (src/textures/checkerboard.cpp), GridTexture (src/textures/gridtexture.cpp) under Texture2D's uv transform
+// (src/librender/texture.cpp:81-121), inside any number of ScaleTextures (src/textures/scale.cpp; innermost first).
+struct Texture {
+    int type = 0;
+    Spectrum color0, color1;
+    float lineWidth = 0.01f;
+    Vec2 uvOffset{ 0, 0 }, uvScale{ 1, 1 };
+    std::vector<float> scales;
+    Spectrum eval(const Vec2 &uv) const;
+    Spectrum getMaximum() const;
+    Spectrum getAverage() const;
+};
+// bRec.its.uv of the BSDF query in progress on this thread (the reference hands the intersection to the BSDF; here the
+// integrator sets it before it calls eval / pdf / sample)
+extern thread_local Vec2 g_textureUV;
+
 struct Material {
     orc_material m;
     // derived at configure() time
-    Spectrum diffuse, specular, transmittance;   // after ensureEnergyConservation
+    Texture diffuseTex, specularTex, transmittanceTex;   // after ensureEnergyConservation
+    Spectrum D() const { return diffuseTex.eval(g_textureUV); }
+    Spectrum S() const { return specularTex.eval(g_textureUV); }
+    Spectrum T() const { return transmittanceTex.eval(g_textureUV); }
     Spectrum condEta, condK;                     // divided by extEta
     float eta = 1, invEta = 1, invEta2 = 1;
     float specularSamplingWeight = 0;
@@ -60,7 +80,7 @@ struct Material {
     std::vector<const Material *> mixChildren;
     std::vector<float> mixWeights;
     DiscreteDistribution mixPdf;
-    void configure();
+    void configure(const orc_texture *textures, uint32_t nTextures);
 };
 
 // BSDF::EBSDFType bits (include/mitsuba/render/bsdf.h:230-284)

@@ -19,7 +19,8 @@ def _scenes():
             "mixed": S.cornell_mixed(96, 96), "sky": S.small_test_scene(sky=(0.6, 0.8, 1.2), sky_weight=2.0),
             "sky_hidden": S.small_test_scene(sky=(0.6, 0.8, 1.2), hide_emitters=1),
             "lamps": S.small_test_scene(lamps=True), "lamps_only": S.small_test_scene(lamps=True, area_lights=False),
-            "blend": S.small_test_scene(blend=True)}
+            "blend": S.small_test_scene(blend=True), "textured": S.small_test_scene(textured=True),
+            "textured_blend": S.small_test_scene(textured=True, blend=True, sky=(0.3, 0.3, 0.4))}
 
 
 @pytest.fixture(scope="module")
@@ -175,6 +176,65 @@ def test_bsdf_eval_pdf_parity(material_pair):
         assert np.array_equal(fg == 0, fo == 0) or (np.mean((fg == 0) != (fo == 0)) < 1e-5)
 
 
+def test_textured_bsdf_parity(gpu, oracle_mod):
+    """BSDF::eval / pdf / sample with checkerboard and grid textures in place of constant colours (diffuse.cpp:110-118 and
+    its like: the colour comes from m_reflectance->eval(bRec.its)), at uv positions on both sides of every pattern edge:
+    the device against the restatement, and both against the same record with the colour a Python evaluation of the
+    texture gives at that uv."""
+    sd = S.small_test_scene(textured=True, blend=True)
+    g, o = gpu.Scene(sd), oracle_mod.OracleScene(sd)
+    rng = np.random.default_rng(31)
+    n = 20000
+    slots = (("diffuse_texture", "diffuse_reflectance"), ("specular_texture", "specular_reflectance"),
+             ("transmittance_texture", "specular_transmittance"))
+
+    def tex_value(t, u, v):
+        x, y = np.float32(u) * np.float32(t["u_scale"]) + np.float32(t["u_offset"]), np.float32(v) * np.float32(t["v_scale"]) + np.float32(t["v_offset"])
+        if t["type"] == S.TEX_CHECKERBOARD:
+            first = (2 * (int(x * 2) % 2) - 1) * (2 * (int(y * 2) % 2) - 1) == 1
+        else:
+            fx, fy = x - np.floor(x), y - np.floor(y)
+            fx, fy = (fx - 1 if fx > 0.5 else fx), (fy - 1 if fy > 0.5 else fy)
+            first = not (abs(fx) < t["line_width"] or abs(fy) < t["line_width"])
+        return np.float32(t["color0"] if first else t["color1"]) * np.float32(t["scale"])
+
+    textured = [i for i, m in enumerate(sd.materials) if any(m[k] for k, _ in slots)]
+    assert len(textured) >= 6
+    for u, v in ((0.1, 0.1), (0.3, 0.1), (0.26, 0.74), (0.55, 0.02), (0.999, 0.5), (2.3, -0.7)):
+        g.bsdf_query_uv(u, v)
+        o.bsdf_query_uv(u, v)
+        # the same materials with the colours at (u, v) written in as constants
+        flat = S.small_test_scene(textured=True, blend=True)
+        for m in flat.materials:
+            for k, c in slots:
+                if m[k]:
+                    m[c] = tuple(float(x) for x in tex_value(flat.textures[m[k] - 1], u, v))
+                    m[k] = 0
+        flat.textures = []
+        gf = gpu.Scene(flat)
+        for mi in range(len(sd.materials)):
+            wi, wo = _wi(n, rng), _wi(n, rng)
+            wo[::7, 2] *= -1
+            if sd.materials[mi]["type"] in (S.BSDF_DIELECTRIC, S.BSDF_ROUGHDIELECTRIC, S.BSDF_MIXTURE) or sd.materials[mi]["two_sided"]:
+                wi[::2, 2] *= -1
+            fg, fo = g.bsdf_eval(mi, wi, wo), o.bsdf_eval(mi, wi, wo)
+            assert _close(fg, fo).mean() > 0.9999, ("eval", mi, u, v)
+            assert _close(g.bsdf_pdf(mi, wi, wo), o.bsdf_pdf(mi, wi, wo)).mean() > 0.9999, ("pdf", mi, u, v)
+            s2 = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+            a, b = g.bsdf_sample(mi, wi, s2), o.bsdf_sample(mi, wi, s2)
+            ok = a[4] == b[4]
+            assert ok.mean() > 0.999 and np.mean(np.all(_close(a[1][ok], b[1][ok], 1e-4, 1e-5), axis=1)) > 0.998, ("sample", mi, u, v)
+            if mi in textured:
+                # energy conservation and the sampling weights come from the textures' maxima and averages, not from the
+                # colour at one point, so only materials without either are comparable with the flattened record
+                m = sd.materials[mi]
+                tex = [sd.textures[m[k] - 1] for k, _ in slots if m[k]]
+                plain = m["type"] == S.BSDF_DIFFUSE and all(max(max(t["color0"]), max(t["color1"])) * t["scale"] <= 1 for t in tex)
+                if plain:
+                    assert np.allclose(fg, gf.bsdf_eval(mi, wi, wo), rtol=1e-6, atol=1e-7), (mi, u, v)
+    g.bsdf_query_uv(0.0, 0.0)
+
+
 def test_bsdf_sample_parity(material_pair):
     mats, g, o = material_pair
     rng = np.random.default_rng(22)
@@ -218,7 +278,8 @@ def test_emitter_sampling_parity(pairs):
                 assert np.allclose(x, y, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["small", "cornell", "veach", "mixed", "sky", "sky_hidden", "lamps", "lamps_only", "blend"])
+@pytest.mark.parametrize("name", ["small", "cornell", "veach", "mixed", "sky", "sky_hidden", "lamps", "lamps_only", "blend", "textured",
+                                  "textured_blend"])
 def test_per_sample_radiance_parity(pairs, name):
     """MIPathTracer::Li per camera sample with the shared sample stream: same ray counts, same radiance."""
     sd, g, o = pairs[name]
@@ -233,7 +294,7 @@ def test_per_sample_radiance_parity(pairs, name):
     assert abs(Lg[..., :3].mean() - Lo[..., :3].mean()) < 2e-3 * Lo[..., :3].mean() + 1e-6
 
 
-@pytest.mark.parametrize("name", ["small", "mixed", "sky", "lamps", "blend"])
+@pytest.mark.parametrize("name", ["small", "mixed", "sky", "lamps", "blend", "textured_blend"])
 def test_pass_finishing_kernel_matches_wavefront_loop(gpu, name, monkeypatch):
     """Below MTSAMD_TAIL_BELOW live paths one launch follows each path to its end; above, every bounce is an extend /
     shade / shadow round of launches. Both run the same shading and traversal code: identical radiance and ray counts."""
@@ -256,7 +317,7 @@ def test_direct_integrator_parity(gpu, oracle_mod, ne, nb):
     """MIDirectIntegrator::Li (direct.cpp:146-309) per camera sample: same ray counts, same radiance, on scenes with area
     lights, an environment, lamps, mixtures and a frosted dielectric."""
     for sd in (S.small_test_scene(sky=(0.6, 0.8, 1.2), lamps=True, blend=True), S.cornell_mixed(64, 64),
-               S.small_test_scene(hide_emitters=1, sky=(0.2, 0.2, 0.3))):
+               S.small_test_scene(hide_emitters=1, sky=(0.2, 0.2, 0.3)), S.small_test_scene(textured=True, blend=True)):
         sd.integrator.update(type="direct", emitter_samples=ne, bsdf_samples=nb)
         g, o = gpu.Scene(sd), oracle_mod.OracleScene(sd)
         Lg, pg, sg = g.li(4, seed=7)
@@ -311,7 +372,7 @@ def test_film_put_parity(pairs):
     assert np.allclose(fg, fo, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["small", "cornell", "mixed", "sky", "lamps", "blend"])
+@pytest.mark.parametrize("name", ["small", "cornell", "mixed", "sky", "lamps", "blend", "textured"])
 def test_render_film_parity(pairs, name):
     sd, g, o = pairs[name]
     fg, sg = g.render(4, seed=9)
