@@ -96,15 +96,29 @@ typedef struct {
     int32_t diffuse_texture, specular_texture, transmittance_texture;
 } mtsamd_material;
 
-/* Procedural 2-D textures (Texture2D, src/librender/texture.cpp:81-121: uv * (uscale, vscale) + (uoffset, voffset), then
-   src/textures/checkerboard.cpp:66-75 or src/textures/gridtexture.cpp:75-88). */
-enum { MTSAMD_TEX_CHECKERBOARD = 1, MTSAMD_TEX_GRID = 2 };
+/* 2-D textures (Texture2D, src/librender/texture.cpp:81-121: uv * (uscale, vscale) + (uoffset, voffset)), then
+   src/textures/checkerboard.cpp:66-75, src/textures/gridtexture.cpp:75-88 or, MTSAMD_TEX_BITMAP, the image lookup of
+   src/textures/bitmap.cpp:431-499 over the MIP map of include/mitsuba/render/mipmap.h (levels resampled with the
+   two-lobed Lanczos filter and kept in half precision like the reference's; nearest, bilinear, trilinear and
+   elliptically-weighted-average lookups; the filtered ones use the uv partials Intersection::computePartials derives
+   from the camera ray's offset rays, i.e. at the first vertex of a path, src/librender/intersection.cpp:5-76). */
+enum { MTSAMD_TEX_CHECKERBOARD = 1, MTSAMD_TEX_GRID = 2, MTSAMD_TEX_BITMAP = 3 };
+/* EMIPFilterType (mipmap.h:52-61) and ReconstructionFilter::EBoundaryCondition (include/mitsuba/core/rfilter.h:53-64) */
+enum { MTSAMD_MIP_NEAREST = 0, MTSAMD_MIP_BILINEAR = 1, MTSAMD_MIP_TRILINEAR = 2, MTSAMD_MIP_EWA = 3 };
+enum { MTSAMD_WRAP_CLAMP = 0, MTSAMD_WRAP_REPEAT = 1, MTSAMD_WRAP_MIRROR = 2, MTSAMD_WRAP_ZERO = 3, MTSAMD_WRAP_ONE = 4 };
 typedef struct {
     int32_t type;
     float color0[3], color1[3];
     float line_width;           /* gridtexture (default 0.01) */
     float u_offset, v_offset, u_scale, v_scale;
     float scale;                /* factor of a `scale` texture wrapped around it (src/textures/scale.cpp); 1 = none */
+    /* MTSAMD_TEX_BITMAP: the decoded image as BitmapTexture hands it to its MIP map (bitmap.cpp:246-300): width * height *
+       channels linear floats (gamma already undone), first row = top of the image, channels 1 (luminance) or 3 (RGB);
+       see mtsamd_image_load. filterType (default ewa), wrapModeU / wrapModeV (default repeat), maxAnisotropy (default 20). */
+    const float *pixels;
+    int32_t width, height, channels;
+    int32_t filter_type, wrap_u, wrap_v;
+    float max_anisotropy;
 } mtsamd_texture;
 
 /* Emitter record. type MTSAMD_EMITTER_SURFACE: an AreaLight attached to a mesh (src/emitters/area.cpp; the shape's
@@ -232,9 +246,9 @@ const char *mtsamd_last_error(void);
    are never reordered). A caller compiled against another version must not pass them in: compare MTSAMD_ABI_VERSION with
    mtsamd_abi_version(), and where records are mirrored by hand (FFI bindings) their sizes with mtsamd_sizeof(). No
    counterpart in the reference, whose plugins are compiled against its own headers. */
-#define MTSAMD_ABI_VERSION 9
+#define MTSAMD_ABI_VERSION 10
 enum { MTSAMD_SIZEOF_SCENE_DESC = 0, MTSAMD_SIZEOF_MATERIAL = 1, MTSAMD_SIZEOF_EMITTER = 2, MTSAMD_SIZEOF_SHAPE = 3,
-       MTSAMD_SIZEOF_RENDER_OPTS = 4, MTSAMD_SIZEOF_STATS = 5, MTSAMD_SIZEOF_LDR_OPTS = 6 };
+       MTSAMD_SIZEOF_RENDER_OPTS = 4, MTSAMD_SIZEOF_STATS = 5, MTSAMD_SIZEOF_LDR_OPTS = 6, MTSAMD_SIZEOF_TEXTURE = 7 };
 int mtsamd_abi_version(void);
 int64_t mtsamd_sizeof(int record);      /* -1 for an unknown record */
 
@@ -328,6 +342,12 @@ int mtsamd_bsdf_pdf(mtsamd_scene *scene, int material, uint64_t n, const float *
 int mtsamd_bsdf_sample(mtsamd_scene *scene, int material, uint64_t n, const float *wi, const float *sample,
                        float *wo, float *weight, float *pdf, float *eta, uint32_t *sampled_type, const float *sampler_1d);
 
+/* Texture::eval(its) of texture `texture` (1-based, as the materials name it) on its own, with the `scale` factor but
+   without a BSDF's energy-conservation factor: uv n*2; duv n*4 (dudx, dvdx, dudy, dvdy: an intersection with uv
+   partials, Texture2D::eval -> eval(uv, d0, d1), texture.cpp:112-121) or NULL (no partials: the full-resolution lookup)
+   -> out n*3 */
+int mtsamd_texture_eval(mtsamd_scene *scene, int texture, uint64_t n, const float *uv, const float *duv, float *out);
+
 /* Scene::sampleEmitterDirect without the visibility test (src/librender/scene.cpp:828-852):
    ref n*3, ref_n n*3 (DirectSamplingRecord::refN), sample n*2 -> d n*3, dist n, pdf n, value n*3 */
 int mtsamd_sample_emitter_direct(mtsamd_scene *scene, uint64_t n, const float *ref, const float *ref_n,
@@ -366,6 +386,17 @@ int mtsamd_rtrans_reduce(const void *dat, uint64_t size, float eta, float alpha,
    empty file and for wavelengths that do not increase. */
 int mtsamd_spd_to_rgb(const float *wavelengths, const float *values, uint32_t n, float rgb[3]);
 int mtsamd_spd_file_to_rgb(const char *path, float rgb[3]);
+
+/* Bitmap(EAuto, stream) followed by the conversion BitmapTexture's MIP map applies (src/libcore/bitmap.cpp:2534-2541
+   and :284-286 for the gamma of a file, src/libcore/fmtconv.cpp:1093-1160 for undoing it; src/textures/bitmap.cpp:246-278):
+   reads an image file into linear floats, 1 channel (luminance and luminance-alpha files) or 3 (RGB and RGBA files;
+   alpha is dropped), first row = top. `gamma`: 0 = the file's own (sRGB for 8- and 16-bit files unless a PNG says
+   otherwise, linear for floating-point ones), else the value of the texture's `gamma` property (-1 = sRGB). Formats: PNG
+   (not interlaced), PFM, OpenEXR scan-line files with no, ZIPS or ZIP compression (R, G, B or Y channels). The pixels
+   belong to the library until mtsamd_image_free. Needs no device. */
+typedef struct { int32_t width, height, channels; float *pixels; } mtsamd_image;
+int mtsamd_image_load(const char *path, float gamma, mtsamd_image *out);
+void mtsamd_image_free(mtsamd_image *image);
 
 /* The host builder of the acceleration structure alone (binned-SAH sweep, collapse to 8-wide nodes, depth bounded to
    what the traversal stack holds): fills `info`, keeps nothing, needs no device. Counterpart of building a ShapeKDTree and

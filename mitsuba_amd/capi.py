@@ -36,7 +36,8 @@ class Material(C.Structure):
 class Texture(C.Structure):
     _fields_ = [("type", C.c_int32), ("color0", C.c_float * 3), ("color1", C.c_float * 3), ("line_width", C.c_float),
                 ("u_offset", C.c_float), ("v_offset", C.c_float), ("u_scale", C.c_float), ("v_scale", C.c_float),
-                ("scale", C.c_float)]
+                ("scale", C.c_float), ("pixels", _f32p), ("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32),
+                ("filter_type", C.c_int32), ("wrap_u", C.c_int32), ("wrap_v", C.c_int32), ("max_anisotropy", C.c_float)]
 
 
 class Emitter(C.Structure):
@@ -107,10 +108,10 @@ EXPORTS = ["mtsamd_last_error", "mtsamd_init", "mtsamd_scene_create", "mtsamd_sc
            "mtsamd_sample_emitter_direct", "mtsamd_camera_rays", "mtsamd_li", "mtsamd_film_put", "mtsamd_film_develop_ldr", "mtsamd_abi_version", "mtsamd_sizeof", "mtsamd_filter_table", "mtsamd_rng_stream",
            "mtsamd_rtrans_reduce", "mtsamd_filter_gaussian", "mtsamd_filter_box", "mtsamd_bvh_host_info", "mtsamd_bvh_max_depth",
            "mtsamd_trace_device_static", "mtsamd_trace_device_static_max", "mtsamd_render_multi", "mtsamd_spd_to_rgb",
-           "mtsamd_spd_file_to_rgb", "mtsamd_bsdf_query_uv"]
+           "mtsamd_spd_file_to_rgb", "mtsamd_bsdf_query_uv", "mtsamd_texture_eval", "mtsamd_image_load", "mtsamd_image_free"]
 
 _lib = None
-ABI_VERSION = 9     # MTSAMD_ABI_VERSION of include/mtsamd.h
+ABI_VERSION = 10    # MTSAMD_ABI_VERSION of include/mtsamd.h
 
 
 class MtsamdError(RuntimeError):
@@ -136,7 +137,7 @@ def lib():
         if L.mtsamd_abi_version() != ABI_VERSION:
             raise MtsamdError("%s implements ABI version %d, this binding %d: rebuild with `make -C mitsuba_amd/csrc`"
                               % (_LIB_PATH, L.mtsamd_abi_version(), ABI_VERSION))
-        for record, cls in enumerate((SceneDesc, Material, Emitter, Shape, RenderOpts, Stats, LdrOpts)):
+        for record, cls in enumerate((SceneDesc, Material, Emitter, Shape, RenderOpts, Stats, LdrOpts, Texture)):
             if L.mtsamd_sizeof(record) != C.sizeof(cls):
                 raise MtsamdError("record %s is %d bytes in %s and %d bytes in this binding"
                                   % (cls.__name__, L.mtsamd_sizeof(record), _LIB_PATH, C.sizeof(cls)))
@@ -228,6 +229,14 @@ def fill_desc(sd):
             texs[i].color0, texs[i].color1 = (C.c_float * 3)(*t["color0"]), (C.c_float * 3)(*t["color1"])
             for k in ("line_width", "u_offset", "v_offset", "u_scale", "v_scale", "scale"):
                 setattr(texs[i], k, t[k])
+            if t.get("pixels") is not None:     # bitmap: height x width (x 3) linear floats, rows from the top
+                px = np.ascontiguousarray(t["pixels"], np.float32)
+                keep.append(px)
+                texs[i].pixels = px.ctypes.data_as(_f32p)
+                texs[i].height, texs[i].width = px.shape[0], px.shape[1]
+                texs[i].channels = 1 if px.ndim == 2 else px.shape[2]
+                for k in ("filter_type", "wrap_u", "wrap_v", "max_anisotropy"):
+                    setattr(texs[i], k, t[k])
         keep.append(texs)
         d.n_textures, d.textures = len(tex_list), texs
     d.integrator.type = {"path": 0, "direct": 1}[sd.integrator.get("type", "path")]
@@ -357,6 +366,14 @@ class Scene:
         """Where on the surface bsdf_eval / bsdf_pdf / bsdf_sample evaluate a material's textures."""
         _check(self.L.mtsamd_bsdf_query_uv(self.h, C.c_float(u), C.c_float(v)))
 
+    def texture_eval(self, texture, uv, duv=None):
+        """Texture `texture` (1-based) of the scene at uv (n x 2); duv (n x 4: dudx, dvdx, dudy, dvdy) makes it a filtered lookup."""
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        d = None if duv is None else np.ascontiguousarray(duv, np.float32).reshape(-1, 4)
+        out = np.zeros((uv.shape[0], 3), np.float32)
+        _check(self.L.mtsamd_texture_eval(self.h, int(texture), C.c_uint64(uv.shape[0]), _fp(uv), None if d is None else _fp(d), _fp(out)))
+        return out
+
     def bsdf_eval(self, mat, wi, wo):
         wi, wo = np.ascontiguousarray(wi, np.float32), np.ascontiguousarray(wo, np.float32)
         out = np.zeros_like(wi)
@@ -450,6 +467,25 @@ def spd_file_to_rgb(path):
     if lib().mtsamd_spd_file_to_rgb(os.fsencode(path), _fp(out)) != 0:
         raise MtsamdError('InterpolatedSpectrum: could not read "%s"' % path)
     return out
+
+
+class Image(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32), ("pixels", _f32p)]
+
+
+def image_load(path, gamma=0.0):
+    """mtsamd_image_load: an image file as linear floats, height x width (luminance) or height x width x 3."""
+    img = Image()
+    L = lib()
+    L.mtsamd_image_load.argtypes = [C.c_char_p, C.c_float, C.POINTER(Image)]
+    L.mtsamd_image_free.argtypes = [C.POINTER(Image)]
+    _check(L.mtsamd_image_load(os.fsencode(path), C.c_float(gamma), C.byref(img)))
+    try:
+        n = img.width * img.height * img.channels
+        out = np.ctypeslib.as_array(img.pixels, shape=(n,)).copy()
+    finally:
+        L.mtsamd_image_free(C.byref(img))
+    return out.reshape(img.height, img.width) if img.channels == 1 else out.reshape(img.height, img.width, img.channels)
 
 
 def rng_stream(seed, key, n):

@@ -66,6 +66,20 @@ static void describe(const LoadedScene &s) {
         printf("]}");
         firstMix = false;
     }
+    printf("], \"material_textures\": [");
+    for (size_t i = 0; i < s.materials.size(); ++i)
+        printf("%s[%d, %d, %d]", i ? ", " : "", s.materials[i].diffuse_texture, s.materials[i].specular_texture, s.materials[i].transmittance_texture);
+    printf("], \"textures\": [");
+    for (size_t i = 0; i < s.textures.size(); ++i) {
+        const mtsamd_texture &t = s.textures[i];
+        double sum = 0;
+        for (float v : s.texturePixels[i]) sum += v;
+        printf("%s{\"type\": %d, \"color0\": [%.9g, %.9g, %.9g], \"color1\": [%.9g, %.9g, %.9g], \"line_width\": %.9g, \"uv\": [%.9g, %.9g, %.9g, %.9g], "
+               "\"scale\": %.9g, \"size\": [%d, %d, %d], \"filter_type\": %d, \"wrap\": [%d, %d], \"max_anisotropy\": %.9g, \"sum_pixels\": %.9g}",
+               i ? ", " : "", t.type, t.color0[0], t.color0[1], t.color0[2], t.color1[0], t.color1[1], t.color1[2], t.line_width,
+               t.u_offset, t.v_offset, t.u_scale, t.v_scale, t.scale, t.width, t.height, t.channels, t.filter_type, t.wrap_u, t.wrap_v,
+               t.max_anisotropy, sum);
+    }
     printf("], \"shape_triangles\": [");
     for (size_t i = 0; i < s.shapes.size(); ++i) printf("%s%u", i ? ", " : "", s.shapes[i].n_triangles);
     printf("], \"emitter_records\": [");

@@ -256,6 +256,99 @@ void conductorConstants(const Props &p, const LoadOptions &opts, mtsamd_material
     }
 }
 
+// ---- textures ----------------------------------------------------------------------------------------------------------------
+// A <texture> element as a record of the scene's texture list; returns its 1-based index. `scale` textures
+// (src/textures/scale.cpp:56-66) fold into the `scale` factor of a copy of the texture they wrap.
+uint32_t makeTexture(const Element &node, LoadedScene &out) {
+    const std::string type = node.get("type");
+    const Props p = parseProps(node);
+    mtsamd_texture t;
+    memset(&t, 0, sizeof(t));
+    t.scale = 1.0f;
+    std::vector<float> pixels;
+    auto uvTransform = [&]() {          // Texture2D (src/librender/texture.cpp:81-95)
+        t.u_offset = (float) getF(p, "uoffset", 0.0); t.v_offset = (float) getF(p, "voffset", 0.0);
+        t.u_scale = (float) getF(p, "uscale", 1.0); t.v_scale = (float) getF(p, "vscale", 1.0);
+    };
+    if (type == "scale") {
+        const Element *nested = nullptr;
+        for (const auto &c : node.children)
+            if (c->tag == "texture" || c->tag == "ref") { if (nested) throw Fail("scale texture: exactly one nested texture is expected"); nested = c.get(); }
+        if (!nested) throw Fail("scale texture: a nested texture is required");
+        uint32_t inner;
+        if (nested->tag == "ref") {
+            if (!out.namedTextures.count(nested->get("id"))) throw Fail("reference to unknown texture '" + nested->get("id") + "'");
+            inner = out.namedTextures.at(nested->get("id"));
+        } else inner = makeTexture(*nested, out);
+        float factor[3];
+        getRgb(p, "scale", 1.0f, 1.0f, 1.0f, factor);
+        if (factor[0] != factor[1] || factor[0] != factor[2]) throw Fail("scale texture: only a scalar (or grey) scale factor is supported");
+        t = out.textures[inner - 1];
+        pixels = out.texturePixels[inner - 1];
+        t.scale *= factor[0];
+    } else if (type == "checkerboard") {        // src/textures/checkerboard.cpp:48-51
+        t.type = MTSAMD_TEX_CHECKERBOARD;
+        getRgb(p, "color0", 0.4f, 0.4f, 0.4f, t.color0); getRgb(p, "color1", 0.2f, 0.2f, 0.2f, t.color1);
+        uvTransform();
+    } else if (type == "gridtexture") {         // src/textures/gridtexture.cpp:55-59
+        t.type = MTSAMD_TEX_GRID;
+        getRgb(p, "color0", 0.2f, 0.2f, 0.2f, t.color0); getRgb(p, "color1", 0.4f, 0.4f, 0.4f, t.color1);
+        t.line_width = (float) getF(p, "lineWidth", 0.01);
+        uvTransform();
+    } else if (type == "bitmap") {              // src/textures/bitmap.cpp:179-235
+        t.type = MTSAMD_TEX_BITMAP;
+        uvTransform();
+        if (!p.count("filename")) throw Fail("bitmap texture: the 'filename' parameter is missing");
+        if (!getS(p, "channel", "").empty()) throw Fail("bitmap texture: the 'channel' parameter is not supported");
+        std::string file = getS(p, "filename", "");
+        if (!file.empty() && file[0] != '/') file = out.sceneDir + "/" + file;
+        const std::string filter = lower(getS(p, "filterType", "ewa"));
+        if (filter == "ewa") t.filter_type = MTSAMD_MIP_EWA; else if (filter == "bilinear") t.filter_type = MTSAMD_MIP_BILINEAR;
+        else if (filter == "trilinear") t.filter_type = MTSAMD_MIP_TRILINEAR; else if (filter == "nearest") t.filter_type = MTSAMD_MIP_NEAREST;
+        else throw Fail("Unknown filter type '" + filter + "' -- must be 'ewa', 'trilinear', or 'nearest'!");
+        auto wrap = [&](const std::string &mode) {      // bitmap.cpp:324-339
+            if (mode == "repeat") return (int) MTSAMD_WRAP_REPEAT;
+            if (mode == "clamp") return (int) MTSAMD_WRAP_CLAMP;
+            if (mode == "mirror") return (int) MTSAMD_WRAP_MIRROR;
+            if (mode == "zero" || mode == "black") return (int) MTSAMD_WRAP_ZERO;
+            if (mode == "one" || mode == "white") return (int) MTSAMD_WRAP_ONE;
+            throw Fail("Unknown wrap mode '" + mode + "' -- must be 'repeat', 'clamp', 'black', or 'white'!");
+        };
+        const std::string both = getS(p, "wrapMode", "repeat");
+        t.wrap_u = wrap(getS(p, "wrapModeU", both)); t.wrap_v = wrap(getS(p, "wrapModeV", both));
+        t.max_anisotropy = (float) getF(p, "maxAnisotropy", 20.0);
+        mtsamd_image img;
+        if (mtsamd_image_load(file.c_str(), (float) getF(p, "gamma", 0.0), &img) != MTSAMD_OK) throw Fail(mtsamd_last_error());
+        pixels.assign(img.pixels, img.pixels + (size_t) img.width * img.height * img.channels);
+        t.width = img.width; t.height = img.height; t.channels = img.channels;
+        mtsamd_image_free(&img);
+    } else {
+        throw Fail("texture type '" + type + "' is not supported (checkerboard, gridtexture, bitmap, scale)");
+    }
+    out.textures.push_back(t);
+    out.texturePixels.push_back(std::move(pixels));
+    return (uint32_t) out.textures.size();
+}
+
+// The textures a <bsdf> element names for its colour parameters: nested <texture name="..."> elements and
+// <ref name="..." id="..."/> to textures declared at the top level
+void attachTextures(const Element &node, LoadedScene &out, mtsamd_material &m) {
+    for (const auto &c : node.children) {
+        uint32_t index = 0;
+        if (c->tag == "texture") index = makeTexture(*c, out);
+        else if (c->tag == "ref" && out.namedTextures.count(c->get("id"))) index = out.namedTextures.at(c->get("id"));
+        else continue;
+        const std::string name = c->get("name");
+        const bool diffuseName = name == "diffuseReflectance" || (name == "reflectance" && m.type == MTSAMD_BSDF_DIFFUSE);
+        const bool usesDiffuse = m.type == MTSAMD_BSDF_DIFFUSE || m.type == MTSAMD_BSDF_ROUGHPLASTIC || m.type == MTSAMD_BSDF_PLASTIC || m.type == MTSAMD_BSDF_WARD;
+        const bool usesTransmittance = m.type == MTSAMD_BSDF_DIELECTRIC || m.type == MTSAMD_BSDF_ROUGHDIELECTRIC;
+        if (diffuseName && usesDiffuse) m.diffuse_texture = (int32_t) index;
+        else if (name == "specularReflectance" && m.type != MTSAMD_BSDF_DIFFUSE) m.specular_texture = (int32_t) index;
+        else if (name == "specularTransmittance" && usesTransmittance) m.transmittance_texture = (int32_t) index;
+        else throw Fail("a texture for the parameter '" + name + "' of <bsdf type=\"" + node.get("type") + "\"> is not supported");
+    }
+}
+
 // ---- BSDFs -------------------------------------------------------------------------------------------------------------------
 uint32_t addMaterial(LoadedScene &out, const mtsamd_material &m);
 
@@ -344,7 +437,7 @@ mtsamd_material makeBsdf(const Element &node, const LoadOptions &opts, LoadedSce
         return m;
     }
     for (const auto &c : node.children)
-        if (c->tag == "texture" || c->tag == "bsdf")
+        if (c->tag == "bsdf")
             throw Fail("nested <" + c->tag + "> inside <bsdf type=\"" + type + "\"> is not supported");
     const Props p = parseProps(node);
     mtsamd_material m;
@@ -427,6 +520,7 @@ mtsamd_material makeBsdf(const Element &node, const LoadOptions &opts, LoadedSce
     } else {
         throw Fail("BSDF type '" + type + "' is outside the path hot path of this core");
     }
+    attachTextures(node, out, m);
     return m;
 }
 
@@ -648,6 +742,9 @@ mtsamd_scene_desc LoadedScene::desc() const {
     size_t table = 0;
     for (mtsamd_material &m : self->materials)
         if (m.type == MTSAMD_BSDF_ROUGHPLASTIC) m.rtrans = rtransTables[table++].data();
+    for (size_t i = 0; i < textures.size(); ++i)
+        self->textures[i].pixels = texturePixels[i].empty() ? nullptr : texturePixels[i].data();
+    d.n_textures = (uint32_t) textures.size(); d.textures = textures.empty() ? nullptr : textures.data();
     d.shapes = shapes.data(); d.materials = materials.data(); d.emitters = emitters.empty() ? nullptr : emitters.data();
     d.camera = camera; d.film = film; d.integrator = integrator;
     return d;
@@ -1155,6 +1252,12 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
         std::map<std::string, std::string> params = opts.params;
         expandIncludes(*root, base, params, 0);
         std::map<std::string, uint32_t> namedBsdfs;
+        out.sceneDir = base;
+        for (const auto &el : root->children)       // textures first: BSDFs refer to them by id
+            if (el->tag == "texture") {
+                const uint32_t idx = makeTexture(*el, out);
+                if (el->has("id")) out.namedTextures[el->get("id")] = idx;
+            }
         int defaultBsdf = -1;
         bool haveSensor = false;
         memset(&out.integrator, 0, sizeof(out.integrator));
@@ -1398,8 +1501,7 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
             } else if (el.tag == "default" || el.tag == "alias") {
                 // handled above
             } else if (el.tag == "medium" || el.tag == "texture") {
-                if (el.tag == "medium") continue;   // a medium no shape refers to is inert
-                return "<" + el.tag + "> is not supported";
+                // a medium no shape refers to is inert; textures were read before the BSDFs
             }
         }
         if (!haveSensor) return "scene has no sensor";

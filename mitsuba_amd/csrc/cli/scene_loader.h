@@ -1,6 +1,7 @@
 // Host-side scene ingest in C++ for the subset of the Mitsuba 0.5 scene format that the `path` hot path needs:
 // the XML description (src/librender/scenehandler.cpp:306-693) restricted to scene / integrator / sensor / sampler /
-// film / rfilter / bsdf / shape / emitter / ref / transform / include / default / alias and the scalar property tags
+// film / rfilter / bsdf / texture (checkerboard, gridtexture, bitmap, scale) / shape / emitter / ref / transform /
+// include / default / alias and the scalar property tags
 // with "$parameter" substitution; triangle meshes from `.serialized` containers (src/librender/trimesh.cpp:175-294),
 // Wavefront OBJ files (src/shapes/obj.cpp, whole file as one mesh), Stanford PLY files (src/shapes/ply.cpp) and the
 // `cube` plugin (src/shapes/cube.cpp). Everything else is rejected with a message -- nothing is
@@ -28,6 +29,10 @@ struct LoadedScene {
     std::vector<mtsamd_material> materials;
     std::vector<std::vector<float>> rtransTables;   // storage behind mtsamd_material::rtrans
     std::vector<mtsamd_emitter> emitters;
+    std::vector<mtsamd_texture> textures;           // what the materials' *_texture fields index (1-based)
+    std::vector<std::vector<float>> texturePixels;  // storage behind mtsamd_texture::pixels, one entry per texture (empty if not a bitmap)
+    std::map<std::string, uint32_t> namedTextures;  // <texture id="..."> declared at the top level of the scene
+    std::string sceneDir;                           // where relative file names of the scene file are looked up
     mtsamd_camera camera;
     mtsamd_film film;
     mtsamd_integrator integrator;

@@ -7,6 +7,7 @@ namespace mtsamd {
 
 struct Isect {
     V3 p, geoN, wi;
+    V3 dpdu, dpdv;      // position partials (read only where uv partials are computed)
     Frame3 sh;
     float uvx, uvy;
     uint32_t shape, material, flags;
@@ -31,11 +32,13 @@ MTS_DEV void fillIntersection(const DevScene &sc, uint32_t tri, float u, float v
     const float len = length(faceNormal);
     if (!isZero(faceNormal)) faceNormal = faceNormal / len;
     V3 dpdu = side1;
+    its.dpdv = side2;
     its.uvx = by; its.uvy = bz;
     if (its.flags & 2u) {       // TriMesh::computeUVTangents result (trimesh.cpp:683-735) and interpolated texture coordinates
         const float4 *q = sc.shadeUV + 3 * (size_t) tri;
         const float4 q0 = q[0], q1 = q[1], q2 = q[2];
         dpdu = mk(q1.z, q1.w, q2.x);
+        its.dpdv = mk(q2.y, q2.z, q2.w);
         its.uvx = q0.x * bx + q0.z * by + q1.x * bz;
         its.uvy = q0.y * bx + q0.w * by + q1.y * bz;
     }
@@ -48,6 +51,7 @@ MTS_DEV void fillIntersection(const DevScene &sc, uint32_t tri, float u, float v
         shN = faceNormal;
     }
     its.geoN = faceNormal;
+    its.dpdu = dpdu;
     its.sh.n = shN;
     its.sh.s = normalize(dpdu - shN * dot(shN, dpdu));
     its.sh.t = cross(shN, its.sh.s);
@@ -692,36 +696,169 @@ MTS_DEV bool resolveTwoSided(const DevScene &sc, uint32_t &self, float wiZ, DevM
     return true;
 }
 
-// ---- Texture2D::eval(its) (src/librender/texture.cpp:112-121) for the two procedural textures ---------------------
-MTS_DEV V3 textureEval(const DevTexture &t, float u, float v) {
-    const float x = u * t.uScale + t.uOffset, y = v * t.vScale + t.vOffset;
+// ---- bitmap textures: lookups into the MIP pyramid (include/mitsuba/render/mipmap.h:503-834) -------------------------
+struct MipRef { const DevScene *sc; uint32_t first, levels, bcu, bcv; float maxAnisotropy; };
+
+MTS_DEV int wrapTexel(int x, int n, uint32_t bc, int &constant) {
+    if (x >= 0 && x < n) return x;
+    switch (bc) {
+        case 1: { const int r = x % n; return r < 0 ? r + n : r; }                          // repeat
+        case 0: return min(n - 1, max(0, x));                                              // clamp
+        case 2: { int r = x % (2 * n); if (r < 0) r += 2 * n; return r >= n ? 2 * n - r - 1 : r; }     // mirror
+        case 3: constant = 0; return 0;
+        default: constant = 1; return 0;
+    }
+}
+
+MTS_DEV V3 mipTexel(const MipRef &m, uint32_t level, int x, int y) {        // evalTexel (mipmap.h:503-563)
+    const DevMipLevel L = m.sc->mipLevels[m.first + level];
+    int constant = -1;
+    x = wrapTexel(x, L.w, m.bcu, constant);
+    if (constant >= 0) return mk((float) constant);
+    y = wrapTexel(y, L.h, m.bcv, constant);
+    if (constant >= 0) return mk((float) constant);
+    const uint2 t = m.sc->texels[(size_t) L.offset + (size_t) y * (size_t) L.w + (size_t) x];
+    union { uint32_t u; _Float16 h[2]; } a, b;
+    a.u = t.x; b.u = t.y;
+    return mk((float) a.h[0], (float) a.h[1], (float) b.h[0]);
+}
+
+MTS_DEV V3 mipBox(const MipRef &m, uint32_t level, float u, float v) {       // evalBox (mipmap.h:566-569)
+    const DevMipLevel L = m.sc->mipLevels[m.first + level];
+    return mipTexel(m, level, (int) floorf(u * (float) L.w), (int) floorf(v * (float) L.h));
+}
+
+MTS_DEV V3 mipBilinear(const MipRef &m, uint32_t level, float uu, float vv) {    // evalBilinear (mipmap.h:575-596)
+    if (!isfinite(uu) || !isfinite(vv)) return mk(0.0f);
+    if (level >= m.levels) return mipBox(m, m.levels - 1, uu, vv);
+    const DevMipLevel L = m.sc->mipLevels[m.first + level];
+    const float u = uu * (float) L.w - 0.5f, v = vv * (float) L.h - 0.5f;
+    const int xPos = (int) floorf(u), yPos = (int) floorf(v);
+    const float dx1 = u - (float) xPos, dx2 = 1.0f - dx1, dy1 = v - (float) yPos, dy2 = 1.0f - dy1;
+    return mipTexel(m, level, xPos, yPos) * dx2 * dy2 + mipTexel(m, level, xPos, yPos + 1) * dx2 * dy1
+         + mipTexel(m, level, xPos + 1, yPos) * dx1 * dy2 + mipTexel(m, level, xPos + 1, yPos + 1) * dx1 * dy1;
+}
+
+MTS_DEV V3 mipEWA(const MipRef &m, uint32_t level, float uu, float vv, float A, float B, float C) {    // evalEWA (mipmap.h:764-834)
+    if (!isfinite(A + B + C + uu + vv)) return mk(0.0f);
+    if (level >= m.levels) return mipBox(m, m.levels - 1, uu, vv);
+    const DevMipLevel L = m.sc->mipLevels[m.first + level];
+    const float u = uu * (float) L.w - 0.5f, v = vv * (float) L.h - 0.5f;
+    A /= L.ratioX * L.ratioX; B /= L.ratioX * L.ratioY; C /= L.ratioY * L.ratioY;
+    const float invDet = 1.0f / (-B * B + 4.0f * A * C), deltaU = 2.0f * sqrtf(C * invDet), deltaV = 2.0f * sqrtf(A * invDet);
+    const int u0 = (int) ceilf(u - deltaU), u1 = (int) floorf(u + deltaU), v0 = (int) ceilf(v - deltaV), v1 = (int) floorf(v + deltaV);
+    const float As = A * 64, Bs = B * 64, Cs = C * 64;
+    V3 result = mk(0.0f);
+    float denominator = 0.0f;
+    const float ddq = 2 * As, uu0 = (float) u0 - u;
+    for (int vt = v0; vt <= v1; ++vt) {
+        const float vd = (float) vt - v;
+        float q = As * uu0 * uu0 + (Bs * uu0 + Cs * vd) * vd;
+        float dq = As * (2 * uu0 + 1) + Bs * vd;
+        for (int ut = u0; ut <= u1; ++ut) {
+            // the reference's test is on (uint32_t) q, which lets values in (-1, 0) through as entry 0
+            if (q < 64.0f && q > -1.0f) {
+                const float weight = m.sc->ewaLut[(int) q];
+                result = result + mipTexel(m, level, ut, vt) * weight;
+                denominator += weight;
+            }
+            q += dq;
+            dq += ddq;
+        }
+    }
+    if (denominator == 0) return mipBilinear(m, level, uu, vv);
+    return result / denominator;
+}
+
+MTS_DEV float log2Ref(float value) {        // math::log2 (src/libcore/math.cpp:103-106): fastlog times 1 / log(2.0f)
+    return logRef(value) * (1.0f / 0.693147182464599609375f);
+}
+
+// TMIPMap::eval(uv, d0, d1) (mipmap.h:629-715)
+MTS_DEV V3 mipFiltered(const MipRef &m, uint32_t filter, float u, float v, float d0x, float d0y, float d1x, float d1y) {
+    if (filter == 0) return mipBox(m, 0, u, v);
+    if (filter == 1) return mipBilinear(m, 0, u, v);
+    const DevMipLevel L0 = m.sc->mipLevels[m.first];
+    const float du0 = d0x * (float) L0.w, dv0 = d0y * (float) L0.h, du1 = d1x * (float) L0.w, dv1 = d1y * (float) L0.h;
+    float A = dv0 * dv0 + dv1 * dv1, B = -2.0f * (du0 * dv0 + du1 * dv1), C = du0 * du0 + du1 * du1, F = A * C - B * B * 0.25f;
+    const float root = hypot2(A - C, B), Aprime = 0.5f * (A + C - root), Cprime = 0.5f * (A + C + root);
+    float majorRadius = Aprime != 0 ? sqrtf(F / Aprime) : 0, minorRadius = Cprime != 0 ? sqrtf(F / Cprime) : 0;
+    if (filter == 2 || !(minorRadius > 0) || !(majorRadius > 0) || F < 0) {
+        const float level = log2Ref(fmaxf(majorRadius, kEpsilon));
+        const int ilevel = (int) floorf(level);
+        if (ilevel < 0) return mipBilinear(m, 0, u, v);
+        const float a = level - (float) ilevel;
+        return mipBilinear(m, (uint32_t) ilevel, u, v) * (1.0f - a) + mipBilinear(m, (uint32_t) ilevel + 1, u, v) * a;
+    }
+    if (minorRadius * m.maxAnisotropy < majorRadius) {
+        minorRadius = majorRadius / m.maxAnisotropy;
+        const float theta = 0.5f * atanM(B / (A - C));
+        float sinTheta, cosTheta;
+        sincosM(theta, &sinTheta, &cosTheta);
+        const float a2 = majorRadius * majorRadius, b2 = minorRadius * minorRadius, sinTheta2 = sinTheta * sinTheta,
+                    cosTheta2 = cosTheta * cosTheta, sin2Theta = 2 * sinTheta * cosTheta;
+        A = a2 * cosTheta2 + b2 * sinTheta2;
+        B = (a2 - b2) * sin2Theta;
+        C = a2 * sinTheta2 + b2 * cosTheta2;
+        F = a2 * b2;
+    }
+    const float scale = 1.0f / F;
+    A *= scale; B *= scale; C *= scale;
+    const float level = fmaxf(0.0f, log2Ref(minorRadius));
+    const int ilevel = (int) level;
+    const float a = level - (float) ilevel;
+    if (majorRadius < 1 || !(A > 0 && C > 0)) return mipBilinear(m, (uint32_t) ilevel, u, v);
+    return mipEWA(m, (uint32_t) ilevel, u, v, A, B, C) * (1.0f - a) + mipEWA(m, (uint32_t) ilevel + 1, u, v, A, B, C) * a;
+}
+
+// BitmapTexture::eval (src/textures/bitmap.cpp:431-454 without partials, :486-499 with) at the transformed uv. A real
+// call: the lookups are long, and the shading kernels evaluate textures in many places.
+__device__ __attribute__((noinline)) inline float4 bitmapEval(const DevScene *sc, const DevTexture *tp, float x, float y, float4 duv, uint32_t filtered) {
+    const DevTexture &t = *tp;
+    const uint32_t mode = __float_as_uint(t.color1[2]), filter = mode & 0xffu;
+    MipRef m;
+    m.sc = sc; m.first = __float_as_uint(t.color1[0]); m.levels = __float_as_uint(t.color1[1]);
+    m.bcu = (mode >> 8) & 0xffu; m.bcv = (mode >> 16) & 0xffu; m.maxAnisotropy = t.lineWidth;
+    V3 value;
+    if (filtered) value = mipFiltered(m, filter, x, y, duv.x, duv.y, duv.z, duv.w);
+    else value = filter != 0 ? mipBilinear(m, 0, x, y) : mipBox(m, 0, x, y);
+    value = value * ld3(t.color0);
+    return make_float4(value.x, value.y, value.z, 0.0f);
+}
+
+// ---- Texture2D::eval(its, filter = true) (src/librender/texture.cpp:112-121) ------------------------------------------
+MTS_DEV V3 textureEval(const DevScene &sc, const DevTexture &t, const SurfUV &q) {
+    const float x = q.u * t.uScale + t.uOffset, y = q.v * t.vScale + t.vOffset;
     bool second;
     if (t.type == 1) {      // Checkerboard::eval (src/textures/checkerboard.cpp:66-75); math::modulo of a truncated int
         int xi = (int) (x * 2) % 2, yi = (int) (y * 2) % 2;
         if (xi < 0) xi += 2;
         if (yi < 0) yi += 2;
         second = (2 * xi - 1) * (2 * yi - 1) != 1;
-    } else {                // GridTexture::eval (src/textures/gridtexture.cpp:75-88)
+    } else if (t.type == 2) {   // GridTexture::eval (src/textures/gridtexture.cpp:75-88)
         float fx = x - (float) (int) floorf(x), fy = y - (float) (int) floorf(y);
         if (fx > 0.5f) fx -= 1;
         if (fy > 0.5f) fy -= 1;
         second = fabsf(fx) < t.lineWidth || fabsf(fy) < t.lineWidth;
+    } else {
+        const float4 r = bitmapEval(&sc, &t, x, y, make_float4(q.dudx * t.uScale, q.dvdx * t.vScale, q.dudy * t.uScale, q.dvdy * t.vScale), q.filtered);
+        return mk(r.x, r.y, r.z);
     }
     return second ? ld3(t.color1) : ld3(t.color0);
 }
 
 // The colours of record `index` that are textured, evaluated at the intersection's uv and written over the constants
 // in m: what m_reflectance->eval(bRec.its) etc. return inside the BSDF (e.g. src/bsdfs/diffuse.cpp:110-118)
-MTS_DEV void applyTextures(const DevScene &sc, uint32_t index, float u, float v, DevMaterial &m) {
+MTS_DEV void applyTextures(const DevScene &sc, uint32_t index, const SurfUV &q, DevMaterial &m) {
     if (!sc.materialTextures) return;
     const uint4 b = sc.materialTextures[index];
-    if (b.x) { const V3 c = textureEval(sc.textures[b.x - 1], u, v); m.diffuse[0] = c.x; m.diffuse[1] = c.y; m.diffuse[2] = c.z; }
-    if (b.y) { const V3 c = textureEval(sc.textures[b.y - 1], u, v); m.specular[0] = c.x; m.specular[1] = c.y; m.specular[2] = c.z; }
-    if (b.z) { const V3 c = textureEval(sc.textures[b.z - 1], u, v); m.transmittance[0] = c.x; m.transmittance[1] = c.y; m.transmittance[2] = c.z; }
+    if (b.x) { const V3 c = textureEval(sc, sc.textures[b.x - 1], q); m.diffuse[0] = c.x; m.diffuse[1] = c.y; m.diffuse[2] = c.z; }
+    if (b.y) { const V3 c = textureEval(sc, sc.textures[b.y - 1], q); m.specular[0] = c.x; m.specular[1] = c.y; m.specular[2] = c.z; }
+    if (b.z) { const V3 c = textureEval(sc, sc.textures[b.z - 1], q); m.transmittance[0] = c.x; m.transmittance[1] = c.y; m.transmittance[2] = c.z; }
 }
-MTS_DEV void loadMaterialAt(const DevScene &sc, uint32_t index, float2 uv, DevMaterial &m) {
+MTS_DEV void loadMaterialAt(const DevScene &sc, uint32_t index, const SurfUV &uv, DevMaterial &m) {
     loadMaterial(sc, index, m);
-    applyTextures(sc, index, uv.x, uv.y, m);
+    applyTextures(sc, index, uv, m);
 }
 
 MTS_DEV V3 mirrorZ(V3 v) { return mk(v.x, v.y, -v.z); }
@@ -842,7 +979,7 @@ MTS_DEV float bsdfPdfDiscrete(const DevMaterial &m, V3 wi, V3 wo) {
     return 0.0f;
 }
 
-MTS_DEV V3 mixEval(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, float2 uv) {
+MTS_DEV V3 mixEval(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, const SurfUV &uv) {
     V3 result = mk(0.0f);
 #pragma unroll 1
     for (int i = 0; i < m.variant; ++i) {
@@ -853,7 +990,7 @@ MTS_DEV V3 mixEval(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, float
     return result;
 }
 
-MTS_DEV float mixPdf(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, float2 uv) {
+MTS_DEV float mixPdf(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, const SurfUV &uv) {
     float result = 0.0f;
 #pragma unroll 1
     for (int i = 0; i < m.variant; ++i) {
@@ -885,7 +1022,7 @@ MTS_DEV bool bsdfDrawsFromSampler(const DevMaterial &m, float sx) {
     return m.type == 7;
 }
 
-MTS_DEV V3 mixSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, float su, V3 &wo, float &pdf, float &eta, uint32_t &sampledType, float2 uv) {
+MTS_DEV V3 mixSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, float su, V3 &wo, float &pdf, float &eta, uint32_t &sampledType, const SurfUV &uv) {
     const int n = m.variant;
     const int entry = mixEntry(m, sx);
     const float lower = mixCdf(m, entry), width = mixCdf(m, entry + 1) - lower;
@@ -909,18 +1046,18 @@ MTS_DEV V3 mixSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, 
 
 // What the integrator calls on the record that answers for this side: a mixture (only compiled in with MIX) or a plain model
 template <bool RD = true, bool MIX = true>
-MTS_DEV V3 bsdfEvalAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, float2 uv = make_float2(0, 0)) {
+MTS_DEV V3 bsdfEvalAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, const SurfUV &uv = surfUV(0, 0)) {
     if (MIX && m.type == 8) return mixEval(sc, m, wi, wo, uv);
     return bsdfEval<RD>(sc, m, wi, wo);
 }
 template <bool RD = true, bool MIX = true>
-MTS_DEV float bsdfPdfAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, float2 uv = make_float2(0, 0)) {
+MTS_DEV float bsdfPdfAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, const SurfUV &uv = surfUV(0, 0)) {
     if (MIX && m.type == 8) return mixPdf(sc, m, wi, wo, uv);
     return bsdfPdf<RD>(sc, m, wi, wo);
 }
 template <bool RD = true, bool MIX = true>
 MTS_DEV V3 bsdfSampleAny(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, float su, V3 &wo, float &pdf, float &eta, uint32_t &sampledType,
-                         float2 uv = make_float2(0, 0)) {
+                         const SurfUV &uv = surfUV(0, 0)) {
     if (MIX && m.type == 8) return mixSample(sc, m, wi, sx, sy, su, wo, pdf, eta, sampledType, uv);
     return bsdfSample<RD>(sc, m, wi, sx, sy, su, wo, pdf, eta, sampledType);
 }
@@ -1092,6 +1229,51 @@ MTS_DEV void cameraRay(const DevScene &sc, float px, float py, V3 &o, V3 &d, flo
     d = mk(W[0] * dl.x + W[1] * dl.y + W[2] * dl.z, W[4] * dl.x + W[5] * dl.y + W[6] * dl.z, W[8] * dl.x + W[9] * dl.y + W[10] * dl.z);
     mint = sc.nearClip * invZ;
     maxt = sc.farClip * invZ;
+}
+
+// Intersection::computePartials (src/librender/intersection.cpp:5-76) for the vertex a camera ray reaches: the offset
+// rays of PerspectiveCameraImpl::sampleRayDifferential (perspective.cpp:289-293; position differentials on the near
+// plane :158-162) scaled by 1 / sqrt(sampleCount) (integrator.cpp:150,177; ray.h:163-168), intersected with the
+// tangent plane; two of the three equations p' - p = dpdu * du + dpdv * dv are solved for (du, dv).
+MTS_DEV V3 sampleToCameraPoint(const DevScene &sc, float sx, float sy) {
+    const float *M = sc.sampleToCamera;
+    V3 p = mk(M[0] * sx + M[1] * sy + M[3], M[4] * sx + M[5] * sy + M[7], M[8] * sx + M[9] * sy + M[11]);
+    const float w = M[12] * sx + M[13] * sy + M[15];
+    if (w != 1.0f) p = p / w;
+    return p;
+}
+
+MTS_DEV void cameraUVPartials(const DevScene &sc, const PassParams &pp, float2 pos, const Isect &its, float4 rayO, V3 d, SurfUV &uv) {
+    uv.filtered = 1u;
+    uv.dudx = uv.dvdx = uv.dudy = uv.dvdy = 0.0f;
+    if (isZero(its.dpdu) && isZero(its.dpdv)) return;
+    const V3 o = mk(rayO.x, rayO.y, rayO.z);
+    const V3 nearP = sampleToCameraPoint(sc, pos.x * sc.invResX, pos.y * sc.invResY);
+    const V3 origin = sampleToCameraPoint(sc, 0.0f, 0.0f);
+    const V3 dx = sampleToCameraPoint(sc, sc.invResX, 0.0f) - origin, dy = sampleToCameraPoint(sc, 0.0f, sc.invResY) - origin;
+    const float *W = sc.camToWorld;
+    const V3 lx = normalize(nearP + dx), ly = normalize(nearP + dy);
+    const V3 rx = mk(W[0] * lx.x + W[1] * lx.y + W[2] * lx.z, W[4] * lx.x + W[5] * lx.y + W[6] * lx.z, W[8] * lx.x + W[9] * lx.y + W[10] * lx.z);
+    const V3 ry = mk(W[0] * ly.x + W[1] * ly.y + W[2] * ly.z, W[4] * ly.x + W[5] * ly.y + W[6] * ly.z, W[8] * ly.x + W[9] * ly.y + W[10] * ly.z);
+    const float amount = 1.0f / sqrtf((float) pp.sppTotal);
+    const V3 rxD = d + (rx - d) * amount, ryD = d + (ry - d) * amount;
+    const V3 n = its.geoN;
+    const float ppn = dot(n, its.p), po = dot(n, o), prx = dot(n, rxD), pry = dot(n, ryD);
+    if (prx == 0 || pry == 0) return;
+    const float tx = (ppn - po) / prx, ty = (ppn - po) / pry;
+    const float absX = fabsf(n.x), absY = fabsf(n.y), absZ = fabsf(n.z);
+    float a00, a01, a10, a11, bx0, bx1, by0, by1;
+    const V3 px = o + rxD * tx, py = o + ryD * ty;
+    const V3 ex = px - its.p, ey = py - its.p;
+    if (absX > absY && absX > absZ) { a00 = its.dpdu.y; a01 = its.dpdv.y; a10 = its.dpdu.z; a11 = its.dpdv.z; bx0 = ex.y; bx1 = ex.z; by0 = ey.y; by1 = ey.z; }
+    else if (absY > absZ) { a00 = its.dpdu.x; a01 = its.dpdv.x; a10 = its.dpdu.z; a11 = its.dpdv.z; bx0 = ex.x; bx1 = ex.z; by0 = ey.x; by1 = ey.z; }
+    else { a00 = its.dpdu.x; a01 = its.dpdv.x; a10 = its.dpdu.y; a11 = its.dpdv.y; bx0 = ex.x; bx1 = ex.y; by0 = ey.x; by1 = ey.y; }
+    // solveLinearSystem2x2 (src/libcore/util.cpp:527-539)
+    const float det = a00 * a11 - a01 * a10;
+    if (fabsf(det) <= 0x1p-128f) { uv.dudx = 1; uv.dudy = 1; return; }     // intersection.cpp:68-75 (dvdy is left unset there)
+    const float inverse = 1.0f / det;
+    uv.dudx = (a11 * bx0 - a01 * bx1) * inverse; uv.dvdx = (a00 * bx1 - a10 * bx0) * inverse;
+    uv.dudy = (a11 * by0 - a01 * by1) * inverse; uv.dvdy = (a00 * by1 - a10 * by0) * inverse;
 }
 
 }  // namespace mtsamd

@@ -32,11 +32,31 @@ struct alignas(16) DevMaterial {
 
 // Two-colour procedural texture (src/textures/checkerboard.cpp, gridtexture.cpp) with the colours as the BSDF sees
 // them (scale textures and the energy-conservation factor applied)
+// Bitmap texture (type 3, src/textures/bitmap.cpp): color0 is the factor on the looked-up value (scale textures and
+// the energy-conservation factor), color1 holds, as raw bits, the first entry of the texture's levels in
+// DevScene::mipLevels, their number, and filter type | wrapU << 8 | wrapV << 16; lineWidth is the anisotropy bound.
 struct alignas(16) DevTexture {
     float color0[3]; int32_t type;
     float color1[3]; float lineWidth;
     float uOffset, vOffset, uScale, vScale;
 };
+
+// One level of a MIP pyramid: where its texels start (in texels of four halves: R, G, B, unused), its size and
+// TMIPMap::m_sizeRatio (include/mitsuba/render/mipmap.h:264-266)
+struct alignas(16) DevMipLevel {
+    uint32_t offset; int32_t w, h; float ratioX;
+    float ratioY; uint32_t pad[3];
+};
+
+// Where on a surface a BSDF's textures are looked up: Intersection::uv and, when the intersection has them
+// (Intersection::hasUVPartials, set for the first vertex of a camera path whose BSDF filters its textures), the
+// partials dudx, dvdx, dudy, dvdy (include/mitsuba/render/shape.h:150-165)
+struct SurfUV {
+    float u, v;
+    float dudx, dvdx, dudy, dvdy;
+    uint32_t filtered;
+};
+__host__ __device__ inline SurfUV surfUV(float u, float v) { return SurfUV{ u, v, 0.0f, 0.0f, 0.0f, 0.0f, 0u }; }
 
 struct DevShape {
     uint32_t firstTri, nTris;
@@ -85,6 +105,11 @@ struct DevScene {
     // transmittance colour (0 = the constant in the record), and the textures
     const uint4 *materialTextures;
     const DevTexture *textures;
+    // Only with bitmap textures: the levels of all MIP pyramids, their texels, and the 64-entry weight table of the
+    // elliptically weighted average (mipmap.h:296-302)
+    const DevMipLevel *mipLevels;
+    const uint2 *texels;
+    const float *ewaLut;
     uint32_t nEmitters, nTris, nShapes, nMaterials;
     float aabbMin[3], aabbMax[3];       // enlarged scene bounds (gkdtree.h:1213-1220)
     float sampleToCamera[16];

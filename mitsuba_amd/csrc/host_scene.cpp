@@ -1,4 +1,5 @@
 #include "host_scene.h"
+#include "mipmap.h"
 
 #include <algorithm>
 #include <cmath>
@@ -19,6 +20,8 @@ float max3(const float *s) { return std::max(std::max(s[0], s[1]), s[2]); }
 // around it as `scale` textures (the scene's own, then BSDF::ensureEnergyConservation's, src/librender/bsdf.cpp:88-113)
 struct Colour {
     const mtsamd_texture *tex = nullptr;
+    int32_t texIndex = 0;               // 1-based, as the material names it
+    const MipPyramid *mip = nullptr;    // bitmap textures
     float base0[3], base1[3];
     float userScale = 1.0f, energyScale = 1.0f;
 
@@ -26,13 +29,17 @@ struct Colour {
         const float *b = which ? base1 : base0;
         for (int i = 0; i < 3; ++i) out[i] = (b[i] * userScale) * energyScale;
     }
-    void maximum(float out[3]) const {      // Checkerboard / GridTexture::getMaximum, ScaleTexture::getMaximum
-        for (int i = 0; i < 3; ++i) out[i] = (tex ? std::max(base0[i], base1[i]) : base0[i]) * userScale;
+    void factor(float out[3]) const {   // what a looked-up bitmap value is multiplied by
+        for (int i = 0; i < 3; ++i) out[i] = userScale * energyScale;
     }
-    void average(float out[3]) const {      // ::getAverage (checkerboard.cpp:96-98, gridtexture.cpp:113-118, scale.cpp)
+    void maximum(float out[3]) const {      // Checkerboard / GridTexture / BitmapTexture::getMaximum, ScaleTexture::getMaximum
+        for (int i = 0; i < 3; ++i) out[i] = (mip ? mip->maximum[i] : tex ? std::max(base0[i], base1[i]) : base0[i]) * userScale;
+    }
+    void average(float out[3]) const {      // ::getAverage (checkerboard.cpp:96-98, gridtexture.cpp:113-118, bitmap.cpp:501-511, scale.cpp)
         for (int i = 0; i < 3; ++i) {
             float a = base0[i];
-            if (tex && tex->type == MTSAMD_TEX_CHECKERBOARD) a = (base0[i] + base1[i]) * 0.5f;
+            if (mip) a = mip->average[i];
+            else if (tex && tex->type == MTSAMD_TEX_CHECKERBOARD) a = (base0[i] + base1[i]) * 0.5f;
             else if (tex) {
                 const float interiorWidth = std::max(0.0f, 1 - 2 * tex->line_width), interiorArea = interiorWidth * interiorWidth,
                             lineArea = 1 - interiorArea;
@@ -41,14 +48,17 @@ struct Colour {
             out[i] = (a * userScale) * energyScale;
         }
     }
+    bool usesRayDifferentials() const { return mip != nullptr; }     // bitmap.cpp:541-543
 };
-std::string makeColour(const mtsamd_scene_desc *d, const float *constant, int32_t texture, Colour &c) {
+std::string makeColour(const mtsamd_scene_desc *d, const std::vector<MipPyramid> &pyramids, const float *constant, int32_t texture, Colour &c) {
     memcpy(c.base0, constant, 12); memcpy(c.base1, constant, 12);
     if (texture == 0) return "";
     if (texture < 0 || (uint32_t) texture > d->n_textures || !d->textures) return "material texture index out of range";
     c.tex = &d->textures[texture - 1];
-    if (c.tex->type != MTSAMD_TEX_CHECKERBOARD && c.tex->type != MTSAMD_TEX_GRID) return "unsupported texture type";
+    c.texIndex = texture;
+    if (c.tex->type < MTSAMD_TEX_CHECKERBOARD || c.tex->type > MTSAMD_TEX_BITMAP) return "unsupported texture type";
     memcpy(c.base0, c.tex->color0, 12); memcpy(c.base1, c.tex->color1, 12);
+    if (c.tex->type == MTSAMD_TEX_BITMAP) c.mip = &pyramids[texture - 1];
     c.userScale = c.tex->scale;
     return "";
 }
@@ -170,6 +180,45 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
     for (size_t i = 0; i < hs.indices.size(); ++i)
         if (hs.indices[i] >= d->n_vertices) return "vertex index out of range";
 
+    // ---- bitmap textures: one MIP pyramid per texture of the description (TMIPMap's constructor) ----------
+    std::vector<MipPyramid> pyramids(d->textures ? d->n_textures : 0);
+    std::vector<uint32_t> pyramidFirstLevel(pyramids.size(), 0);
+    for (size_t i = 0; i < pyramids.size(); ++i) {
+        const mtsamd_texture &t = d->textures[i];
+        if (t.type != MTSAMD_TEX_BITMAP) continue;
+        const std::string err = buildMipPyramid(t, 1.0f, pyramids[i]);
+        if (!err.empty()) return err;
+        pyramidFirstLevel[i] = (uint32_t) hs.mipLevels.size();
+        const uint32_t base = (uint32_t) (hs.texels.size() / 4);
+        for (DevMipLevel L : pyramids[i].levels) { L.offset += base; hs.mipLevels.push_back(L); }
+        hs.texels.insert(hs.texels.end(), pyramids[i].texels.begin(), pyramids[i].texels.end());
+        pyramids[i].texels.clear(); pyramids[i].texels.shrink_to_fit();
+        if (hs.texels.size() / 4 > 0xffffffffull) return "bitmap textures: more than 2^32 texels";
+    }
+    // a texture of the description as the device evaluates it, with the factors a BSDF wraps around it
+    auto deviceTexture = [&](const mtsamd_texture &t, uint32_t index /* 0-based */, const float c0[3], const float c1[3]) {
+        DevTexture dt;
+        memcpy(dt.color0, c0, 12); memcpy(dt.color1, c1, 12);
+        dt.type = t.type; dt.lineWidth = t.line_width;
+        dt.uOffset = t.u_offset; dt.vOffset = t.v_offset; dt.uScale = t.u_scale; dt.vScale = t.v_scale;
+        if (t.type == MTSAMD_TEX_BITMAP) {
+            const uint32_t words[3] = { pyramidFirstLevel[index], (uint32_t) pyramids[index].levels.size(),
+                                        (uint32_t) t.filter_type | ((uint32_t) t.wrap_u << 8) | ((uint32_t) t.wrap_v << 16) };
+            memcpy(dt.color1, words, 12);
+            dt.lineWidth = t.filter_type == MTSAMD_MIP_EWA ? t.max_anisotropy : 1.0f;     // bitmap.cpp:232-235
+        }
+        return dt;
+    };
+    // the textures on their own (mtsamd_texture_eval): the scene's scale factor only
+    for (size_t i = 0; i < pyramids.size(); ++i) {
+        const mtsamd_texture &t = d->textures[i];
+        if (t.type < MTSAMD_TEX_CHECKERBOARD || t.type > MTSAMD_TEX_BITMAP) return "unsupported texture type";
+        float c0[3], c1[3];
+        for (int k = 0; k < 3; ++k) { c0[k] = t.type == MTSAMD_TEX_BITMAP ? t.scale : t.color0[k] * t.scale; c1[k] = t.color1[k] * t.scale; }
+        hs.plainTextures.push_back(deviceTexture(t, (uint32_t) i, c0, c1));
+    }
+    std::vector<uint8_t> wantsPartials(d->n_materials, 0);      // BSDF::usesRayDifferentials of the record on its own
+
     // ---- materials ------------------------------------------------------------------------------------
     hs.materials.resize(d->n_materials);
     for (uint32_t i = 0; i < d->n_materials; ++i) {
@@ -181,10 +230,20 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         dm.eta = 1; dm.invEta = 1; dm.invEta2 = 1;
         const bool ee = m.ensure_energy_conservation != 0;
         Colour diff, spec, trans;
-        for (const std::string &err : { makeColour(d, m.diffuse_reflectance, m.diffuse_texture, diff),
-                                        makeColour(d, m.specular_reflectance, m.specular_texture, spec),
-                                        makeColour(d, m.specular_transmittance, m.transmittance_texture, trans) })
+        for (const std::string &err : { makeColour(d, pyramids, m.diffuse_reflectance, m.diffuse_texture, diff),
+                                        makeColour(d, pyramids, m.specular_reflectance, m.specular_texture, spec),
+                                        makeColour(d, pyramids, m.specular_transmittance, m.transmittance_texture, trans) })
             if (!err.empty()) return err;
+        {   // m_usesRayDifferentials as the plugins' configure() sets it (e.g. diffuse.cpp:101, roughplastic.cpp:301-304)
+            const bool dd = diff.usesRayDifferentials(), ss = spec.usesRayDifferentials(), tt = trans.usesRayDifferentials();
+            switch (m.type) {
+                case MTSAMD_BSDF_DIFFUSE: wantsPartials[i] = dd; break;
+                case MTSAMD_BSDF_ROUGHCONDUCTOR: case MTSAMD_BSDF_CONDUCTOR: wantsPartials[i] = ss; break;
+                case MTSAMD_BSDF_ROUGHPLASTIC: case MTSAMD_BSDF_PLASTIC: case MTSAMD_BSDF_WARD: wantsPartials[i] = dd || ss; break;
+                case MTSAMD_BSDF_DIELECTRIC: case MTSAMD_BSDF_ROUGHDIELECTRIC: wantsPartials[i] = ss || tt; break;
+                default: break;
+            }
+        }
         const unsigned aniso = m.alpha_u != m.alpha_v ? EAnisotropic : 0u;
         if (m.type == MTSAMD_BSDF_ROUGHCONDUCTOR || m.type == MTSAMD_BSDF_ROUGHPLASTIC || m.type == MTSAMD_BSDF_ROUGHDIELECTRIC) {
             if (m.distribution != MTSAMD_DISTR_BECKMANN && m.distribution != MTSAMD_DISTR_GGX)
@@ -281,11 +340,10 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
             for (int k = 0; k < 3; ++k) {
                 if (!slots[k]->tex) continue;
                 const mtsamd_texture &t = *slots[k]->tex;
-                DevTexture dt;
-                slots[k]->value(0, dt.color0); slots[k]->value(1, dt.color1);
-                dt.type = t.type; dt.lineWidth = t.line_width;
-                dt.uOffset = t.u_offset; dt.vOffset = t.v_offset; dt.uScale = t.u_scale; dt.vScale = t.v_scale;
-                hs.textures.push_back(dt);
+                float c0[3], c1[3];
+                slots[k]->value(0, c0); slots[k]->value(1, c1);
+                if (t.type == MTSAMD_TEX_BITMAP) slots[k]->factor(c0);
+                hs.textures.push_back(deviceTexture(t, (uint32_t) slots[k]->texIndex - 1, c0, c1));
                 hs.materialTextures[(size_t) i * 4 + k] = (uint32_t) hs.textures.size();
             }
             hs.mixture = true;      // textured scenes run the kernels that know every feature
@@ -327,6 +385,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
             w[k] = scale != 1.0f ? m.mix_weight[k] * scale : m.mix_weight[k];
             cdf[k + 1] = cdf[k] + w[k];
             flags |= hs.materials[c].ownFlags;
+            if (wantsPartials[c]) wantsPartials[i] = 1;     // mixturebsdf.cpp:167
         }
         normalizeCdf(cdf, (size_t) n, nullptr);
         for (int k = n + 1; k <= 4; ++k) cdf[k] = cdf[n];
@@ -349,6 +408,13 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         const unsigned f = dm.ownFlags, k = hs.materials[dm.backMaterial].ownFlags;
         if ((f | k) & ETransmission) return "Only materials without a transmission component can be nested!";
         dm.typeFlags = (f ? ((f & ~EBackSide) | EFrontSide) : 0u) | (k ? ((k & ~EFrontSide) | EBackSide) : 0u);
+    }
+    // Which records make Intersection::getBSDF(ray) compute uv partials (records.inl:69-75): BSDF::usesRayDifferentials
+    // of what the shape holds, i.e. of the twosided adapter where there is one (twosided.cpp:91-92)
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const DevMaterial &dm = hs.materials[i];
+        const bool wants = wantsPartials[i] || (dm.twoSided && wantsPartials[dm.backMaterial]);
+        if (wants && !hs.materialTextures.empty()) hs.materialTextures[(size_t) i * 4 + 3] = 1u;
     }
 
     // ---- shapes ----------------------------------------------------------------------------------------
@@ -377,7 +443,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
 
     // per-triangle UV tangents (TriMesh::computeUVTangents, src/librender/trimesh.cpp:683-735)
     if (anyUV) {
-        hs.uvDpdu.assign((size_t) d->n_triangles * 3, 0.0f);
+        hs.uvDpdu.assign((size_t) d->n_triangles * 6, 0.0f);      // dpdu, dpdv
         for (uint32_t s = 0; s < d->n_shapes; ++s) {
             const DevShape &sh = hs.shapes[s];
             if (!(sh.flags & MTSAMD_SHAPE_HAS_TEXCOORDS)) continue;
@@ -392,7 +458,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
                 float length = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
                 if (length == 0) continue;
                 float determinant = dUV1[0] * dUV2[1] - dUV1[1] * dUV2[0];
-                float *out = &hs.uvDpdu[3 * (size_t) t];
+                float *out = &hs.uvDpdu[6 * (size_t) t];
                 if (determinant == 0) {
                     // coordinateSystem(n/length, dpdu, dpdv) (src/libcore/util.cpp:592-601): dpdu = cross(c, a)
                     float r = 1.0f / length;
@@ -405,9 +471,11 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
                         c[0] = 0.0f; c[1] = a[2] * invLen; c[2] = -a[1] * invLen;
                     }
                     out[0] = c[1] * a[2] - c[2] * a[1]; out[1] = c[2] * a[0] - c[0] * a[2]; out[2] = c[0] * a[1] - c[1] * a[0];
+                    out[3] = c[0]; out[4] = c[1]; out[5] = c[2];
                 } else {
                     float invDet = 1.0f / determinant;
                     for (int k = 0; k < 3; ++k) out[k] = (dUV2[1] * dP1[k] - dUV1[1] * dP2[k]) * invDet;
+                    for (int k = 0; k < 3; ++k) out[3 + k] = (-dUV2[0] * dP1[k] + dUV1[0] * dP2[k]) * invDet;
                 }
             }
         }
@@ -548,7 +616,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         if (sh.flags & MTSAMD_SHAPE_HAS_TEXCOORDS) {
             float *u = &hs.shadeUV[(size_t) t * 12];
             for (int k = 0; k < 3; ++k) memcpy(u + 2 * k, &hs.texcoords[2 * (size_t) hs.indices[3 * (size_t) t + k]], 8);
-            memcpy(u + 6, &hs.uvDpdu[3 * (size_t) t], 12);
+            memcpy(u + 6, &hs.uvDpdu[6 * (size_t) t], 24);     // dpdu, dpdv
         }
     }
     if (d->n_materials >= (1u << 24)) return "too many materials";

@@ -19,6 +19,9 @@ struct HostScene {
     std::vector<float> emitterCdf, areaCdf, rtrans;
     std::vector<DevTexture> textures;           // one per (material, colour) that is textured
     std::vector<uint32_t> materialTextures;     // 4 per material (see DevScene), empty without textures
+    std::vector<DevTexture> plainTextures;      // the description's textures on their own, in its order (mtsamd_texture_eval)
+    std::vector<DevMipLevel> mipLevels;         // levels of all bitmap textures' pyramids
+    std::vector<uint16_t> texels;               // their texels, four halves each
     BVH bvh;
     DevScene params;        // scalar members filled; pointers left null until upload
     mtsamd_scene_desc desc; // copy of the scalar parts of the description

@@ -111,8 +111,8 @@ struct HeldPath {
 // `park` (workgroup memory, two float4 per thread of the workgroup) or nullptr: where the shadow ray's direction and
 // contribution wait while the BSDF is sampled, instead of in eight registers.
 template <bool ENV, bool RD, bool MIX, bool PARK, typename Path>
-MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &in, const float4 hit, float4 *sampleL, ShadeOut &o,
-                         float4 *park = nullptr) {
+MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &in, const float4 hit, float4 *sampleL, const float2 *samplePos,
+                         ShadeOut &o, float4 *park = nullptr) {
     const uint32_t triWord = __float_as_uint(hit.w);
     if (triWord != kMiss) {
         const uint32_t tri = triWord & kTriIndexMask;
@@ -140,12 +140,16 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
         // what the integrator asks of the BSDF as a whole (for a two-sided record: the adapter's type) ...
         const uint32_t bsdfType = bsdf.typeFlags;
         const float wiZ = its.wi.z;
+        // its.getBSDF(ray) (path.cpp:145, records.inl:69-75): uv partials for the vertex a camera ray reaches, if its BSDF
+        // filters its textures
+        SurfUV uv = surfUV(its.uvx, its.uvy);
+        if (MIX && prevDepth == 0 && sc.mipLevels && sc.materialTextures[its.material].w)
+            cameraUVPartials(sc, pp, samplePos[slot], its, in.rayO(), rayD, uv);
         // ... and the BRDF that answers on this side (twosided.cpp:108-183)
         const bool flipped = resolveTwoSided(sc, its.material, wiZ, bsdf);
         const V3 wiLocal = flipped ? mirrorZ(its.wi) : its.wi;
         // textured colours of the answering record, at this hit (only scenes with textures run the MIX kernels with a table)
-        const float2 uv = make_float2(its.uvx, its.uvy);
-        if (MIX) applyTextures(sc, its.material, uv.x, uv.y, bsdf);
+        if (MIX) applyTextures(sc, its.material, uv, bsdf);
         // The sample's radiance is only fetched where something is added to it: at the camera vertex it still is
         // what k_raygen wrote (zero), later only paths that hit an emitter touch it.
         float4 L = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -349,7 +353,7 @@ MTS_DEV void sortByBsdfType(const float4 *hits, uint32_t first, uint32_t n, uint
 // RD: the scene has a rough dielectric material.
 template <int ROUNDS, bool ENV, bool RD, bool MIX>
 __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out,
-                                                       ShadowQueue sq, float4 *sampleL, uint32_t *counters, uint32_t n) {
+                                                       ShadowQueue sq, float4 *sampleL, const float2 *samplePos, uint32_t *counters, uint32_t n) {
     constexpr int kWaves = kShadeBlock / 64;
     __shared__ uint32_t sCount[kShadeSortKeys * ROUNDS * kWaves];
     __shared__ uint32_t sOrder[kShadeBlock * ROUNDS];
@@ -366,7 +370,7 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
     asm volatile("" : "+v"(tidS));
     const uint32_t i = first + sOrder[round * kShadeBlock + tidS];
     ShadeOut o;
-    if (i < n) shadeVertex<ENV, RD, MIX, kShadePark>(sc, pp, QueuedPath{ in, i }, hits[i], sampleL, o, sPark);
+    if (i < n) shadeVertex<ENV, RD, MIX, kShadePark>(sc, pp, QueuedPath{ in, i }, hits[i], sampleL, samplePos, o, sPark);
     const bool alive = o.alive, wantShadow = o.wantShadow;
     uint32_t tidL = threadIdx.x;
     asm volatile("" : "+v"(tidL));
@@ -412,7 +416,7 @@ __global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene
 // shadow rays traced (the reference's two ray counters).
 static constexpr int kTailBlock = 64;
 template <bool ENV, bool RD, bool MIX>
-__global__ void __launch_bounds__(kTailBlock) k_tail(DevScene sc, PassParams pp, PathQueue in, float4 *sampleL, uint32_t n,
+__global__ void __launch_bounds__(kTailBlock) k_tail(DevScene sc, PassParams pp, PathQueue in, float4 *sampleL, const float2 *samplePos, uint32_t n,
                                                      uint32_t triShare, unsigned long long *counts) {
     __shared__ uint2 sStack[kLdsStack * kTailBlock];
     LdsUint2 *ldsStack = (LdsUint2 *) sStack;
@@ -442,7 +446,7 @@ __global__ void __launch_bounds__(kTailBlock) k_tail(DevScene sc, PassParams pp,
         traceHeldRays<false>(sc, r, busy, ldsStack, kTailBlock, triShare);
         // shade
         ShadeOut o;
-        if (active) shadeVertex<ENV, RD, MIX, false>(sc, pp, path, make_float4(r.hit.t, r.hit.u, r.hit.v, __uint_as_float(r.hit.tri)), sampleL, o);
+        if (active) shadeVertex<ENV, RD, MIX, false>(sc, pp, path, make_float4(r.hit.t, r.hit.u, r.hit.v, __uint_as_float(r.hit.tri)), sampleL, samplePos, o);
         // shadow ray of the emitter sample (scene.cpp:839-843), then path.cpp:196-198
         const bool wantShadow = active && o.wantShadow;
         busy = false;
@@ -495,7 +499,7 @@ static constexpr uint32_t PF_IDLE = 0x8000u;
 
 static constexpr int kDirectRounds = 16;    // sweeps per workgroup, sorted by BSDF type like k_shade
 __global__ void __launch_bounds__(kShadeBlock) k_direct_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out, ShadowQueue sq,
-                                                             float4 *sampleL, unsigned long long *counts, uint32_t n, int nEmitter, int nBsdf) {
+                                                             float4 *sampleL, const float2 *samplePos, unsigned long long *counts, uint32_t n, int nEmitter, int nBsdf) {
     __shared__ uint32_t sCount[kShadeSortKeys * kDirectRounds * (kShadeBlock / 64)];
     __shared__ uint32_t sOrder[kShadeBlock * kDirectRounds];
     const uint32_t first = blockIdx.x * (kShadeBlock * kDirectRounds);
@@ -536,11 +540,15 @@ __global__ void __launch_bounds__(kShadeBlock) k_direct_shade(DevScene sc, PassP
         uint32_t bsdfType = 0;
         bool flipped = false;
         V3 wiLocal = mk(0.0f), refN = mk(0.0f);
+        SurfUV uv = surfUV(0.0f, 0.0f);
         if (shade) {
             bsdfType = bsdf.typeFlags;
+            uv = surfUV(its.uvx, its.uvy);
+            if (sc.mipLevels && sc.materialTextures[its.material].w)     // its.getBSDF(ray) (direct.cpp:176)
+                cameraUVPartials(sc, pp, samplePos[slot], its, in.rayO[i], rayD, uv);
             flipped = resolveTwoSided(sc, its.material, its.wi.z, bsdf);
             wiLocal = flipped ? mirrorZ(its.wi) : its.wi;
-            applyTextures(sc, its.material, its.uvx, its.uvy, bsdf);
+            applyTextures(sc, its.material, uv, bsdf);
             if ((bsdfType & (ETransmission | EBackSide)) == 0) refN = its.sh.n;
         }
         // MIDirectIntegrator::configure (direct.cpp:128-136)
@@ -560,9 +568,9 @@ __global__ void __launch_bounds__(kShadeBlock) k_direct_shade(DevScene sc, PassP
                         V3 c = mk(0.0f);
                         const V3 wo = toLocal(its.sh, dRec.d);
                         const V3 woSide = flipped ? mirrorZ(wo) : wo;
-                        const V3 bsdfVal = bsdfEvalAny(sc, bsdf, wiLocal, woSide, make_float2(its.uvx, its.uvy));
+                        const V3 bsdfVal = bsdfEvalAny(sc, bsdf, wiLocal, woSide, uv);
                         if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
-                            const float bPdf = dRec.delta ? 0.0f : bsdfPdfAny(sc, bsdf, wiLocal, woSide, make_float2(its.uvx, its.uvy));
+                            const float bPdf = dRec.delta ? 0.0f : bsdfPdfAny(sc, bsdf, wiLocal, woSide, uv);
                             c = value * bsdfVal * (miWeight(dRec.pdf * fracLum, bPdf * fracBSDF) * weightLum);
                         }
                         ++nShadow;
@@ -585,7 +593,7 @@ __global__ void __launch_bounds__(kShadeBlock) k_direct_shade(DevScene sc, PassP
                 const float bx = rng.next1D(), by = rng.next1D();
                 const float bu = bsdfDrawsFromSampler(bsdf, bx) ? rng.next1D() : 0.0f;
                 V3 woLocal; float bPdf, bEta; uint32_t sampledType;
-                const V3 bsdfVal = bsdfSampleAny(sc, bsdf, wiLocal, bx, by, bu, woLocal, bPdf, bEta, sampledType, make_float2(its.uvx, its.uvy));
+                const V3 bsdfVal = bsdfSampleAny(sc, bsdf, wiLocal, bx, by, bu, woLocal, bPdf, bEta, sampledType, uv);
                 if (flipped && !isZero(bsdfVal) && bPdf != 0) woLocal.z = -woLocal.z;
                 if (!isZero(bsdfVal)) {
                     const V3 wo = toWorld(its.sh, woLocal);
@@ -820,7 +828,7 @@ __global__ void k_hits_to_records(DevScene sc, const float4 *hits, uint32_t n, m
 }
 
 // mode 0: eval -> out[3n]; 1: pdf -> out[n]
-__global__ void k_bsdf_evalpdf(DevScene sc, int material, float2 uv, int mode, uint32_t n, const float *wi, const float *wo, float *out) {
+__global__ void k_bsdf_evalpdf(DevScene sc, int material, float2 uvIn, int mode, uint32_t n, const float *wi, const float *wo, float *out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     DevMaterial m;
@@ -828,12 +836,13 @@ __global__ void k_bsdf_evalpdf(DevScene sc, int material, float2 uv, int mode, u
     loadMaterial(sc, index, m);
     V3 a = ld3(wi, i), b = ld3(wo, i);
     if (resolveTwoSided(sc, index, a.z, m)) { a = mirrorZ(a); b = mirrorZ(b); }
-    applyTextures(sc, index, uv.x, uv.y, m);
+    const SurfUV uv = surfUV(uvIn.x, uvIn.y);
+    applyTextures(sc, index, uv, m);
     if (mode == 0) { const V3 r = bsdfEvalAny(sc, m, a, b, uv); out[3 * (size_t) i] = r.x; out[3 * (size_t) i + 1] = r.y; out[3 * (size_t) i + 2] = r.z; }
     else out[i] = bsdfPdfAny(sc, m, a, b, uv);
 }
 
-__global__ void k_bsdf_sample(DevScene sc, int material, float2 uv, uint32_t n, const float *wi, const float *sample, const float *sampler1D,
+__global__ void k_bsdf_sample(DevScene sc, int material, float2 uvIn, uint32_t n, const float *wi, const float *sample, const float *sampler1D,
                               float *wo, float *weight, float *pdf, float *eta, uint32_t *sampledType) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -843,13 +852,24 @@ __global__ void k_bsdf_sample(DevScene sc, int material, float2 uv, uint32_t n, 
     V3 a = ld3(wi, i);
     const bool flipped = resolveTwoSided(sc, index, a.z, m);
     if (flipped) a = mirrorZ(a);
-    applyTextures(sc, index, uv.x, uv.y, m);
+    const SurfUV uv = surfUV(uvIn.x, uvIn.y);
+    applyTextures(sc, index, uv, m);
     V3 o; float p, e; uint32_t t;
     const V3 w = bsdfSampleAny(sc, m, a, sample[2 * (size_t) i], sample[2 * (size_t) i + 1], sampler1D ? sampler1D[i] : 0.5f, o, p, e, t, uv);
     if (flipped && !isZero(w) && p != 0) o.z = -o.z;
     wo[3 * (size_t) i] = o.x; wo[3 * (size_t) i + 1] = o.y; wo[3 * (size_t) i + 2] = o.z;
     weight[3 * (size_t) i] = w.x; weight[3 * (size_t) i + 1] = w.y; weight[3 * (size_t) i + 2] = w.z;
     pdf[i] = p; eta[i] = e; sampledType[i] = t;
+}
+
+// Texture::eval(its) for textures on their own: uv n*2, duv n*4 or null
+__global__ void k_texture_eval(DevScene sc, const DevTexture *textures, int texture, uint32_t n, const float *uv, const float *duv, float *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    SurfUV q = surfUV(uv[2 * (size_t) i], uv[2 * (size_t) i + 1]);
+    if (duv) { q.filtered = 1u; q.dudx = duv[4 * (size_t) i]; q.dvdx = duv[4 * (size_t) i + 1]; q.dudy = duv[4 * (size_t) i + 2]; q.dvdy = duv[4 * (size_t) i + 3]; }
+    const V3 v = textureEval(sc, textures[texture], q);
+    out[3 * (size_t) i] = v.x; out[3 * (size_t) i + 1] = v.y; out[3 * (size_t) i + 2] = v.z;
 }
 
 __global__ void k_emitter_sample(DevScene sc, uint32_t n, const float *ref, const float *refN, const float *sample, float *d, float *dist,

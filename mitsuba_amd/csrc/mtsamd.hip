@@ -2,6 +2,7 @@
 // (raygen -> [extend -> shade -> shadow-connect]* -> film) and the batch entry points of the parity harness.
 #include "../../include/mtsamd.h"
 #include "host_scene.h"
+#include "mipmap.h"
 #include "kernels.h"
 #include "bvh_internal.h"
 
@@ -30,6 +31,13 @@ int fail(int code, const char *fmt, ...) {
     g_error = buf;
     return code;
 }
+
+}  // namespace
+
+// for the host-side helpers in the other translation units of the library
+namespace mtsamd { void setLastError(const std::string &msg) { g_error = msg; } }
+
+namespace {
 
 #define HIP_TRY(expr)                                                                               \
     do {                                                                                            \
@@ -101,7 +109,7 @@ struct mtsamd_scene {
     DevScene dev;
     int device = 0;
     DeviceBuffer nodes, tris, shadeTris, shadeUV, shapes, materials, emitters, deltaEmitters,
-        emitterCdf, areaCdf, rtrans, textures, materialTextures;
+        emitterCdf, areaCdf, rtrans, textures, materialTextures, plainTextures, mipLevels, texels, ewaLut;
     // work buffers of the wavefront loop
     DeviceBuffer fetchHeads, qbuf[2][6], hits, sbuf[3], sampleL, samplePos, shadowFlags, counters, scratch[8];
     size_t capacity = 0;
@@ -232,6 +240,14 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
         HIP_TRY(upload(s->emitterCdf, h.emitterCdf));
         HIP_TRY(upload(s->areaCdf, h.areaCdf));
         if (!h.textures.empty()) { HIP_TRY(upload(s->textures, h.textures)); HIP_TRY(upload(s->materialTextures, h.materialTextures)); }
+        if (!h.plainTextures.empty()) HIP_TRY(upload(s->plainTextures, h.plainTextures));
+        if (!h.mipLevels.empty()) {
+            HIP_TRY(upload(s->mipLevels, h.mipLevels));
+            HIP_TRY(upload(s->texels, h.texels));
+            std::vector<float> lut(64);
+            ewaWeightTable(lut.data());
+            HIP_TRY(upload(s->ewaLut, lut));
+        }
         HIP_TRY(upload(s->rtrans, h.rtrans));
         if (h.bvh.builder == BVH_BUILDER_DEVICE && h.desc.n_triangles > 0) {
             // the acceleration structure is built where it will be used; the records then learn their BSDF types
@@ -276,6 +292,9 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
     d.emitterCdf = s->emitterCdf.as<float>(); d.areaCdf = s->areaCdf.as<float>(); d.rtrans = s->rtrans.as<float>();
     d.textures = h.textures.empty() ? nullptr : s->textures.as<DevTexture>();
     d.materialTextures = h.textures.empty() ? nullptr : s->materialTextures.as<uint4>();
+    d.mipLevels = h.mipLevels.empty() ? nullptr : s->mipLevels.as<DevMipLevel>();
+    d.texels = h.mipLevels.empty() ? nullptr : s->texels.as<uint2>();
+    d.ewaLut = h.mipLevels.empty() ? nullptr : s->ewaLut.as<float>();
     s->dev = d;
     const char *ct = getenv("MTSAMD_COUNT_TRAVERSAL");
     s->countTraversal = ct && *ct == '1';
@@ -475,7 +494,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         unsigned long long *counts = cnt64 + CNT64_TAIL_NORMAL;
         HIP_TRY(hipMemsetAsync(counts, 0, 2 * sizeof(unsigned long long), st));
         timer.begin(T_SHADE);
-        hipLaunchKernelGGL(k_direct_shade, dim3(blocksFor(n, kShadeBlock * kDirectRounds)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, counts, n, nE, nB);
+        hipLaunchKernelGGL(k_direct_shade, dim3(blocksFor(n, kShadeBlock * kDirectRounds)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, samplePos, counts, n, nE, nB);
         timer.end(T_SHADE);
         if (nE > 0) {
             TraceArgs sa;
@@ -511,7 +530,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
             unsigned long long *tailCounts = cnt64 + CNT64_TAIL_NORMAL;
             HIP_TRY(hipMemsetAsync(tailCounts, 0, 2 * sizeof(unsigned long long), st));
             timer.begin(T_TAIL);
-#define MTS_LAUNCH_TAIL(E, R, M) hipLaunchKernelGGL((k_tail<E, R, M>), dim3(blocksFor(n, kTailBlock)), dim3(kTailBlock), 0, st, sc, pp, s->queue(cur), sampleL, n, s->triShare, tailCounts)
+#define MTS_LAUNCH_TAIL(E, R, M) hipLaunchKernelGGL((k_tail<E, R, M>), dim3(blocksFor(n, kTailBlock)), dim3(kTailBlock), 0, st, sc, pp, s->queue(cur), sampleL, samplePos, n, s->triShare, tailCounts)
             // scenes with a mixturebsdf run the variant that knows every feature
             if (s->host.mixture) MTS_LAUNCH_TAIL(true, true, true);
             else if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_TAIL(true, true, false); else MTS_LAUNCH_TAIL(true, false, false); }
@@ -543,7 +562,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         timer.begin(T_SHADE);
         // large queues: several sweeps per workgroup (purer wavefronts); small ones: one, to keep every CU busy
         const int rounds = n >= s->shadeRoundsAbove ? s->shadeRounds : 1;
-#define MTS_LAUNCH_SHADE_AS(R, E, D, M) hipLaunchKernelGGL((k_shade<R, E, D, M>), dim3(blocksFor(n, kShadeBlock * R)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, cnt, n)
+#define MTS_LAUNCH_SHADE_AS(R, E, D, M) hipLaunchKernelGGL((k_shade<R, E, D, M>), dim3(blocksFor(n, kShadeBlock * R)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, samplePos, cnt, n)
 #define MTS_LAUNCH_SHADE(R) do { \
             if (s->host.mixture) MTS_LAUNCH_SHADE_AS(R, true, true, true); \
             else if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true, false); else MTS_LAUNCH_SHADE_AS(R, true, false, false); } \
@@ -710,6 +729,7 @@ extern "C" int64_t mtsamd_sizeof(int record) {
         case MTSAMD_SIZEOF_RENDER_OPTS: return (int64_t) sizeof(mtsamd_render_opts);
         case MTSAMD_SIZEOF_STATS: return (int64_t) sizeof(mtsamd_stats);
         case MTSAMD_SIZEOF_LDR_OPTS: return (int64_t) sizeof(mtsamd_ldr_opts);
+        case MTSAMD_SIZEOF_TEXTURE: return (int64_t) sizeof(mtsamd_texture);
         default: return -1;
     }
 }
@@ -1003,6 +1023,22 @@ static int bsdfEvalPdf(mtsamd_scene *s, int material, int mode, uint64_t n, cons
     hipLaunchKernelGGL(k_bsdf_evalpdf, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, material, s->queryUv, mode, (uint32_t) n, (const float *) dI, (const float *) dW, (float *) dO);
     TRY(finish(s->stream));
     HIP_TRY(hipMemcpy(out, dO, ob, hipMemcpyDeviceToHost));
+    return MTSAMD_OK;
+}
+
+extern "C" int mtsamd_texture_eval(mtsamd_scene *s, int texture, uint64_t n, const float *uv, const float *duv, float *out) {
+    TRY(checkBatch(s, n));
+    if (texture < 1 || (size_t) texture > s->host.plainTextures.size()) return fail(MTSAMD_EINVAL, "texture index out of range");
+    if (n == 0) return MTSAMD_OK;
+    if (!uv || !out) return fail(MTSAMD_EINVAL, "null argument");
+    Staging sg; void *dU, *dD = nullptr, *dO;
+    TRY(sg.in(uv, n * 8, &dU));
+    if (duv) TRY(sg.in(duv, n * 16, &dD));
+    TRY(sg.out(n * 12, &dO));
+    hipLaunchKernelGGL(k_texture_eval, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, s->plainTextures.as<DevTexture>(), texture - 1,
+                       (uint32_t) n, (const float *) dU, (const float *) dD, (float *) dO);
+    TRY(finish(s->stream));
+    HIP_TRY(hipMemcpy(out, dO, n * 12, hipMemcpyDeviceToHost));
     return MTSAMD_OK;
 }
 

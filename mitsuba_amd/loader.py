@@ -276,7 +276,81 @@ def _conductor_constants(p: Dict, data_dir: Optional[str]):
     return out[0], out[1]
 
 
-def _make_bsdf(node, data_dir: Optional[str], add_material=None, named: Optional[Dict] = None) -> Dict:
+def _make_texture(node, ctx) -> int:
+    """A <texture> element as an entry of the scene's texture list; returns its 1-based index. `scale` textures
+    (src/textures/scale.cpp) fold into the scale factor of a copy of the texture they wrap."""
+    t = node.get("type")
+    p = _props(node)
+    uvt = dict(uoffset=p.get("uoffset", 0.0), voffset=p.get("voffset", 0.0), uscale=p.get("uscale", 1.0), vscale=p.get("vscale", 1.0))
+    if t == "scale":
+        nested = [c for c in node if c.tag in ("texture", "ref")]
+        if len(nested) != 1:
+            raise SceneFormatError("scale texture: exactly one nested texture is expected")
+        if nested[0].tag == "ref":
+            if nested[0].get("id") not in ctx["named_textures"]:
+                raise SceneFormatError("reference to unknown texture '%s'" % nested[0].get("id"))
+            inner = ctx["named_textures"][nested[0].get("id")]
+        else:
+            inner = _make_texture(nested[0], ctx)
+        f = p.get("scale", 1.0)
+        if isinstance(f, tuple):
+            if not f[0] == f[1] == f[2]:
+                raise SceneFormatError("scale texture: only a scalar (or grey) scale factor is supported")
+            f = f[0]
+        rec = dict(ctx["textures"][inner - 1])
+        rec["scale"] = float(np.float32(rec["scale"]) * np.float32(f))
+    elif t == "checkerboard":
+        rec = S.checkerboard(p.get("color0", (0.4, 0.4, 0.4)), p.get("color1", (0.2, 0.2, 0.2)), **uvt)
+    elif t == "gridtexture":
+        rec = S.gridtexture(p.get("color0", (0.2, 0.2, 0.2)), p.get("color1", (0.4, 0.4, 0.4)), line_width=p.get("lineWidth", 0.01), **uvt)
+    elif t == "bitmap":     # src/textures/bitmap.cpp:179-235
+        if "filename" not in p:
+            raise SceneFormatError("bitmap texture: the 'filename' parameter is missing")
+        if p.get("channel"):
+            raise SceneFormatError("bitmap texture: the 'channel' parameter is not supported")
+        from . import capi
+        try:
+            pixels = capi.image_load(os.path.join(ctx["base"], p["filename"]), gamma=p.get("gamma", 0.0))
+        except capi.MtsamdError as e:
+            raise SceneFormatError(str(e))
+        both = p.get("wrapMode", "repeat")
+        try:
+            rec = S.bitmap(pixels, p.get("filterType", "ewa"), wrap_mode_u=p.get("wrapModeU", both), wrap_mode_v=p.get("wrapModeV", both),
+                           max_anisotropy=p.get("maxAnisotropy", 20.0), **uvt)
+        except KeyError as e:
+            raise SceneFormatError("Unknown filter type or wrap mode %s" % e)
+    else:
+        raise SceneFormatError("texture type '%s' is not supported (checkerboard, gridtexture, bitmap, scale)" % t)
+    ctx["textures"].append(rec)
+    return len(ctx["textures"])
+
+
+def _attach_textures(node, m: Dict, ctx) -> None:
+    """Nested <texture name="..."> elements and <ref name="..." id="..."/> to textures declared at the top level."""
+    if ctx is None:
+        if any(c.tag == "texture" for c in node):
+            raise SceneFormatError("nested <texture> needs a scene to add it to")
+        return
+    for c in node:
+        if c.tag == "texture":
+            index = _make_texture(c, ctx)
+        elif c.tag == "ref" and c.get("id") in ctx["named_textures"]:
+            index = ctx["named_textures"][c.get("id")]
+        else:
+            continue
+        name, ty = c.get("name"), m["type"]
+        uses_diffuse = ty in (S.BSDF_DIFFUSE, S.BSDF_ROUGHPLASTIC, S.BSDF_PLASTIC, S.BSDF_WARD)
+        if (name == "diffuseReflectance" or (name == "reflectance" and ty == S.BSDF_DIFFUSE)) and uses_diffuse:
+            m["diffuse_texture"] = index
+        elif name == "specularReflectance" and ty != S.BSDF_DIFFUSE:
+            m["specular_texture"] = index
+        elif name == "specularTransmittance" and ty in (S.BSDF_DIELECTRIC, S.BSDF_ROUGHDIELECTRIC):
+            m["transmittance_texture"] = index
+        else:
+            raise SceneFormatError("a texture for the parameter '%s' of <bsdf type=\"%s\"> is not supported" % (name, node.get("type")))
+
+
+def _make_bsdf(node, data_dir: Optional[str], add_material=None, named: Optional[Dict] = None, ctx=None) -> Dict:
     t = node.get("type")
     p = _props(node)
     if t == "twosided":     # src/bsdfs/twosided.cpp:84-106,185-196: one or two nested reflection-only BRDFs
@@ -285,7 +359,7 @@ def _make_bsdf(node, data_dir: Optional[str], add_material=None, named: Optional
             if c.tag == "bsdf":
                 if c.get("type") == "twosided":
                     raise SceneFormatError("a <bsdf type=\"twosided\"> nested in another one is not supported")
-                nested.append(_make_bsdf(c, data_dir, add_material, named))
+                nested.append(_make_bsdf(c, data_dir, add_material, named, ctx))
             elif c.tag == "ref":
                 if named is None or c.get("id") not in named:
                     raise SceneFormatError("reference to unknown bsdf '%s'" % c.get("id"))
@@ -321,7 +395,7 @@ def _make_bsdf(node, data_dir: Optional[str], add_material=None, named: Optional
 
         for c in node:
             if c.tag == "bsdf":
-                nest(_make_bsdf(c, data_dir, add_material, named))
+                nest(_make_bsdf(c, data_dir, add_material, named, ctx))
             elif c.tag == "ref":
                 if named is None or c.get("id") not in named:
                     raise SceneFormatError("reference to unknown bsdf '%s'" % c.get("id"))
@@ -331,7 +405,7 @@ def _make_bsdf(node, data_dir: Optional[str], add_material=None, named: Optional
         except ValueError as e:
             raise SceneFormatError(str(e))
     for c in node:
-        if c.tag in ("texture", "bsdf"):
+        if c.tag == "bsdf":
             raise SceneFormatError("nested <%s> inside a <bsdf type=\"%s\"> is not supported" % (c.tag, t))
     ee = p.get("ensureEnergyConservation", True)
     distr = p.get("distribution", "beckmann").lower()
@@ -385,6 +459,7 @@ def _make_bsdf(node, data_dir: Optional[str], add_material=None, named: Optional
     else:
         raise SceneFormatError("BSDF type '%s' is outside the path hot path of this core" % t)
     m["ensure_energy_conservation"] = int(bool(ee))
+    _attach_textures(node, m, ctx)
     return m
 
 
@@ -405,8 +480,15 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
 
     named_records: Dict[str, Dict] = {}
 
+    ctx = dict(base=base, textures=b.textures, named_textures={})
+    for el in root:         # textures first: BSDFs refer to them by id
+        if el.tag == "texture":
+            idx = _make_texture(el, ctx)
+            if el.get("id"):
+                ctx["named_textures"][el.get("id")] = idx
+
     def bsdf_index(node) -> int:
-        rec = _make_bsdf(node, data_dir, b.add_material, named_records)
+        rec = _make_bsdf(node, data_dir, b.add_material, named_records, ctx)
         idx = b.add_material(rec)
         if node.get("id"):
             named_bsdfs[node.get("id")] = idx

@@ -183,7 +183,10 @@ def _mat(**kw) -> Dict:
     return m
 
 
-TEX_CHECKERBOARD, TEX_GRID = 1, 2
+TEX_CHECKERBOARD, TEX_GRID, TEX_BITMAP = 1, 2, 3
+# EMIPFilterType (include/mitsuba/render/mipmap.h:52-61), ReconstructionFilter::EBoundaryCondition (rfilter.h:53-64)
+MIP_FILTERS = dict(nearest=0, bilinear=1, trilinear=2, ewa=3)
+WRAP_MODES = dict(clamp=0, repeat=1, mirror=2, zero=3, black=3, one=4, white=4)
 
 
 def _tex(kind, color0, color1, line_width, uoffset, voffset, uscale, vscale, scale) -> Dict:
@@ -201,6 +204,21 @@ def gridtexture(color0=(0.2, 0.2, 0.2), color1=(0.4, 0.4, 0.4), line_width=0.01,
                 scale=1.0) -> Dict:
     """src/textures/gridtexture.cpp:55-59"""
     return _tex(TEX_GRID, color0, color1, line_width, uoffset, voffset, uscale, vscale, scale)
+
+
+def bitmap(pixels, filter_type="ewa", wrap_mode="repeat", wrap_mode_u=None, wrap_mode_v=None, max_anisotropy=20.0,
+           uoffset=0.0, voffset=0.0, uscale=1.0, vscale=1.0, scale=1.0) -> Dict:
+    """src/textures/bitmap.cpp:179-235: `pixels` is the decoded image, height x width (luminance) or height x width x 3
+    (RGB), linear floats, first row = top of the image."""
+    t = _tex(TEX_BITMAP, (0, 0, 0), (0, 0, 0), 0.0, uoffset, voffset, uscale, vscale, scale)
+    px = np.ascontiguousarray(pixels, np.float32)
+    if px.ndim not in (2, 3) or (px.ndim == 3 and px.shape[2] not in (1, 3)):
+        raise ValueError("bitmap texture: pixels must be height x width or height x width x 3")
+    if px.ndim == 3 and px.shape[2] == 1:
+        px = px[:, :, 0]
+    t.update(pixels=px, filter_type=MIP_FILTERS[filter_type.lower()], wrap_u=WRAP_MODES[(wrap_mode_u or wrap_mode)],
+             wrap_v=WRAP_MODES[(wrap_mode_v or wrap_mode)], max_anisotropy=float(max_anisotropy))
+    return t
 
 
 def diffuse(reflectance=(0.5, 0.5, 0.5)) -> Dict:
@@ -680,6 +698,25 @@ def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_
         M[mats[3]]["transmittance_texture"] = b.add_texture(checkerboard((1.0, 0.6, 0.6), (0.6, 1.0, 0.7), uscale=2.0, vscale=2.0))
         M[mats[4]]["diffuse_texture"] = b.add_texture(checkerboard((0.6, 0.5, 0.1), (0.1, 0.1, 0.5), uscale=4.0, vscale=4.0))
         M[mats[4]]["specular_texture"] = b.add_texture(gridtexture((0.7, 0.6, 0.5), (0.2, 0.9, 0.2), line_width=0.15, uscale=3.0, vscale=3.0))
+    if textured == "bitmap":
+        # image textures in place of some of the procedural ones: every lookup mode, wrap modes, RGB and luminance
+        # images of odd sizes, values above one, a scale factor
+        trng = np.random.default_rng(11)
+
+        def image(h, w, channels, lo=0.05, hi=0.95, smooth=3):
+            img = trng.uniform(lo, hi, (h, w, channels)).astype(np.float32)
+            for _ in range(smooth):     # some structure at several scales, so that the MIP levels differ
+                img = (img + np.roll(img, 1, 0) + np.roll(img, 1, 1) + np.roll(np.roll(img, 1, 0), 1, 1)) * np.float32(0.25)
+            img = img * np.float32(2.0) - np.float32(0.5) + (np.indices((h, w)).sum(0)[..., None] % 8 < 4) * np.float32(0.3)
+            img = np.clip(img, lo, hi + 0.3).astype(np.float32)
+            return img[:, :, 0] if channels == 1 else img
+
+        M[m_ground]["diffuse_texture"] = b.add_texture(bitmap(image(61, 47, 3), "ewa", uscale=3.0, vscale=2.0, uoffset=0.25))
+        M[mats[0]]["diffuse_texture"] = b.add_texture(bitmap(image(32, 32, 1), "trilinear", wrap_mode="mirror", uscale=2.0, vscale=2.0))
+        M[mats[1]]["specular_texture"] = b.add_texture(bitmap(image(16, 24, 3), "bilinear", wrap_mode="clamp", scale=0.8))
+        M[mats[2]]["diffuse_texture"] = b.add_texture(bitmap(image(9, 13, 3), "nearest", uscale=2.0, vscale=4.0))
+        M[mats[3]]["transmittance_texture"] = b.add_texture(bitmap(image(40, 20, 3, hi=1.2), "ewa", wrap_mode_u="zero", wrap_mode_v="one", max_anisotropy=4.0))
+        M[mats[4]]["diffuse_texture"] = b.add_texture(bitmap(image(128, 128, 3, smooth=1), "ewa", uscale=1.5, vscale=1.5))
     if blend:
         m_ground = b.add_material(twosided(mixture([m_ground, mats[1]], [0.75, 0.25])))
         mats[0] = b.add_material(mixture([mats[0], mats[2], mats[4]], [0.6, 0.5, 0.4]))      # weights above one: rescaled

@@ -378,32 +378,60 @@ Vec2 MicrofacetDistribution::sampleVisible11(float thetaI, Vec2 sample) const {
 static Spectrum toSpec(const float *v) { return Spectrum(v[0], v[1], v[2]); }
 
 thread_local Vec2 g_textureUV{ 0, 0 };
+thread_local UVPartials g_texturePartials;
 
 static int modulo(int a, int b) { int r = a % b; return r < 0 ? r + b : r; }     // math::modulo
+
+Spectrum Texture::evalAt(const Vec2 &uv, bool filtered, const Vec2 &d0, const Vec2 &d1) const {
+    if (type == 1) {        // checkerboard.cpp:66-75 (its filtered variant is the same function)
+        const int x = 2 * modulo((int) (uv.x * 2), 2) - 1, y = 2 * modulo((int) (uv.y * 2), 2) - 1;
+        return x * y == 1 ? color0 : color1;
+    } else if (type == 2) { // gridtexture.cpp:75-88
+        float x = uv.x - (float) (int) std::floor(uv.x), y = uv.y - (float) (int) std::floor(uv.y);
+        if (x > .5) x -= 1;
+        if (y > .5) y -= 1;
+        return (std::abs(x) < lineWidth || std::abs(y) < lineWidth) ? color1 : color0;
+    } else if (type == 3) { // bitmap.cpp:431-454 (no partials: full-resolution level), :486-499 (filtered)
+        if (filtered) return mip->eval(uv, d0, d1);
+        return mip->filterType != MIP_NEAREST ? mip->evalBilinear(0, uv) : mip->evalBox(0, uv);
+    }
+    return color0;
+}
 
 Spectrum Texture::eval(const Vec2 &its_uv) const {
     Spectrum value = color0;
     if (type != 0) {
-        // Texture2D::eval(its) (texture.cpp:112-121), no uv partials in the path integrators' BSDF queries after the first hit
-        // and no filtering in either texture
+        // Texture2D::eval(its, filter) (texture.cpp:112-121)
         const Vec2 uv{ its_uv.x * uvScale.x + uvOffset.x, its_uv.y * uvScale.y + uvOffset.y };
-        if (type == 1) {        // checkerboard.cpp:66-75
-            const int x = 2 * modulo((int) (uv.x * 2), 2) - 1, y = 2 * modulo((int) (uv.y * 2), 2) - 1;
-            value = x * y == 1 ? color0 : color1;
-        } else {                // gridtexture.cpp:75-88
-            float x = uv.x - (float) (int) std::floor(uv.x), y = uv.y - (float) (int) std::floor(uv.y);
-            if (x > .5) x -= 1;
-            if (y > .5) y -= 1;
-            value = (std::abs(x) < lineWidth || std::abs(y) < lineWidth) ? color1 : color0;
-        }
+        const UVPartials &pt = g_texturePartials;
+        value = evalAt(uv, pt.has, Vec2{ pt.dudx * uvScale.x, pt.dvdx * uvScale.y }, Vec2{ pt.dudy * uvScale.x, pt.dvdy * uvScale.y });
     }
     for (float sc : scales) value *= sc;      // ScaleTexture::eval
     return value;
 }
 
+void Texture::evalGradient(const Vec2 &its_uv, Spectrum *gradient) const {
+    gradient[0] = gradient[1] = Spectrum(0.0f);
+    if (type == 0) return;  // ConstantSpectrumTexture: Texture::evalGradient leaves zero (texture.cpp:40-42)
+    const Vec2 uv{ its_uv.x * uvScale.x + uvOffset.x, its_uv.y * uvScale.y + uvOffset.y };
+    if (type == 3) {        // bitmap.cpp:456-480
+        if (mip->filterType != MIP_NEAREST) mip->evalGradientBilinear(0, uv, gradient);
+    } else {                // Texture2D::evalGradient(uv, gradient): forward differences (texture.cpp:132-141)
+        const float eps = Epsilon;
+        const Vec2 none{ 0, 0 };
+        const Spectrum value = evalAt(uv, false, none, none), valueU = evalAt(Vec2{ uv.x + eps, uv.y }, false, none, none),
+                       valueV = evalAt(Vec2{ uv.x, uv.y + eps }, false, none, none);
+        gradient[0] = (valueU - value) * (1 / eps);
+        gradient[1] = (valueV - value) * (1 / eps);
+    }
+    gradient[0] *= uvScale.x; gradient[1] *= uvScale.y;
+    for (float sc : scales) { gradient[0] *= sc; gradient[1] *= sc; }     // ScaleTexture::evalGradient (scale.cpp)
+}
+
 Spectrum Texture::getMaximum() const {
     Spectrum m = color0;
-    if (type != 0) m = Spectrum(std::max(color0.x, color1.x), std::max(color0.y, color1.y), std::max(color0.z, color1.z));
+    if (type == 3) m = mip->maximum;
+    else if (type != 0) m = Spectrum(std::max(color0.x, color1.x), std::max(color0.y, color1.y), std::max(color0.z, color1.z));
     for (float sc : scales) m *= sc;
     return m;
 }
@@ -414,23 +442,36 @@ Spectrum Texture::getAverage() const {
     else if (type == 2) {
         const float interiorWidth = std::max(0.0f, 1 - 2 * lineWidth), interiorArea = interiorWidth * interiorWidth, lineArea = 1 - interiorArea;
         a = color1 * lineArea + color0 * interiorArea;
-    }
+    } else if (type == 3) a = mip->average;
     for (float sc : scales) a *= sc;
     return a;
 }
 
-static const char *makeTexture(const float *constant, int32_t index, const orc_texture *textures, uint32_t n, Texture &out) {
+// A texture of the scene description on its own
+const char *buildTexture(const orc_texture &t, Texture &out) {
     out = Texture();
-    out.color0 = out.color1 = toSpec(constant);
-    if (index == 0) return nullptr;
-    if (index < 0 || (uint32_t) index > n || !textures) return "material texture index out of range";
-    const orc_texture &t = textures[index - 1];
-    if (t.type != 1 && t.type != 2) return "unsupported texture type";
+    if (t.type < 1 || t.type > 3) return "unsupported texture type";
     out.type = t.type;
     out.color0 = toSpec(t.color0); out.color1 = toSpec(t.color1);
     out.lineWidth = t.line_width;
     out.uvOffset = Vec2{ t.u_offset, t.v_offset }; out.uvScale = Vec2{ t.u_scale, t.v_scale };
     if (t.scale != 1.0f) out.scales.push_back(t.scale);
+    if (t.type == 3) {
+        if (!t.pixels || t.width <= 0 || t.height <= 0 || (t.channels != 1 && t.channels != 3)) return "bitmap texture: invalid image";
+        if (t.filter_type < 0 || t.filter_type > 3 || t.wrap_u < 0 || t.wrap_u > 4 || t.wrap_v < 0 || t.wrap_v > 4) return "bitmap texture: invalid filter or wrap mode";
+        // bitmap.cpp:232-235: only the EWA filter keeps its anisotropy bound
+        out.mip = std::make_shared<MIPMap>(t.pixels, t.width, t.height, t.channels, t.wrap_u, t.wrap_v, t.filter_type,
+                                           t.filter_type == MIP_EWA ? t.max_anisotropy : 1.0f);
+    }
+    return nullptr;
+}
+
+static const char *makeTexture(const float *constant, int32_t index, const std::vector<Texture> &textures, Texture &out) {
+    out = Texture();
+    out.color0 = out.color1 = toSpec(constant);
+    if (index == 0) return nullptr;
+    if (index < 0 || (size_t) index > textures.size()) return "material texture index out of range";
+    out = textures[index - 1];
     return nullptr;
 }
 
@@ -459,13 +500,23 @@ static float fresnelDiffuseReflectance(float eta) {
     return (float) (sum / n);
 }
 
-void Material::configure(const orc_texture *textures, uint32_t nTextures) {
+void Material::configure(const std::vector<Texture> &textures) {
     bool ee = m.ensure_energy_conservation != 0;
     Texture &diffuse = diffuseTex, &specular = specularTex, &transmittance = transmittanceTex;
-    for (const char *err : { makeTexture(m.diffuse_reflectance, m.diffuse_texture, textures, nTextures, diffuse),
-                             makeTexture(m.specular_reflectance, m.specular_texture, textures, nTextures, specular),
-                             makeTexture(m.specular_transmittance, m.transmittance_texture, textures, nTextures, transmittance) })
+    for (const char *err : { makeTexture(m.diffuse_reflectance, m.diffuse_texture, textures, diffuse),
+                             makeTexture(m.specular_reflectance, m.specular_texture, textures, specular),
+                             makeTexture(m.specular_transmittance, m.transmittance_texture, textures, transmittance) })
         if (err) throw std::runtime_error(err);
+    {   // m_usesRayDifferentials of the plugins' configure() (e.g. diffuse.cpp:101, roughplastic.cpp:301-304, dielectric.cpp:197-199)
+        const bool d = diffuse.usesRayDifferentials(), sp = specular.usesRayDifferentials(), tr = transmittance.usesRayDifferentials();
+        switch (m.type) {
+            case ORC_BSDF_DIFFUSE: usesRayDifferentials = d; break;
+            case ORC_BSDF_ROUGHCONDUCTOR: case ORC_BSDF_CONDUCTOR: usesRayDifferentials = sp; break;
+            case ORC_BSDF_ROUGHPLASTIC: case ORC_BSDF_PLASTIC: case ORC_BSDF_WARD: usesRayDifferentials = d || sp; break;
+            case ORC_BSDF_DIELECTRIC: case ORC_BSDF_ROUGHDIELECTRIC: usesRayDifferentials = sp || tr; break;
+            default: usesRayDifferentials = false;
+        }
+    }
     unsigned aniso = (m.alpha_u != m.alpha_v) ? EAnisotropic : 0;
     switch (m.type) {
         case ORC_BSDF_DIFFUSE:   // src/bsdfs/diffuse.cpp:93-104
@@ -562,6 +613,7 @@ const char *linkMixtures(std::vector<Material> &materials) {
             mat.mixWeights.push_back(scale != 1.0f ? mat.m.mix_weight[i] * scale : mat.m.mix_weight[i]);
             mat.mixPdf.append(mat.mixWeights.back());
             mat.own_flags |= child.own_flags;
+            mat.usesRayDifferentials |= child.usesRayDifferentials;     // mixturebsdf.cpp:167
         }
         mat.mixPdf.normalize();
         mat.type_flags = mat.own_flags;
@@ -581,6 +633,8 @@ const char *linkTwoSided(std::vector<Material> &materials) {
         if ((f | k) & ETransmission) return "Only materials without a transmission component can be nested!";
         mat.type_flags = (f ? ((f & ~EBackSide) | EFrontSide) : 0u) | (k ? ((k & ~EFrontSide) | EBackSide) : 0u);
     }
+    for (Material &mat : materials)     // twosided.cpp:91-92 (after every record's own flag is final)
+        if (mat.m.two_sided && mat.back) mat.twoSidedRayDifferentials = mat.usesRayDifferentials || mat.back->usesRayDifferentials;
     return nullptr;
 }
 

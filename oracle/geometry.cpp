@@ -607,10 +607,12 @@ void Scene::fillIntersectionRecord(const Ray &ray, Intersection &its) const {
     if ((sh.flags & ORC_SHAPE_HAS_TEXCOORDS) && uvDpduValid[tri]) {
         // per-triangle UV tangents (src/librender/trimesh.cpp:683-735), computed in Scene::build
         its.dpdu = uvDpdu[tri];
+        its.dpdv = uvDpdv[tri];
     } else if (sh.flags & ORC_SHAPE_HAS_TEXCOORDS) {
-        its.dpdu = Vec3(0.0f);   // zero-initialised TangentSpace of a degenerate triangle
+        its.dpdu = its.dpdv = Vec3(0.0f);   // zero-initialised TangentSpace of a degenerate triangle
     } else {
         its.dpdu = side1;
+        its.dpdv = side2;
     }
     Vec3 shN;
     if (sh.flags & ORC_SHAPE_HAS_NORMALS) {

@@ -52,7 +52,9 @@ typedef struct {
     int32_t diffuse_texture, specular_texture, transmittance_texture;
 } orc_material;
 
-/* type 1: checkerboard (src/textures/checkerboard.cpp), 2: gridtexture (src/textures/gridtexture.cpp); uv offset and
+/* type 1: checkerboard (src/textures/checkerboard.cpp), 2: gridtexture (src/textures/gridtexture.cpp), 3: bitmap
+   (src/textures/bitmap.cpp: `pixels` = width * height * channels linear floats, rows from the top, channels 1 or 3;
+   filter_type = EMIPFilterType, wrap_u / wrap_v = ReconstructionFilter::EBoundaryCondition); uv offset and
    scale of Texture2D (src/librender/texture.cpp:81-95); `scale`: factor of a ScaleTexture around it (src/textures/scale.cpp) */
 typedef struct {
     int32_t type;
@@ -60,6 +62,10 @@ typedef struct {
     float line_width;
     float u_offset, v_offset, u_scale, v_scale;
     float scale;
+    const float *pixels;
+    int32_t width, height, channels;
+    int32_t filter_type, wrap_u, wrap_v;
+    float max_anisotropy;
 } orc_texture;
 
 /* type 0: attached to `shape` (area light) or, with shape = -1, the constant environment emitter;
@@ -152,6 +158,11 @@ int orc_bsdf_pdf(const orc_scene *s, int material, uint64_t n, const float *wi, 
 /* sampler_1d (n values, may be NULL = 0.5): the number a BSDF flagged EUsesSampler takes from the sampler itself */
 int orc_bsdf_sample(const orc_scene *s, int material, uint64_t n, const float *wi, const float *sample,
                     float *wo, float *weight, float *pdf, float *eta, uint32_t *sampled_type, const float *sampler_1d);
+
+/* Texture::eval(its) of texture `texture` (1-based, as the materials name it) without any BSDF around it: uv n*2;
+   duv n*4 (dudx, dvdx, dudy, dvdy: Intersection::hasUVPartials set) or NULL (unfiltered lookup) -> out n*3.
+   gradient != 0: Texture::evalGradient (d/du, d/dv) instead, out n*6 */
+int orc_texture_eval(const orc_scene *s, int texture, uint64_t n, const float *uv, const float *duv, int gradient, float *out);
 
 /* Emitter sampling without the visibility test: ref[n*3], ref_n[n*3], sample[n*2] ->
    d[n*3], dist[n], pdf[n], value[n*3] (value = radiance/pdf/emPdf, 0 if rejected) */

@@ -34,7 +34,8 @@ class Material(C.Structure):
 class Texture(C.Structure):
     _fields_ = [("type", C.c_int32), ("color0", C.c_float * 3), ("color1", C.c_float * 3), ("line_width", C.c_float),
                 ("u_offset", C.c_float), ("v_offset", C.c_float), ("u_scale", C.c_float), ("v_scale", C.c_float),
-                ("scale", C.c_float)]
+                ("scale", C.c_float), ("pixels", _f32p), ("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32),
+                ("filter_type", C.c_int32), ("wrap_u", C.c_int32), ("wrap_v", C.c_int32), ("max_anisotropy", C.c_float)]
 
 
 class Emitter(C.Structure):
@@ -155,6 +156,14 @@ def fill_desc(sd, desc_cls=SceneDesc, shape_cls=Shape, mat_cls=Material, em_cls=
             texs[i].color0, texs[i].color1 = (C.c_float * 3)(*t["color0"]), (C.c_float * 3)(*t["color1"])
             for k in ("line_width", "u_offset", "v_offset", "u_scale", "v_scale", "scale"):
                 setattr(texs[i], k, t[k])
+            if t.get("pixels") is not None:     # bitmap: height x width (x 3) linear floats, rows from the top
+                px = np.ascontiguousarray(t["pixels"], np.float32)
+                keep.append(px)
+                texs[i].pixels = px.ctypes.data_as(_f32p)
+                texs[i].height, texs[i].width = px.shape[0], px.shape[1]
+                texs[i].channels = 1 if px.ndim == 2 else px.shape[2]
+                for k in ("filter_type", "wrap_u", "wrap_v", "max_anisotropy"):
+                    setattr(texs[i], k, t[k])
         keep.append(texs)
         d.n_textures, d.textures = len(tex_list), texs
     d.integrator.type = {"path": 0, "direct": 1}[sd.integrator.get("type", "path")]
@@ -220,6 +229,18 @@ class OracleScene:
 
     def bsdf_query_uv(self, u, v):
         self.L.orc_bsdf_query_uv(C.c_float(u), C.c_float(v))
+
+    def texture_eval(self, texture, uv, duv=None, gradient=False):
+        """Texture `texture` (1-based) at uv (n x 2); duv (n x 4: dudx, dvdx, dudy, dvdy) makes the lookup a filtered one;
+        gradient=True returns n x 2 x 3 (d/du, d/dv)."""
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        d = None if duv is None else np.ascontiguousarray(duv, np.float32).reshape(-1, 4)
+        out = np.zeros((uv.shape[0], 6 if gradient else 3), np.float32)
+        rc = self.L.orc_texture_eval(C.c_void_p(self.h), int(texture), C.c_uint64(uv.shape[0]), _fp(uv), None if d is None else _fp(d),
+                                     int(bool(gradient)), _fp(out))
+        if rc != 0:
+            raise RuntimeError("oracle: texture index out of range")
+        return out.reshape(-1, 2, 3) if gradient else out
 
     def bsdf_eval(self, mat, wi, wo):
         wi, wo = np.ascontiguousarray(wi, np.float32), np.ascontiguousarray(wo, np.float32)

@@ -106,7 +106,10 @@ std::string Scene::build(const orc_scene_desc *d) {
     emitters.assign(d->emitters, d->emitters + d->n_emitters);
     materials.resize(d->n_materials);
     try {
-        for (uint32_t i = 0; i < d->n_materials; ++i) { materials[i].m = d->materials[i]; materials[i].configure(d->textures, d->n_textures); }
+        textures.resize(d->textures ? d->n_textures : 0);
+        for (size_t i = 0; i < textures.size(); ++i)
+            if (const char *err = buildTexture(d->textures[i], textures[i])) throw std::runtime_error(err);
+        for (uint32_t i = 0; i < d->n_materials; ++i) { materials[i].m = d->materials[i]; materials[i].configure(textures); }
     } catch (const std::runtime_error &e) {
         static thread_local std::string message;
         message = e.what();
@@ -114,9 +117,12 @@ std::string Scene::build(const orc_scene_desc *d) {
     }
     if (const char *err = linkMixtures(materials)) return err;
     if (const char *err = linkTwoSided(materials)) return err;
+    anyRayDifferentials = false;
+    for (const Material &m : materials) anyRayDifferentials |= m.usesRayDifferentials;
 
     triShape.assign(d->n_triangles, 0xFFFFFFFFu);
     uvDpdu.assign(d->n_triangles, Vec3(0.0f));
+    uvDpdv.assign(d->n_triangles, Vec3(0.0f));
     uvDpduValid.assign(d->n_triangles, 0);
     for (uint32_t s = 0; s < d->n_shapes; ++s) {
         const orc_shape &sh = shapes[s];
@@ -142,9 +148,11 @@ std::string Scene::build(const orc_scene_desc *d) {
                     Vec3 dpdu, dpdv;
                     coordinateSystem(n / length, dpdu, dpdv);
                     uvDpdu[t] = dpdu;
+                    uvDpdv[t] = dpdv;
                 } else {
                     float invDet = 1.0f / determinant;
                     uvDpdu[t] = (dUV2.y * dP1 - dUV1.y * dP2) * invDet;
+                    uvDpdv[t] = (-dUV2.x * dP1 + dUV1.x * dP2) * invDet;
                 }
                 uvDpduValid[t] = 1;
             }
@@ -414,11 +422,53 @@ static inline float miWeight(float pdfA, float pdfB) {
 
 struct RayCounters { uint64_t normal = 0, shadow = 0; TraversalCounters trav; };
 
+// The offset rays of a RayDifferential (include/mitsuba/core/ray.h:129-175); the perspective camera's start at the
+// ray origin (perspective.cpp:289)
+struct RayDifferentials { bool has = false; Vec3 rxDirection, ryDirection; };
+
+// Intersection::computePartials (src/librender/intersection.cpp:5-76) for offset rays that start at the ray origin
+static UVPartials computePartials(const Intersection &its, const Ray &ray, const RayDifferentials &rd) {
+    UVPartials out;
+    if (!rd.has) return out;
+    out.has = true;
+    if (its.dpdu.isZero() && its.dpdv.isZero()) return out;
+    const Vec3 &n = its.geoFrame.n;
+    const float pp = dot(n, its.p), pox = dot(n, ray.o), poy = dot(n, ray.o), prx = dot(n, rd.rxDirection), pry = dot(n, rd.ryDirection);
+    if (prx == 0 || pry == 0) return out;
+    const float tx = (pp - pox) / prx, ty = (pp - poy) / pry;
+    const float absX = std::abs(n.x), absY = std::abs(n.y), absZ = std::abs(n.z);
+    int axes[2];
+    if (absX > absY && absX > absZ) { axes[0] = 1; axes[1] = 2; }
+    else if (absY > absZ) { axes[0] = 0; axes[1] = 2; }
+    else { axes[0] = 0; axes[1] = 1; }
+    const float A[2][2] = { { its.dpdu[axes[0]], its.dpdv[axes[0]] }, { its.dpdu[axes[1]], its.dpdv[axes[1]] } };
+    const Vec3 px = ray.o + rd.rxDirection * tx, py = ray.o + rd.ryDirection * ty;
+    const float Bx[2] = { px[axes[0]] - its.p[axes[0]], px[axes[1]] - its.p[axes[1]] };
+    const float By[2] = { py[axes[0]] - its.p[axes[0]], py[axes[1]] - its.p[axes[1]] };
+    // solveLinearSystem2x2 (src/libcore/util.cpp:527-539)
+    const float det = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+    if (std::abs(det) <= RCPOVERFLOW_F) {
+        out.dudx = 1; out.dvdx = 0;
+        out.dudy = 1; out.dvdy = 0;     // intersection.cpp:74 assigns dudy twice: 0, then 1; dvdy keeps its initial value
+        return out;
+    }
+    const float inverse = 1.0f / det;
+    out.dudx = (A[1][1] * Bx[0] - A[0][1] * Bx[1]) * inverse; out.dvdx = (A[0][0] * Bx[1] - A[1][0] * Bx[0]) * inverse;
+    out.dudy = (A[1][1] * By[0] - A[0][1] * By[1]) * inverse; out.dvdy = (A[0][0] * By[1] - A[1][0] * By[0]) * inverse;
+    return out;
+}
+// Intersection::getBSDF(ray) (records.inl:69-75): the partials exist only if the BSDF asks for them
+static UVPartials partialsFor(const Material &bsdf, const Intersection &its, const Ray &ray, const RayDifferentials &rd) {
+    const bool wants = bsdf.m.two_sided ? bsdf.twoSidedRayDifferentials : bsdf.usesRayDifferentials;
+    return wants ? computePartials(its, ray, rd) : UVPartials();
+}
+
 // ---- MIPathTracer::Li (src/integrators/path/path.cpp:119-294) -------------------------------------------
-static Spectrum Li(const Scene &sc, const Ray &r, Pcg32 &rng, float &alpha, RayCounters &cnt) {
+static Spectrum Li(const Scene &sc, const Ray &r, const RayDifferentials &rd0, Pcg32 &rng, float &alpha, RayCounters &cnt) {
     const orc_integrator &ig = sc.desc.integrator;
     Intersection its;
     Ray ray(r);
+    RayDifferentials rd = rd0;
     Spectrum Li(0.0f);
     bool scattered = false;
     bool emittedRadiance = true;   // rRec.type & EEmittedRadiance
@@ -443,6 +493,8 @@ static Spectrum Li(const Scene &sc, const Ray &r, Pcg32 &rng, float &alpha, RayC
         const orc_shape &shape = sc.shapes[its.shape];
         const Material &bsdf = sc.materials[shape.material];
         g_textureUV = its.uv;       // the intersection the BSDF queries of this vertex refer to
+        g_texturePartials = partialsFor(bsdf, its, ray, rd);        // its.getBSDF(ray) (path.cpp:145)
+        rd.has = false;             // the rays that follow are plain Rays (path.cpp:222: ray = Ray(its.p, wo, ray.time))
 
         if (shape.emitter >= 0 && emittedRadiance && (!ig.hide_emitters || scattered)) {
             // AreaLight::eval (area.cpp:104-109)
@@ -548,7 +600,7 @@ static Spectrum Li(const Scene &sc, const Ray &r, Pcg32 &rng, float &alpha, RayC
 // ---- MIDirectIntegrator::Li (src/integrators/direct/direct.cpp:146-309) -----------------------------------
 // Sample order per camera sample: the emitter samples' 2-D numbers, then for every BSDF sample its 2-D number
 // followed by what the BSDF itself takes from the sampler.
-static Spectrum LiDirect(const Scene &sc, const Ray &r, Pcg32 &rng, float &alpha, RayCounters &cnt) {
+static Spectrum LiDirect(const Scene &sc, const Ray &r, const RayDifferentials &rd, Pcg32 &rng, float &alpha, RayCounters &cnt) {
     const orc_integrator &ig = sc.desc.integrator;
     Intersection its;
     Ray ray(r);
@@ -566,6 +618,7 @@ static Spectrum LiDirect(const Scene &sc, const Ray &r, Pcg32 &rng, float &alpha
     const orc_shape &shape = sc.shapes[its.shape];
     const Material &bsdf = sc.materials[shape.material];
     g_textureUV = its.uv;
+    g_texturePartials = partialsFor(bsdf, its, ray, rd);    // its.getBSDF(ray) (direct.cpp:176)
     if (shape.emitter >= 0 && !ig.hide_emitters) {      // direct.cpp:166-167, AreaLight::eval (area.cpp:104-109)
         const orc_emitter &em = sc.emitters[shape.emitter];
         if (dot(its.shFrame.n, -ray.d) > 0) Li += Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]);
@@ -642,7 +695,18 @@ static Spectrum LiDirect(const Scene &sc, const Ray &r, Pcg32 &rng, float &alpha
 }
 
 // ---- PerspectiveCameraImpl::sampleRayDifferential (perspective.cpp:271-298), ray part ---------------------
-static Ray cameraRay(const Scene &sc, float px, float py) {
+// Transform::operator()(Point) of the sample-to-camera matrix
+static Vec3 sampleToCameraPoint(const Scene &sc, float sx, float sy) {
+    const float *M = sc.sampleToCamera;
+    Vec3 p(M[0] * sx + M[1] * sy + M[3], M[4] * sx + M[5] * sy + M[7], M[8] * sx + M[9] * sy + M[11]);
+    const float w = M[12] * sx + M[13] * sy + M[15];
+    if (w != 1.0f) p = p / w;
+    return p;
+}
+
+// `diff`, if given, receives the offset rays scaled by `diffScale` (RayDifferential::scaleDifferential, ray.h:163-168;
+// renderBlock scales by 1 / sqrt(sampleCount), integrator.cpp:150,177)
+static Ray cameraRay(const Scene &sc, float px, float py, RayDifferentials *diff = nullptr, float diffScale = 1.0f) {
     const float *M = sc.sampleToCamera;
     float sx = px * sc.invResolution.x, sy = py * sc.invResolution.y;
     // Transform::operator()(Point) with homogeneous divide (transform.h)
@@ -659,6 +723,18 @@ static Ray cameraRay(const Scene &sc, float px, float py) {
     Vec3 dw(W[0] * d.x + W[1] * d.y + W[2] * d.z,
             W[4] * d.x + W[5] * d.y + W[6] * d.z,
             W[8] * d.x + W[9] * d.y + W[10] * d.z);
+    if (diff) {
+        // position differentials on the near plane (perspective.cpp:158-162)
+        const Vec3 origin = sampleToCameraPoint(sc, 0.0f, 0.0f);
+        const Vec3 dxv = sampleToCameraPoint(sc, sc.invResolution.x, 0.0f) - origin, dyv = sampleToCameraPoint(sc, 0.0f, sc.invResolution.y) - origin;
+        auto toWorld = [&](const Vec3 &v) {
+            return Vec3(W[0] * v.x + W[1] * v.y + W[2] * v.z, W[4] * v.x + W[5] * v.y + W[6] * v.z, W[8] * v.x + W[9] * v.y + W[10] * v.z);
+        };
+        const Vec3 rx = toWorld(normalize(nearP + dxv)), ry = toWorld(normalize(nearP + dyv));
+        diff->has = true;
+        diff->rxDirection = dw + (rx - dw) * diffScale;
+        diff->ryDirection = dw + (ry - dw) * diffScale;
+    }
     return Ray(o, dw, sc.desc.camera.near_clip * invZ, sc.desc.camera.far_clip * invZ);
 }
 
@@ -764,6 +840,7 @@ extern "C" int orc_bsdf_eval(const orc_scene *s, int material, uint64_t n, const
     if (material < 0 || (size_t) material >= s->s.materials.size()) return -1;
     const Material &m = s->s.materials[material];
     g_textureUV = g_queryUV;
+    g_texturePartials = UVPartials();
     for (uint64_t i = 0; i < n; ++i) {
         Spectrum r = bsdfEval(m, Vec3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), Vec3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]));
         out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
@@ -775,6 +852,7 @@ extern "C" int orc_bsdf_pdf(const orc_scene *s, int material, uint64_t n, const 
     if (material < 0 || (size_t) material >= s->s.materials.size()) return -1;
     const Material &m = s->s.materials[material];
     g_textureUV = g_queryUV;
+    g_texturePartials = UVPartials();
     for (uint64_t i = 0; i < n; ++i)
         out[i] = bsdfPdf(m, Vec3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), Vec3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]));
     return 0;
@@ -785,6 +863,7 @@ extern "C" int orc_bsdf_sample(const orc_scene *s, int material, uint64_t n, con
     if (material < 0 || (size_t) material >= s->s.materials.size()) return -1;
     const Material &m = s->s.materials[material];
     g_textureUV = g_queryUV;
+    g_texturePartials = UVPartials();
     struct Fixed : Sampler1D { float v = 0.5f; float next1D() override { return v; } } fixed;
     for (uint64_t i = 0; i < n; ++i) {
         BSDFSample bs;
@@ -811,6 +890,27 @@ extern "C" int orc_sample_emitter_direct(const orc_scene *s, uint64_t n, const f
     return 0;
 }
 
+extern "C" int orc_texture_eval(const orc_scene *s, int texture, uint64_t n, const float *uv, const float *duv, int gradient, float *out) {
+    if (texture < 1 || (size_t) texture > s->s.textures.size()) return -1;
+    const Texture &t = s->s.textures[texture - 1];
+    for (uint64_t i = 0; i < n; ++i) {
+        g_texturePartials = UVPartials();
+        if (duv) { g_texturePartials.has = true; g_texturePartials.dudx = duv[4 * i]; g_texturePartials.dvdx = duv[4 * i + 1];
+                   g_texturePartials.dudy = duv[4 * i + 2]; g_texturePartials.dvdy = duv[4 * i + 3]; }
+        const Vec2 p{ uv[2 * i], uv[2 * i + 1] };
+        if (gradient) {
+            Spectrum g[2];
+            t.evalGradient(p, g);
+            for (int k = 0; k < 3; ++k) { out[6 * i + k] = g[0][k]; out[6 * i + 3 + k] = g[1][k]; }
+        } else {
+            const Spectrum v = t.eval(p);
+            for (int k = 0; k < 3; ++k) out[3 * i + k] = v[k];
+        }
+    }
+    g_texturePartials = UVPartials();
+    return 0;
+}
+
 extern "C" int orc_camera_rays(const orc_scene *s, uint64_t n, const float *pos, float *rays) {
     for (uint64_t i = 0; i < n; ++i) {
         Ray r = cameraRay(s->s, pos[2 * i], pos[2 * i + 1]);
@@ -834,9 +934,10 @@ static inline void renderSample(const Scene &sc, const orc_render_opts *o, int x
     Pcg32 rng(o->seed, pixelIndex * (uint64_t) o->spp_total + (uint64_t) sIdx);
     Vec2 j = rng.next2D();
     pos[0] = (float) x + j.x; pos[1] = (float) y + j.y;
-    Ray ray = cameraRay(sc, pos[0], pos[1]);
+    RayDifferentials rd;
+    Ray ray = sc.anyRayDifferentials ? cameraRay(sc, pos[0], pos[1], &rd, 1.0f / std::sqrt((float) o->spp_total)) : cameraRay(sc, pos[0], pos[1]);
     float alpha;
-    Spectrum L = sc.desc.integrator.type == 1 ? LiDirect(sc, ray, rng, alpha, cnt) : Li(sc, ray, rng, alpha, cnt);
+    Spectrum L = sc.desc.integrator.type == 1 ? LiDirect(sc, ray, rd, rng, alpha, cnt) : Li(sc, ray, rd, rng, alpha, cnt);
     rgba[0] = L.x; rgba[1] = L.y; rgba[2] = L.z; rgba[3] = alpha;
 }
 

@@ -2,6 +2,8 @@
 #pragma once
 #include "vec.h"
 #include "oracle.h"
+#include "texture.h"
+#include <memory>
 #include <vector>
 #include <atomic>
 #include <string>
@@ -47,19 +49,31 @@ struct DiscreteDistribution {
 // A colour parameter of a BSDF as the reference holds it: a Texture. ConstantSpectrumTexture (type 0), Checkerboard
 // (src/textures/checkerboard.cpp), GridTexture (src/textures/gridtexture.cpp) under Texture2D's uv transform
 // (src/librender/texture.cpp:81-121), inside any number of ScaleTextures (src/textures/scale.cpp; innermost first).
+// Type 3: BitmapTexture (src/textures/bitmap.cpp) over a MIP map.
 struct Texture {
     int type = 0;
     Spectrum color0, color1;
     float lineWidth = 0.01f;
     Vec2 uvOffset{ 0, 0 }, uvScale{ 1, 1 };
     std::vector<float> scales;
+    std::shared_ptr<MIPMap> mip;
+    // Texture2D::eval(its, filter = true) (texture.cpp:112-121) with the intersection of the query in progress
     Spectrum eval(const Vec2 &uv) const;
+    // Texture2D::evalGradient(its, gradient) (texture.cpp:123-141; bitmap.cpp:456-480)
+    void evalGradient(const Vec2 &uv, Spectrum *gradient) const;
     Spectrum getMaximum() const;
     Spectrum getAverage() const;
+    bool usesRayDifferentials() const { return type == 3; }     // bitmap.cpp:541-543; false for the procedural ones
+private:
+    Spectrum evalAt(const Vec2 &uv, bool filtered, const Vec2 &d0, const Vec2 &d1) const;    // before the ScaleTextures
 };
 // bRec.its.uv of the BSDF query in progress on this thread (the reference hands the intersection to the BSDF; here the
-// integrator sets it before it calls eval / pdf / sample)
+// integrator sets it before it calls eval / pdf / sample), and its uv partials if it has any (Intersection::hasUVPartials,
+// dudx, dvdx, dudy, dvdy: set by Intersection::computePartials for the first vertex of a camera path)
 extern thread_local Vec2 g_textureUV;
+struct UVPartials { bool has = false; float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0; };
+extern thread_local UVPartials g_texturePartials;
+const char *buildTexture(const orc_texture &t, Texture &out);
 
 struct Material {
     orc_material m;
@@ -80,7 +94,9 @@ struct Material {
     std::vector<const Material *> mixChildren;
     std::vector<float> mixWeights;
     DiscreteDistribution mixPdf;
-    void configure(const orc_texture *textures, uint32_t nTextures);
+    bool usesRayDifferentials = false;           // BSDF::usesRayDifferentials(): some texture of it filters its lookups
+    bool twoSidedRayDifferentials = false;       // the same of the twosided adapter around it (either side's)
+    void configure(const std::vector<Texture> &textures);
 };
 
 // BSDF::EBSDFType bits (include/mitsuba/render/bsdf.h:230-284)
@@ -117,9 +133,11 @@ struct Scene {
     std::vector<uint32_t> indices;
     std::vector<orc_shape> shapes;
     std::vector<Material> materials;
+    std::vector<Texture> textures;             // the description's textures on their own (orc_texture_eval)
+    bool anyRayDifferentials = false;          // some BSDF filters its texture lookups: camera rays carry their offset rays
     std::vector<orc_emitter> emitters;
     std::vector<uint32_t> triShape;            // triangle -> shape
-    std::vector<Vec3> uvDpdu;                  // per-triangle UV tangent (meshes with texcoords)
+    std::vector<Vec3> uvDpdu, uvDpdv;          // per-triangle UV tangents (meshes with texcoords)
     std::vector<uint8_t> uvDpduValid;
     std::vector<DiscreteDistribution> areaDistr;   // per shape (emitters only)
     std::vector<float> invSurfaceArea;

@@ -1,0 +1,318 @@
+"""Bitmap textures on the CPU: the oracle's restatement of the reference's MIP map (include/mitsuba/render/mipmap.h),
+resampler (include/mitsuba/core/rfilter.h:107-468) and uv partials (src/librender/intersection.cpp:5-76) against closed
+forms, and the library's image reader (mtsamd_image_load, no device needed) against values computed here.
+The reference holds no expected texture values (its texture tests are visual), so these lookups are parity unpinned:
+the restatement is checked by the properties below, the GPU against the restatement (tests/test_gpu_parity.py)."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from mitsuba_amd import scene as S
+
+
+def _scene_with(textures):
+    sd = S.cornell_box(16, 16)
+    sd.textures = list(textures)
+    return sd
+
+
+def _half(a):
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+def test_half_storage_nearest_lookup_and_statistics(oracle_mod):
+    rng = np.random.default_rng(0)
+    img = rng.uniform(0, 3, (7, 11, 3)).astype(np.float32)
+    img[0, 0] = [1e-7, 65504.0, 1e5]          # a half denormal, the largest half, overflow to infinity
+    o = oracle_mod.OracleScene(_scene_with([S.bitmap(img, "nearest")]))
+    ys, xs = np.mgrid[0:7, 0:11]
+    uv = np.stack([(xs.ravel() + 0.5) / 11, (ys.ravel() + 0.5) / 7], -1)
+    got = o.texture_eval(1, uv).reshape(7, 11, 3)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(got, _half(img))      # evalBox: the texel itself, stored as half (round to nearest even)
+    # repeat wrap: one period further on is the same texel
+    assert np.array_equal(o.texture_eval(1, uv + [3, -2]).reshape(7, 11, 3), got)
+
+
+def test_bilinear_lookup_wrap_modes_and_gradient(oracle_mod):
+    rng = np.random.default_rng(1)
+    img = rng.uniform(0, 1, (5, 6)).astype(np.float32)
+    h = _half(img)
+    texs = [S.bitmap(img, "bilinear", wrap_mode=m) for m in ("repeat", "clamp", "mirror", "zero", "one")]
+    o = oracle_mod.OracleScene(_scene_with(texs))
+    # at texel centres bilinear interpolation returns the texel
+    ys, xs = np.mgrid[0:5, 0:6]
+    centres = np.stack([(xs.ravel() + 0.5) / 6, (ys.ravel() + 0.5) / 5], -1)
+    for ti in range(1, 6):
+        assert np.allclose(o.texture_eval(ti, centres)[:, 0].reshape(5, 6), h, atol=1e-6)
+    # half a texel left of the first column: the average of the first column and whatever the wrap mode puts beside it
+    uv = np.float32([[0.0, 0.5 / 5]])
+    first, last = h[0, 0], h[0, -1]
+    expect = {1: (first + last) / 2, 2: first, 3: first, 4: first / 2, 5: (first + 1) / 2}
+    for ti, e in expect.items():
+        assert np.isclose(o.texture_eval(ti, uv)[0, 0], e, atol=1e-6), ti
+    # gradient of a ramp along u (evalGradientBilinear, mipmap.h:601-626): slope per unit of u
+    ramp = np.tile(np.linspace(0, 1, 9, dtype=np.float32) * np.float32(0.5), (4, 1))     # exact in half
+    o2 = oracle_mod.OracleScene(_scene_with([S.bitmap(ramp, "bilinear", wrap_mode="clamp", uscale=2.0, scale=3.0)]))
+    g = o2.texture_eval(1, np.float32([[0.2, 0.4]]), gradient=True)[0]
+    # texel step 0.5 / 8 per 1 / 9 of u, times uscale (Texture2D::evalGradient) and the scale texture's factor
+    assert np.allclose(g[0], 0.5 / 8 * 9 * 2.0 * 3.0, rtol=1e-4) and np.allclose(g[1], 0, atol=1e-5)
+
+
+def test_pyramid_levels_of_a_constant_and_of_a_ramp(oracle_mod):
+    """Levels halve rounding up until 1 x 1 (mipmap.h:244-270); resampling keeps a constant constant (normalised
+    weights) and a ramp a ramp away from the borders (the Lanczos filter is symmetric)."""
+    const = np.full((13, 21, 3), 0.375, np.float32)
+    w = 64
+    ramp = np.tile(np.linspace(0.1, 0.9, w, dtype=np.float32), (w, 1))
+    o = oracle_mod.OracleScene(_scene_with([S.bitmap(const, "trilinear"), S.bitmap(ramp, "trilinear", wrap_mode="clamp"),
+                                            S.bitmap(const, "ewa")]))
+    rng = np.random.default_rng(2)
+    uv = rng.uniform(0, 1, (200, 2)).astype(np.float32)
+    for footprint in (1e-4, 0.01, 0.1, 0.5, 3.0):         # from below one texel to beyond the whole image
+        duv = np.tile(np.float32([footprint, 0, 0, footprint]), (200, 1))
+        assert np.allclose(o.texture_eval(1, uv, duv), 0.375, atol=2e-4)
+        assert np.allclose(o.texture_eval(3, uv, duv), 0.375, atol=2e-4)
+    # a footprint of 4 texels selects level 2 (log2 of the major radius, mipmap.h:654-668); in the interior the ramp's value
+    inner = uv[(uv[:, 0] > 0.3) & (uv[:, 0] < 0.7)]
+    duv = np.tile(np.float32([4.0 / w, 0, 0, 4.0 / w]), (inner.shape[0], 1))
+    got = o.texture_eval(2, inner, duv)[:, 0]
+    expect = 0.1 + 0.8 * (inner[:, 0] * w - 0.5) / (w - 1)
+    assert np.allclose(got, expect, atol=3e-3)
+
+
+def test_ewa_lookup_properties(oracle_mod):
+    rng = np.random.default_rng(3)
+    w = 128
+    ramp = np.tile(np.linspace(0.0, 1.0, w, dtype=np.float32)[None, :], (w, 1))
+    noise = rng.uniform(0, 1, (w, w, 3)).astype(np.float32)
+    o = oracle_mod.OracleScene(_scene_with([S.bitmap(ramp, "ewa", wrap_mode="clamp"), S.bitmap(noise, "ewa"),
+                                            S.bitmap(noise, "ewa", max_anisotropy=2.0), S.bitmap(noise, "bilinear")]))
+    uv = rng.uniform(0.3, 0.7, (300, 2)).astype(np.float32)
+    # an elliptical average of a ramp is the ramp's value at the centre (the weights are symmetric), whatever the
+    # orientation and the eccentricity of the ellipse
+    for d in ([0.03, 0.0, 0.0, 0.03], [0.05, 0.02, -0.01, 0.02], [0.08, 0.0, 0.0, 0.004]):
+        got = o.texture_eval(1, uv, np.tile(np.float32(d), (300, 1)))[:, 0]
+        expect = (uv[:, 0] * w - 0.5) / (w - 1)
+        assert np.allclose(got, expect, atol=6e-3), d
+    # footprints below one texel fall back to the bilinear lookup of level 0 (mipmap.h:709-710)
+    tiny = np.tile(np.float32([1e-4, 0, 0, 1e-4]), (300, 1))
+    assert np.allclose(o.texture_eval(2, uv, tiny), o.texture_eval(4, uv), atol=1e-6)
+    # a wider footprint averages more: the variance over positions drops
+    v = [o.texture_eval(2, uv, np.tile(np.float32([f, 0, 0, f]), (300, 1))).var() for f in (0.01, 0.04, 0.16)]
+    assert v[0] > v[1] > v[2]
+    # a tighter anisotropy bound widens the minor axis of a skinny ellipse: more blur
+    skinny = np.tile(np.float32([0.2, 0, 0, 0.004]), (300, 1))
+    assert o.texture_eval(3, uv, skinny).var() < o.texture_eval(2, uv, skinny).var()
+
+
+def test_camera_uv_partials_on_a_facing_plane(oracle_mod):
+    """Intersection::computePartials for a plane facing a perspective camera: one pixel step moves the hit point by
+    2 d tan(fov / 2) / width, scaled by 1 / sqrt(sampleCount) (integrator.cpp:150,177), and uv follows through dpdu /
+    dpdv. Seen through a trilinear lookup of a one-texel checker: a footprint of 4 texels reads level 2 (the checker
+    averaged out), the same view at 64 samples per pixel has a footprint of half a texel and reads the checker itself.
+    The albedo a sample saw is its radiance divided by that of the same scene with a constant albedo (same sample
+    stream, same path: the diffuse BSDF's sampling does not depend on its colour)."""
+    n = 64
+    yy, xx = np.mgrid[0:n, 0:n]
+    checker = ((xx + yy) % 2).astype(np.float32)
+
+    def scene(texture):
+        b = S.SceneBuilder()
+        m = b.add_material(S.diffuse((0.5, 0.5, 0.5)))
+        if texture is not None:
+            b.materials[m]["diffuse_texture"] = b.add_texture(texture)
+        half = 2.0      # uv runs over [0, 2]: two world units per unit of uv, texels of 1 / 32
+        b.add_mesh(np.float32([[-half, -half, 0], [half, -half, 0], [half, half, 0], [-half, half, 0]]),
+                   np.uint32([[0, 1, 2], [0, 2, 3]]), m, texcoords=np.float32([[0, 0], [2, 0], [2, 2], [0, 2]]))
+        b.add_constant_emitter((1.0, 1.0, 1.0))
+        dist = 10.0     # 16 pixels across 2 world units at the plane: 4 texels per pixel
+        cam = S.make_camera([0, 0, dist], [0, 0, 0], [0, 1, 0], float(2 * np.degrees(np.arctan(1.0 / dist))), near_clip=0.1, far_clip=100)
+        return b.finish(cam, S.make_film(16, 16), dict(max_depth=2))
+
+    flat = oracle_mod.OracleScene(scene(None))
+    tex = oracle_mod.OracleScene(scene(S.bitmap(checker, "trilinear")))
+    albedo = {}
+    for spp_total in (1, 64):
+        Lt, pt, _ = tex.li(1, spp_total=spp_total, seed=4)
+        Lf, pf, _ = flat.li(1, spp_total=spp_total, seed=4)
+        assert np.array_equal(pt, pf)
+        ok = Lf[..., 0] > 1e-3
+        assert ok.mean() > 0.9
+        albedo[spp_total] = 0.5 * Lt[..., 0][ok] / Lf[..., 0][ok]
+    assert np.allclose(albedo[1], 0.5, atol=0.02)           # level 2 of a one-texel checker: grey
+    assert albedo[64].std() > 0.12 and albedo[64].min() < 0.2 and albedo[64].max() > 0.8    # level 0: the checker, interpolated
+
+
+# ---- image files -------------------------------------------------------------------------------------------------------
+def _png(path, arr, colour, depth, extra=b"", palette=None):
+    h, w = arr.shape[:2]
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    rows = []
+    for y in range(h):
+        row = arr[y]
+        if depth == 16:
+            data = row.astype(">u2").tobytes()
+        elif depth == 8:
+            data = row.astype(np.uint8).tobytes()
+        else:
+            bits = "".join(format(int(v), "0%db" % depth) for v in row.ravel())
+            bits += "0" * (-len(bits) % 8)
+            data = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+        # alternate the row filters; all but "none" need the previous bytes, so only none / sub are written here
+        rows.append(b"\x00" + data)
+    body = chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, colour, 0, 0, 0)) + extra
+    if palette is not None:
+        body += chunk(b"PLTE", bytes(palette))
+    body += chunk(b"IDAT", zlib.compress(b"".join(rows))) + chunk(b"IEND", b"")
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + body)
+    return chunk
+
+
+def _srgb_to_linear(v):
+    v = np.asarray(v, np.float32)
+    lo = v * np.float32(1.0 / 12.92)
+    hi = np.power(((v + np.float32(0.055)) * np.float32(1.0 / 1.055)).astype(np.float32), np.float32(2.4)).astype(np.float32)
+    return np.where(v <= np.float32(0.04045), lo, hi)
+
+
+def test_image_load_png(tmp_path):
+    from mitsuba_amd import capi
+    rng = np.random.default_rng(5)
+    rgb = rng.integers(0, 256, (5, 7, 3))
+    p = str(tmp_path / "rgb8.png")
+    _png(p, rgb, 2, 8)
+    got = capi.image_load(p)
+    assert got.shape == (5, 7, 3)
+    assert np.allclose(got, _srgb_to_linear(rgb.astype(np.float32) * np.float32(1 / 255.0)), rtol=2e-6, atol=1e-7)
+    # the texture's gamma property overrides the file's (here: linear)
+    assert np.array_equal(capi.image_load(p, gamma=1.0), rgb.astype(np.float32) * np.float32(1 / 255.0))
+    assert np.allclose(capi.image_load(p, gamma=2.2), np.power(rgb.astype(np.float32) * np.float32(1 / 255.0), np.float32(2.2)), rtol=2e-6)
+    # 16-bit grey, grey + alpha (alpha dropped), RGBA, 4-bit grey, palette
+    g16 = rng.integers(0, 65536, (4, 3))
+    _png(p, g16, 0, 16)
+    assert np.allclose(capi.image_load(p), _srgb_to_linear(g16.astype(np.float32) * np.float32(1 / 65535.0)), rtol=2e-6, atol=1e-8)
+    ga = rng.integers(0, 256, (3, 4, 2))
+    _png(p, ga, 4, 8)
+    assert np.allclose(capi.image_load(p), _srgb_to_linear(ga[..., 0].astype(np.float32) * np.float32(1 / 255.0)), rtol=2e-6, atol=1e-7)
+    rgba = rng.integers(0, 256, (3, 4, 4))
+    _png(p, rgba, 6, 8)
+    assert np.allclose(capi.image_load(p), _srgb_to_linear(rgba[..., :3].astype(np.float32) * np.float32(1 / 255.0)), rtol=2e-6, atol=1e-7)
+    g4 = rng.integers(0, 16, (3, 5))
+    _png(p, g4, 0, 4)
+    assert np.allclose(capi.image_load(p), _srgb_to_linear((g4 * 17).astype(np.float32) * np.float32(1 / 255.0)), rtol=2e-6, atol=1e-7)
+    pal = rng.integers(0, 256, (6, 3))
+    idx = rng.integers(0, 6, (4, 4))
+    _png(p, idx, 3, 8, palette=pal.ravel().tolist())
+    assert np.allclose(capi.image_load(p), _srgb_to_linear(pal[idx].astype(np.float32) * np.float32(1 / 255.0)), rtol=2e-6, atol=1e-7)
+    # a gAMA chunk without an sRGB chunk sets the decoding exponent (bitmap.cpp:2534-2541)
+    chunk = _png(p, rgb, 2, 8)
+    _png(p, rgb, 2, 8, extra=chunk(b"gAMA", struct.pack(">I", 50000)))
+    assert np.allclose(capi.image_load(p), np.power(rgb.astype(np.float32) * np.float32(1 / 255.0), np.float32(2.0)), rtol=2e-6)
+    # filtered rows (sub / up / average / Paeth) as zlib-compressed by a real encoder: the CLI's own PNG writer is
+    # covered in tests/test_cli.py; here a hand-filtered image
+    h, w = 6, 5
+    img = rng.integers(0, 256, (h, w, 3)).astype(np.int64)
+    raw = bytearray()
+    prev = np.zeros(w * 3, np.int64)
+    for y in range(h):
+        cur = img[y].ravel()
+        ft = (y % 4) + 1
+        left = np.concatenate([np.zeros(3, np.int64), cur[:-3]])
+        upleft = np.concatenate([np.zeros(3, np.int64), prev[:-3]])
+        if ft == 1:
+            pred = left
+        elif ft == 2:
+            pred = prev
+        elif ft == 3:
+            pred = (left + prev) // 2
+        else:
+            pa, pb, pc = abs(prev - upleft), abs(left - upleft), abs(left + prev - 2 * upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+        raw += bytes([ft]) + bytes(((cur - pred) % 256).astype(np.uint8))
+        prev = cur
+
+    def chunk2(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    open(p, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk2(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+                        chunk2(b"IDAT", zlib.compress(bytes(raw))) + chunk2(b"IEND", b""))
+    assert np.array_equal(capi.image_load(p, gamma=1.0), img.astype(np.float32) * np.float32(1 / 255.0))
+    with pytest.raises(capi.MtsamdError):
+        capi.image_load(str(tmp_path / "missing.png"))
+    open(p, "wb").write(b"\xff\xd8\xff\xe0 not really a jpeg")
+    with pytest.raises(capi.MtsamdError, match="JPEG"):
+        capi.image_load(p)
+
+
+def test_image_load_pfm_and_openexr(tmp_path):
+    from mitsuba_amd import capi
+    rng = np.random.default_rng(6)
+    img = rng.uniform(0, 4, (5, 3, 3)).astype(np.float32)
+    p = str(tmp_path / "a.pfm")
+    with open(p, "wb") as f:        # rows bottom to top, little endian, scale 2
+        f.write(b"PF\n3 5\n-2.0\n")
+        f.write(img[::-1].astype("<f4").tobytes())
+    assert np.array_equal(capi.image_load(p), img * np.float32(2.0))
+    lum = rng.uniform(0, 1, (4, 6)).astype(np.float32)
+    with open(p, "wb") as f:        # big endian, luminance
+        f.write(b"Pf\n6 4\n1.0\n")
+        f.write(lum[::-1].astype(">f4").tobytes())
+    assert np.array_equal(capi.image_load(p), lum)
+
+    def exr(path, planes, names, types, compression):
+        h, w = planes[0].shape
+        order = np.argsort(names)
+        hdr = b"\x76\x2f\x31\x01" + struct.pack("<I", 2)
+
+        def attr(name, typ, data):
+            return name + b"\0" + typ + b"\0" + struct.pack("<I", len(data)) + data
+        chl = b"".join(names[i].encode() + b"\0" + struct.pack("<IBBBBII", types[i], 0, 0, 0, 0, 1, 1) for i in order) + b"\0"
+        hdr += attr(b"channels", b"chlist", chl) + attr(b"compression", b"compression", bytes([compression]))
+        box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+        hdr += attr(b"dataWindow", b"box2i", box) + attr(b"displayWindow", b"box2i", box)
+        hdr += attr(b"lineOrder", b"lineOrder", b"\0") + attr(b"pixelAspectRatio", b"float", struct.pack("<f", 1))
+        hdr += attr(b"screenWindowCenter", b"v2f", struct.pack("<ff", 0, 0)) + attr(b"screenWindowWidth", b"float", struct.pack("<f", 1)) + b"\0"
+        lines = {0: 1, 2: 1, 3: 16}[compression]
+        blocks = []
+        for y0 in range(0, h, lines):
+            raw = b""
+            for y in range(y0, min(h, y0 + lines)):
+                for i in order:
+                    raw += planes[i][y].astype("<f2" if types[i] == 1 else "<f4").tobytes()
+            data = raw
+            if compression:
+                a = np.frombuffer(raw, np.uint8)
+                t = np.concatenate([a[0::2], a[1::2]]).astype(np.int64)
+                t[1:] = (t[1:] - t[:-1] + 128 + 256) % 256
+                comp = zlib.compress(bytes(t.astype(np.uint8)))
+                data = comp if len(comp) < len(raw) else raw
+            blocks.append(struct.pack("<iI", y0, len(data)) + data)
+        table_at = len(hdr)
+        offs, pos = [], table_at + 8 * len(blocks)
+        for bl in blocks:
+            offs.append(pos)
+            pos += len(bl)
+        open(path, "wb").write(hdr + b"".join(struct.pack("<Q", o) for o in offs) + b"".join(blocks))
+
+    p = str(tmp_path / "a.exr")
+    big = rng.uniform(0, 2, (37, 9, 3)).astype(np.float32)
+    exr(p, [big[..., 0], big[..., 1], big[..., 2]], ["R", "G", "B"], [2, 2, 2], 0)
+    assert np.array_equal(capi.image_load(p), big)
+    exr(p, [big[..., 0], big[..., 1], big[..., 2]], ["R", "G", "B"], [1, 1, 1], 3)     # ZIP, half
+    assert np.array_equal(capi.image_load(p), big.astype(np.float16).astype(np.float32))
+    exr(p, [big[..., 0], big[..., 1], big[..., 2], big[..., 0]], ["R", "G", "B", "A"], [1, 2, 1, 2], 2)   # ZIPS, mixed types, alpha ignored
+    expect = big.copy()
+    expect[..., 0] = _half(big[..., 0]); expect[..., 2] = _half(big[..., 2])
+    assert np.array_equal(capi.image_load(p), expect)
+    exr(p, [big[..., 1]], ["Y"], [2], 3)
+    assert np.array_equal(capi.image_load(p), big[..., 1])
+    # the environment map the reference ships is PIZ-compressed: refused with a message that says so
+    ref = "/root/reference/testScene/testScenes/envmap.exr"
+    if os.path.exists(ref):
+        with pytest.raises(capi.MtsamdError, match="compression"):
+            capi.image_load(ref)
