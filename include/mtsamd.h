@@ -94,7 +94,14 @@ typedef struct {
        specularReflectance, specularTransmittance): 1-based index into mtsamd_scene_desc.textures, 0 = the constant.
        The BSDF evaluates them at the intersection's uv like `m_reflectance->eval(bRec.its)` (e.g. diffuse.cpp:110-118). */
     int32_t diffuse_texture, specular_texture, transmittance_texture;
+    /* BumpMap / NormalMap (src/bsdfs/bumpmap.cpp:135-237, src/bsdfs/normalmap.cpp:107-260): frame_kind != 0 = this record is
+       the BSDF nested in such an adapter, which evaluates it in a shading frame perturbed by the gradient of the
+       displacement texture (MTSAMD_FRAME_BUMPMAP) or turned towards the normal the texture stores as a colour
+       (MTSAMD_FRAME_NORMALMAP); frame_texture is that texture (1-based). Any record but a mixture may be wrapped, a wrapped
+       record may in turn sit in a `twosided` adapter; wrapped records cannot be nested in a mixture. */
+    int32_t frame_kind, frame_texture;
 } mtsamd_material;
+enum { MTSAMD_FRAME_NONE = 0, MTSAMD_FRAME_BUMPMAP = 1, MTSAMD_FRAME_NORMALMAP = 2 };
 
 /* 2-D textures (Texture2D, src/librender/texture.cpp:81-121: uv * (uscale, vscale) + (uoffset, voffset)), then
    src/textures/checkerboard.cpp:66-75, src/textures/gridtexture.cpp:75-88 or, MTSAMD_TEX_BITMAP, the image lookup of
@@ -246,7 +253,7 @@ const char *mtsamd_last_error(void);
    are never reordered). A caller compiled against another version must not pass them in: compare MTSAMD_ABI_VERSION with
    mtsamd_abi_version(), and where records are mirrored by hand (FFI bindings) their sizes with mtsamd_sizeof(). No
    counterpart in the reference, whose plugins are compiled against its own headers. */
-#define MTSAMD_ABI_VERSION 10
+#define MTSAMD_ABI_VERSION 11
 enum { MTSAMD_SIZEOF_SCENE_DESC = 0, MTSAMD_SIZEOF_MATERIAL = 1, MTSAMD_SIZEOF_EMITTER = 2, MTSAMD_SIZEOF_SHAPE = 3,
        MTSAMD_SIZEOF_RENDER_OPTS = 4, MTSAMD_SIZEOF_STATS = 5, MTSAMD_SIZEOF_LDR_OPTS = 6, MTSAMD_SIZEOF_TEXTURE = 7 };
 int mtsamd_abi_version(void);

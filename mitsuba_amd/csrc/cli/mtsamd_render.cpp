@@ -69,6 +69,8 @@ static void describe(const LoadedScene &s) {
     printf("], \"material_textures\": [");
     for (size_t i = 0; i < s.materials.size(); ++i)
         printf("%s[%d, %d, %d]", i ? ", " : "", s.materials[i].diffuse_texture, s.materials[i].specular_texture, s.materials[i].transmittance_texture);
+    printf("], \"frames\": [");
+    for (size_t i = 0; i < s.materials.size(); ++i) printf("%s[%d, %d]", i ? ", " : "", s.materials[i].frame_kind, s.materials[i].frame_texture);
     printf("], \"textures\": [");
     for (size_t i = 0; i < s.textures.size(); ++i) {
         const mtsamd_texture &t = s.textures[i];

@@ -394,6 +394,37 @@ mtsamd_material makeBsdf(const Element &node, const LoadOptions &opts, LoadedSce
         m.back_material = back;
         return m;
     }
+    if (type == "bumpmap" || type == "normalmap") {     // src/bsdfs/bumpmap.cpp:116-133, src/bsdfs/normalmap.cpp:88-105
+        const Element *nestedBsdf = nullptr, *texture = nullptr;
+        for (const auto &c : node.children) {
+            const bool isTextureRef = c->tag == "ref" && out.namedTextures.count(c->get("id"));
+            if (c->tag == "texture" || isTextureRef) {
+                if (texture) throw Fail(type == "bumpmap" ? "Only a single displacement texture can be specified!" : "Only a single normal texture can be specified!");
+                texture = c.get();
+            } else if (c->tag == "bsdf" || c->tag == "ref") {
+                if (nestedBsdf) throw Fail("Only a single nested BSDF can be added!");
+                nestedBsdf = c.get();
+            }
+        }
+        if (!nestedBsdf) throw Fail("A child BSDF instance is required");
+        if (!texture) throw Fail(type == "bumpmap" ? "A displacement texture must be specified" : "A normal map texture must be specified");
+        if (texture->tag == "texture" && texture->get("type") == "bitmap") {
+            bool hasGamma = false;
+            for (const auto &c : texture->children) hasGamma |= c->get("name") == "gamma";
+            if (!hasGamma) throw Fail("When using a bitmap texture as a bump map, please explicitly specify the 'gamma' parameter of the bitmap plugin. "
+                                      "In most cases the following is the correct choice: <float name=\"gamma\" value=\"1.0\"/>");
+        }
+        mtsamd_material m;
+        if (nestedBsdf->tag == "ref") {
+            if (!named || !named->count(nestedBsdf->get("id"))) throw Fail("reference to unknown bsdf '" + nestedBsdf->get("id") + "'");
+            m = copyMaterial(out, named->at(nestedBsdf->get("id")));
+        } else m = makeBsdf(*nestedBsdf, opts, out, named);
+        if (m.type == MTSAMD_BSDF_MIXTURE || m.two_sided || m.frame_kind)
+            throw Fail(type + ": the nested BSDF must be a plain model (not a mixturebsdf, twosided, bumpmap or normalmap)");
+        m.frame_kind = type == "bumpmap" ? MTSAMD_FRAME_BUMPMAP : MTSAMD_FRAME_NORMALMAP;
+        m.frame_texture = (int32_t) (texture->tag == "ref" ? out.namedTextures.at(texture->get("id")) : makeTexture(*texture, out));
+        return m;
+    }
     if (type == "mixturebsdf") {                // src/bsdfs/mixturebsdf.cpp:66-85,279-287
         const Props mp = parseProps(node);
         std::vector<double> weights;
@@ -423,6 +454,7 @@ mtsamd_material makeBsdf(const Element &node, const LoadOptions &opts, LoadedSce
             const mtsamd_material &cm = out.materials[(size_t) c];
             if (cm.two_sided || cm.type == MTSAMD_BSDF_MIXTURE)
                 throw Fail("mixturebsdf: twosided and mixturebsdf cannot be nested");
+            if (cm.frame_kind) throw Fail("mixturebsdf: bumpmap and normalmap cannot be nested");
         }
         if (children.size() != weights.size())
             throw Fail("BSDF count mismatch: " + std::to_string(children.size()) + " bsdfs, but specified " + std::to_string(weights.size()) + " weights");

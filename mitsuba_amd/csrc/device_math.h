@@ -68,6 +68,8 @@ MTS_DEV float maxComp(V3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
 MTS_DEV V3 ld3(const float *p, uint32_t i) { return mk(p[3 * (size_t) i], p[3 * (size_t) i + 1], p[3 * (size_t) i + 2]); }
 MTS_DEV V3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
 MTS_DEV float safeSqrt(float v) { return sqrtf(fmaxf(0.0f, v)); }
+// Spectrum::getLuminance (include/mitsuba/core/spectrum.h:754-756)
+MTS_DEV float luminance(V3 s) { return s.x * 0.212671f + s.y * 0.715160f + s.z * 0.072169f; }
 
 struct Frame3 { V3 s, t, n; };
 

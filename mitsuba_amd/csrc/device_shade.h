@@ -826,6 +826,26 @@ __device__ __attribute__((noinline)) inline float4 bitmapEval(const DevScene *sc
     return make_float4(value.x, value.y, value.z, 0.0f);
 }
 
+// evalGradientBilinear (mipmap.h:601-626) of level 0, times the texture's factor
+__device__ __attribute__((noinline)) inline void bitmapGradient(const DevScene *sc, const DevTexture *tp, float uu, float vv, float *out /* 6 */) {
+    const DevTexture &t = *tp;
+    const uint32_t mode = __float_as_uint(t.color1[2]), filter = mode & 0xffu;
+    for (int i = 0; i < 6; ++i) out[i] = 0.0f;
+    if (filter == 0 || !isfinite(uu) || !isfinite(vv)) return;      // bitmap.cpp:456-480: no gradient with the nearest filter
+    MipRef m;
+    m.sc = sc; m.first = __float_as_uint(t.color1[0]); m.levels = __float_as_uint(t.color1[1]);
+    m.bcu = (mode >> 8) & 0xffu; m.bcv = (mode >> 16) & 0xffu; m.maxAnisotropy = t.lineWidth;
+    const DevMipLevel L = sc->mipLevels[m.first];
+    const float u = uu * (float) L.w - 0.5f, v = vv * (float) L.h - 0.5f;
+    const int xPos = (int) floorf(u), yPos = (int) floorf(v);
+    const float dx = u - (float) xPos, dy = v - (float) yPos;
+    const V3 p00 = mipTexel(m, 0, xPos, yPos), p10 = mipTexel(m, 0, xPos + 1, yPos), p01 = mipTexel(m, 0, xPos, yPos + 1),
+             p11 = mipTexel(m, 0, xPos + 1, yPos + 1);
+    const V3 tmp = p01 + p10 - p11;
+    const V3 gu = (p10 + p00 * (dy - 1) - tmp * dy) * (float) L.w, gv = (p01 + p00 * (dx - 1) - tmp * dx) * (float) L.h;
+    out[0] = gu.x; out[1] = gu.y; out[2] = gu.z; out[3] = gv.x; out[4] = gv.y; out[5] = gv.z;
+}
+
 // ---- Texture2D::eval(its, filter = true) (src/librender/texture.cpp:112-121) ------------------------------------------
 MTS_DEV V3 textureEval(const DevScene &sc, const DevTexture &t, const SurfUV &q) {
     const float x = q.u * t.uScale + t.uOffset, y = q.v * t.vScale + t.vOffset;
@@ -842,9 +862,54 @@ MTS_DEV V3 textureEval(const DevScene &sc, const DevTexture &t, const SurfUV &q)
         second = fabsf(fx) < t.lineWidth || fabsf(fy) < t.lineWidth;
     } else {
         const float4 r = bitmapEval(&sc, &t, x, y, make_float4(q.dudx * t.uScale, q.dvdx * t.vScale, q.dudy * t.uScale, q.dvdy * t.vScale), q.filtered);
-        return mk(r.x, r.y, r.z);
+        return mk(r.x, r.y, r.z) * t.scale;
     }
-    return second ? ld3(t.color1) : ld3(t.color0);
+    return (second ? ld3(t.color1) : ld3(t.color0)) * t.scale;
+}
+
+// Texture2D::evalGradient(its, gradient) (texture.cpp:123-141): the bitmap's bilinear gradient (bitmap.cpp:456-480) or
+// forward differences of the unfiltered lookup, times the uv scale
+MTS_DEV void textureGradient(const DevScene &sc, const DevTexture &t, float u, float v, V3 &gu, V3 &gv) {
+    const float x = u * t.uScale + t.uOffset, y = v * t.vScale + t.vOffset;
+    if (t.type == 3) {
+        float g[6];
+        bitmapGradient(&sc, &t, x, y, g);
+        const V3 f = ld3(t.color0);
+        gu = mk(g[0], g[1], g[2]) * f; gv = mk(g[3], g[4], g[5]) * f;
+    } else {
+        // the lookups below apply the uv transform themselves: hand them coordinates whose transform is (x, y), (x + eps, y), (x, y + eps)
+        DevTexture plain = t;
+        plain.uScale = plain.vScale = 1.0f; plain.uOffset = plain.vOffset = 0.0f; plain.scale = 1.0f;
+        const float eps = kEpsilon;
+        const V3 value = textureEval(sc, plain, surfUV(x, y)), valueU = textureEval(sc, plain, surfUV(x + eps, y)),
+                 valueV = textureEval(sc, plain, surfUV(x, y + eps));
+        gu = (valueU - value) * (1 / eps); gv = (valueV - value) * (1 / eps);
+    }
+    gu = gu * t.uScale * t.scale; gv = gv * t.vScale * t.scale;    // Texture2D::evalGradient, then ScaleTexture::evalGradient
+}
+
+// BumpMap::getFrame (src/bsdfs/bumpmap.cpp:135-159) / NormalMap::getFrame (src/bsdfs/normalmap.cpp:107-124): the shading
+// frame the nested BSDF is asked in. `frameWord` = kind << 1 | texture << 8 (see DevScene::materialTextures).
+MTS_DEV Frame3 perturbedFrame(const DevScene &sc, uint32_t frameWord, const Frame3 &sh, V3 geoN, V3 dpdu0, V3 dpdv0, float u, float v) {
+    const DevTexture &t = sc.plainTextures[(frameWord >> 8) - 1];
+    Frame3 r;
+    if (((frameWord >> 1) & 3u) == 1u) {
+        V3 gu, gv;
+        textureGradient(sc, t, u, v, gu, gv);
+        const float dDispDu = luminance(gu), dDispDv = luminance(gv);
+        const V3 dpdu = dpdu0 + sh.n * (dDispDu - dot(sh.n, dpdu0)), dpdv = dpdv0 + sh.n * (dDispDv - dot(sh.n, dpdv0));
+        r.n = normalize(cross(dpdu, dpdv));
+        r.s = normalize(dpdu - r.n * dot(r.n, dpdu));
+        r.t = cross(r.n, r.s);
+        if (dot(r.n, geoN) < 0) r.n = -r.n;
+    } else {
+        const V3 c = textureEval(sc, t, surfUV(u, v));
+        const V3 n = mk(2 * c.x - 1, 2 * c.y - 1, 2 * c.z - 1);
+        r.n = normalize(toWorld(sh, n));
+        r.s = normalize(dpdu0 - r.n * dot(r.n, dpdu0));
+        r.t = cross(r.n, r.s);
+    }
+    return r;
 }
 
 // The colours of record `index` that are textured, evaluated at the intersection's uv and written over the constants

@@ -35,10 +35,14 @@ struct alignas(16) DevMaterial {
 // Bitmap texture (type 3, src/textures/bitmap.cpp): color0 is the factor on the looked-up value (scale textures and
 // the energy-conservation factor), color1 holds, as raw bits, the first entry of the texture's levels in
 // DevScene::mipLevels, their number, and filter type | wrapU << 8 | wrapV << 16; lineWidth is the anisotropy bound.
+// `scale`: a factor still to be applied to the looked-up value (the textures on their own keep their scale texture's
+// factor apart, so that a gradient is scaled after the difference is taken, like ScaleTexture::evalGradient); 1 where
+// the colours already carry every factor.
 struct alignas(16) DevTexture {
     float color0[3]; int32_t type;
     float color1[3]; float lineWidth;
     float uOffset, vOffset, uScale, vScale;
+    float scale, pad[3];
 };
 
 // One level of a MIP pyramid: where its texels start (in texels of four halves: R, G, B, unused), its size and
@@ -102,9 +106,12 @@ struct DevScene {
     const float *areaCdf;       // concatenated per-emitter triangle CDFs (nTris + 1 each)
     const float *rtrans;        // concatenated reduced transmittance tables
     // Only when some material has a texture: per material the 1-based texture of its diffuse, specular and
-    // transmittance colour (0 = the constant in the record), and the textures
+    // transmittance colour (0 = the constant in the record), and the textures. w: bit 0 = the BSDF the shape holds wants
+    // uv partials at the first vertex of a path (BSDF::usesRayDifferentials); bits 1-2 = the record sits in a bumpmap (1) or
+    // normalmap (2) adapter whose texture is entry (w >> 8) - 1 of plainTextures
     const uint4 *materialTextures;
     const DevTexture *textures;
+    const DevTexture *plainTextures;    // the description's textures on their own (scale factor applied), in its order
     // Only with bitmap textures: the levels of all MIP pyramids, their texels, and the 64-entry weight table of the
     // elliptically weighted average (mipmap.h:296-302)
     const DevMipLevel *mipLevels;

@@ -198,6 +198,8 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
     // a texture of the description as the device evaluates it, with the factors a BSDF wraps around it
     auto deviceTexture = [&](const mtsamd_texture &t, uint32_t index /* 0-based */, const float c0[3], const float c1[3]) {
         DevTexture dt;
+        memset(&dt, 0, sizeof(dt));
+        dt.scale = 1.0f;
         memcpy(dt.color0, c0, 12); memcpy(dt.color1, c1, 12);
         dt.type = t.type; dt.lineWidth = t.line_width;
         dt.uOffset = t.u_offset; dt.vOffset = t.v_offset; dt.uScale = t.u_scale; dt.vScale = t.v_scale;
@@ -213,9 +215,9 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
     for (size_t i = 0; i < pyramids.size(); ++i) {
         const mtsamd_texture &t = d->textures[i];
         if (t.type < MTSAMD_TEX_CHECKERBOARD || t.type > MTSAMD_TEX_BITMAP) return "unsupported texture type";
-        float c0[3], c1[3];
-        for (int k = 0; k < 3; ++k) { c0[k] = t.type == MTSAMD_TEX_BITMAP ? t.scale : t.color0[k] * t.scale; c1[k] = t.color1[k] * t.scale; }
-        hs.plainTextures.push_back(deviceTexture(t, (uint32_t) i, c0, c1));
+        const float one[3] = { 1.0f, 1.0f, 1.0f };
+        hs.plainTextures.push_back(deviceTexture(t, (uint32_t) i, t.type == MTSAMD_TEX_BITMAP ? one : t.color0, t.color1));
+        hs.plainTextures.back().scale = t.scale;
     }
     std::vector<uint8_t> wantsPartials(d->n_materials, 0);      // BSDF::usesRayDifferentials of the record on its own
 
@@ -334,6 +336,16 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
                 return "unsupported BSDF type";
         }
         diff.value(0, dm.diffuse); spec.value(0, dm.specular); trans.value(0, dm.transmittance);
+        if (m.frame_kind != MTSAMD_FRAME_NONE) {        // bumpmap.cpp:86-99, normalmap.cpp:58-71
+            if (m.frame_kind != MTSAMD_FRAME_BUMPMAP && m.frame_kind != MTSAMD_FRAME_NORMALMAP) return "unknown frame adapter";
+            if (m.type == MTSAMD_BSDF_MIXTURE) return "bumpmap / normalmap around a mixturebsdf is not supported";
+            if (m.frame_texture < 1 || (uint32_t) m.frame_texture > d->n_textures || !d->textures) return "bumpmap / normalmap: texture index out of range";
+            if (dm.typeFlags) dm.typeFlags |= EAnisotropic;
+            wantsPartials[i] = 1;
+            if (hs.materialTextures.empty()) hs.materialTextures.assign((size_t) d->n_materials * 4, 0u);
+            hs.materialTextures[(size_t) i * 4 + 3] |= ((uint32_t) m.frame_kind << 1) | ((uint32_t) m.frame_texture << 8);
+            hs.mixture = true;
+        }
         if (m.type != MTSAMD_BSDF_MIXTURE && (diff.tex || spec.tex || trans.tex)) {
             if (hs.materialTextures.empty()) hs.materialTextures.assign((size_t) d->n_materials * 4, 0u);
             const Colour *slots[3] = { &diff, &spec, &trans };
@@ -380,6 +392,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
             const int t = d->materials[c].type;
             if (d->materials[c].two_sided || t == MTSAMD_BSDF_MIXTURE)
                 return "mixturebsdf: twosided and mixturebsdf cannot be nested";
+            if (d->materials[c].frame_kind) return "mixturebsdf: bumpmap and normalmap cannot be nested";
             childTypes |= (uint32_t) t << (8 * k);
             child[k] = c;
             w[k] = scale != 1.0f ? m.mix_weight[k] * scale : m.mix_weight[k];
@@ -414,7 +427,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const DevMaterial &dm = hs.materials[i];
         const bool wants = wantsPartials[i] || (dm.twoSided && wantsPartials[dm.backMaterial]);
-        if (wants && !hs.materialTextures.empty()) hs.materialTextures[(size_t) i * 4 + 3] = 1u;
+        if (wants && !hs.materialTextures.empty()) hs.materialTextures[(size_t) i * 4 + 3] |= 1u;
     }
 
     // ---- shapes ----------------------------------------------------------------------------------------

@@ -143,13 +143,21 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
         // its.getBSDF(ray) (path.cpp:145, records.inl:69-75): uv partials for the vertex a camera ray reaches, if its BSDF
         // filters its textures
         SurfUV uv = surfUV(its.uvx, its.uvy);
-        if (MIX && prevDepth == 0 && sc.mipLevels && sc.materialTextures[its.material].w)
+        if (MIX && prevDepth == 0 && sc.materialTextures && (sc.materialTextures[its.material].w & 1u))
             cameraUVPartials(sc, pp, samplePos[slot], its, in.rayO(), rayD, uv);
         // ... and the BRDF that answers on this side (twosided.cpp:108-183)
         const bool flipped = resolveTwoSided(sc, its.material, wiZ, bsdf);
         const V3 wiLocal = flipped ? mirrorZ(its.wi) : its.wi;
         // textured colours of the answering record, at this hit (only scenes with textures run the MIX kernels with a table)
         if (MIX) applyTextures(sc, its.material, uv, bsdf);
+        // bumpmap / normalmap around the answering record: it is asked in a perturbed frame (bumpmap.cpp:161-237)
+        bool framed = false;
+        Frame3 pf;
+        if (MIX && sc.materialTextures) {
+            const uint32_t fw = sc.materialTextures[its.material].w;
+            if (fw & 6u) { framed = true; pf = perturbedFrame(sc, fw, its.sh, its.geoN, its.dpdu, its.dpdv, its.uvx, its.uvy); }
+        }
+        const V3 wiB = framed ? toLocal(pf, toWorld(its.sh, wiLocal)) : wiLocal;
         // The sample's radiance is only fetched where something is added to it: at the camera vertex it still is
         // what k_raygen wrote (zero), later only paths that hit an emitter touch it.
         float4 L = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -216,10 +224,12 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                     V3 c = mk(0.0f);
                     const V3 wo = toLocal(its.sh, dRec.d);
                     const V3 woSide = flipped ? mirrorZ(wo) : wo;
-                    const V3 bsdfVal = bsdfEvalAny<RD, MIX>(sc, bsdf, wiLocal, woSide, uv);
+                    const V3 woB = framed ? toLocal(pf, toWorld(its.sh, woSide)) : woSide;
+                    const bool sameSide = !framed || woSide.z * woB.z > 0;
+                    const V3 bsdfVal = sameSide ? bsdfEvalAny<RD, MIX>(sc, bsdf, wiB, woB, uv) : mk(0.0f);
                     if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
                         // path.cpp:192-193: only emitters with a surface, sampled in the solid-angle measure, compete with BSDF sampling
-                        const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX>(sc, bsdf, wiLocal, woSide, uv);
+                        const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX>(sc, bsdf, wiB, woB, uv);
                         c = throughput * value * bsdfVal * miWeight(dRec.pdf, bPdf);
                     }
                     o.wantShadow = true;
@@ -235,7 +245,12 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             const float bx = rng.next1D(), by = rng.next1D();
             V3 woLocal; float bPdf, bEta; uint32_t sampledType;
             const float bu = RD && bsdfDrawsFromSampler<MIX>(bsdf, bx) ? rng.next1D() : 0.0f;     // bRec.sampler->next1D() inside BSDF::sample
-            const V3 bsdfWeight = bsdfSampleAny<RD, MIX>(sc, bsdf, wiLocal, bx, by, bu, woLocal, bPdf, bEta, sampledType, uv);
+            V3 bsdfWeight = bsdfSampleAny<RD, MIX>(sc, bsdf, wiB, bx, by, bu, woLocal, bPdf, bEta, sampledType, uv);
+            if (framed && !isZero(bsdfWeight)) {        // back into the unperturbed frame (bumpmap.cpp:227-234)
+                const V3 pwo = woLocal;
+                woLocal = toLocal(its.sh, toWorld(pf, pwo));
+                if (woLocal.z * pwo.z <= 0) bsdfWeight = mk(0.0f);
+            }
             if (flipped && !isZero(bsdfWeight) && bPdf != 0) woLocal.z = -woLocal.z;      // twosided.cpp:172-181
             if (!isZero(bsdfWeight)) {
                 if (sampledType != ENull) flags |= PF_SCATTERED;
@@ -539,16 +554,23 @@ __global__ void __launch_bounds__(kShadeBlock) k_direct_shade(DevScene sc, PassP
 
         uint32_t bsdfType = 0;
         bool flipped = false;
-        V3 wiLocal = mk(0.0f), refN = mk(0.0f);
+        V3 wiLocal = mk(0.0f), refN = mk(0.0f), wiB = mk(0.0f);
         SurfUV uv = surfUV(0.0f, 0.0f);
+        bool framed = false;
+        Frame3 pf;
         if (shade) {
             bsdfType = bsdf.typeFlags;
             uv = surfUV(its.uvx, its.uvy);
-            if (sc.mipLevels && sc.materialTextures[its.material].w)     // its.getBSDF(ray) (direct.cpp:176)
+            if (sc.materialTextures && (sc.materialTextures[its.material].w & 1u))     // its.getBSDF(ray) (direct.cpp:176)
                 cameraUVPartials(sc, pp, samplePos[slot], its, in.rayO[i], rayD, uv);
             flipped = resolveTwoSided(sc, its.material, its.wi.z, bsdf);
             wiLocal = flipped ? mirrorZ(its.wi) : its.wi;
             applyTextures(sc, its.material, uv, bsdf);
+            if (sc.materialTextures) {      // bumpmap / normalmap around the answering record
+                const uint32_t fw = sc.materialTextures[its.material].w;
+                if (fw & 6u) { framed = true; pf = perturbedFrame(sc, fw, its.sh, its.geoN, its.dpdu, its.dpdv, its.uvx, its.uvy); }
+            }
+            wiB = framed ? toLocal(pf, toWorld(its.sh, wiLocal)) : wiLocal;
             if ((bsdfType & (ETransmission | EBackSide)) == 0) refN = its.sh.n;
         }
         // MIDirectIntegrator::configure (direct.cpp:128-136)
@@ -568,9 +590,11 @@ __global__ void __launch_bounds__(kShadeBlock) k_direct_shade(DevScene sc, PassP
                         V3 c = mk(0.0f);
                         const V3 wo = toLocal(its.sh, dRec.d);
                         const V3 woSide = flipped ? mirrorZ(wo) : wo;
-                        const V3 bsdfVal = bsdfEvalAny(sc, bsdf, wiLocal, woSide, uv);
+                        const V3 woB = framed ? toLocal(pf, toWorld(its.sh, woSide)) : woSide;
+                        const bool sameSide = !framed || woSide.z * woB.z > 0;
+                        const V3 bsdfVal = sameSide ? bsdfEvalAny(sc, bsdf, wiB, woB, uv) : mk(0.0f);
                         if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
-                            const float bPdf = dRec.delta ? 0.0f : bsdfPdfAny(sc, bsdf, wiLocal, woSide, uv);
+                            const float bPdf = dRec.delta ? 0.0f : bsdfPdfAny(sc, bsdf, wiB, woB, uv);
                             c = value * bsdfVal * (miWeight(dRec.pdf * fracLum, bPdf * fracBSDF) * weightLum);
                         }
                         ++nShadow;
@@ -593,7 +617,12 @@ __global__ void __launch_bounds__(kShadeBlock) k_direct_shade(DevScene sc, PassP
                 const float bx = rng.next1D(), by = rng.next1D();
                 const float bu = bsdfDrawsFromSampler(bsdf, bx) ? rng.next1D() : 0.0f;
                 V3 woLocal; float bPdf, bEta; uint32_t sampledType;
-                const V3 bsdfVal = bsdfSampleAny(sc, bsdf, wiLocal, bx, by, bu, woLocal, bPdf, bEta, sampledType, uv);
+                V3 bsdfVal = bsdfSampleAny(sc, bsdf, wiB, bx, by, bu, woLocal, bPdf, bEta, sampledType, uv);
+                if (framed && !isZero(bsdfVal)) {
+                    const V3 pwo = woLocal;
+                    woLocal = toLocal(its.sh, toWorld(pf, pwo));
+                    if (woLocal.z * pwo.z <= 0) bsdfVal = mk(0.0f);
+                }
                 if (flipped && !isZero(bsdfVal) && bPdf != 0) woLocal.z = -woLocal.z;
                 if (!isZero(bsdfVal)) {
                     const V3 wo = toWorld(its.sh, woLocal);
@@ -838,8 +867,16 @@ __global__ void k_bsdf_evalpdf(DevScene sc, int material, float2 uvIn, int mode,
     if (resolveTwoSided(sc, index, a.z, m)) { a = mirrorZ(a); b = mirrorZ(b); }
     const SurfUV uv = surfUV(uvIn.x, uvIn.y);
     applyTextures(sc, index, uv, m);
-    if (mode == 0) { const V3 r = bsdfEvalAny(sc, m, a, b, uv); out[3 * (size_t) i] = r.x; out[3 * (size_t) i + 1] = r.y; out[3 * (size_t) i + 2] = r.z; }
-    else out[i] = bsdfPdfAny(sc, m, a, b, uv);
+    bool zero = false;
+    if (sc.materialTextures && (sc.materialTextures[index].w & 6u)) {       // a query without an intersection: the canonical local frame
+        Frame3 sh; sh.s = mk(1, 0, 0); sh.t = mk(0, 1, 0); sh.n = mk(0, 0, 1);
+        const Frame3 pf = perturbedFrame(sc, sc.materialTextures[index].w, sh, sh.n, sh.s, sh.t, uv.u, uv.v);
+        const V3 pb = toLocal(pf, b);
+        zero = b.z * pb.z <= 0;
+        a = toLocal(pf, a); b = pb;
+    }
+    if (mode == 0) { const V3 r = zero ? mk(0.0f) : bsdfEvalAny(sc, m, a, b, uv); out[3 * (size_t) i] = r.x; out[3 * (size_t) i + 1] = r.y; out[3 * (size_t) i + 2] = r.z; }
+    else out[i] = zero ? 0.0f : bsdfPdfAny(sc, m, a, b, uv);
 }
 
 __global__ void k_bsdf_sample(DevScene sc, int material, float2 uvIn, uint32_t n, const float *wi, const float *sample, const float *sampler1D,
@@ -855,7 +892,19 @@ __global__ void k_bsdf_sample(DevScene sc, int material, float2 uvIn, uint32_t n
     const SurfUV uv = surfUV(uvIn.x, uvIn.y);
     applyTextures(sc, index, uv, m);
     V3 o; float p, e; uint32_t t;
-    const V3 w = bsdfSampleAny(sc, m, a, sample[2 * (size_t) i], sample[2 * (size_t) i + 1], sampler1D ? sampler1D[i] : 0.5f, o, p, e, t, uv);
+    const bool framed = sc.materialTextures && (sc.materialTextures[index].w & 6u);
+    Frame3 pf;
+    if (framed) {
+        Frame3 sh; sh.s = mk(1, 0, 0); sh.t = mk(0, 1, 0); sh.n = mk(0, 0, 1);
+        pf = perturbedFrame(sc, sc.materialTextures[index].w, sh, sh.n, sh.s, sh.t, uv.u, uv.v);
+        a = toLocal(pf, a);
+    }
+    V3 w = bsdfSampleAny(sc, m, a, sample[2 * (size_t) i], sample[2 * (size_t) i + 1], sampler1D ? sampler1D[i] : 0.5f, o, p, e, t, uv);
+    if (framed && !isZero(w)) {
+        const V3 pwo = o;
+        o = toWorld(pf, pwo);
+        if (o.z * pwo.z <= 0) w = mk(0.0f);
+    }
     if (flipped && !isZero(w) && p != 0) o.z = -o.z;
     wo[3 * (size_t) i] = o.x; wo[3 * (size_t) i + 1] = o.y; wo[3 * (size_t) i + 2] = o.z;
     weight[3 * (size_t) i] = w.x; weight[3 * (size_t) i + 1] = w.y; weight[3 * (size_t) i + 2] = w.z;

@@ -239,7 +239,8 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
         HIP_TRY(upload(s->deltaEmitters, h.deltaEmitters));
         HIP_TRY(upload(s->emitterCdf, h.emitterCdf));
         HIP_TRY(upload(s->areaCdf, h.areaCdf));
-        if (!h.textures.empty()) { HIP_TRY(upload(s->textures, h.textures)); HIP_TRY(upload(s->materialTextures, h.materialTextures)); }
+        if (!h.textures.empty()) HIP_TRY(upload(s->textures, h.textures));
+        if (!h.materialTextures.empty()) HIP_TRY(upload(s->materialTextures, h.materialTextures));
         if (!h.plainTextures.empty()) HIP_TRY(upload(s->plainTextures, h.plainTextures));
         if (!h.mipLevels.empty()) {
             HIP_TRY(upload(s->mipLevels, h.mipLevels));
@@ -291,7 +292,8 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
     d.deltaEmitters = s->deltaEmitters.as<DevDeltaEmitter>();
     d.emitterCdf = s->emitterCdf.as<float>(); d.areaCdf = s->areaCdf.as<float>(); d.rtrans = s->rtrans.as<float>();
     d.textures = h.textures.empty() ? nullptr : s->textures.as<DevTexture>();
-    d.materialTextures = h.textures.empty() ? nullptr : s->materialTextures.as<uint4>();
+    d.materialTextures = h.materialTextures.empty() ? nullptr : s->materialTextures.as<uint4>();
+    d.plainTextures = h.plainTextures.empty() ? nullptr : s->plainTextures.as<DevTexture>();
     d.mipLevels = h.mipLevels.empty() ? nullptr : s->mipLevels.as<DevMipLevel>();
     d.texels = h.mipLevels.empty() ? nullptr : s->texels.as<uint2>();
     d.ewaLut = h.mipLevels.empty() ? nullptr : s->ewaLut.as<float>();

@@ -377,6 +377,35 @@ def _make_bsdf(node, data_dir: Optional[str], add_material=None, named: Optional
                 raise SceneFormatError("twosided with two nested BRDFs needs a material list to add the second one to")
             back = add_material(nested[1])
         return S.twosided(nested[0], back)
+    if t in ("bumpmap", "normalmap"):   # src/bsdfs/bumpmap.cpp:116-133, src/bsdfs/normalmap.cpp:88-105
+        nested = tex = None
+        for c in node:
+            is_texture_ref = c.tag == "ref" and ctx is not None and c.get("id") in ctx["named_textures"]
+            if c.tag == "texture" or is_texture_ref:
+                if tex is not None:
+                    raise SceneFormatError("Only a single %s texture can be specified!" % ("displacement" if t == "bumpmap" else "normal"))
+                tex = c
+            elif c.tag in ("bsdf", "ref"):
+                if nested is not None:
+                    raise SceneFormatError("Only a single nested BSDF can be added!")
+                nested = c
+        if nested is None:
+            raise SceneFormatError("A child BSDF instance is required")
+        if tex is None or ctx is None:
+            raise SceneFormatError("A displacement texture must be specified" if t == "bumpmap" else "A normal map texture must be specified")
+        if tex.tag == "texture" and tex.get("type") == "bitmap" and not any(c.get("name") == "gamma" for c in tex):
+            raise SceneFormatError("When using a bitmap texture as a bump map, please explicitly specify the 'gamma' parameter of the bitmap plugin. "
+                                   "In most cases the following is the correct choice: <float name=\"gamma\" value=\"1.0\"/>")
+        if nested.tag == "ref":
+            if named is None or nested.get("id") not in named:
+                raise SceneFormatError("reference to unknown bsdf '%s'" % nested.get("id"))
+            rec = dict(named[nested.get("id")])
+        else:
+            rec = _make_bsdf(nested, data_dir, add_material, named, ctx)
+        if rec["type"] == S.BSDF_MIXTURE or rec["two_sided"] or rec.get("frame_kind"):
+            raise SceneFormatError("%s: the nested BSDF must be a plain model (not a mixturebsdf, twosided, bumpmap or normalmap)" % t)
+        index = ctx["named_textures"][tex.get("id")] if tex.tag == "ref" else _make_texture(tex, ctx)
+        return S.bumpmap(rec, index) if t == "bumpmap" else S.normalmap(rec, index)
     if t == "mixturebsdf":  # src/bsdfs/mixturebsdf.cpp:66-85,279-287
         try:
             weights = [float(w) for w in p.get("weights", "").replace(",", " ").split()]
@@ -391,6 +420,8 @@ def _make_bsdf(node, data_dir: Optional[str], add_material=None, named: Optional
         def nest(rec):
             if rec["two_sided"] or rec["type"] == S.BSDF_MIXTURE:
                 raise SceneFormatError("mixturebsdf: twosided and mixturebsdf cannot be nested")
+            if rec.get("frame_kind"):
+                raise SceneFormatError("mixturebsdf: bumpmap and normalmap cannot be nested")
             children.append(add_material(rec))
 
         for c in node:

@@ -178,9 +178,22 @@ def _mat(**kw) -> Dict:
              specular_transmittance=(1.0, 1.0, 1.0), eta=(0.0, 0.0, 0.0), k=(1.0, 1.0, 1.0),
              ext_eta=1.000277, ensure_energy_conservation=1,
              rtrans=None, rtrans_diffuse_ext=0.0, rtrans_diffuse_int=0.0, two_sided=0, back_material=-1,
-             diffuse_texture=0, specular_texture=0, transmittance_texture=0)
+             diffuse_texture=0, specular_texture=0, transmittance_texture=0, frame_kind=0, frame_texture=0)
     m.update(kw)
     return m
+
+
+FRAME_BUMPMAP, FRAME_NORMALMAP = 1, 2
+
+
+def bumpmap(nested: Dict, texture: int) -> Dict:
+    """src/bsdfs/bumpmap.cpp: `nested` evaluated in a shading frame displaced by texture `texture` (1-based)."""
+    return dict(nested, frame_kind=FRAME_BUMPMAP, frame_texture=int(texture))
+
+
+def normalmap(nested: Dict, texture: int) -> Dict:
+    """src/bsdfs/normalmap.cpp: `nested` evaluated in the frame whose normal texture `texture` stores as (n + 1) / 2."""
+    return dict(nested, frame_kind=FRAME_NORMALMAP, frame_texture=int(texture))
 
 
 TEX_CHECKERBOARD, TEX_GRID, TEX_BITMAP = 1, 2, 3
@@ -670,7 +683,7 @@ def config5(width=3840, height=2160) -> SceneData:
 
 
 def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_weight=1.0, hide_emitters=0, lamps=False, area_lights=True,
-                     blend=False, textured=False) -> SceneData:
+                     blend=False, textured=False, bumps=False) -> SceneData:
     """A few hundred triangles with every BSDF type present; used by the parity tests. `sky` adds a constant
     environment emitter of that radiance next to the two area lights; `lamps` adds a point, a spot and a directional light;
     `blend` makes the ground and two of the blobs mixtures of the other materials; `textured` puts checkerboard and grid
@@ -717,6 +730,20 @@ def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_
         M[mats[2]]["diffuse_texture"] = b.add_texture(bitmap(image(9, 13, 3), "nearest", uscale=2.0, vscale=4.0))
         M[mats[3]]["transmittance_texture"] = b.add_texture(bitmap(image(40, 20, 3, hi=1.2), "ewa", wrap_mode_u="zero", wrap_mode_v="one", max_anisotropy=4.0))
         M[mats[4]]["diffuse_texture"] = b.add_texture(bitmap(image(128, 128, 3, smooth=1), "ewa", uscale=1.5, vscale=1.5))
+        if bumps:
+            # bump and normal maps: a height image (bitmap gradient), a procedural height (forward differences), a
+            # normal image; around plain, textured, two-sided and transmissive records
+            bump_img = image(48, 48, 1, smooth=4)
+            yy, xx = np.mgrid[0:32, 0:32]
+            nrm = np.stack([0.5 + 0.25 * np.sin(xx / 3.0), 0.5 + 0.25 * np.cos(yy / 4.0), np.full(xx.shape, 0.9)], -1).astype(np.float32)
+            t_height = b.add_texture(bitmap(bump_img, "bilinear", uscale=3.0, vscale=3.0, scale=0.3))
+            t_grid = b.add_texture(gridtexture((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), line_width=0.2, uscale=5.0, vscale=5.0, scale=2e-5))
+            t_normal = b.add_texture(bitmap(nrm, "bilinear", uscale=2.0, vscale=2.0))
+            M[m_ground] = bumpmap(M[m_ground], t_height)
+            M[mats[1]] = normalmap(M[mats[1]], t_normal)
+            M[mats[2]] = bumpmap(M[mats[2]], t_grid)
+            M[mats[3]] = bumpmap(M[mats[3]], t_height)
+            M[mats[5]] = twosided(normalmap(M[mats[5]], t_normal))
     if blend:
         m_ground = b.add_material(twosided(mixture([m_ground, mats[1]], [0.75, 0.25])))
         mats[0] = b.add_material(mixture([mats[0], mats[2], mats[4]], [0.6, 0.5, 0.4]))      # weights above one: rescaled

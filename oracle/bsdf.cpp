@@ -379,6 +379,7 @@ static Spectrum toSpec(const float *v) { return Spectrum(v[0], v[1], v[2]); }
 
 thread_local Vec2 g_textureUV{ 0, 0 };
 thread_local UVPartials g_texturePartials;
+thread_local const Intersection *g_bsdfIts = nullptr;
 
 static int modulo(int a, int b) { int r = a % b; return r < 0 ? r + b : r; }     // math::modulo
 
@@ -507,6 +508,13 @@ void Material::configure(const std::vector<Texture> &textures) {
                              makeTexture(m.specular_reflectance, m.specular_texture, textures, specular),
                              makeTexture(m.specular_transmittance, m.transmittance_texture, textures, transmittance) })
         if (err) throw std::runtime_error(err);
+    frameKind = m.frame_kind;
+    if (frameKind < 0 || frameKind > 2) throw std::runtime_error("unknown frame adapter");
+    if (frameKind) {
+        if (m.type == ORC_BSDF_MIXTURE) throw std::runtime_error("bumpmap / normalmap around a mixturebsdf is not supported");
+        if (m.frame_texture < 1 || (size_t) m.frame_texture > textures.size()) throw std::runtime_error("bumpmap / normalmap: texture index out of range");
+        frameTex = textures[m.frame_texture - 1];
+    }
     {   // m_usesRayDifferentials of the plugins' configure() (e.g. diffuse.cpp:101, roughplastic.cpp:301-304, dielectric.cpp:197-199)
         const bool d = diffuse.usesRayDifferentials(), sp = specular.usesRayDifferentials(), tr = transmittance.usesRayDifferentials();
         switch (m.type) {
@@ -579,6 +587,10 @@ void Material::configure(const std::vector<Texture> &textures) {
             break;
         }
     }
+    if (frameKind) {        // bumpmap.cpp:92-96, normalmap.cpp:64-68: every component becomes anisotropic, partials are wanted
+        if (type_flags) type_flags |= EAnisotropic;
+        usesRayDifferentials = true;
+    }
     own_flags = type_flags;
     back = nullptr;
 }
@@ -609,6 +621,7 @@ const char *linkMixtures(std::vector<Material> &materials) {
             (void) t;
             if (child.m.two_sided || child.m.type == ORC_BSDF_MIXTURE)
                 return "mixturebsdf: twosided and mixturebsdf cannot be nested";
+            if (child.frameKind) return "mixturebsdf: bumpmap and normalmap cannot be nested";
             mat.mixChildren.push_back(&child);
             mat.mixWeights.push_back(scale != 1.0f ? mat.m.mix_weight[i] * scale : mat.m.mix_weight[i]);
             mat.mixPdf.append(mat.mixWeights.back());
@@ -1081,9 +1094,13 @@ static float pdfDiscrete(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
     return 0.0f;
 }
 
+static Spectrum evalFramed(const Material &mat, const Vec3 &wi, const Vec3 &wo);
+static float pdfFramed(const Material &mat, const Vec3 &wi, const Vec3 &wo);
+static Spectrum sampleFramed(const Material &mat, const Vec3 &wi, const Vec2 &sample, BSDFSample &out, float &pdf, Sampler1D *sampler1D);
+
 // ---- MixtureBSDF::eval / pdf / sample (src/bsdfs/mixturebsdf.cpp:174-277), all components requested -------------
 static Spectrum evalPlain(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
-    if (mat.m.type != ORC_BSDF_MIXTURE) return evalOneSided(mat, wi, wo);
+    if (mat.m.type != ORC_BSDF_MIXTURE) return evalFramed(mat, wi, wo);
     Spectrum result(0.0f);
     for (size_t i = 0; i < mat.mixChildren.size(); ++i)
         result += evalOneSided(*mat.mixChildren[i], wi, wo) * mat.mixWeights[i];
@@ -1091,7 +1108,7 @@ static Spectrum evalPlain(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
 }
 
 static float pdfPlain(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
-    if (mat.m.type != ORC_BSDF_MIXTURE) return pdfOneSided(mat, wi, wo);
+    if (mat.m.type != ORC_BSDF_MIXTURE) return pdfFramed(mat, wi, wo);
     float result = 0.0f;
     for (size_t i = 0; i < mat.mixChildren.size(); ++i)
         result += pdfOneSided(*mat.mixChildren[i], wi, wo) * mat.mixPdf[i];
@@ -1099,7 +1116,7 @@ static float pdfPlain(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
 }
 
 static Spectrum samplePlain(const Material &mat, const Vec3 &wi, const Vec2 &sample_, BSDFSample &out, float &pdf, Sampler1D *sampler1D) {
-    if (mat.m.type != ORC_BSDF_MIXTURE) return sampleOneSided(mat, wi, sample_, out, pdf, sampler1D);
+    if (mat.m.type != ORC_BSDF_MIXTURE) return sampleFramed(mat, wi, sample_, out, pdf, sampler1D);
     Vec2 sample(sample_);
     const size_t entry = mat.mixPdf.sampleReuse(sample.x);
     Spectrum result = sampleOneSided(*mat.mixChildren[entry], wi, sample, out, pdf, sampler1D);
@@ -1114,6 +1131,74 @@ static Spectrum samplePlain(const Material &mat, const Vec3 &wi, const Vec2 &sam
         result += (discrete ? evalDiscrete(c, wi, out.wo) : evalOneSided(c, wi, out.wo)) * mat.mixWeights[i];
     }
     return result / pdf;
+}
+
+// ---- BumpMap / NormalMap (src/bsdfs/bumpmap.cpp:135-237, src/bsdfs/normalmap.cpp:107-260): the nested BSDF is asked in
+// a perturbed shading frame; directions that change sides between the two frames carry nothing ----------------
+static const Intersection &queryIntersection() {
+    if (g_bsdfIts) return *g_bsdfIts;
+    static thread_local Intersection canonical;
+    canonical.shFrame.s = Vec3(1, 0, 0); canonical.shFrame.t = Vec3(0, 1, 0); canonical.shFrame.n = Vec3(0, 0, 1);
+    canonical.geoFrame = canonical.shFrame;
+    canonical.dpdu = Vec3(1, 0, 0); canonical.dpdv = Vec3(0, 1, 0);
+    canonical.uv = g_textureUV;
+    return canonical;
+}
+
+static Frame perturbedFrame(const Material &mat, const Intersection &its) {
+    Frame result;
+    if (mat.frameKind == 1) {           // BumpMap::getFrame (bumpmap.cpp:135-159)
+        Spectrum grad[2];
+        mat.frameTex.evalGradient(its.uv, grad);
+        const float dDispDu = luminance(grad[0]), dDispDv = luminance(grad[1]);
+        const Vec3 dpdu = its.dpdu + its.shFrame.n * (dDispDu - dot(its.shFrame.n, its.dpdu));
+        const Vec3 dpdv = its.dpdv + its.shFrame.n * (dDispDv - dot(its.shFrame.n, its.dpdv));
+        result.n = normalize(cross(dpdu, dpdv));
+        result.s = normalize(dpdu - result.n * dot(result.n, dpdu));
+        result.t = cross(result.n, result.s);
+        if (dot(result.n, its.geoFrame.n) < 0) result.n *= -1;
+    } else {                            // NormalMap::getFrame (normalmap.cpp:107-124): an unfiltered lookup
+        const UVPartials saved = g_texturePartials;
+        g_texturePartials = UVPartials();
+        const Spectrum c = mat.frameTex.eval(its.uv);
+        g_texturePartials = saved;
+        const Vec3 n(2 * c.x - 1, 2 * c.y - 1, 2 * c.z - 1);
+        result.n = normalize(its.shFrame.toWorld(n));
+        result.s = normalize(its.dpdu - result.n * dot(result.n, its.dpdu));
+        result.t = cross(result.n, result.s);
+    }
+    return result;
+}
+
+static Spectrum evalFramed(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
+    if (!mat.frameKind) return evalOneSided(mat, wi, wo);
+    const Intersection &its = queryIntersection();
+    const Frame p = perturbedFrame(mat, its);
+    const Vec3 pwi = p.toLocal(its.shFrame.toWorld(wi)), pwo = p.toLocal(its.shFrame.toWorld(wo));
+    if (Frame::cosTheta(wo) * Frame::cosTheta(pwo) <= 0) return Spectrum(0.0f);
+    return evalOneSided(mat, pwi, pwo);
+}
+
+static float pdfFramed(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
+    if (!mat.frameKind) return pdfOneSided(mat, wi, wo);
+    const Intersection &its = queryIntersection();
+    const Frame p = perturbedFrame(mat, its);
+    const Vec3 pwi = p.toLocal(its.shFrame.toWorld(wi)), pwo = p.toLocal(its.shFrame.toWorld(wo));
+    if (Frame::cosTheta(wo) * Frame::cosTheta(pwo) <= 0) return 0.0f;
+    return pdfOneSided(mat, pwi, pwo);
+}
+
+static Spectrum sampleFramed(const Material &mat, const Vec3 &wi, const Vec2 &sample, BSDFSample &out, float &pdf, Sampler1D *sampler1D) {
+    if (!mat.frameKind) return sampleOneSided(mat, wi, sample, out, pdf, sampler1D);
+    const Intersection &its = queryIntersection();
+    const Frame p = perturbedFrame(mat, its);
+    Spectrum result = sampleOneSided(mat, p.toLocal(its.shFrame.toWorld(wi)), sample, out, pdf, sampler1D);
+    if (!result.isZero()) {
+        const Vec3 pwo = out.wo;
+        out.wo = its.shFrame.toLocal(p.toWorld(pwo));
+        if (Frame::cosTheta(out.wo) * Frame::cosTheta(pwo) <= 0) return Spectrum(0.0f);
+    }
+    return result;
 }
 
 // ---- the entry points the integrator calls: the BSDF itself, or the same through the twosided adapter

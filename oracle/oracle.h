@@ -50,6 +50,9 @@ typedef struct {
     float mix_weight[4];
     /* a <texture> in place of the constant colours above: 1-based index into orc_scene_desc.textures, 0 = none */
     int32_t diffuse_texture, specular_texture, transmittance_texture;
+    /* the record is the BSDF nested in a bumpmap (1, src/bsdfs/bumpmap.cpp) or normalmap (2, src/bsdfs/normalmap.cpp)
+       adapter with that displacement / normal texture (1-based) */
+    int32_t frame_kind, frame_texture;
 } orc_material;
 
 /* type 1: checkerboard (src/textures/checkerboard.cpp), 2: gridtexture (src/textures/gridtexture.cpp), 3: bitmap

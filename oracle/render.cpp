@@ -493,6 +493,7 @@ static Spectrum Li(const Scene &sc, const Ray &r, const RayDifferentials &rd0, P
         const orc_shape &shape = sc.shapes[its.shape];
         const Material &bsdf = sc.materials[shape.material];
         g_textureUV = its.uv;       // the intersection the BSDF queries of this vertex refer to
+        g_bsdfIts = &its;
         g_texturePartials = partialsFor(bsdf, its, ray, rd);        // its.getBSDF(ray) (path.cpp:145)
         rd.has = false;             // the rays that follow are plain Rays (path.cpp:222: ray = Ray(its.p, wo, ray.time))
 
@@ -618,6 +619,7 @@ static Spectrum LiDirect(const Scene &sc, const Ray &r, const RayDifferentials &
     const orc_shape &shape = sc.shapes[its.shape];
     const Material &bsdf = sc.materials[shape.material];
     g_textureUV = its.uv;
+    g_bsdfIts = &its;
     g_texturePartials = partialsFor(bsdf, its, ray, rd);    // its.getBSDF(ray) (direct.cpp:176)
     if (shape.emitter >= 0 && !ig.hide_emitters) {      // direct.cpp:166-167, AreaLight::eval (area.cpp:104-109)
         const orc_emitter &em = sc.emitters[shape.emitter];
@@ -841,6 +843,7 @@ extern "C" int orc_bsdf_eval(const orc_scene *s, int material, uint64_t n, const
     const Material &m = s->s.materials[material];
     g_textureUV = g_queryUV;
     g_texturePartials = UVPartials();
+    g_bsdfIts = nullptr;
     for (uint64_t i = 0; i < n; ++i) {
         Spectrum r = bsdfEval(m, Vec3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), Vec3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]));
         out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
@@ -853,6 +856,7 @@ extern "C" int orc_bsdf_pdf(const orc_scene *s, int material, uint64_t n, const 
     const Material &m = s->s.materials[material];
     g_textureUV = g_queryUV;
     g_texturePartials = UVPartials();
+    g_bsdfIts = nullptr;
     for (uint64_t i = 0; i < n; ++i)
         out[i] = bsdfPdf(m, Vec3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), Vec3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]));
     return 0;
@@ -864,6 +868,7 @@ extern "C" int orc_bsdf_sample(const orc_scene *s, int material, uint64_t n, con
     const Material &m = s->s.materials[material];
     g_textureUV = g_queryUV;
     g_texturePartials = UVPartials();
+    g_bsdfIts = nullptr;
     struct Fixed : Sampler1D { float v = 0.5f; float next1D() override { return v; } } fixed;
     for (uint64_t i = 0; i < n; ++i) {
         BSDFSample bs;

@@ -96,6 +96,9 @@ struct Material {
     DiscreteDistribution mixPdf;
     bool usesRayDifferentials = false;           // BSDF::usesRayDifferentials(): some texture of it filters its lookups
     bool twoSidedRayDifferentials = false;       // the same of the twosided adapter around it (either side's)
+    // BumpMap / NormalMap adapter around this BSDF (src/bsdfs/bumpmap.cpp, normalmap.cpp): 0 none, 1 bump, 2 normal
+    int frameKind = 0;
+    Texture frameTex;
     void configure(const std::vector<Texture> &textures);
 };
 
@@ -123,6 +126,10 @@ struct Intersection {
     Vec3 toLocal(const Vec3 &v_) const { return shFrame.toLocal(v_); }
     Vec3 toWorld(const Vec3 &v_) const { return shFrame.toWorld(v_); }
 };
+
+// bRec.its of the BSDF query in progress on this thread, for the adapters that perturb the shading frame; null = a
+// query without an intersection (the batch entry points): the local frame is then the canonical one
+extern thread_local const Intersection *g_bsdfIts;
 
 struct TraversalCounters { uint64_t steps = 0, tests = 0; };
 

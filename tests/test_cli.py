@@ -634,6 +634,14 @@ TEXTURED = """
     <bsdf type="twosided"><bsdf type="conductor"><string name="material" value="none"/>
       <texture type="bitmap" name="specularReflectance"><string name="filename" value="wood.png"/><string name="filterType" value="trilinear"/>
         <float name="gamma" value="1"/></texture></bsdf></bsdf></shape>
+  <shape type="serialized"><string name="filename" value="meshes.serialized"/><integer name="shapeIndex" value="1"/>
+    <transform name="toWorld"><translate y="2.2"/></transform>
+    <bsdf type="twosided"><bsdf type="bumpmap"><ref id="metal"/>
+      <texture type="scale"><float name="scale" value="0.05"/><texture type="bitmap"><string name="filename" value="wood.png"/>
+        <float name="gamma" value="1"/><string name="filterType" value="bilinear"/></texture></texture></bsdf></bsdf></shape>
+  <shape type="serialized"><string name="filename" value="meshes.serialized"/><integer name="shapeIndex" value="1"/>
+    <transform name="toWorld"><translate y="-2.2"/></transform>
+    <bsdf type="normalmap"><bsdf type="diffuse"/><ref id="wood"/></bsdf></shape>
 """
 
 
@@ -654,7 +662,9 @@ def test_cli_textures(scene_dir, tmp_path):
     f, img = _textured_scene(scene_dir, tmp_path)
     d = _describe(f)
     sd, _ = loader.load_xml(str(f))
-    assert len(d["textures"]) == len(sd.textures) == 5
+    assert len(d["textures"]) == len(sd.textures) == 7
+    assert d["frames"] == [[m["frame_kind"], m["frame_texture"]] for m in sd.materials]
+    assert sorted(f for f in d["frames"] if f[0]) == [[1, 7], [2, 2]]
     for a, b in zip(d["textures"], sd.textures):
         assert a["type"] == b["type"]
         assert np.allclose(a["uv"], [b["u_offset"], b["v_offset"], b["u_scale"], b["v_scale"]])
@@ -668,6 +678,7 @@ def test_cli_textures(scene_dir, tmp_path):
     assert d["material_textures"] == [[m["diffuse_texture"], m["specular_texture"], m["transmittance_texture"]] for m in sd.materials]
     used = sorted({i for row in d["material_textures"] for i in row if i})
     assert used == [1, 2, 4, 5]          # texture 3 is the grid inside the scale texture: only its scaled copy is used
+    assert sd.textures[6]["scale"] == np.float32(0.05) and sd.textures[6]["type"] == 3      # the bump map: texture 6 scaled
     wood, lin = sd.textures[1], sd.textures[4]
     assert (wood["wrap_u"], wood["wrap_v"], wood["filter_type"], wood["max_anisotropy"]) == (2, 1, 3, 8.0)
     assert np.array_equal(lin["pixels"], img.astype(np.float32) * np.float32(1 / 255.0)) and lin["filter_type"] == 2      # gamma 1: linear
@@ -675,7 +686,10 @@ def test_cli_textures(scene_dir, tmp_path):
     # what is not supported says so
     for body, msg in (('<bsdf type="diffuse"><texture type="wood" name="reflectance"/></bsdf>', "texture type 'wood'"),
                       ('<bsdf type="roughconductor"><string name="material" value="none"/><texture type="checkerboard" name="alpha"/></bsdf>', "parameter 'alpha'"),
-                      ('<bsdf type="diffuse"><texture type="bitmap" name="reflectance"><string name="filename" value="nope.png"/></texture></bsdf>', "nope.png")):
+                      ('<bsdf type="diffuse"><texture type="bitmap" name="reflectance"><string name="filename" value="nope.png"/></texture></bsdf>', "nope.png"),
+                      ('<bsdf type="bumpmap"><bsdf type="diffuse"/><texture type="bitmap"><string name="filename" value="wood.png"/></texture></bsdf>', "'gamma' parameter"),
+                      ('<bsdf type="bumpmap"><bsdf type="diffuse"/></bsdf>', "displacement texture must be specified"),
+                      ('<bsdf type="normalmap"><texture type="checkerboard"/></bsdf>', "child BSDF instance is required")):
         g = tmp_path / "bad.xml"
         g.write_text(SCENE % body)
         out = subprocess.run([CLI, str(g), "--describe"], capture_output=True, text=True, timeout=60)

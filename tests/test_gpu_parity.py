@@ -21,7 +21,8 @@ def _scenes():
             "lamps": S.small_test_scene(lamps=True), "lamps_only": S.small_test_scene(lamps=True, area_lights=False),
             "blend": S.small_test_scene(blend=True), "textured": S.small_test_scene(textured=True),
             "textured_blend": S.small_test_scene(textured=True, blend=True, sky=(0.3, 0.3, 0.4)),
-            "bitmap": S.small_test_scene(textured="bitmap"), "bitmap_blend": S.small_test_scene(textured="bitmap", blend=True, lamps=True)}
+            "bitmap": S.small_test_scene(textured="bitmap"), "bitmap_blend": S.small_test_scene(textured="bitmap", blend=True, lamps=True),
+            "bump": S.small_test_scene(textured="bitmap", bumps=True, sky=(0.3, 0.3, 0.4))}
 
 
 @pytest.fixture(scope="module")
@@ -307,8 +308,37 @@ def test_bitmap_texture_lookups(pairs):
     assert len(kinds) >= 6
 
 
+def test_bump_and_normal_mapped_bsdf_parity(pairs):
+    """BumpMap / NormalMap eval, pdf and sample (bumpmap.cpp:161-237, normalmap.cpp:167-260) around diffuse, rough
+    conductor, rough plastic and dielectric records, one of them two-sided, in the canonical frame of the batch queries
+    at several uv (bitmap gradient, forward differences of a procedural texture, normal image)."""
+    sd, g, o = pairs["bump"]
+    rng = np.random.default_rng(12)
+    n = 20000
+    framed = [i for i, m in enumerate(sd.materials) if m.get("frame_kind")]
+    assert len(framed) >= 5 and {sd.materials[i]["frame_kind"] for i in framed} == {1, 2}
+
+    def dirs():
+        d = rng.normal(size=(n, 3))
+        return (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    for mi in framed:
+        for u, v in ((0.3, 0.7), (0.52, 0.11), (1.7, -0.4)):
+            g.bsdf_query_uv(u, v)
+            o.bsdf_query_uv(u, v)
+            wi, wo, smp = dirs(), dirs(), rng.random((n, 2)).astype(np.float32)
+            assert np.mean(np.isclose(g.bsdf_eval(mi, wi, wo), o.bsdf_eval(mi, wi, wo), rtol=1e-4, atol=1e-6).all(-1)) > 0.9995
+            assert np.mean(np.isclose(g.bsdf_pdf(mi, wi, wo), o.bsdf_pdf(mi, wi, wo), rtol=1e-4, atol=1e-6)) > 0.9995
+            wg, kg, pg, eg, tg = g.bsdf_sample(mi, wi, smp)
+            wo_, ko, po_, eo, to = o.bsdf_sample(mi, wi, smp)
+            same = (tg == to) & np.isclose(pg, po_, rtol=1e-3, atol=1e-6) & np.isclose(kg, ko, rtol=1e-3, atol=1e-5).all(-1) & \
+                np.isclose(wg, wo_, rtol=0, atol=1e-4).all(-1)
+            assert same.mean() > 0.998, (mi, same.mean())
+    g.bsdf_query_uv(0.0, 0.0)
+    o.bsdf_query_uv(0.0, 0.0)
+
+
 @pytest.mark.parametrize("name", ["small", "cornell", "veach", "mixed", "sky", "sky_hidden", "lamps", "lamps_only", "blend", "textured",
-                                  "textured_blend", "bitmap", "bitmap_blend"])
+                                  "textured_blend", "bitmap", "bitmap_blend", "bump"])
 def test_per_sample_radiance_parity(pairs, name):
     """MIPathTracer::Li per camera sample with the shared sample stream: same ray counts, same radiance."""
     sd, g, o = pairs[name]
@@ -316,14 +346,19 @@ def test_per_sample_radiance_parity(pairs, name):
     Lg, pg, sg = g.li(4, rect=rect, seed=3)
     Lo, pos, so = o.li(4, rect=rect, seed=3)
     assert np.array_equal(pg, pos)
-    assert sg.normal_rays == so.normal_rays and sg.shadow_rays == so.shadow_rays
+    if name == "bump":
+        # the perturbed frames add normalisations and products whose last bits can differ between the two sides, and a
+        # path whose sampled direction differs in the last bit may find another triangle: a few paths in ten thousand
+        assert abs(int(sg.normal_rays) - int(so.normal_rays)) <= 3 and abs(int(sg.shadow_rays) - int(so.shadow_rays)) <= 3
+    else:
+        assert sg.normal_rays == so.normal_rays and sg.shadow_rays == so.shadow_rays
     assert np.array_equal(Lg[..., 3], Lo[..., 3])
     rel = np.abs(Lg[..., :3] - Lo[..., :3]).max(-1) / (np.abs(Lo[..., :3]).max(-1) + 1e-3)
     assert np.mean(rel < 1e-3) > 0.995
     assert abs(Lg[..., :3].mean() - Lo[..., :3].mean()) < 2e-3 * Lo[..., :3].mean() + 1e-6
 
 
-@pytest.mark.parametrize("name", ["small", "mixed", "sky", "lamps", "blend", "textured_blend", "bitmap_blend"])
+@pytest.mark.parametrize("name", ["small", "mixed", "sky", "lamps", "blend", "textured_blend", "bitmap_blend", "bump"])
 def test_pass_finishing_kernel_matches_wavefront_loop(gpu, name, monkeypatch):
     """Below MTSAMD_TAIL_BELOW live paths one launch follows each path to its end; above, every bounce is an extend /
     shade / shadow round of launches. Both run the same shading and traversal code: identical radiance and ray counts."""
@@ -347,13 +382,14 @@ def test_direct_integrator_parity(gpu, oracle_mod, ne, nb):
     lights, an environment, lamps, mixtures and a frosted dielectric."""
     for sd in (S.small_test_scene(sky=(0.6, 0.8, 1.2), lamps=True, blend=True), S.cornell_mixed(64, 64),
                S.small_test_scene(hide_emitters=1, sky=(0.2, 0.2, 0.3)), S.small_test_scene(textured=True, blend=True),
-               S.small_test_scene(textured="bitmap")):
+               S.small_test_scene(textured="bitmap"), S.small_test_scene(textured="bitmap", bumps=True)):
         sd.integrator.update(type="direct", emitter_samples=ne, bsdf_samples=nb)
         g, o = gpu.Scene(sd), oracle_mod.OracleScene(sd)
         Lg, pg, sg = g.li(4, seed=7)
         Lo, po_, so = o.li(4, seed=7)
         assert np.array_equal(pg, po_)
-        assert (sg.normal_rays, sg.shadow_rays) == (so.normal_rays, so.shadow_rays)
+        slack = 3 if any(m.get("frame_kind") for m in sd.materials) else 0      # see test_per_sample_radiance_parity
+        assert abs(int(sg.normal_rays) - int(so.normal_rays)) <= slack and abs(int(sg.shadow_rays) - int(so.shadow_rays)) <= slack
         assert np.array_equal(Lg[..., 3], Lo[..., 3])
         rel = np.abs(Lg[..., :3] - Lo[..., :3]).max(-1) / (np.abs(Lo[..., :3]).max(-1) + 1e-3)
         assert np.mean(rel < 1e-3) > 0.995
@@ -402,12 +438,13 @@ def test_film_put_parity(pairs):
     assert np.allclose(fg, fo, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["small", "cornell", "mixed", "sky", "lamps", "blend", "textured", "bitmap"])
+@pytest.mark.parametrize("name", ["small", "cornell", "mixed", "sky", "lamps", "blend", "textured", "bitmap", "bump"])
 def test_render_film_parity(pairs, name):
     sd, g, o = pairs[name]
     fg, sg = g.render(4, seed=9)
     fo, so = o.render(4, seed=9)
-    assert (sg.normal_rays, sg.shadow_rays) == (so.normal_rays, so.shadow_rays)
+    slack = 3 if name == "bump" else 0      # see test_per_sample_radiance_parity
+    assert abs(int(sg.normal_rays) - int(so.normal_rays)) <= slack and abs(int(sg.shadow_rays) - int(so.shadow_rays)) <= slack
     assert np.allclose(fg[..., 4], fo[..., 4], rtol=1e-5, atol=1e-6)
     dg, do = g.develop(fg), o.develop(fo)
     rel_mse = np.mean((dg[..., :3] - do[..., :3]) ** 2 / (do[..., :3] ** 2 + 1e-2))

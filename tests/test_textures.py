@@ -316,3 +316,63 @@ def test_image_load_pfm_and_openexr(tmp_path):
     if os.path.exists(ref):
         with pytest.raises(capi.MtsamdError, match="compression"):
             capi.image_load(ref)
+
+
+def test_bump_and_normal_map_frames(oracle_mod):
+    """BumpMap::getFrame (bumpmap.cpp:135-159) and NormalMap::getFrame (normalmap.cpp:107-124) through a diffuse BSDF,
+    whose value is albedo / pi times the cosine to the perturbed normal. The batch queries have no intersection: they
+    use the canonical frame (dpdu = x, dpdv = y, n = z), so a height a * u tilts the normal to (-a, 0, 1) / sqrt(1 + a^2)."""
+    w = 33
+    ramp = np.tile(np.linspace(0.0, 1.0, w, dtype=np.float32)[None, :], (4, 1))
+    sd = S.cornell_box(16, 16)
+    slope = 0.5 * (w / (w - 1.0))          # one unit of u spans w texels, the ramp rises by 1 / (w - 1) per texel; times the scale
+    sd.textures = [S.bitmap(ramp, "bilinear", wrap_mode="clamp", scale=0.5),
+                   S.bitmap(np.full((4, 4, 3), 0.5, np.float32) * [1, 1, 2], "nearest"),          # (0.5, 0.5, 1): the unperturbed normal
+                   S.bitmap(np.full((4, 4, 3), 1.0, np.float32) * [0.75, 0.5, 1.0], "bilinear"),  # n = (0.5, 0, 1) normalised (exact in half)
+                   S.checkerboard((0.3, 0.3, 0.3), (0.3, 0.3, 0.3))]                             # a flat displacement
+    base = S.diffuse((0.6, 0.4, 0.2))
+    sd.materials = list(sd.materials) + [S.bumpmap(base, 1), S.normalmap(base, 2), S.normalmap(base, 3), S.bumpmap(base, 4), base,
+                                         S.twosided(S.bumpmap(base, 1))]
+    k = len(sd.materials) - 6
+    o = oracle_mod.OracleScene(sd)
+    rng = np.random.default_rng(8)
+    n = 4000
+    wo = rng.normal(size=(n, 3)).astype(np.float32)
+    wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    wi = np.tile(np.float32([0.1, 0.2, 0.97]), (n, 1))
+    wi /= np.linalg.norm(wi[0])
+    o.bsdf_query_uv(0.4, 0.5)
+    albedo = np.float32([0.6, 0.4, 0.2])
+
+    def lambert(normal):
+        normal = np.float32(normal) / np.linalg.norm(normal)
+        c = wo @ normal
+        ok = (c > 0) & (wi[0] @ normal > 0) & (wo[:, 2] * c > 0)      # same side in both frames (bumpmap.cpp:169-170)
+        return np.where(ok[:, None], albedo[None, :] / np.pi * c[:, None], 0)
+
+    assert np.allclose(o.bsdf_eval(k, wi, wo), lambert([-slope, 0, 1]), atol=2e-5)
+    assert np.allclose(o.bsdf_eval(k + 1, wi, wo), o.bsdf_eval(k + 4, wi, wo), atol=1e-6)       # (0.5, 0.5, 1) changes nothing
+    assert np.allclose(o.bsdf_eval(k + 2, wi, wo), lambert([0.5, 0.0, 1.0]), atol=2e-5)
+    assert np.allclose(o.bsdf_eval(k + 3, wi, wo), o.bsdf_eval(k + 4, wi, wo), atol=1e-6)       # zero gradient changes nothing
+    # pdf and sample agree with eval in the perturbed frame: weight = eval / pdf = albedo, directions on the tilted hemisphere
+    pdf = o.bsdf_pdf(k, wi, wo)
+    normal = np.float32([-slope, 0, 1]) / np.linalg.norm([-slope, 0, 1])
+    assert np.allclose(pdf, np.where(lambert(normal)[:, 0] > 0, (wo @ normal) / np.pi, 0), atol=2e-5)
+    swo, weight, spdf, eta, typ = o.bsdf_sample(k, wi, rng.random((n, 2)).astype(np.float32))
+    live = weight[:, 0] > 0
+    assert live.mean() > 0.7 and np.allclose(weight[live], albedo, atol=1e-5)
+    assert ((swo[live] @ normal) > 0).all() and (swo[live][:, 2] > 0).all()
+    assert np.allclose(np.linalg.norm(swo[live], axis=1), 1, atol=1e-5)
+    # seen from behind through twosided: the mirrored query of the bumped BRDF (twosided.cpp:108-183)
+    back_wi, back_wo = wi * [1, 1, -1], wo * [1, 1, -1]
+    assert np.allclose(o.bsdf_eval(k + 5, back_wi.astype(np.float32), back_wo.astype(np.float32)), o.bsdf_eval(k, wi, wo), atol=1e-6)
+    # adapters cannot sit inside a mixture, and need a texture
+    bad = S.cornell_box(16, 16)
+    bad.textures = sd.textures
+    bad.materials = list(bad.materials) + [S.bumpmap(base, 1)]
+    bad.materials.append(S.mixture([len(bad.materials) - 1], [1.0]))
+    with pytest.raises(RuntimeError, match="cannot be nested"):
+        oracle_mod.OracleScene(bad)
+    bad.materials = list(bad.materials)[:-2] + [S.bumpmap(base, 9)]
+    with pytest.raises(RuntimeError, match="out of range"):
+        oracle_mod.OracleScene(bad)
