@@ -135,7 +135,8 @@ typedef struct {
    (src/emitters/point.cpp, `radiance` = intensity), MTSAMD_EMITTER_SPOT (src/emitters/spot.cpp, `radiance` = intensity,
    constant texture) and MTSAMD_EMITTER_DIRECTIONAL (src/emitters/directional.cpp, `radiance` = irradiance); they take
    their position and direction (+z) from to_world, and `shape` is ignored. */
-enum { MTSAMD_EMITTER_SURFACE = 0, MTSAMD_EMITTER_POINT = 1, MTSAMD_EMITTER_SPOT = 2, MTSAMD_EMITTER_DIRECTIONAL = 3 };
+enum { MTSAMD_EMITTER_SURFACE = 0, MTSAMD_EMITTER_POINT = 1, MTSAMD_EMITTER_SPOT = 2, MTSAMD_EMITTER_DIRECTIONAL = 3,
+       MTSAMD_EMITTER_ENVMAP = 4 };
 typedef struct {
     int32_t shape;
     float radiance[3];
@@ -144,6 +145,15 @@ typedef struct {
     float to_world[16];         /* row-major emitter-to-world (Emitter::getWorldTransform) */
     float cutoff_angle;         /* spot: degrees (spot.cpp:70) */
     float beam_width;           /* spot: degrees (spot.cpp:71) */
+    /* MTSAMD_EMITTER_ENVMAP (src/emitters/envmap.cpp): the environment emitter as a latitude-longitude image, width * height
+       * 3 linear floats (see mtsamd_image_load; a luminance image is replicated by the caller), first row = +y of the
+       emitter's frame (to_world), radiance multiplied by `scale` (default 1). Sampled by luminance * sin(theta) with
+       bilinear interpolation (envmap.cpp:567-633); rays that leave the scene look it up bilinearly, camera rays through the
+       elliptical filter of its MIP map (envmap.cpp:380-410). `shape` is -1, `radiance` is ignored. At most one
+       environment emitter (this or the constant one) per scene. */
+    const float *pixels;
+    int32_t width, height;
+    float scale;
 } mtsamd_emitter;
 
 /* PerspectiveCamera (src/sensors/perspective.cpp) */
@@ -253,7 +263,7 @@ const char *mtsamd_last_error(void);
    are never reordered). A caller compiled against another version must not pass them in: compare MTSAMD_ABI_VERSION with
    mtsamd_abi_version(), and where records are mirrored by hand (FFI bindings) their sizes with mtsamd_sizeof(). No
    counterpart in the reference, whose plugins are compiled against its own headers. */
-#define MTSAMD_ABI_VERSION 11
+#define MTSAMD_ABI_VERSION 12
 enum { MTSAMD_SIZEOF_SCENE_DESC = 0, MTSAMD_SIZEOF_MATERIAL = 1, MTSAMD_SIZEOF_EMITTER = 2, MTSAMD_SIZEOF_SHAPE = 3,
        MTSAMD_SIZEOF_RENDER_OPTS = 4, MTSAMD_SIZEOF_STATS = 5, MTSAMD_SIZEOF_LDR_OPTS = 6, MTSAMD_SIZEOF_TEXTURE = 7 };
 int mtsamd_abi_version(void);
@@ -354,6 +364,13 @@ int mtsamd_bsdf_sample(mtsamd_scene *scene, int material, uint64_t n, const floa
    partials, Texture2D::eval -> eval(uv, d0, d1), texture.cpp:112-121) or NULL (no partials: the full-resolution lookup)
    -> out n*3 */
 int mtsamd_texture_eval(mtsamd_scene *scene, int texture, uint64_t n, const float *uv, const float *duv, float *out);
+
+/* The environment emitter for n world-space directions d (n*3): Scene::evalEnvironment for a ray without offset rays
+   (value n*3; src/emitters/constant.cpp, src/emitters/envmap.cpp:380-410) and Emitter::pdfDirect in the solid-angle
+   measure times the probability of picking the emitter (pdf n; for the constant emitter relative to the reference
+   normals ref_n n*3, a zero normal standing for none; constant.cpp:218-233, envmap.cpp:545-551, :603-633).
+   MTSAMD_EINVAL without an environment emitter. */
+int mtsamd_env_eval(mtsamd_scene *scene, uint64_t n, const float *d, const float *ref_n, float *value, float *pdf);
 
 /* Scene::sampleEmitterDirect without the visibility test (src/librender/scene.cpp:828-852):
    ref n*3, ref_n n*3 (DirectSamplingRecord::refN), sample n*2 -> d n*3, dist n, pdf n, value n*3 */

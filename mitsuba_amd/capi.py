@@ -43,7 +43,8 @@ class Texture(C.Structure):
 
 class Emitter(C.Structure):
     _fields_ = [("shape", C.c_int32), ("radiance", C.c_float * 3), ("sampling_weight", C.c_float), ("type", C.c_int32),
-                ("to_world", C.c_float * 16), ("cutoff_angle", C.c_float), ("beam_width", C.c_float)]
+                ("to_world", C.c_float * 16), ("cutoff_angle", C.c_float), ("beam_width", C.c_float),
+                ("pixels", _f32p), ("width", C.c_int32), ("height", C.c_int32), ("scale", C.c_float)]
 
 
 class LdrOpts(C.Structure):
@@ -109,10 +110,10 @@ EXPORTS = ["mtsamd_last_error", "mtsamd_init", "mtsamd_scene_create", "mtsamd_sc
            "mtsamd_sample_emitter_direct", "mtsamd_camera_rays", "mtsamd_li", "mtsamd_film_put", "mtsamd_film_develop_ldr", "mtsamd_abi_version", "mtsamd_sizeof", "mtsamd_filter_table", "mtsamd_rng_stream",
            "mtsamd_rtrans_reduce", "mtsamd_filter_gaussian", "mtsamd_filter_box", "mtsamd_bvh_host_info", "mtsamd_bvh_max_depth",
            "mtsamd_trace_device_static", "mtsamd_trace_device_static_max", "mtsamd_render_multi", "mtsamd_spd_to_rgb",
-           "mtsamd_spd_file_to_rgb", "mtsamd_bsdf_query_uv", "mtsamd_texture_eval", "mtsamd_image_load", "mtsamd_image_free"]
+           "mtsamd_spd_file_to_rgb", "mtsamd_bsdf_query_uv", "mtsamd_texture_eval", "mtsamd_image_load", "mtsamd_image_free", "mtsamd_env_eval"]
 
 _lib = None
-ABI_VERSION = 11    # MTSAMD_ABI_VERSION of include/mtsamd.h
+ABI_VERSION = 12    # MTSAMD_ABI_VERSION of include/mtsamd.h
 
 
 class MtsamdError(RuntimeError):
@@ -210,6 +211,10 @@ def fill_desc(sd):
         ems[i].type = e.get("type", 0)
         ems[i].to_world = (C.c_float * 16)(*np.asarray(e.get("to_world", np.eye(4)), np.float32).reshape(-1))
         ems[i].cutoff_angle, ems[i].beam_width = e.get("cutoff_angle", 20.0), e.get("beam_width", 15.0)
+        if e.get("pixels") is not None:     # environment map: height x width x 3 linear floats
+            px = np.ascontiguousarray(e["pixels"], np.float32)
+            keep.append(px)
+            ems[i].pixels, ems[i].height, ems[i].width, ems[i].scale = px.ctypes.data_as(_f32p), px.shape[0], px.shape[1], e.get("scale", 1.0)
     keep += [shapes, mats, ems]
     d.n_shapes, d.n_materials, d.n_emitters = len(sd.shapes), len(sd.materials), len(sd.emitters)
     d.shapes, d.materials, d.emitters = shapes, mats, ems
@@ -366,6 +371,14 @@ class Scene:
     def bsdf_query_uv(self, u, v):
         """Where on the surface bsdf_eval / bsdf_pdf / bsdf_sample evaluate a material's textures."""
         _check(self.L.mtsamd_bsdf_query_uv(self.h, C.c_float(u), C.c_float(v)))
+
+    def env_eval(self, d, ref_n=None):
+        """The environment emitter along directions d (n x 3): (radiance n x 3, emitter-sampling density n)."""
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        rn = np.zeros_like(d) if ref_n is None else np.ascontiguousarray(ref_n, np.float32).reshape(-1, 3)
+        value, pdf = np.zeros_like(d), np.zeros(d.shape[0], np.float32)
+        _check(self.L.mtsamd_env_eval(self.h, C.c_uint64(d.shape[0]), _fp(d), _fp(rn), _fp(value), _fp(pdf)))
+        return value, pdf
 
     def texture_eval(self, texture, uv, duv=None):
         """Texture `texture` (1-based) of the scene at uv (n x 2); duv (n x 4: dudx, dvdx, dudy, dvdy) makes it a filtered lookup."""

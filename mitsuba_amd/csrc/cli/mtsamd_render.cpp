@@ -69,6 +69,19 @@ static void describe(const LoadedScene &s) {
     printf("], \"material_textures\": [");
     for (size_t i = 0; i < s.materials.size(); ++i)
         printf("%s[%d, %d, %d]", i ? ", " : "", s.materials[i].diffuse_texture, s.materials[i].specular_texture, s.materials[i].transmittance_texture);
+    printf("], \"envmaps\": [");
+    bool firstEnv = true;
+    for (size_t i = 0; i < s.emitters.size(); ++i) {
+        const mtsamd_emitter &e = s.emitters[i];
+        if (e.type != MTSAMD_EMITTER_ENVMAP) continue;
+        double sum = 0;
+        for (float v : s.emitterPixels[i]) sum += v;
+        printf("%s{\"emitter\": %zu, \"size\": [%d, %d], \"scale\": %.9g, \"weight\": %.9g, \"sum_pixels\": %.9g, \"to_world\": [", firstEnv ? "" : ", ", i,
+               e.width, e.height, e.scale, e.sampling_weight, sum);
+        for (int k = 0; k < 16; ++k) printf("%s%.9g", k ? ", " : "", e.to_world[k]);
+        printf("]}");
+        firstEnv = false;
+    }
     printf("], \"frames\": [");
     for (size_t i = 0; i < s.materials.size(); ++i) printf("%s[%d, %d]", i ? ", " : "", s.materials[i].frame_kind, s.materials[i].frame_texture);
     printf("], \"textures\": [");

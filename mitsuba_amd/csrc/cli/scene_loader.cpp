@@ -777,6 +777,8 @@ mtsamd_scene_desc LoadedScene::desc() const {
     for (size_t i = 0; i < textures.size(); ++i)
         self->textures[i].pixels = texturePixels[i].empty() ? nullptr : texturePixels[i].data();
     d.n_textures = (uint32_t) textures.size(); d.textures = textures.empty() ? nullptr : textures.data();
+    for (size_t i = 0; i < emitters.size() && i < emitterPixels.size(); ++i)
+        if (!emitterPixels[i].empty()) self->emitters[i].pixels = emitterPixels[i].data();
     d.shapes = shapes.data(); d.materials = materials.data(); d.emitters = emitters.empty() ? nullptr : emitters.data();
     d.camera = camera; d.film = film; d.integrator = integrator;
     return d;
@@ -1487,6 +1489,22 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
                 Mat4 toWorld = ep.count("toWorld") ? ep.at("toWorld").t : Mat4::identity();
                 if (etype == "constant") {          // src/emitters/constant.cpp:47-50
                     getRgb(ep, "radiance", 1, 1, 1, e.radiance);
+                } else if (etype == "envmap") {     // src/emitters/envmap.cpp:105-189
+                    e.type = MTSAMD_EMITTER_ENVMAP;
+                    if (!ep.count("filename")) return "envmap: the 'filename' parameter is missing";
+                    if (ep.count("intensityScale")) return "The 'intensityScale' parameter has been deprecated and is now called scale.";
+                    std::string file = getS(ep, "filename", "");
+                    if (!file.empty() && file[0] != '/') file = out.sceneDir + "/" + file;
+                    mtsamd_image img;
+                    if (mtsamd_image_load(file.c_str(), (float) getF(ep, "gamma", 0.0), &img) != MTSAMD_OK) return mtsamd_last_error();
+                    std::vector<float> px((size_t) img.width * img.height * 3);
+                    for (size_t k = 0; k < (size_t) img.width * img.height; ++k)
+                        for (int c = 0; c < 3; ++c) px[3 * k + c] = img.pixels[k * img.channels + (img.channels == 3 ? c : 0)];
+                    e.width = img.width; e.height = img.height;
+                    e.scale = (float) getF(ep, "scale", 1.0);
+                    mtsamd_image_free(&img);
+                    out.emitterPixels.resize(out.emitters.size() + 1);
+                    out.emitterPixels.back() = std::move(px);
                 } else if (etype == "point") {      // src/emitters/point.cpp:58-69
                     e.type = MTSAMD_EMITTER_POINT;
                     getRgb(ep, "intensity", 1, 1, 1, e.radiance);
@@ -1526,7 +1544,7 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
                         toWorld = lookAt({ 0, 0, 0 }, { a[0], a[1], a[2] }, { u[0], u[1], u[2] });
                     }
                 } else {
-                    return "emitter type '" + etype + "' is not supported (area, constant, point, spot, directional)";
+                    return "emitter type '" + etype + "' is not supported (area, constant, envmap, point, spot, directional)";
                 }
                 for (int i = 0; i < 16; ++i) e.to_world[i] = (float) toWorld.m[i];
                 out.emitters.push_back(e);

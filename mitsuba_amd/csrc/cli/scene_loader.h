@@ -29,6 +29,7 @@ struct LoadedScene {
     std::vector<mtsamd_material> materials;
     std::vector<std::vector<float>> rtransTables;   // storage behind mtsamd_material::rtrans
     std::vector<mtsamd_emitter> emitters;
+    std::vector<std::vector<float>> emitterPixels;  // storage behind mtsamd_emitter::pixels (environment maps), indexed like `emitters`
     std::vector<mtsamd_texture> textures;           // what the materials' *_texture fields index (1-based)
     std::vector<std::vector<float>> texturePixels;  // storage behind mtsamd_texture::pixels, one entry per texture (empty if not a bitmap)
     std::map<std::string, uint32_t> namedTextures;  // <texture id="..."> declared at the top level of the scene

@@ -1161,10 +1161,18 @@ MTS_DEV bool environmentExit(const DevScene &sc, V3 ro, V3 rd, float &farT) {
     return x0 < 0 && x1 > 0;
 }
 
+__device__ __attribute__((noinline)) inline float4 envSampleDirect(const DevScene *scp, V3 ref, float sx, float sy, float emPdf, float4 *dOut);
+
 // ConstantBackgroundEmitter::sampleDirect (src/emitters/constant.cpp:178-216) inside Scene::sampleEmitterDirect
 // (src/librender/scene.cpp:828-852): a sample on the back side of the reference normal keeps its pdf (so its
 // shadow ray is still traced and counted) but carries no radiance.
 MTS_DEV V3 sampleEnvironmentDirect(const DevScene &sc, V3 ref, V3 refN, float sx, float sy, float emPdf, DirectRec &dRec) {
+    if (sc.envIsMap) {
+        float4 dd;
+        const float4 r = envSampleDirect(&sc, ref, sx, sy, emPdf, &dd);
+        dRec.d = mk(dd.x, dd.y, dd.z); dRec.dist = dd.w; dRec.pdf = r.w;
+        return mk(r.x, r.y, r.z);
+    }
     V3 d;
     float pdf;
     const bool haveN = !isZero(refN);
@@ -1192,6 +1200,115 @@ MTS_DEV V3 sampleEnvironmentDirect(const DevScene &sc, V3 ref, V3 refN, float sx
 MTS_DEV float environmentPdfDirect(const DevScene &sc, float refCos) {
     const float pdfSA = refCos > -1.5f ? kInvPi * fmaxf(0.0f, refCos) : 0.07957747154594766788f;
     return pdfSA * sc.envPdfDiscrete;
+}
+
+// ---- EnvironmentMap (src/emitters/envmap.cpp) ------------------------------------------------------------------------
+MTS_DEV V3 envToWorld(const DevScene &sc, V3 v) {
+    const float *T = sc.envToWorld;
+    return mk(T[0] * v.x + T[1] * v.y + T[2] * v.z, T[3] * v.x + T[4] * v.y + T[5] * v.z, T[6] * v.x + T[7] * v.y + T[8] * v.z);
+}
+MTS_DEV V3 envToLocal(const DevScene &sc, V3 v) {
+    const float *T = sc.envToLocal;
+    return mk(T[0] * v.x + T[1] * v.y + T[2] * v.z, T[3] * v.x + T[4] * v.y + T[5] * v.z, T[6] * v.x + T[7] * v.y + T[8] * v.z);
+}
+MTS_DEV MipRef envMipRef(const DevScene &sc) {
+    MipRef m;
+    m.sc = &sc; m.first = sc.envFirstLevel; m.levels = sc.envLevels; m.bcu = 1u; m.bcv = 0u; m.maxAnisotropy = 10.0f;    // repeat / clamp (envmap.cpp:141-146)
+    return m;
+}
+MTS_DEV float intervalToTent(float sample) {        // src/libcore/warp.cpp:151-163
+    float sign;
+    if (sample < 0.5f) { sign = 1; sample *= 2; }
+    else { sign = -1; sample = 2 * (sample - 0.5f); }
+    return sign * (1 - sqrtf(sample));
+}
+// EnvironmentMap::sampleReuse (envmap.cpp:657-662): lower_bound over cdf[0 .. size]
+MTS_DEV uint32_t envSampleReuse(const float *cdf, uint32_t size, float &sample) {
+    uint32_t lo = 0, count = size + 1;
+    while (count > 0) {
+        const uint32_t step = count / 2;
+        if (cdf[lo + step] < sample) { lo += step + 1; count -= step + 1; }
+        else count = step;
+    }
+    const uint32_t index = min((uint32_t) max((int) lo - 1, 0), size - 1);
+    sample = (sample - cdf[index]) / (cdf[index + 1] - cdf[index]);
+    return index;
+}
+// the two rows of the bilinear interpolation around a fractional pixel position (envmap.cpp:577-591, :618-632)
+MTS_DEV void envRows(const DevScene &sc, int xPos, int yPos, float dx1, float dy1, V3 &value1, V3 &value2) {
+    const MipRef m = envMipRef(sc);
+    const float dx2 = 1.0f - dx1, dy2 = 1.0f - dy1;
+    value1 = mipTexel(m, 0, xPos, yPos) * dx2 * dy2 + mipTexel(m, 0, xPos + 1, yPos) * dx1 * dy2;
+    value2 = mipTexel(m, 0, xPos, yPos + 1) * dx2 * dy1 + mipTexel(m, 0, xPos + 1, yPos + 1) * dx1 * dy1;
+}
+MTS_DEV float envRowPdf(const DevScene &sc, V3 value1, V3 value2, int yPos) {
+    const int h = (int) sc.envH;
+    return (luminance(value1) * sc.envRowWeights[min(h - 1, max(0, yPos))] + luminance(value2) * sc.envRowWeights[min(h - 1, max(0, yPos + 1))]) * sc.envNormalization;
+}
+// EnvironmentMap::internalPdfDirection (envmap.cpp:603-633), d in the emitter's frame
+__device__ __attribute__((noinline)) inline float envPdfDirection(const DevScene *scp, float dx, float dy, float dz) {
+    const DevScene &sc = *scp;
+    const float uu = atan2M(dx, -dz) * 0.15915494309189533577f, vv = acosM(fminf(1.0f, fmaxf(-1.0f, dy))) * kInvPi;
+    if (!isfinite(uu) || !isfinite(vv)) return 0.0f;
+    const float u = uu * (float) sc.envW - 0.5f, v = vv * (float) sc.envH - 0.5f;
+    const int xPos = (int) floorf(u), yPos = (int) floorf(v);
+    V3 value1, value2;
+    envRows(sc, xPos, yPos, u - (float) xPos, v - (float) yPos, value1, value2);
+    const float sinTheta = safeSqrt(1 - dy * dy);
+    return envRowPdf(sc, value1, value2, yPos) / fmaxf(fabsf(sinTheta), kEpsilon);
+}
+// EnvironmentMap::evalEnvironment (envmap.cpp:380-410) for a world-space direction; with offset rays (a camera ray) the
+// lookup is filtered
+__device__ __attribute__((noinline)) inline float4 envEvalMap(const DevScene *scp, V3 rayD, bool filtered, V3 rxD, V3 ryD) {
+    const DevScene &sc = *scp;
+    const V3 v = envToLocal(sc, rayD);
+    const float uu = atan2M(v.x, -v.z) * 0.15915494309189533577f, vv = acosM(fminf(1.0f, fmaxf(-1.0f, v.y))) * kInvPi;
+    const MipRef m = envMipRef(sc);
+    V3 value;
+    if (!filtered) value = mipBilinear(m, 0, uu, vv);
+    else {
+        const V3 dvdx = envToLocal(sc, rxD) - v, dvdy = envToLocal(sc, ryD) - v;
+        const float t1 = 0.15915494309189533577f / (v.x * v.x + v.z * v.z), t2 = -kInvPi / fmaxf(safeSqrt(1.0f - v.y * v.y), kEpsilon);
+        value = mipFiltered(m, 3u, uu, vv, t1 * (dvdx.z * v.x - dvdx.x * v.z), t2 * dvdx.y, t1 * (dvdy.z * v.x - dvdy.x * v.z), t2 * dvdy.y);
+    }
+    value = value * sc.envScale;
+    return make_float4(value.x, value.y, value.z, 0.0f);
+}
+// EnvironmentMap::sampleDirect (envmap.cpp:516-543, internalSampleDirection :567-600) inside Scene::sampleEmitterDirect
+__device__ __attribute__((noinline)) inline float4 envSampleDirect(const DevScene *scp, V3 ref, float sx, float sy, float emPdf, float4 *dOut /* d.xyz, dist */) {
+    const DevScene &sc = *scp;
+    const uint32_t row = envSampleReuse(sc.envCdfRows, sc.envH, sy), col = envSampleReuse(sc.envCdfCols + (size_t) row * (sc.envW + 1), sc.envW, sx);
+    const float px = (float) col + intervalToTent(sx), py = (float) row + intervalToTent(sy);
+    const int xPos = (int) floorf(px), yPos = (int) floorf(py);
+    V3 value1, value2;
+    envRows(sc, xPos, yPos, px - (float) xPos, py - (float) yPos, value1, value2);
+    const V3 value = (value1 + value2) * sc.envScale;
+    float pdf = envRowPdf(sc, value1, value2, yPos);
+    float sinPhi, cosPhi, sinTheta, cosTheta;
+    sincosM(sc.envPixelX * (px + 0.5f), &sinPhi, &cosPhi);
+    sincosM(sc.envPixelY * (py + 0.5f), &sinTheta, &cosTheta);
+    pdf /= fmaxf(fabsf(sinTheta), kEpsilon);
+    const V3 d = envToWorld(sc, mk(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta));
+    *dOut = make_float4(d.x, d.y, d.z, 0.0f);
+    // the sample counts only if the reference point lies inside the environment sphere (nearT < 0 < farT, envmap.cpp:527-533)
+    float farT;
+    if (isZero(value) || pdf == 0 || !environmentExit(sc, ref, d, farT)) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    dOut->w = farT;
+    const V3 r = (value / pdf) / emPdf;
+    return make_float4(r.x, r.y, r.z, pdf * emPdf);
+}
+
+// The radiance a ray that leaves the scene collects (Scene::evalEnvironment), and the density with which emitter
+// sampling would have produced its direction (pdfEmitterDirect), for the constant emitter or the map
+MTS_DEV V3 environmentRadiance(const DevScene &sc, V3 rayD) {
+    if (!sc.envIsMap) return ld3(sc.envRadiance);
+    const float4 r = envEvalMap(&sc, rayD, false, rayD, rayD);
+    return mk(r.x, r.y, r.z);
+}
+MTS_DEV float environmentPdf(const DevScene &sc, V3 rayD, float refCos) {
+    if (!sc.envIsMap) return environmentPdfDirect(sc, refCos);
+    const V3 v = envToLocal(sc, rayD);
+    return envPdfDirection(&sc, v.x, v.y, v.z) * sc.envPdfDiscrete;     // EnvironmentMap::pdfDirect (envmap.cpp:545-551)
 }
 
 // PointEmitter::sampleDirect (src/emitters/point.cpp:131-147), SpotEmitter::sampleDirect with falloffCurve
@@ -1308,11 +1425,8 @@ MTS_DEV V3 sampleToCameraPoint(const DevScene &sc, float sx, float sy) {
     return p;
 }
 
-MTS_DEV void cameraUVPartials(const DevScene &sc, const PassParams &pp, float2 pos, const Isect &its, float4 rayO, V3 d, SurfUV &uv) {
-    uv.filtered = 1u;
-    uv.dudx = uv.dvdx = uv.dudy = uv.dvdy = 0.0f;
-    if (isZero(its.dpdu) && isZero(its.dpdv)) return;
-    const V3 o = mk(rayO.x, rayO.y, rayO.z);
+// The directions of a camera ray's offset rays after RayDifferential::scaleDifferential (their origins are the ray's)
+MTS_DEV void cameraOffsetRays(const DevScene &sc, const PassParams &pp, float2 pos, V3 d, V3 &rxD, V3 &ryD) {
     const V3 nearP = sampleToCameraPoint(sc, pos.x * sc.invResX, pos.y * sc.invResY);
     const V3 origin = sampleToCameraPoint(sc, 0.0f, 0.0f);
     const V3 dx = sampleToCameraPoint(sc, sc.invResX, 0.0f) - origin, dy = sampleToCameraPoint(sc, 0.0f, sc.invResY) - origin;
@@ -1321,7 +1435,24 @@ MTS_DEV void cameraUVPartials(const DevScene &sc, const PassParams &pp, float2 p
     const V3 rx = mk(W[0] * lx.x + W[1] * lx.y + W[2] * lx.z, W[4] * lx.x + W[5] * lx.y + W[6] * lx.z, W[8] * lx.x + W[9] * lx.y + W[10] * lx.z);
     const V3 ry = mk(W[0] * ly.x + W[1] * ly.y + W[2] * ly.z, W[4] * ly.x + W[5] * ly.y + W[6] * ly.z, W[8] * ly.x + W[9] * ly.y + W[10] * ly.z);
     const float amount = 1.0f / sqrtf((float) pp.sppTotal);
-    const V3 rxD = d + (rx - d) * amount, ryD = d + (ry - d) * amount;
+    rxD = d + (rx - d) * amount; ryD = d + (ry - d) * amount;
+}
+
+// Scene::evalEnvironment for a camera ray that leaves the scene: the map through its filtered lookup (envmap.cpp:391-407)
+MTS_DEV V3 cameraEnvironmentRadiance(const DevScene &sc, const PassParams &pp, float2 pos, V3 d) {
+    V3 rxD, ryD;
+    cameraOffsetRays(sc, pp, pos, d, rxD, ryD);
+    const float4 r = envEvalMap(&sc, d, true, rxD, ryD);
+    return mk(r.x, r.y, r.z);
+}
+
+MTS_DEV void cameraUVPartials(const DevScene &sc, const PassParams &pp, float2 pos, const Isect &its, float4 rayO, V3 d, SurfUV &uv) {
+    uv.filtered = 1u;
+    uv.dudx = uv.dvdx = uv.dudy = uv.dvdy = 0.0f;
+    if (isZero(its.dpdu) && isZero(its.dpdv)) return;
+    const V3 o = mk(rayO.x, rayO.y, rayO.z);
+    V3 rxD, ryD;
+    cameraOffsetRays(sc, pp, pos, d, rxD, ryD);
     const V3 n = its.geoN;
     const float ppn = dot(n, its.p), po = dot(n, o), prx = dot(n, rxD), pry = dot(n, ryD);
     if (prx == 0 || pry == 0) return;

@@ -130,6 +130,15 @@ struct DevScene {
     // it sits on (1.5 x the bounding sphere of scene and camera) and its share of the emitter choice
     int32_t envEmitter;
     float envRadiance[3], envCenter[3], envRadius, envPdfDiscrete;
+    // environment map (src/emitters/envmap.cpp) in place of the constant radiance: its MIP pyramid (entries of mipLevels),
+    // the marginal / conditional distributions over luminance * sin(theta) (envmap.cpp:260-329), the emitter's frame
+    int32_t envIsMap;
+    uint32_t envFirstLevel, envLevels, envW, envH;
+    float envNormalization, envScale, envPixelX, envPixelY;
+    float envToWorld[9], envToLocal[9];
+    const float *envCdfRows;    // envH + 1
+    const float *envCdfCols;    // envH rows of envW + 1
+    const float *envRowWeights; // envH
 };
 
 // Wavefront queue of live paths (structure of arrays, one float4/uint4 stream each)

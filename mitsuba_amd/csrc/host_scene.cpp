@@ -506,9 +506,11 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
     //      emitter CDF (scene.cpp:375-380) ------------------------------------------------------------------
     hs.emitters.resize(d->n_emitters);
     hs.emitterCdf.assign(1, 0.0f);
+    DevScene envParams;         // the environment map's scalars, copied into the scene's parameters further down
+    memset(&envParams, 0, sizeof(envParams));
     for (uint32_t e = 0; e < d->n_emitters; ++e) {
         const mtsamd_emitter &em = d->emitters[e];
-        if (em.type != MTSAMD_EMITTER_SURFACE) {
+        if (em.type != MTSAMD_EMITTER_SURFACE && em.type != MTSAMD_EMITTER_ENVMAP) {
             // PointEmitter, SpotEmitter, DirectionalEmitter: no surface, reached by emitter sampling only
             if (em.type < MTSAMD_EMITTER_POINT || em.type > MTSAMD_EMITTER_DIRECTIONAL) return "unknown emitter type";
             DevEmitter de;
@@ -538,6 +540,72 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
                 dd.invTransitionWidth = 1.0f / (cutoff - beam);
             }
             hs.deltaEmitters.push_back(dd);
+            hs.emitters[e] = de;
+            hs.emitterCdf.push_back(hs.emitterCdf.back() + em.sampling_weight);
+            hs.extEmitters = true;
+            continue;
+        }
+        if (em.type == MTSAMD_EMITTER_ENVMAP) {     // EnvironmentMap::EnvironmentMap / configure (src/emitters/envmap.cpp:105-189,260-329)
+            if (hs.envEmitter >= 0) return "The scene may only contain one environment emitter";
+            if (!em.pixels || em.width <= 0 || em.height <= 0) return "envmap: invalid image";
+            if (std::max(em.width, em.height) > 0xFFFF) return "Environment maps images must be smaller than 65536 pixels in width and height";
+            hs.envEmitter = (int32_t) e;
+            mtsamd_texture image;
+            memset(&image, 0, sizeof(image));
+            image.type = MTSAMD_TEX_BITMAP; image.pixels = em.pixels; image.width = em.width; image.height = em.height; image.channels = 3;
+            image.filter_type = MTSAMD_MIP_EWA; image.wrap_u = MTSAMD_WRAP_REPEAT; image.wrap_v = MTSAMD_WRAP_CLAMP; image.max_anisotropy = 10.0f;
+            MipPyramid pyr;
+            const std::string err = buildMipPyramid(image, std::numeric_limits<float>::infinity(), pyr);
+            if (!err.empty()) return "envmap: " + err;
+            DevScene &p = envParams;
+            p.envIsMap = 1;
+            p.envFirstLevel = (uint32_t) hs.mipLevels.size(); p.envLevels = (uint32_t) pyr.levels.size();
+            const uint32_t base = (uint32_t) (hs.texels.size() / 4);
+            for (DevMipLevel L : pyr.levels) { L.offset += base; hs.mipLevels.push_back(L); }
+            hs.texels.insert(hs.texels.end(), pyr.texels.begin(), pyr.texels.end());
+            const int w = em.width, h = em.height;
+            p.envW = (uint32_t) w; p.envH = (uint32_t) h; p.envScale = em.scale;
+            hs.envCdfCols.resize((size_t) (w + 1) * h); hs.envCdfRows.resize(h + 1); hs.envRowWeights.resize(h);
+            size_t colPos = 0, rowPos = 0;
+            float rowSum = 0.0f;
+            hs.envCdfRows[rowPos++] = 0;
+            for (int y = 0; y < h; ++y) {
+                float colSum = 0;
+                hs.envCdfCols[colPos++] = 0;
+                for (int x = 0; x < w; ++x) {
+                    const uint16_t *t = &pyr.texels[((size_t) y * w + x) * 4];      // the stored texel, as the reference reads it back
+                    const float rgb[3] = { fromHalf(t[0]), fromHalf(t[1]), fromHalf(t[2]) };
+                    colSum += luminance(rgb);
+                    hs.envCdfCols[colPos++] = colSum;
+                }
+                const float normalization = 1.0f / colSum;
+                for (int x = 1; x < w; ++x) hs.envCdfCols[colPos - x - 1] *= normalization;
+                hs.envCdfCols[colPos - 1] = 1.0f;
+                const float weight = std::sin((y + 0.5f) * 3.14159265358979323846f / h);
+                hs.envRowWeights[y] = weight;
+                rowSum += colSum * weight;
+                hs.envCdfRows[rowPos++] = rowSum;
+            }
+            const float normalization = 1.0f / rowSum;
+            for (int y = 1; y < h; ++y) hs.envCdfRows[rowPos - y - 1] *= normalization;
+            hs.envCdfRows[rowPos - 1] = 1.0f;
+            if (rowSum == 0) return "The environment map is completely black -- this is not allowed.";
+            if (!std::isfinite(rowSum)) return "The environment map contains an invalid floating point value (nan/inf) -- giving up.";
+            const float pi = 3.14159265358979323846f;
+            p.envNormalization = 1.0f / (rowSum * (2 * pi / w) * (pi / h));
+            p.envPixelX = 2 * pi / w; p.envPixelY = pi / h;
+            const float *T = em.to_world;
+            const double a = T[0], b = T[1], c = T[2], dd = T[4], ee = T[5], f = T[6], g = T[8], hh = T[9], i = T[10];
+            const double det = a * (ee * i - f * hh) - b * (dd * i - f * g) + c * (dd * hh - ee * g);
+            if (det == 0) return "envmap: singular toWorld transform";
+            const double inv[9] = { (ee * i - f * hh) / det, (c * hh - b * i) / det, (b * f - c * ee) / det,
+                                    (f * g - dd * i) / det, (a * i - c * g) / det, (c * dd - a * f) / det,
+                                    (dd * hh - ee * g) / det, (b * g - a * hh) / det, (a * ee - b * dd) / det };
+            for (int k = 0; k < 9; ++k) { p.envToWorld[k] = T[(k / 3) * 4 + k % 3]; p.envToLocal[k] = (float) inv[k]; }
+            DevEmitter de;
+            memset(&de, 0, sizeof(de));
+            de.shape = 0xffffffffu;
+            de.kind = 1;            // the environment emitter; DevScene::envIsMap tells the map from the constant
             hs.emitters[e] = de;
             hs.emitterCdf.push_back(hs.emitterCdf.back() + em.sampling_weight);
             hs.extEmitters = true;
@@ -665,6 +733,11 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         p.envRadius = std::max(1e-4f, std::sqrt(r2) * 1.5f);
         memcpy(p.envRadiance, hs.emitters[hs.envEmitter].radiance, 12);
         p.envPdfDiscrete = hs.emitters[hs.envEmitter].pdfDiscrete;
+        p.envIsMap = envParams.envIsMap;
+        p.envFirstLevel = envParams.envFirstLevel; p.envLevels = envParams.envLevels; p.envW = envParams.envW; p.envH = envParams.envH;
+        p.envNormalization = envParams.envNormalization; p.envScale = envParams.envScale;
+        p.envPixelX = envParams.envPixelX; p.envPixelY = envParams.envPixelY;
+        memcpy(p.envToWorld, envParams.envToWorld, sizeof(p.envToWorld)); memcpy(p.envToLocal, envParams.envToLocal, sizeof(p.envToLocal));
     }
     if (!hs.deltaEmitters.empty()) {
         // DirectionalEmitter::createShape (directional.cpp:88-94): 1.1 x the bounding sphere (aabb.cpp:44-47) of the

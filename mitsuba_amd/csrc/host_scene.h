@@ -22,6 +22,7 @@ struct HostScene {
     std::vector<DevTexture> plainTextures;      // the description's textures on their own, in its order (mtsamd_texture_eval)
     std::vector<DevMipLevel> mipLevels;         // levels of all bitmap textures' pyramids
     std::vector<uint16_t> texels;               // their texels, four halves each
+    std::vector<float> envCdfRows, envCdfCols, envRowWeights;   // environment map sampling tables (see DevScene)
     BVH bvh;
     DevScene params;        // scalar members filled; pointers left null until upload
     mtsamd_scene_desc desc; // copy of the scalar parts of the description

@@ -277,20 +277,23 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
         const uint4 misc = in.misc();
         const uint32_t slot = misc.x, prevDepth = misc.y & 0xffffu, flags = misc.y >> 16;
         const float4 th = in.thr();
-        const V3 throughput = mk(th.x, th.y, th.z), radiance = ld3(sc.envRadiance);
+        const V3 throughput = mk(th.x, th.y, th.z);
+        const float4 rd = in.rayD();
+        const V3 rayD = mk(rd.x, rd.y, rd.z);
         if (prevDepth == 0) {
-            // camera ray (path.cpp:136-143): alpha stays 0 (records.inl:121-137)
+            // camera ray (path.cpp:136-143): alpha stays 0 (records.inl:121-137); scene->evalEnvironment(ray) sees the
+            // camera ray's offset rays, so a map is looked up with the elliptical filter
             if (!sc.hideEmitters) {
-                const V3 c = throughput * radiance;
+                const V3 c = throughput * (sc.envIsMap ? cameraEnvironmentRadiance(sc, pp, samplePos[slot], rayD) : ld3(sc.envRadiance));
                 sampleL[slot] = make_float4(c.x, c.y, c.z, 0.0f);
             }
         } else if (!(sc.hideEmitters && !(flags & PF_SCATTERED))) {
-            // ray from BSDF sampling (path.cpp:233-247,257-264): MIS against ConstantBackgroundEmitter::pdfDirect
-            const float4 ro = in.rayO(), rd = in.rayD();
+            // ray from BSDF sampling (path.cpp:233-247,257-264): MIS against the environment emitter's pdfDirect
+            const float4 ro = in.rayO();
             float farT;
-            if (environmentExit(sc, mk(ro.x, ro.y, ro.z), mk(rd.x, rd.y, rd.z), farT)) {     // fillDirectSamplingRecord (constant.cpp:245-261)
-                const float lumPdf = (flags & PF_PREV_DELTA) ? 0.0f : environmentPdfDirect(sc, in.refCos());
-                const V3 c = throughput * radiance * miWeight(in.bsdfPdf(), lumPdf);
+            if (environmentExit(sc, mk(ro.x, ro.y, ro.z), rayD, farT)) {     // fillDirectSamplingRecord (constant.cpp:245-261, envmap.cpp:358-374)
+                const float lumPdf = (flags & PF_PREV_DELTA) ? 0.0f : environmentPdf(sc, rayD, in.refCos());
+                const V3 c = throughput * environmentRadiance(sc, rayD) * miWeight(in.bsdfPdf(), lumPdf);
                 if (c.x != 0 || c.y != 0 || c.z != 0) {
                     float4 L = sampleL[slot];
                     L.x += c.x; L.y += c.y; L.z += c.z;
@@ -535,7 +538,10 @@ __global__ void __launch_bounds__(kShadeBlock) k_direct_shade(DevScene sc, PassP
         Rng rng;
         if (triWord == kMiss) {
             // direct.cpp:156-163: the environment seen directly, alpha 0
-            if (sc.envEmitter >= 0 && !sc.hideEmitters) { L.x = sc.envRadiance[0]; L.y = sc.envRadiance[1]; L.z = sc.envRadiance[2]; }
+            if (sc.envEmitter >= 0 && !sc.hideEmitters) {
+                const V3 e = sc.envIsMap ? cameraEnvironmentRadiance(sc, pp, samplePos[slot], rayD) : ld3(sc.envRadiance);
+                L.x = e.x; L.y = e.y; L.z = e.z;
+            }
         } else {
             int px, py, sIdx;
             const uint64_t key = sampleKey(sc, pp, slot, px, py, sIdx);
@@ -688,8 +694,8 @@ __global__ void __launch_bounds__(256) k_direct_gather(DevScene sc, PathQueue in
             const float4 ro = rays.rayO[e];
             float farT;
             if (!environmentExit(sc, mk(ro.x, ro.y, ro.z), rayD, farT)) continue;
-            value = ld3(sc.envRadiance);
-            if (!(flags & PF_PREV_DELTA)) lumPdf = environmentPdfDirect(sc, rays.refCos[e]);
+            value = environmentRadiance(sc, rayD);
+            if (!(flags & PF_PREV_DELTA)) lumPdf = environmentPdf(sc, rayD, rays.refCos[e]);
         }
         const V3 c = value * mk(th.x, th.y, th.z) * (miWeight(rays.bsdfPdf[e] * fracBSDF, lumPdf * fracLum) * weightBSDF);
         L.x += c.x; L.y += c.y; L.z += c.z;
@@ -909,6 +915,16 @@ __global__ void k_bsdf_sample(DevScene sc, int material, float2 uvIn, uint32_t n
     wo[3 * (size_t) i] = o.x; wo[3 * (size_t) i + 1] = o.y; wo[3 * (size_t) i + 2] = o.z;
     weight[3 * (size_t) i] = w.x; weight[3 * (size_t) i + 1] = w.y; weight[3 * (size_t) i + 2] = w.z;
     pdf[i] = p; eta[i] = e; sampledType[i] = t;
+}
+
+// Scene::evalEnvironment and the environment emitter's pdfDirect times its discrete probability for n directions
+__global__ void k_env_eval(DevScene sc, uint32_t n, const float *d, const float *refN, float *value, float *pdf) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 dir = ld3(d, i), rn = ld3(refN, i);
+    const V3 v = environmentRadiance(sc, dir);
+    value[3 * (size_t) i] = v.x; value[3 * (size_t) i + 1] = v.y; value[3 * (size_t) i + 2] = v.z;
+    pdf[i] = environmentPdf(sc, dir, isZero(rn) ? -2.0f : dot(dir, rn));
 }
 
 // Texture::eval(its) for textures on their own: uv n*2, duv n*4 or null

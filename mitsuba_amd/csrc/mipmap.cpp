@@ -36,6 +36,24 @@ uint16_t toHalf(float f) {
     return (uint16_t) (sign | r);
 }
 
+float fromHalf(uint16_t h) {
+    const uint32_t sign = ((uint32_t) h & 0x8000u) << 16, mant = h & 0x3ffu;
+    const int exp = (h >> 10) & 0x1f;
+    uint32_t x;
+    if (exp == 0) {
+        if (mant == 0) x = sign;
+        else {      // denormal: value = mant * 2^-24
+            float f = (float) mant * 0x1p-24f;
+            memcpy(&x, &f, 4);
+            x |= sign;
+        }
+    } else if (exp == 31) x = sign | 0x7f800000u | (mant << 13);
+    else x = sign | ((uint32_t) (exp + 112) << 23) | (mant << 13);
+    float out;
+    memcpy(&out, &x, 4);
+    return out;
+}
+
 namespace {
 
 inline int wrapIndex(int pos, int n, int bc, int &constant) {

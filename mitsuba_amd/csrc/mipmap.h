@@ -17,6 +17,7 @@ struct MipPyramid {
 std::string buildMipPyramid(const mtsamd_texture &t, float maxValue, MipPyramid &out);
 void ewaWeightTable(float lut[64]);
 uint16_t toHalf(float f);
+float fromHalf(uint16_t h);
 
 std::string loadImage(const char *path, float gammaOverride, int &w, int &h, int &channels, std::vector<float> &pixels);
 

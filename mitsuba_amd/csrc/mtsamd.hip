@@ -109,7 +109,7 @@ struct mtsamd_scene {
     DevScene dev;
     int device = 0;
     DeviceBuffer nodes, tris, shadeTris, shadeUV, shapes, materials, emitters, deltaEmitters,
-        emitterCdf, areaCdf, rtrans, textures, materialTextures, plainTextures, mipLevels, texels, ewaLut;
+        emitterCdf, areaCdf, rtrans, textures, materialTextures, plainTextures, mipLevels, texels, ewaLut, envCdfRows, envCdfCols, envRowWeights;
     // work buffers of the wavefront loop
     DeviceBuffer fetchHeads, qbuf[2][6], hits, sbuf[3], sampleL, samplePos, shadowFlags, counters, scratch[8];
     size_t capacity = 0;
@@ -249,6 +249,9 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
             ewaWeightTable(lut.data());
             HIP_TRY(upload(s->ewaLut, lut));
         }
+        if (!h.envCdfRows.empty()) {
+            HIP_TRY(upload(s->envCdfRows, h.envCdfRows)); HIP_TRY(upload(s->envCdfCols, h.envCdfCols)); HIP_TRY(upload(s->envRowWeights, h.envRowWeights));
+        }
         HIP_TRY(upload(s->rtrans, h.rtrans));
         if (h.bvh.builder == BVH_BUILDER_DEVICE && h.desc.n_triangles > 0) {
             // the acceleration structure is built where it will be used; the records then learn their BSDF types
@@ -297,6 +300,9 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
     d.mipLevels = h.mipLevels.empty() ? nullptr : s->mipLevels.as<DevMipLevel>();
     d.texels = h.mipLevels.empty() ? nullptr : s->texels.as<uint2>();
     d.ewaLut = h.mipLevels.empty() ? nullptr : s->ewaLut.as<float>();
+    d.envCdfRows = h.envCdfRows.empty() ? nullptr : s->envCdfRows.as<float>();
+    d.envCdfCols = h.envCdfRows.empty() ? nullptr : s->envCdfCols.as<float>();
+    d.envRowWeights = h.envRowWeights.empty() ? nullptr : s->envRowWeights.as<float>();
     s->dev = d;
     const char *ct = getenv("MTSAMD_COUNT_TRAVERSAL");
     s->countTraversal = ct && *ct == '1';
@@ -1041,6 +1047,21 @@ extern "C" int mtsamd_texture_eval(mtsamd_scene *s, int texture, uint64_t n, con
                        (uint32_t) n, (const float *) dU, (const float *) dD, (float *) dO);
     TRY(finish(s->stream));
     HIP_TRY(hipMemcpy(out, dO, n * 12, hipMemcpyDeviceToHost));
+    return MTSAMD_OK;
+}
+
+extern "C" int mtsamd_env_eval(mtsamd_scene *s, uint64_t n, const float *d, const float *refN, float *value, float *pdf) {
+    TRY(checkBatch(s, n));
+    if (s->dev.envEmitter < 0) return fail(MTSAMD_EINVAL, "the scene has no environment emitter");
+    if (n == 0) return MTSAMD_OK;
+    if (!d || !refN || !value || !pdf) return fail(MTSAMD_EINVAL, "null argument");
+    Staging sg; void *dD, *dN, *dV, *dP;
+    TRY(sg.in(d, n * 12, &dD)); TRY(sg.in(refN, n * 12, &dN)); TRY(sg.out(n * 12, &dV)); TRY(sg.out(n * 4, &dP));
+    hipLaunchKernelGGL(k_env_eval, dim3(blocksFor(n, 256)), dim3(256), 0, s->stream, s->dev, (uint32_t) n, (const float *) dD, (const float *) dN,
+                       (float *) dV, (float *) dP);
+    TRY(finish(s->stream));
+    HIP_TRY(hipMemcpy(value, dV, n * 12, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pdf, dP, n * 4, hipMemcpyDeviceToHost));
     return MTSAMD_OK;
 }
 

@@ -655,6 +655,17 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
             weight = p.get("samplingWeight", 1.0)
             if t == "constant":         # src/emitters/constant.cpp:47-50
                 b.add_constant_emitter(p.get("radiance", (1.0, 1.0, 1.0)), weight)
+            elif t == "envmap":         # src/emitters/envmap.cpp:105-189
+                if "filename" not in p:
+                    raise SceneFormatError("envmap: the 'filename' parameter is missing")
+                if "intensityScale" in p:
+                    raise SceneFormatError("The 'intensityScale' parameter has been deprecated and is now called scale.")
+                from . import capi
+                try:
+                    pixels = capi.image_load(os.path.join(base, p["filename"]), gamma=p.get("gamma", 0.0))
+                except capi.MtsamdError as e:
+                    raise SceneFormatError(str(e))
+                b.add_envmap_emitter(pixels, p.get("toWorld"), p.get("scale", 1.0), weight)
             elif t == "point":          # src/emitters/point.cpp:58-69
                 m = np.array(p.get("toWorld", np.eye(4)), np.float32)
                 if "position" in p:
@@ -674,7 +685,7 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
                                           to_world=None if "direction" in p else p.get("toWorld", np.eye(4, dtype=np.float32)),
                                           sampling_weight=weight)
             else:
-                raise SceneFormatError("emitter type '%s' is not supported (area, constant, point, spot, directional)" % t)
+                raise SceneFormatError("emitter type '%s' is not supported (area, constant, envmap, point, spot, directional)" % t)
     if camera is None:
         raise SceneFormatError("scene has no sensor")
     if integrator_override:

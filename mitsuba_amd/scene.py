@@ -19,7 +19,7 @@ BSDF_DIFFUSE, BSDF_ROUGHCONDUCTOR, BSDF_ROUGHPLASTIC, BSDF_DIELECTRIC, BSDF_WARD
     BSDF_ROUGHDIELECTRIC, BSDF_MIXTURE = range(9)
 DISTR_BECKMANN, DISTR_GGX = 0, 1
 SHAPE_HAS_NORMALS, SHAPE_HAS_TEXCOORDS = 1, 2
-EMITTER_SURFACE, EMITTER_POINT, EMITTER_SPOT, EMITTER_DIRECTIONAL = range(4)
+EMITTER_SURFACE, EMITTER_POINT, EMITTER_SPOT, EMITTER_DIRECTIONAL, EMITTER_ENVMAP = range(5)
 
 _DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
@@ -376,6 +376,18 @@ class SceneBuilder:
         self.emitters.append(dict(shape=-1, radiance=tuple(float(x) for x in radiance), sampling_weight=float(sampling_weight)))
         return len(self.emitters) - 1
 
+    def add_envmap_emitter(self, pixels, to_world=None, scale=1.0, sampling_weight=1.0) -> int:
+        """Environment map (src/emitters/envmap.cpp): a latitude-longitude image, height x width x 3 linear floats (a
+        luminance image is replicated), first row = +y of the emitter's frame."""
+        px = np.ascontiguousarray(pixels, np.float32)
+        if px.ndim == 2:
+            px = np.repeat(px[:, :, None], 3, 2)
+        if px.ndim != 3 or px.shape[2] != 3:
+            raise ValueError("envmap: pixels must be height x width x 3")
+        self.emitters.append(dict(shape=-1, type=EMITTER_ENVMAP, radiance=(0.0, 0.0, 0.0), sampling_weight=float(sampling_weight), pixels=px,
+                                  scale=float(scale), to_world=np.asarray(np.eye(4) if to_world is None else to_world, np.float32).reshape(4, 4)))
+        return len(self.emitters) - 1
+
     def _add_delta_emitter(self, kind, value, to_world, sampling_weight, **extra) -> int:
         self.emitters.append(dict(shape=-1, type=kind, radiance=tuple(float(x) for x in value),
                                   to_world=np.asarray(to_world, np.float32).reshape(4, 4), sampling_weight=float(sampling_weight), **extra))
@@ -682,6 +694,32 @@ def config5(width=3840, height=2160) -> SceneData:
                             max_depth=16, emitters_grid=32)
 
 
+def rotation_about(axis, degrees) -> np.ndarray:
+    """Transform::rotate (src/libcore/transform.cpp) as a 4 x 4 matrix."""
+    a = np.asarray(axis, np.float64)
+    x, y, z = a / np.linalg.norm(a)
+    t = np.radians(degrees)
+    c, s_ = np.cos(t), np.sin(t)
+    m = np.eye(4)
+    m[:3, :3] = [[c + x * x * (1 - c), x * y * (1 - c) - z * s_, x * z * (1 - c) + y * s_],
+                 [y * x * (1 - c) + z * s_, c + y * y * (1 - c), y * z * (1 - c) - x * s_],
+                 [z * x * (1 - c) - y * s_, z * y * (1 - c) + x * s_, c + z * z * (1 - c)]]
+    return m.astype(np.float32)
+
+
+def test_environment_map(width=64, height=32, seed=5) -> np.ndarray:
+    """A synthetic high-dynamic-range latitude-longitude image: a smooth sky gradient, a dim ground, noise at the texel
+    scale and a small very bright sun, so that importance sampling, the tent offsets and the filtered lookups all matter."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:height, 0:width]
+    theta = (yy + 0.5) / height * np.pi
+    sky = np.where(theta < np.pi / 2, 0.3 + 0.7 * np.cos(theta), 0.05)
+    img = np.stack([sky * 0.6, sky * 0.8, sky * 1.2], -1) * (0.8 + 0.4 * rng.random((height, width, 1)))
+    sun = np.exp(-(((xx - width * 0.3) / 1.5) ** 2 + ((yy - height * 0.25) / 1.5) ** 2))
+    img += sun[..., None] * np.array([400.0, 350.0, 250.0])
+    return img.astype(np.float32)
+
+
 def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_weight=1.0, hide_emitters=0, lamps=False, area_lights=True,
                      blend=False, textured=False, bumps=False) -> SceneData:
     """A few hundred triangles with every BSDF type present; used by the parity tests. `sky` adds a constant
@@ -760,7 +798,10 @@ def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_
     b.add_mesh(gp, gf, m_ground, texcoords=((gp[:, :2] + np.float32([7, 6])) / np.float32([14, 12])).astype(np.float32) if textured else None)
     b.add_quad([-2, -2, 6], [-2, 2, 6], [2, 2, 6], [2, -2, 6], m_light, radiance=(15, 14, 12) if area_lights else None)
     b.add_quad([4, -1, 3.5], [4, 1, 3.5], [5, 1, 4.5], [5, -1, 4.5], m_light, radiance=(6, 9, 12) if area_lights else None, sampling_weight=0.5)
-    if sky is not None:
+    if isinstance(sky, str) and sky == "map":
+        b.add_envmap_emitter(test_environment_map(), to_world=rotation_about([0.2, 0.3, 1.0], 40.0) @ rotation_about([1, 0, 0], 90.0),
+                             scale=0.6, sampling_weight=sky_weight)
+    elif sky is not None:
         b.add_constant_emitter(sky, sky_weight)
     if lamps:
         b.add_point_emitter([-3.0, -4.0, 3.0], (30.0, 20.0, 10.0))

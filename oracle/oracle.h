@@ -72,7 +72,8 @@ typedef struct {
 } orc_texture;
 
 /* type 0: attached to `shape` (area light) or, with shape = -1, the constant environment emitter;
-   1: point (src/emitters/point.cpp), 2: spot (src/emitters/spot.cpp), 3: directional (src/emitters/directional.cpp).
+   1: point (src/emitters/point.cpp), 2: spot (src/emitters/spot.cpp), 3: directional (src/emitters/directional.cpp),
+   4: environment map (src/emitters/envmap.cpp).
    `radiance` holds the intensity of a point/spot light and the irradiance of a directional one. */
 typedef struct {
     int32_t shape;
@@ -81,6 +82,11 @@ typedef struct {
     int32_t type;
     float to_world[16];         /* row-major emitter-to-world; the emitter looks along +z */
     float cutoff_angle, beam_width;     /* spot, degrees */
+    /* type 4: environment map (src/emitters/envmap.cpp): latitude-longitude image of width * height * 3 linear floats,
+       first row = top (+y of the emitter's frame); `scale` multiplies the radiance; shape is -1 */
+    const float *pixels;
+    int32_t width, height;
+    float scale;
 } orc_emitter;
 
 typedef struct {
@@ -166,6 +172,10 @@ int orc_bsdf_sample(const orc_scene *s, int material, uint64_t n, const float *w
    duv n*4 (dudx, dvdx, dudy, dvdy: Intersection::hasUVPartials set) or NULL (unfiltered lookup) -> out n*3.
    gradient != 0: Texture::evalGradient (d/du, d/dv) instead, out n*6 */
 int orc_texture_eval(const orc_scene *s, int texture, uint64_t n, const float *uv, const float *duv, int gradient, float *out);
+
+/* The environment emitter for n world-space directions: value n*3 (Scene::evalEnvironment, no offset rays) and pdf n
+   (pdfDirect in the solid-angle measure times the emitter's discrete probability; ref_n n*3, zero = no normal) */
+int orc_env_eval(const orc_scene *s, uint64_t n, const float *d, const float *ref_n, float *value, float *pdf);
 
 /* Emitter sampling without the visibility test: ref[n*3], ref_n[n*3], sample[n*2] ->
    d[n*3], dist[n], pdf[n], value[n*3] (value = radiance/pdf/emPdf, 0 if rejected) */

@@ -41,7 +41,8 @@ class Texture(C.Structure):
 
 class Emitter(C.Structure):
     _fields_ = [("shape", C.c_int32), ("radiance", C.c_float * 3), ("sampling_weight", C.c_float), ("type", C.c_int32),
-                ("to_world", C.c_float * 16), ("cutoff_angle", C.c_float), ("beam_width", C.c_float)]
+                ("to_world", C.c_float * 16), ("cutoff_angle", C.c_float), ("beam_width", C.c_float),
+                ("pixels", _f32p), ("width", C.c_int32), ("height", C.c_int32), ("scale", C.c_float)]
 
 
 class Camera(C.Structure):
@@ -137,6 +138,10 @@ def fill_desc(sd, desc_cls=SceneDesc, shape_cls=Shape, mat_cls=Material, em_cls=
         ems[i].type = e.get("type", 0)
         ems[i].to_world = (C.c_float * 16)(*np.asarray(e.get("to_world", np.eye(4)), np.float32).reshape(-1))
         ems[i].cutoff_angle, ems[i].beam_width = e.get("cutoff_angle", 20.0), e.get("beam_width", 15.0)
+        if e.get("pixels") is not None:     # environment map: height x width x 3 linear floats
+            px = np.ascontiguousarray(e["pixels"], np.float32)
+            keep.append(px)
+            ems[i].pixels, ems[i].height, ems[i].width, ems[i].scale = px.ctypes.data_as(_f32p), px.shape[0], px.shape[1], e.get("scale", 1.0)
     keep += [shapes, mats, ems]
     d.n_shapes, d.n_materials, d.n_emitters = len(sd.shapes), len(sd.materials), len(sd.emitters)
     d.shapes, d.materials, d.emitters = shapes, mats, ems
@@ -230,6 +235,14 @@ class OracleScene:
 
     def bsdf_query_uv(self, u, v):
         self.L.orc_bsdf_query_uv(C.c_float(u), C.c_float(v))
+
+    def env_eval(self, d, ref_n=None):
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        rn = np.zeros_like(d) if ref_n is None else np.ascontiguousarray(ref_n, np.float32).reshape(-1, 3)
+        value, pdf = np.zeros_like(d), np.zeros(d.shape[0], np.float32)
+        if self.L.orc_env_eval(C.c_void_p(self.h), C.c_uint64(d.shape[0]), _fp(d), _fp(rn), _fp(value), _fp(pdf)) != 0:
+            raise RuntimeError("oracle: the scene has no environment emitter")
+        return value, pdf
 
     def texture_eval(self, texture, uv, duv=None, gradient=False):
         """Texture `texture` (1-based) at uv (n x 2); duv (n x 4: dudx, dvdx, dudy, dvdy) makes the lookup a filtered one;

@@ -85,6 +85,53 @@ static void matTranslate(float x, float y, float z, float *m) {
 }
 
 // ---- Scene::build ----------------------------------------------------------------------------------
+// EnvironmentMap::EnvironmentMap / configure (src/emitters/envmap.cpp:105-189,260-329)
+const char *Scene::buildEnvMap(const orc_emitter &em) {
+    if (!em.pixels || em.width <= 0 || em.height <= 0) return "envmap: invalid image";
+    if (std::max(em.width, em.height) > 0xFFFF) return "Environment maps images must be smaller than 65536 pixels in width and height";
+    auto env = std::make_shared<EnvMap>();
+    env->mip = std::make_shared<MIPMap>(em.pixels, em.width, em.height, 3, BC_REPEAT, BC_CLAMP, MIP_EWA, 10.0f, std::numeric_limits<float>::infinity());
+    env->w = em.width; env->h = em.height; env->scale = em.scale;
+    const int w = env->w, h = env->h;
+    env->cdfCols.resize((size_t) (w + 1) * h); env->cdfRows.resize(h + 1); env->rowWeights.resize(h);
+    size_t colPos = 0, rowPos = 0;
+    float rowSum = 0.0f;
+    env->cdfRows[rowPos++] = 0;
+    for (int y = 0; y < h; ++y) {
+        float colSum = 0;
+        env->cdfCols[colPos++] = 0;
+        for (int x = 0; x < w; ++x) {
+            colSum += luminance(env->mip->evalTexel(0, x, y));     // the stored (half precision) texel
+            env->cdfCols[colPos++] = colSum;
+        }
+        const float normalization = 1.0f / colSum;
+        for (int x = 1; x < w; ++x) env->cdfCols[colPos - x - 1] *= normalization;
+        env->cdfCols[colPos - 1] = 1.0f;
+        const float weight = std::sin((y + 0.5f) * M_PI_F / h);
+        env->rowWeights[y] = weight;
+        rowSum += colSum * weight;
+        env->cdfRows[rowPos++] = rowSum;
+    }
+    const float normalization = 1.0f / rowSum;
+    for (int y = 1; y < h; ++y) env->cdfRows[rowPos - y - 1] *= normalization;
+    env->cdfRows[rowPos - 1] = 1.0f;
+    if (rowSum == 0) return "The environment map is completely black -- this is not allowed.";
+    if (!std::isfinite(rowSum)) return "The environment map contains an invalid floating point value (nan/inf) -- giving up.";
+    env->normalization = 1.0f / (rowSum * (2 * M_PI_F / w) * (M_PI_F / h));
+    env->pixelSize = Vec2{ 2 * M_PI_F / w, M_PI_F / h };
+    // linear part of the transform and of its inverse (Transform keeps both matrices, include/mitsuba/core/transform.h)
+    const float *T = em.to_world;
+    const double a = T[0], b = T[1], c = T[2], d = T[4], e = T[5], f = T[6], g = T[8], hh = T[9], i = T[10];
+    const double det = a * (e * i - f * hh) - b * (d * i - f * g) + c * (d * hh - e * g);
+    if (det == 0) return "envmap: singular toWorld transform";
+    const double inv[9] = { (e * i - f * hh) / det, (c * hh - b * i) / det, (b * f - c * e) / det,
+                            (f * g - d * i) / det, (a * i - c * g) / det, (c * d - a * f) / det,
+                            (d * hh - e * g) / det, (b * g - a * hh) / det, (a * e - b * d) / det };
+    for (int k = 0; k < 9; ++k) { env->toWorld[k] = T[(k / 3) * 4 + k % 3]; env->toLocal[k] = (float) inv[k]; }
+    envMap = env;
+    return nullptr;
+}
+
 std::string Scene::build(const orc_scene_desc *d) {
     desc = *d;
     positions.resize(d->n_vertices);
@@ -119,6 +166,7 @@ std::string Scene::build(const orc_scene_desc *d) {
     if (const char *err = linkTwoSided(materials)) return err;
     anyRayDifferentials = false;
     for (const Material &m : materials) anyRayDifferentials |= m.usesRayDifferentials;
+    for (uint32_t e = 0; e < d->n_emitters; ++e) anyRayDifferentials |= d->emitters[e].type == 4;   // escaping camera rays are filtered
 
     triShape.assign(d->n_triangles, 0xFFFFFFFFu);
     uvDpdu.assign(d->n_triangles, Vec3(0.0f));
@@ -167,6 +215,13 @@ std::string Scene::build(const orc_scene_desc *d) {
     envEmitter = -1;
     for (uint32_t e = 0; e < d->n_emitters; ++e) {
         int s = emitters[e].shape;
+        if (emitters[e].type == 4) {    // environment map
+            if (envEmitter >= 0) return "The scene may only contain one environment emitter";
+            envEmitter = (int) e;
+            if (const char *err = buildEnvMap(emitters[e])) return err;
+            emitterPDF.append(emitters[e].sampling_weight);
+            continue;
+        }
         if (emitters[e].type != 0) {    // point, spot, directional: no surface
             if (emitters[e].type < 1 || emitters[e].type > 3) return "unknown emitter type";
             emitterPDF.append(emitters[e].sampling_weight);
@@ -290,6 +345,79 @@ static bool sphereIntersect(const Vec3 &center, float radius, const Vec3 &ro, co
     return solveQuadratic(A, B, C, nearHit, farHit);
 }
 
+// ---- EnvironmentMap (src/emitters/envmap.cpp) ----------------------------------------------------------------------
+// The offset rays of a RayDifferential (include/mitsuba/core/ray.h:129-175); the perspective camera's start at the
+// ray origin (perspective.cpp:289)
+struct RayDifferentials { bool has = false; Vec3 rxDirection, ryDirection; };
+
+static float intervalToTent(float sample) {     // src/libcore/warp.cpp:151-163
+    float sign;
+    if (sample < 0.5f) { sign = 1; sample *= 2; }
+    else { sign = -1; sample = 2 * (sample - 0.5f); }
+    return sign * (1 - std::sqrt(sample));
+}
+
+static uint32_t envSampleReuse(const float *cdf, uint32_t size, float &sample) {        // envmap.cpp:657-662
+    const float *entry = std::lower_bound(cdf, cdf + size + 1, sample);
+    const uint32_t index = std::min((uint32_t) std::max((ptrdiff_t) 0, entry - cdf - 1), size - 1);
+    sample = (sample - cdf[index]) / (cdf[index + 1] - cdf[index]);
+    return index;
+}
+
+// the four texels around a fractional pixel position, interpolated row by row (envmap.cpp:577-591, :618-632)
+static void envRows(const Scene::EnvMap &env, int xPos, int yPos, float dx1, float dy1, Spectrum &value1, Spectrum &value2) {
+    const float dx2 = 1.0f - dx1, dy2 = 1.0f - dy1;
+    value1 = env.mip->evalTexel(0, xPos, yPos) * dx2 * dy2 + env.mip->evalTexel(0, xPos + 1, yPos) * dx1 * dy2;
+    value2 = env.mip->evalTexel(0, xPos, yPos + 1) * dx2 * dy1 + env.mip->evalTexel(0, xPos + 1, yPos + 1) * dx1 * dy1;
+}
+
+// EnvironmentMap::internalSampleDirection (envmap.cpp:567-600)
+static void envSampleDirection(const Scene::EnvMap &env, Vec2 sample, Vec3 &d, Spectrum &value, float &pdf) {
+    const uint32_t row = envSampleReuse(env.cdfRows.data(), (uint32_t) env.h, sample.y),
+                   col = envSampleReuse(env.cdfCols.data() + (size_t) row * (env.w + 1), (uint32_t) env.w, sample.x);
+    const Vec2 pos{ (float) col + intervalToTent(sample.x), (float) row + intervalToTent(sample.y) };
+    const int xPos = (int) std::floor(pos.x), yPos = (int) std::floor(pos.y);
+    Spectrum value1, value2;
+    envRows(env, xPos, yPos, pos.x - xPos, pos.y - yPos, value1, value2);
+    value = (value1 + value2) * env.scale;
+    pdf = (luminance(value1) * env.rowWeights[std::min(env.h - 1, std::max(0, yPos))] +
+           luminance(value2) * env.rowWeights[std::min(env.h - 1, std::max(0, yPos + 1))]) * env.normalization;
+    float sinPhi, cosPhi, sinTheta, cosTheta;
+    ::sincosf(env.pixelSize.x * (pos.x + 0.5f), &sinPhi, &cosPhi);
+    ::sincosf(env.pixelSize.y * (pos.y + 0.5f), &sinTheta, &cosTheta);
+    d = Vec3(sinPhi * sinTheta, cosTheta, -cosPhi * sinTheta);
+    pdf /= std::max(std::abs(sinTheta), Epsilon);
+}
+
+// EnvironmentMap::internalPdfDirection (envmap.cpp:603-633), d in the emitter's frame
+static float envPdfDirection(const Scene::EnvMap &env, const Vec3 &d) {
+    const Vec2 uv{ std::atan2(d.x, -d.z) * INV_TWOPI_F, std::acos(std::min(1.0f, std::max(-1.0f, d.y))) * INV_PI_F };
+    if (!std::isfinite(uv.x) || !std::isfinite(uv.y)) return 0.0f;
+    const float u = uv.x * env.w - 0.5f, v = uv.y * env.h - 0.5f;
+    const int xPos = (int) std::floor(u), yPos = (int) std::floor(v);
+    Spectrum value1, value2;
+    envRows(env, xPos, yPos, u - xPos, v - yPos, value1, value2);
+    const float sinTheta = safe_sqrt(1 - d.y * d.y);
+    return (luminance(value1) * env.rowWeights[std::min(env.h - 1, std::max(0, yPos))] +
+            luminance(value2) * env.rowWeights[std::min(env.h - 1, std::max(0, yPos + 1))]) * env.normalization / std::max(std::abs(sinTheta), Epsilon);
+}
+
+// EnvironmentMap::evalEnvironment (envmap.cpp:380-410): the radiance arriving along a ray that leaves the scene;
+// a ray with offset rays (a camera ray) gets a filtered lookup
+static Spectrum envEvalMap(const Scene::EnvMap &env, const Vec3 &rayD, const RayDifferentials &rd) {
+    const Vec3 v = env.local(rayD);
+    const Vec2 uv{ std::atan2(v.x, -v.z) * INV_TWOPI_F, std::acos(std::min(1.0f, std::max(-1.0f, v.y))) * INV_PI_F };
+    Spectrum value;
+    if (!rd.has) value = env.mip->evalBilinear(0, uv);
+    else {
+        const Vec3 dvdx = env.local(rd.rxDirection) - v, dvdy = env.local(rd.ryDirection) - v;
+        const float t1 = INV_TWOPI_F / (v.x * v.x + v.z * v.z), t2 = -INV_PI_F / std::max(safe_sqrt(1.0f - v.y * v.y), Epsilon);
+        const Vec2 dudx{ t1 * (dvdx.z * v.x - dvdx.x * v.z), t2 * dvdx.y }, dudy{ t1 * (dvdy.z * v.x - dvdy.x * v.z), t2 * dvdy.y };
+        value = env.mip->eval(uv, dudx, dudy);
+    }
+    return value * env.scale;
+}
+
 // ---- Emitter sampling --------------------------------------------------------------------------------
 struct DirectSample {
     Vec3 p, n, d;
@@ -306,6 +434,26 @@ static Spectrum sampleEmitterDirect(const Scene &sc, const Vec3 &ref, const Vec3
     float emPdf;
     size_t index = sc.emitterPDF.sampleReuse(sample.x, emPdf);
     const orc_emitter &em = sc.emitters[index];
+    if (em.type == 4) {     // EnvironmentMap::sampleDirect (envmap.cpp:516-543)
+        const Scene::EnvMap &env = *sc.envMap;
+        Spectrum value; Vec3 d; float pdf;
+        envSampleDirection(env, sample, d, value, pdf);
+        const Vec3 dw = env.world(d);
+        float nearT, farT;
+        dRec.pdf = 0.0f;
+        if (value.isZero() || pdf == 0 || !sphereIntersect(sc.envCenter, sc.envRadius, ref, dw, nearT, farT) || nearT >= 0 || farT <= 0)
+            return Spectrum(0.0f);
+        dRec.pdf = pdf;
+        dRec.p = ref + dw * farT;
+        dRec.n = normalize(sc.envCenter - dRec.p);
+        dRec.dist = farT;
+        dRec.d = dw;
+        dRec.emitter = (int) index;
+        value = value / pdf;
+        dRec.pdf *= emPdf;
+        value /= emPdf;
+        return value;
+    }
     if (em.type != 0) {
         // PointEmitter::sampleDirect (point.cpp:131-147), SpotEmitter::sampleDirect (spot.cpp:184-200),
         // DirectionalEmitter::sampleDirect (directional.cpp:159-180): one position or direction, discrete measure
@@ -346,7 +494,8 @@ static Spectrum sampleEmitterDirect(const Scene &sc, const Vec3 &ref, const Vec3
         value /= emPdf;
         return value;
     }
-    if (em.shape < 0) {     // ConstantBackgroundEmitter::sampleDirect (constant.cpp:178-216)
+    if (em.type == 0 && em.shape < 0 && sc.envMap) return Spectrum(0.0f);      // (cannot happen: a map is of type 4)
+    if (em.type == 0 && em.shape < 0) {     // ConstantBackgroundEmitter::sampleDirect (constant.cpp:178-216)
         Vec3 d;
         float pdf;
         if (!refN.isZero()) {
@@ -411,8 +560,17 @@ static Spectrum sampleEmitterDirect(const Scene &sc, const Vec3 &ref, const Vec3
 
 // ConstantBackgroundEmitter::pdfDirect in the solid-angle measure (constant.cpp:218-233) times pdfEmitterDiscrete
 static float envPdfDirect(const Scene &sc, const Vec3 &d, const Vec3 &refN) {
+    if (sc.envMap)      // EnvironmentMap::pdfDirect, solid-angle measure (envmap.cpp:545-551)
+        return envPdfDirection(*sc.envMap, sc.envMap->local(d)) * sc.emitters[sc.envEmitter].sampling_weight * sc.emitterPDF.normalization;
     float pdfSA = !refN.isZero() ? INV_PI_F * std::max(0.0f, dot(d, refN)) : INV_FOURPI_F;
     return pdfSA * sc.emitters[sc.envEmitter].sampling_weight * sc.emitterPDF.normalization;
+}
+
+// Scene::evalEnvironment: the constant emitter's radiance or the map's value along the ray
+static Spectrum envRadiance(const Scene &sc, const Vec3 &rayD, const RayDifferentials &rd) {
+    if (sc.envMap) return envEvalMap(*sc.envMap, rayD, rd);
+    const orc_emitter &em = sc.emitters[sc.envEmitter];
+    return Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]);
 }
 
 static inline float miWeight(float pdfA, float pdfB) {
@@ -421,10 +579,6 @@ static inline float miWeight(float pdfA, float pdfB) {
 }
 
 struct RayCounters { uint64_t normal = 0, shadow = 0; TraversalCounters trav; };
-
-// The offset rays of a RayDifferential (include/mitsuba/core/ray.h:129-175); the perspective camera's start at the
-// ray origin (perspective.cpp:289)
-struct RayDifferentials { bool has = false; Vec3 rxDirection, ryDirection; };
 
 // Intersection::computePartials (src/librender/intersection.cpp:5-76) for offset rays that start at the ray origin
 static UVPartials computePartials(const Intersection &its, const Ray &ray, const RayDifferentials &rd) {
@@ -484,10 +638,8 @@ static Spectrum Li(const Scene &sc, const Ray &r, const RayDifferentials &rd0, P
 
     while (depth <= ig.max_depth || ig.max_depth < 0) {
         if (!its.isValid()) {          // path.cpp:136-143
-            if (sc.envEmitter >= 0 && emittedRadiance && (!ig.hide_emitters || scattered)) {
-                const orc_emitter &em = sc.emitters[sc.envEmitter];
-                Li += throughput * Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]);
-            }
+            if (sc.envEmitter >= 0 && emittedRadiance && (!ig.hide_emitters || scattered))
+                Li += throughput * envRadiance(sc, ray.d, rd);      // scene->evalEnvironment(ray): a camera ray keeps its offset rays
             break;
         }
         const orc_shape &shape = sc.shapes[its.shape];
@@ -561,9 +713,8 @@ static Spectrum Li(const Scene &sc, const Ray &r, const RayDifferentials &rd0, P
             // path.cpp:233-247: the environment emitter, if there is one
             if (sc.envEmitter < 0) break;
             if (ig.hide_emitters && !scattered) break;
-            const orc_emitter &em = sc.emitters[sc.envEmitter];
-            value = Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]);
-            float nearT, farT;     // fillDirectSamplingRecord (constant.cpp:245-261)
+            value = envRadiance(sc, ray.d, RayDifferentials());    // evalEnvironment(RayDifferential(ray)): no offset rays
+            float nearT, farT;     // fillDirectSamplingRecord (constant.cpp:245-261, envmap.cpp:358-374)
             if (!sphereIntersect(sc.envCenter, sc.envRadius, ray.o, ray.d, nearT, farT) || nearT > 0 || farT < 0) break;
             hitEnvironment = true;
         }
@@ -610,10 +761,7 @@ static Spectrum LiDirect(const Scene &sc, const Ray &r, const RayDifferentials &
     const bool hit = sc.rayIntersect(ray, its, &cnt.trav);
     alpha = hit ? 1.0f : 0.0f;
     if (!hit) {     // direct.cpp:156-163
-        if (sc.envEmitter >= 0 && !ig.hide_emitters) {
-            const orc_emitter &em = sc.emitters[sc.envEmitter];
-            return Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]);
-        }
+        if (sc.envEmitter >= 0 && !ig.hide_emitters) return envRadiance(sc, ray.d, rd);
         return Spectrum(0.0f);
     }
     const orc_shape &shape = sc.shapes[its.shape];
@@ -684,8 +832,7 @@ static Spectrum LiDirect(const Scene &sc, const Ray &r, const RayDifferentials &
             }
         } else {
             if (sc.envEmitter < 0) continue;    // (hideEmitters only hides what a null interaction would show, direct.cpp:288)
-            const orc_emitter &em = sc.emitters[sc.envEmitter];
-            value = Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]);
+            value = envRadiance(sc, bsdfRay.d, RayDifferentials());
             float nearT, farT;
             if (!sphereIntersect(sc.envCenter, sc.envRadius, bsdfRay.o, bsdfRay.d, nearT, farT) || nearT > 0 || farT < 0) continue;
             if (!(bs.sampledType & EDelta)) lumPdf = envPdfDirect(sc, bsdfRay.d, refN);
@@ -913,6 +1060,17 @@ extern "C" int orc_texture_eval(const orc_scene *s, int texture, uint64_t n, con
         }
     }
     g_texturePartials = UVPartials();
+    return 0;
+}
+
+extern "C" int orc_env_eval(const orc_scene *s, uint64_t n, const float *d, const float *refN, float *value, float *pdf) {
+    if (s->s.envEmitter < 0) return -1;
+    for (uint64_t i = 0; i < n; ++i) {
+        const Vec3 dir(d[3 * i], d[3 * i + 1], d[3 * i + 2]), rn(refN[3 * i], refN[3 * i + 1], refN[3 * i + 2]);
+        const Spectrum v = envRadiance(s->s, dir, RayDifferentials());
+        for (int k = 0; k < 3; ++k) value[3 * i + k] = v[k];
+        pdf[i] = envPdfDirect(s->s, dir, rn);
+    }
     return 0;
 }
 

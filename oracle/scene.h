@@ -154,6 +154,20 @@ struct Scene {
     int envEmitter = -1;
     Vec3 envCenter;
     float envRadius = 0;
+    // EnvironmentMap (src/emitters/envmap.cpp:99-676) when the environment emitter is of type 4: the MIP map of the image
+    // (repeat along u, clamp along v, elliptical filter with anisotropy 10, no upper clamp), the marginal and conditional
+    // distributions over luminance times sin(theta) (:260-329) and the emitter's frame
+    struct EnvMap {
+        std::shared_ptr<MIPMap> mip;
+        std::vector<float> cdfRows, cdfCols, rowWeights;
+        int w = 0, h = 0;
+        float normalization = 0, scale = 1;
+        Vec2 pixelSize{ 0, 0 };
+        float toWorld[9], toLocal[9];       // linear parts of the emitter-to-world transform and of its inverse
+        Vec3 world(const Vec3 &v) const { return Vec3(toWorld[0] * v.x + toWorld[1] * v.y + toWorld[2] * v.z, toWorld[3] * v.x + toWorld[4] * v.y + toWorld[5] * v.z, toWorld[6] * v.x + toWorld[7] * v.y + toWorld[8] * v.z); }
+        Vec3 local(const Vec3 &v) const { return Vec3(toLocal[0] * v.x + toLocal[1] * v.y + toLocal[2] * v.z, toLocal[3] * v.x + toLocal[4] * v.y + toLocal[5] * v.z, toLocal[6] * v.x + toLocal[7] * v.y + toLocal[8] * v.z); }
+    };
+    std::shared_ptr<EnvMap> envMap;
     // Emitters without a surface (point.cpp, spot.cpp, directional.cpp), indexed like `emitters`
     struct DeltaEmitter {
         Vec3 position;              // point, spot: trafo.transformAffine(Point(0))
@@ -180,6 +194,7 @@ struct Scene {
     Vec2 invResolution;
 
     std::string build(const orc_scene_desc *d);
+    const char *buildEnvMap(const orc_emitter &em);
     void buildKDTree();
 
     // src/librender/skdtree.cpp:112-142 / 207-226

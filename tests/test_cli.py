@@ -435,7 +435,8 @@ def test_cli_rejects_unsupported_content(scene_dir, tmp_path):
                          ('<shape type="cube"><bsdf type="coating"/></shape>', "outside the path hot path"),
                          ('<shape type="cube"><bsdf type="twosided"><bsdf type="dielectric"/></bsdf></shape>', "transmission component"),
                          ('<shape type="cube"><bsdf type="twosided"/></shape>', "nested one-sided material is required"),
-                         ('<emitter type="envmap"/>', "emitter type 'envmap' is not supported"),
+                         ('<emitter type="sunsky"/>', "emitter type 'sunsky' is not supported"),
+                         ('<emitter type="envmap"/>', "'filename' parameter is missing"),
                          ('<shape type="cube"><bsdf type="roughconductor"><string name="material" value="Au"/></bsdf></shape>', "needs the measured spectra")):
         f = tmp_path / "bad.xml"
         f.write_text(SCENE % body)
@@ -702,6 +703,59 @@ def test_cli_textures(scene_dir, tmp_path):
 def test_cli_textured_render_matches_binding(scene_dir, tmp_path):
     from mitsuba_amd import capi
     f, _ = _textured_scene(scene_dir, tmp_path)
+    raw = tmp_path / "film.raw"
+    out = subprocess.run([CLI, str(f), "-o", str(tmp_path / "out.pfm"), "--film", str(raw), "--spp", "8", "--seed", "3"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    stats = json.loads(out.stdout)
+    sd, _ = loader.load_xml(str(f))
+    film_py, st = capi.Scene(sd).render(8, seed=3)
+    assert stats["normal_rays"] == st.normal_rays and stats["shadow_rays"] == st.shadow_rays
+    assert np.allclose(np.fromfile(str(raw), np.float32).reshape(48, 64, 5), film_py, rtol=1e-4, atol=1e-5)
+
+
+ENVMAP = """
+  <emitter type="envmap"><string name="filename" value="sky.pfm"/><float name="scale" value="0.5"/><float name="samplingWeight" value="2"/>
+    <transform name="toWorld"><rotate x="1" angle="90"/><rotate z="1" angle="30"/></transform></emitter>
+"""
+
+
+def _envmap_scene(scene_dir, tmp_path):
+    from mitsuba_amd import scene as S
+    img = S.test_environment_map(32, 16)
+    with open(tmp_path / "sky.pfm", "wb") as f:
+        f.write(b"PF\n32 16\n-1.0\n")
+        f.write(img[::-1].astype("<f4").tobytes())
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    f = tmp_path / "env.xml"
+    f.write_text(SCENE % ENVMAP)
+    return f, img
+
+
+def test_cli_envmap_emitter(scene_dir, tmp_path):
+    f, img = _envmap_scene(scene_dir, tmp_path)
+    d = _describe(f)
+    sd, _ = loader.load_xml(str(f))
+    env = [e for e in sd.emitters if e.get("pixels") is not None]
+    assert len(env) == 1 and len(d["envmaps"]) == 1
+    a, b = d["envmaps"][0], env[0]
+    assert sd.emitters[a["emitter"]] is b
+    assert a["size"] == [32, 16] and np.array_equal(b["pixels"], img)
+    assert np.isclose(a["sum_pixels"], img.astype(np.float64).sum(), rtol=1e-6)
+    assert (a["scale"], a["weight"]) == (0.5, 2.0) == (b["scale"], b["sampling_weight"])
+    assert np.allclose(a["to_world"], np.asarray(b["to_world"]).ravel(), atol=1e-6)
+    g = tmp_path / "bad.xml"
+    g.write_text(SCENE % '<emitter type="envmap"><string name="filename" value="nothing.exr"/></emitter>')
+    out = subprocess.run([CLI, str(g), "--describe"], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "nothing.exr" in out.stderr
+    with pytest.raises(loader.SceneFormatError, match="nothing.exr"):
+        loader.load_xml(str(g))
+
+
+@pytest.mark.gpu
+def test_cli_envmap_render_matches_binding(scene_dir, tmp_path):
+    from mitsuba_amd import capi
+    f, _ = _envmap_scene(scene_dir, tmp_path)
     raw = tmp_path / "film.raw"
     out = subprocess.run([CLI, str(f), "-o", str(tmp_path / "out.pfm"), "--film", str(raw), "--spp", "8", "--seed", "3"],
                          capture_output=True, text=True, timeout=300)

@@ -22,7 +22,8 @@ def _scenes():
             "blend": S.small_test_scene(blend=True), "textured": S.small_test_scene(textured=True),
             "textured_blend": S.small_test_scene(textured=True, blend=True, sky=(0.3, 0.3, 0.4)),
             "bitmap": S.small_test_scene(textured="bitmap"), "bitmap_blend": S.small_test_scene(textured="bitmap", blend=True, lamps=True),
-            "bump": S.small_test_scene(textured="bitmap", bumps=True, sky=(0.3, 0.3, 0.4))}
+            "bump": S.small_test_scene(textured="bitmap", bumps=True, sky=(0.3, 0.3, 0.4)),
+            "envmap": S.small_test_scene(sky="map", sky_weight=2.0), "envmap_only": S.small_test_scene(sky="map", area_lights=False, blend=True)}
 
 
 @pytest.fixture(scope="module")
@@ -261,7 +262,7 @@ def test_bsdf_sample_parity(material_pair):
 
 
 def test_emitter_sampling_parity(pairs):
-    for name in ("small", "veach", "sky", "lamps", "lamps_only"):
+    for name in ("small", "veach", "sky", "lamps", "lamps_only", "envmap", "envmap_only"):
         sd, g, o = pairs[name]
         rng = np.random.default_rng(31)
         n = 100000
@@ -278,6 +279,26 @@ def test_emitter_sampling_parity(pairs):
                 assert np.mean(np.isclose(x, y, rtol=1e-4, atol=1e-5)) > 0.9999
             else:
                 assert np.allclose(x, y, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["envmap", "envmap_only", "sky"])
+def test_environment_emitter_queries(pairs, name):
+    """Scene::evalEnvironment (envmap.cpp:380-410, bilinear lookup of level 0) and the emitter-sampling density of a
+    direction (envmap.cpp:545-551, :603-633; constant.cpp:218-233) for directions all over the sphere, the poles and
+    the seam of the map included."""
+    sd, g, o = pairs[name]
+    rng = np.random.default_rng(41)
+    d = rng.normal(size=(100000, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:6] = [[0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [1, 0, 0], [-1, 0, 0]]
+    rn = rng.normal(size=d.shape)
+    rn /= np.linalg.norm(rn, axis=1, keepdims=True)
+    rn[::3] = 0
+    vg, pg = g.env_eval(d, rn)
+    vo, po_ = o.env_eval(d, rn)
+    assert np.mean(np.isclose(vg, vo, rtol=1e-4, atol=1e-6).all(-1)) > 0.9999
+    assert np.mean(np.isclose(pg, po_, rtol=1e-4, atol=1e-7)) > 0.9999
+    assert vo.max() > 0 and po_.max() > 0
 
 
 def test_bitmap_texture_lookups(pairs):
@@ -338,7 +359,7 @@ def test_bump_and_normal_mapped_bsdf_parity(pairs):
 
 
 @pytest.mark.parametrize("name", ["small", "cornell", "veach", "mixed", "sky", "sky_hidden", "lamps", "lamps_only", "blend", "textured",
-                                  "textured_blend", "bitmap", "bitmap_blend", "bump"])
+                                  "textured_blend", "bitmap", "bitmap_blend", "bump", "envmap", "envmap_only"])
 def test_per_sample_radiance_parity(pairs, name):
     """MIPathTracer::Li per camera sample with the shared sample stream: same ray counts, same radiance."""
     sd, g, o = pairs[name]
@@ -358,7 +379,7 @@ def test_per_sample_radiance_parity(pairs, name):
     assert abs(Lg[..., :3].mean() - Lo[..., :3].mean()) < 2e-3 * Lo[..., :3].mean() + 1e-6
 
 
-@pytest.mark.parametrize("name", ["small", "mixed", "sky", "lamps", "blend", "textured_blend", "bitmap_blend", "bump"])
+@pytest.mark.parametrize("name", ["small", "mixed", "sky", "lamps", "blend", "textured_blend", "bitmap_blend", "bump", "envmap_only"])
 def test_pass_finishing_kernel_matches_wavefront_loop(gpu, name, monkeypatch):
     """Below MTSAMD_TAIL_BELOW live paths one launch follows each path to its end; above, every bounce is an extend /
     shade / shadow round of launches. Both run the same shading and traversal code: identical radiance and ray counts."""
@@ -382,7 +403,8 @@ def test_direct_integrator_parity(gpu, oracle_mod, ne, nb):
     lights, an environment, lamps, mixtures and a frosted dielectric."""
     for sd in (S.small_test_scene(sky=(0.6, 0.8, 1.2), lamps=True, blend=True), S.cornell_mixed(64, 64),
                S.small_test_scene(hide_emitters=1, sky=(0.2, 0.2, 0.3)), S.small_test_scene(textured=True, blend=True),
-               S.small_test_scene(textured="bitmap"), S.small_test_scene(textured="bitmap", bumps=True)):
+               S.small_test_scene(textured="bitmap"), S.small_test_scene(textured="bitmap", bumps=True),
+               S.small_test_scene(sky="map", hide_emitters=0), S.small_test_scene(sky="map", area_lights=False, hide_emitters=1)):
         sd.integrator.update(type="direct", emitter_samples=ne, bsdf_samples=nb)
         g, o = gpu.Scene(sd), oracle_mod.OracleScene(sd)
         Lg, pg, sg = g.li(4, seed=7)
@@ -438,7 +460,7 @@ def test_film_put_parity(pairs):
     assert np.allclose(fg, fo, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["small", "cornell", "mixed", "sky", "lamps", "blend", "textured", "bitmap", "bump"])
+@pytest.mark.parametrize("name", ["small", "cornell", "mixed", "sky", "lamps", "blend", "textured", "bitmap", "bump", "envmap"])
 def test_render_film_parity(pairs, name):
     sd, g, o = pairs[name]
     fg, sg = g.render(4, seed=9)
