@@ -97,6 +97,11 @@ static void describe(const LoadedScene &s) {
     }
     printf("], \"shape_triangles\": [");
     for (size_t i = 0; i < s.shapes.size(); ++i) printf("%s%u", i ? ", " : "", s.shapes[i].n_triangles);
+    printf("], \"shape_materials\": [");
+    for (size_t i = 0; i < s.shapes.size(); ++i) printf("%s%d", i ? ", " : "", s.shapes[i].material);
+    printf("], \"diffuse\": [");
+    for (size_t i = 0; i < s.materials.size(); ++i)
+        printf("%s[%.9g, %.9g, %.9g]", i ? ", " : "", s.materials[i].diffuse_reflectance[0], s.materials[i].diffuse_reflectance[1], s.materials[i].diffuse_reflectance[2]);
     printf("], \"emitter_records\": [");
     for (size_t i = 0; i < s.emitters.size(); ++i) {
         const mtsamd_emitter &e = s.emitters[i];

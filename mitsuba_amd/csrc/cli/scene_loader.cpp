@@ -758,6 +758,59 @@ void makeFilter(const Element *rf, mtsamd_film &film) {
     if (rc != MTSAMD_OK) throw Fail("invalid reconstruction filter parameters");
 }
 
+// WavefrontOBJ::addMaterial (src/shapes/obj.cpp:518-573): the BSDF an MTL material stands for. The Phong model (illum 2
+// with a specular colour and an exponent) and opacity masks are BSDFs this core does not have: such a material is an
+// error unless the scene gives the shape a <bsdf name="..."> of its own for it.
+mtsamd_material makeMtlMaterial(const std::string &name, const MtlMaterial &mm, const std::string &dir, const LoadOptions &opts, LoadedScene &out) {
+    if (mm.masked) throw Fail("OBJ material '" + name + "' has an opacity mask (the 'mask' BSDF is not supported); give the shape a <bsdf name=\"" + name + "\">");
+    int model = mm.illum;
+    const bool noSpecular = mm.mapKs.empty() && mm.ks[0] == 0 && mm.ks[1] == 0 && mm.ks[2] == 0;
+    if (model == 2 && (noSpecular || mm.ns == 0)) model = 1;
+    if (model == 2) throw Fail("OBJ material '" + name + "' uses the Phong model (illum 2), which is not supported; give the shape a <bsdf name=\"" + name + "\">");
+    Element e;
+    e.tag = "bsdf";
+    auto child = [&](Element &parent, const char *tag, const char *pname, const std::string &value) -> Element & {
+        parent.children.emplace_back(new Element());
+        Element &c = *parent.children.back();
+        c.tag = tag; c.attrs["name"] = pname; c.attrs["value"] = value;
+        return c;
+    };
+    const std::string savedDir = out.sceneDir;
+    out.sceneDir = dir;         // file names in the library are relative to the OBJ file (obj.cpp:229)
+    mtsamd_material m;
+    try {
+        if (model == 4 || model == 6 || model == 7 || model == 9) e.attrs["type"] = "dielectric";
+        else if (model == 5 || model == 8) { e.attrs["type"] = "conductor"; child(e, "string", "material", "Al"); }
+        else {
+            e.attrs["type"] = "diffuse";
+            if (mm.hasMapKd) {
+                e.children.emplace_back(new Element());
+                Element &t = *e.children.back();
+                t.tag = "texture"; t.attrs["type"] = "bitmap"; t.attrs["name"] = "reflectance";
+                child(t, "string", "filename", mm.mapKd);
+            } else {    // Spectrum::fromSRGB
+                char buf[96];
+                snprintf(buf, sizeof(buf), "%.9g, %.9g, %.9g", mm.kd[0], mm.kd[1], mm.kd[2]);
+                child(e, "srgb", "reflectance", buf);
+            }
+        }
+        m = makeBsdf(e, opts, out);
+        if (!mm.bump.empty()) {     // obj.cpp:551-560: a bitmap read without a gamma curve
+            Element t;
+            t.tag = "texture"; t.attrs["type"] = "bitmap";
+            child(t, "string", "filename", mm.bump);
+            child(t, "float", "gamma", "1");
+            m.frame_kind = MTSAMD_FRAME_BUMPMAP;
+            m.frame_texture = (int32_t) makeTexture(t, out);
+        }
+    } catch (...) {
+        out.sceneDir = savedDir;
+        throw;
+    }
+    out.sceneDir = savedDir;
+    return m;
+}
+
 }  // namespace
 
 // ---- public pieces -----------------------------------------------------------------------------------------------------------
@@ -869,14 +922,51 @@ std::string loadSerialized(const std::string &path, int shapeIndex, Mesh &out) {
 // Wavefront OBJ (src/shapes/obj.cpp:244-335,371-391): v / vn / vt / f, polygons as fans, negative indices not used by the
 // reference either; vertices are made unique per (position, texcoord, normal) index triple. Groups and materials are
 // ignored: the file becomes one mesh.
-std::string loadObj(const std::string &path, bool flipTexCoords, Mesh &out) {
+// WavefrontOBJ (src/shapes/obj.cpp:224-334): the file is cut into one mesh per group ("g") and per material change
+// ("usemtl") unless `collapse` is set; every mesh remembers the material that was current when it was closed.
+std::string loadObjParts(const std::string &path, bool flipTexCoords, bool collapse, std::vector<ObjPart> &parts, std::string &materialLibrary) {
     std::ifstream f(path);
     if (!f) return "cannot read " + path;
     std::vector<float> vp, vn, vt;
-    std::map<std::tuple<int, int, int>, uint32_t> unique;
-    bool anyN = false, anyT = false, allN = true, allT = true;
     struct Corner { int p, t, n; };
     std::vector<Corner> corners;
+    std::string materialName, error;
+    auto trimmed = [](const std::string &s) {
+        const size_t b = s.find_first_not_of(" \t\r\n"), e = s.find_last_not_of(" \t\r\n");
+        return b == std::string::npos ? std::string() : s.substr(b, e - b + 1);
+    };
+    auto flush = [&]() {        // createMesh (obj.cpp:611-714)
+        if (corners.empty()) return true;
+        ObjPart part;
+        part.material = materialName;
+        Mesh &out = part.mesh;
+        std::map<std::tuple<int, int, int>, uint32_t> unique;
+        bool anyN = false, anyT = false, allN = true, allT = true;
+        for (Corner &c : corners) {
+            if (c.p < 0) c.p += (int) (vp.size() / 3) + 1;
+            if (c.n < 0) c.n += (int) (vn.size() / 3) + 1;
+            if (c.t < 0) c.t += (int) (vt.size() / 2) + 1;
+            if (c.p <= 0 || (size_t) c.p > vp.size() / 3) { error = "OBJ face references a vertex that does not exist"; return false; }
+            if (c.n) { anyN = true; if ((size_t) c.n > vn.size() / 3 || c.n < 0) { error = "OBJ face references a normal that does not exist"; return false; } } else allN = false;
+            if (c.t) { anyT = true; if ((size_t) c.t > vt.size() / 2 || c.t < 0) { error = "OBJ face references a texture coordinate that does not exist"; return false; } } else allT = false;
+        }
+        const bool useN = anyN && allN, useT = anyT && allT;
+        for (const Corner &c : corners) {
+            const auto key = std::make_tuple(c.p, useT ? c.t : 0, useN ? c.n : 0);
+            auto it = unique.find(key);
+            if (it == unique.end()) {
+                const uint32_t idx = (uint32_t) (out.positions.size() / 3);
+                it = unique.emplace(key, idx).first;
+                out.positions.insert(out.positions.end(), &vp[3 * (c.p - 1)], &vp[3 * (c.p - 1)] + 3);
+                if (useN) out.normals.insert(out.normals.end(), &vn[3 * (c.n - 1)], &vn[3 * (c.n - 1)] + 3);
+                if (useT) out.texcoords.insert(out.texcoords.end(), &vt[2 * (c.t - 1)], &vt[2 * (c.t - 1)] + 2);
+            }
+            out.indices.push_back(it->second);
+        }
+        parts.push_back(std::move(part));
+        corners.clear();
+        return true;
+    };
     std::string line;
     while (std::getline(f, line)) {
         while (!line.empty() && line.back() == '\\') { std::string next; if (!std::getline(f, next)) break; line.pop_back(); line += next; }
@@ -886,6 +976,12 @@ std::string loadObj(const std::string &path, bool flipTexCoords, Mesh &out) {
         if (tag == "v") { float x, y, z; is >> x >> y >> z; vp.insert(vp.end(), { x, y, z }); }
         else if (tag == "vn") { float x, y, z; is >> x >> y >> z; vn.insert(vn.end(), { x, y, z }); }
         else if (tag == "vt") { float u, v; is >> u >> v; if (flipTexCoords) v = 1 - v; vt.insert(vt.end(), { u, v }); }
+        else if (tag == "g" && !collapse) { if (!flush()) return error; }
+        else if (tag == "usemtl") {
+            if (!collapse && !flush()) return error;
+            materialName = trimmed(line.substr(line.find("usemtl") + 6));
+        }
+        else if (tag == "mtllib") materialLibrary = trimmed(line.substr(line.find("mtllib") + 6));
         else if (tag == "f") {
             std::vector<Corner> poly;
             std::string tok;
@@ -904,25 +1000,51 @@ std::string loadObj(const std::string &path, bool flipTexCoords, Mesh &out) {
             for (size_t i = 2; i < poly.size(); ++i) { corners.push_back(poly[0]); corners.push_back(poly[i - 1]); corners.push_back(poly[i]); }
         }
     }
-    for (const Corner &c : corners) {
-        if (c.p <= 0 || (size_t) c.p > vp.size() / 3) return "OBJ face references a vertex that does not exist";
-        if (c.n) { anyN = true; if ((size_t) c.n > vn.size() / 3 || c.n < 0) return "OBJ face references a normal that does not exist"; } else allN = false;
-        if (c.t) { anyT = true; if ((size_t) c.t > vt.size() / 2 || c.t < 0) return "OBJ face references a texture coordinate that does not exist"; } else allT = false;
-    }
-    const bool useN = anyN && allN, useT = anyT && allT;
-    for (const Corner &c : corners) {
-        const auto key = std::make_tuple(c.p, useT ? c.t : 0, useN ? c.n : 0);
-        auto it = unique.find(key);
-        if (it == unique.end()) {
-            const uint32_t idx = (uint32_t) (out.positions.size() / 3);
-            it = unique.emplace(key, idx).first;
-            out.positions.insert(out.positions.end(), &vp[3 * (c.p - 1)], &vp[3 * (c.p - 1)] + 3);
-            if (useN) out.normals.insert(out.normals.end(), &vn[3 * (c.n - 1)], &vn[3 * (c.n - 1)] + 3);
-            if (useT) out.texcoords.insert(out.texcoords.end(), &vt[2 * (c.t - 1)], &vt[2 * (c.t - 1)] + 2);
+    if (!flush()) return error;
+    if (parts.empty()) return "OBJ file has no faces";
+    return "";
+}
+
+// The whole file as one mesh (what `collapse` gives)
+std::string loadObj(const std::string &path, bool flipTexCoords, Mesh &out) {
+    std::vector<ObjPart> parts;
+    std::string lib;
+    const std::string err = loadObjParts(path, flipTexCoords, true, parts, lib);
+    if (!err.empty()) return err;
+    out = std::move(parts[0].mesh);
+    return "";
+}
+
+// A material library (WavefrontOBJ::loadMaterialLibrary, obj.cpp:423-505): the statements the reference reads
+std::string loadMtl(const std::string &path, std::map<std::string, MtlMaterial> &out) {
+    std::ifstream f(path);
+    if (!f) return "";      // "Could not find referenced material library": a warning in the reference, no materials
+    std::string line, current;
+    while (std::getline(f, line)) {
+        std::istringstream is(line);
+        std::string tag;
+        if (!(is >> tag)) continue;
+        if (tag == "newmtl") {
+            const size_t b = line.find("newmtl") + 6;
+            current = line.substr(b);
+            const size_t s0 = current.find_first_not_of(" \t\r\n"), s1 = current.find_last_not_of(" \t\r\n");
+            current = s0 == std::string::npos ? std::string() : current.substr(s0, s1 - s0 + 1);
+            out[current] = MtlMaterial();
+        } else if (current.empty() && !out.count(current)) {
+            continue;
+        } else {
+            MtlMaterial &m = out[current];
+            if (tag == "Kd") is >> m.kd[0] >> m.kd[1] >> m.kd[2];
+            else if (tag == "Ks") is >> m.ks[0] >> m.ks[1] >> m.ks[2];
+            else if (tag == "Ns") is >> m.ns;
+            else if (tag == "illum") is >> m.illum;
+            else if (tag == "map_Kd") { is >> m.mapKd; m.hasMapKd = true; }
+            else if (tag == "map_Ks") { is >> m.mapKs; }
+            else if (tag == "bump") { is >> m.bump; }
+            else if (tag == "map_d") { m.masked = true; }
+            else if (tag == "d") { float v = 1; is >> v; m.masked = v != 1; }
         }
-        out.indices.push_back(it->second);
     }
-    if (out.indices.empty()) return "OBJ file has no faces";
     return "";
 }
 
@@ -1423,15 +1545,17 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
             } else if (el.tag == "shape") {
                 const Props p = parseProps(el);
                 int mat = -1;
+                std::map<std::string, int> namedMat;     // <bsdf name="..."> children: materials of an OBJ file by name (obj.cpp:736-757)
                 bool emitter = false;
                 float radiance[3] = { 1, 1, 1 }, weight = 1.0f;
                 for (const auto &c : el.children) {
+                    int made = -1;
                     if (c->tag == "ref") {
                         auto it = namedBsdfs.find(c->get("id"));
                         if (it == namedBsdfs.end()) return "reference to unknown id '" + c->get("id") + "'";
-                        mat = (int) it->second;
+                        made = (int) it->second;
                     } else if (c->tag == "bsdf") {
-                        mat = (int) bsdfIndex(*c);
+                        made = (int) bsdfIndex(*c);
                     } else if (c->tag == "emitter") {
                         if (c->get("type") != "area") return "only area emitters are supported";
                         const Props ep = parseProps(*c);
@@ -1441,42 +1565,79 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
                     } else if (c->tag == "medium" || c->tag == "subsurface") {
                         return "<" + c->tag + "> is not handled by the path integrator";
                     }
+                    if (made >= 0) {
+                        if (el.get("type") == "obj" && !c->get("name").empty()) namedMat[c->get("name")] = made;
+                        else mat = made;
+                    }
                 }
-                if (mat < 0) {      // Shape::configure attaches a default diffuse BSDF (src/librender/shape.cpp:48-53)
+                auto defaultMaterial = [&]() {      // Shape::configure attaches a default diffuse BSDF (src/librender/shape.cpp:48-53)
                     if (defaultBsdf < 0) {
                         Element e; e.tag = "bsdf"; e.attrs["type"] = "diffuse";
                         defaultBsdf = (int) addMaterial(out, makeBsdf(e, opts, out));
                     }
-                    mat = defaultBsdf;
-                }
-                Mesh mesh;
+                    return defaultBsdf;
+                };
+                std::vector<std::pair<Mesh, int>> meshes;       // mesh, material
                 const std::string type = el.get("type");
                 std::string err;
-                if (type == "serialized") err = loadSerialized(joinPath(base, getS(p, "filename", "")), (int) getF(p, "shapeIndex", 0), mesh);
-                else if (type == "obj") err = loadObj(joinPath(base, getS(p, "filename", "")), getB(p, "flipTexCoords", true), mesh);
-                else if (type == "ply") err = loadPly(joinPath(base, getS(p, "filename", "")), mesh);
-                else if (type == "cube") makeCube(mesh);
-                else return "shape type '" + type + "' is not supported (triangle meshes only)";
-                if (!err.empty()) return err;
-                const bool faceNormals = getB(p, "faceNormals", false) || mesh.faceNormals;
-                const bool flipNormals = getB(p, "flipNormals", false);
-                if (faceNormals) mesh.normals.clear();
-                applyToWorld(mesh, p.count("toWorld") ? p.at("toWorld").t : Mat4::identity());
-                if (p.count("maxSmoothAngle")) {        // serialized.cpp:204-209, ply.cpp:124-129, obj.cpp
-                    if (faceNormals) return "The properties 'maxSmoothAngle' and 'faceNormals' can't be specified at the same time!";
-                    rebuildTopology(mesh, (float) getF(p, "maxSmoothAngle", 0));
-                }
-                // TriMesh::computeNormals (src/librender/trimesh.cpp:606-672): flipNormals swaps the winding of a
-                // face-normal mesh, negates given vertex normals, and negates computed ones
-                if (faceNormals) {
-                    if (flipNormals)
-                        for (size_t t = 0; t + 2 < mesh.indices.size(); t += 3) std::swap(mesh.indices[t], mesh.indices[t + 1]);
-                } else if (!mesh.normals.empty()) {
-                    if (flipNormals) for (float &c : mesh.normals) c *= -1;
+                if (type == "obj") {
+                    const std::string objPath = joinPath(base, getS(p, "filename", ""));
+                    std::vector<ObjPart> parts;
+                    std::string library;
+                    err = loadObjParts(objPath, getB(p, "flipTexCoords", true), getB(p, "collapse", false), parts, library);
+                    if (!err.empty()) return err;
+                    std::map<std::string, MtlMaterial> mtl;
+                    if (!library.empty() && getB(p, "loadMaterials", true)) {
+                        err = loadMtl(joinPath(dirOf(objPath), library), mtl);
+                        if (!err.empty()) return err;
+                    }
+                    std::map<std::string, int> fromLibrary;
+                    const int shapeIndex = (int) getF(p, "shapeIndex", -1);
+                    for (size_t k = 0; k < parts.size(); ++k) {
+                        if (shapeIndex >= 0 && (int) k != shapeIndex) continue;
+                        int m = -1;
+                        const std::string &name = parts[k].material;
+                        if (namedMat.count(name)) m = namedMat[name];
+                        else if (mat >= 0) m = mat;
+                        else if (mtl.count(name)) {
+                            if (!fromLibrary.count(name)) fromLibrary[name] = (int) addMaterial(out, makeMtlMaterial(name, mtl[name], dirOf(objPath), opts, out));
+                            m = fromLibrary[name];
+                        } else m = defaultMaterial();
+                        meshes.emplace_back(std::move(parts[k].mesh), m);
+                    }
+                    if (meshes.empty()) return "Unable to load the OBJ file: shape index is out of range";
+                    if (emitter && meshes.size() > 1) return "Cannot attach an emitter to an OBJ file containing multiple objects!";
                 } else {
-                    computeNormals(mesh, flipNormals);
+                    Mesh mesh;
+                    if (type == "serialized") err = loadSerialized(joinPath(base, getS(p, "filename", "")), (int) getF(p, "shapeIndex", 0), mesh);
+                    else if (type == "ply") err = loadPly(joinPath(base, getS(p, "filename", "")), mesh);
+                    else if (type == "cube") makeCube(mesh);
+                    else return "shape type '" + type + "' is not supported (triangle meshes only)";
+                    if (!err.empty()) return err;
+                    meshes.emplace_back(std::move(mesh), mat >= 0 ? mat : defaultMaterial());
                 }
-                addMesh(out, mesh, (uint32_t) mat, emitter ? radiance : nullptr, weight);
+                for (auto &entry : meshes) {
+                    Mesh &mesh = entry.first;
+                    const bool faceNormals = getB(p, "faceNormals", false) || mesh.faceNormals;
+                    const bool flipNormals = getB(p, "flipNormals", false);
+                    if (faceNormals) mesh.normals.clear();
+                    applyToWorld(mesh, p.count("toWorld") ? p.at("toWorld").t : Mat4::identity());
+                    if (p.count("maxSmoothAngle")) {        // serialized.cpp:204-209, ply.cpp:124-129, obj.cpp:336-343
+                        if (faceNormals) return "The properties 'maxSmoothAngle' and 'faceNormals' can't be specified at the same time!";
+                        rebuildTopology(mesh, (float) getF(p, "maxSmoothAngle", 0));
+                    }
+                    // TriMesh::computeNormals (src/librender/trimesh.cpp:606-672): flipNormals swaps the winding of a
+                    // face-normal mesh, negates given vertex normals, and negates computed ones
+                    if (faceNormals) {
+                        if (flipNormals)
+                            for (size_t t = 0; t + 2 < mesh.indices.size(); t += 3) std::swap(mesh.indices[t], mesh.indices[t + 1]);
+                    } else if (!mesh.normals.empty()) {
+                        if (flipNormals) for (float &c : mesh.normals) c *= -1;
+                    } else {
+                        computeNormals(mesh, flipNormals);
+                    }
+                    addMesh(out, mesh, (uint32_t) entry.second, emitter ? radiance : nullptr, weight);
+                }
             } else if (el.tag == "bsdf") {
                 // handled above
             } else if (el.tag == "emitter") {

@@ -3,7 +3,8 @@
 // film / rfilter / bsdf / texture (checkerboard, gridtexture, bitmap, scale) / shape / emitter / ref / transform /
 // include / default / alias and the scalar property tags
 // with "$parameter" substitution; triangle meshes from `.serialized` containers (src/librender/trimesh.cpp:175-294),
-// Wavefront OBJ files (src/shapes/obj.cpp, whole file as one mesh), Stanford PLY files (src/shapes/ply.cpp) and the
+// Wavefront OBJ files (src/shapes/obj.cpp: one mesh per group / material change, materials from the MTL library or from
+// named <bsdf> children), Stanford PLY files (src/shapes/ply.cpp) and the
 // `cube` plugin (src/shapes/cube.cpp). Everything else is rejected with a message -- nothing is
 // silently substituted. The result owns flat arrays and hands out a mtsamd_scene_desc for the C ABI.
 #pragma once
@@ -56,9 +57,20 @@ struct Mesh {
     bool faceNormals = false;
 };
 
+// One mesh of a Wavefront OBJ file with the name of the material that was current for it, and a material of an MTL file
+struct ObjPart { Mesh mesh; std::string material; };
+struct MtlMaterial {
+    float kd[3] = { 0, 0, 0 }, ks[3] = { 0, 0, 0 }, ns = 0;      // sRGB values as written in the file
+    int illum = 0;
+    std::string mapKd, mapKs, bump;
+    bool hasMapKd = false, masked = false;
+};
+
 // Each loader returns an empty string on success or an error message.
 std::string loadSerialized(const std::string &path, int shapeIndex, Mesh &out);
 std::string loadObj(const std::string &path, bool flipTexCoords, Mesh &out);
+std::string loadObjParts(const std::string &path, bool flipTexCoords, bool collapse, std::vector<ObjPart> &parts, std::string &materialLibrary);
+std::string loadMtl(const std::string &path, std::map<std::string, MtlMaterial> &out);
 std::string loadPly(const std::string &path, Mesh &out);
 void makeCube(Mesh &out);
 std::string loadSceneXml(const std::string &path, const LoadOptions &opts, LoadedScene &out);

@@ -765,3 +765,61 @@ def test_cli_envmap_render_matches_binding(scene_dir, tmp_path):
     film_py, st = capi.Scene(sd).render(8, seed=3)
     assert stats["normal_rays"] == st.normal_rays and stats["shadow_rays"] == st.shadow_rays
     assert np.allclose(np.fromfile(str(raw), np.float32).reshape(48, 64, 5), film_py, rtol=1e-4, atol=1e-5)
+
+
+def test_cli_obj_groups_and_material_library(scene_dir, tmp_path):
+    """WavefrontOBJ (src/shapes/obj.cpp:224-334,423-573,736-757): one mesh per group and per material change, BSDFs from
+    the MTL library (diffuse from Kd as sRGB or from map_Kd, dielectric for illum 4, a bump map), overridden by <bsdf
+    name="..."> children; shapeIndex picks one mesh, collapse keeps the file whole."""
+    rng = np.random.default_rng(4)
+    _write_png(str(tmp_path / "tiles.png"), rng.integers(0, 256, (8, 8, 3)))
+    (tmp_path / "parts.mtl").write_text(
+        "newmtl red\nKd 0.8 0.2 0.1\nillum 1\n"
+        "newmtl glass\nKd 1 1 1\nillum 4\n"
+        "newmtl tiled\nKd 1 1 1\nmap_Kd tiles.png\nbump tiles.png\nillum 0\n"
+        "newmtl shiny\nKd 0.5 0.5 0.5\nKs 0.5 0.5 0.5\nNs 40\nillum 2\n")
+    quad = lambda z: "v -1 -1 %g\nv 1 -1 %g\nv 1 1 %g\nv -1 1 %g\n" % (z, z, z, z)
+    (tmp_path / "parts.obj").write_text(
+        "mtllib parts.mtl\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n" + quad(0) + quad(1) + quad(2) + quad(3) +
+        "g first\nusemtl red\nf 1/1 2/2 3/3 4/4\n"
+        "usemtl glass\nf 5/1 6/2 7/3\nf 5/1 7/3 8/4\n"
+        "g second\nusemtl tiled\nf 9/1 10/2 11/3 12/4\n"
+        "usemtl shiny\nf -4/1 -3/2 -2/3 -1/4\n")
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    shape = '<shape type="obj"><string name="filename" value="parts.obj"/>%s</shape>'
+    override = '<bsdf type="roughconductor" name="shiny"><string name="material" value="none"/></bsdf>'
+    f = tmp_path / "obj.xml"
+    f.write_text(SCENE % (shape % override))
+    base = _describe(scene_dir / "scene.xml")
+    d = _describe(f)
+    n0, m0 = base["shapes"], base["materials"]
+    assert d["shapes"] == n0 + 4 and d["shape_triangles"][n0:] == [2, 2, 2, 2]
+    mats = d["shape_materials"][n0:]
+    types = [d["material_types"][m] for m in mats]
+    assert types == [0, 3, 0, 1]            # diffuse, dielectric, diffuse (textured, bumped), the override
+    srgb = lambda c: c / 12.92 if c <= 0.04045 else ((c + 0.055) / 1.055) ** 2.4
+    assert np.allclose(d["diffuse"][mats[0]], [srgb(0.8), srgb(0.2), srgb(0.1)], rtol=1e-5)
+    tex = d["material_textures"][mats[2]]
+    assert tex[0] > 0 and d["textures"][tex[0] - 1]["type"] == 3 and d["textures"][tex[0] - 1]["size"] == [8, 8, 3]
+    assert d["frames"][mats[2]][0] == 1 and d["textures"][d["frames"][mats[2]][1] - 1]["type"] == 3
+    assert d["has_texcoords"]
+    # without the override the Phong material is refused by name
+    f.write_text(SCENE % (shape % ""))
+    out = subprocess.run([CLI, str(f), "--describe"], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "'shiny'" in out.stderr and "Phong" in out.stderr
+    # an unnamed BSDF covers every mesh; shapeIndex picks one; collapse makes one mesh of the file
+    f.write_text(SCENE % (shape % '<ref id="metal"/>'))
+    d = _describe(f)
+    assert d["shapes"] == n0 + 4 and len(set(d["shape_materials"][n0:])) == 1 and d["materials"] == m0
+    f.write_text(SCENE % (shape % '<integer name="shapeIndex" value="1"/>'))
+    d = _describe(f)
+    assert d["shapes"] == n0 + 1 and d["material_types"][d["shape_materials"][-1]] == 3
+    f.write_text(SCENE % (shape % '<boolean name="collapse" value="true"/><ref id="grey"/>'))
+    d = _describe(f)
+    assert d["shapes"] == n0 + 1 and d["shape_triangles"][-1] == 8
+    f.write_text(SCENE % (shape % (override + '<emitter type="area"/>')))
+    out = subprocess.run([CLI, str(f), "--describe"], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "multiple objects" in out.stderr
+    f.write_text(SCENE % (shape % '<boolean name="loadMaterials" value="false"/>'))
+    d = _describe(f)
+    assert [d["material_types"][m] for m in d["shape_materials"][n0:]] == [0, 0, 0, 0]
