@@ -411,6 +411,16 @@ int mtsamd_rtrans_reduce(const void *dat, uint64_t size, float eta, float alpha,
 int mtsamd_spd_to_rgb(const float *wavelengths, const float *values, uint32_t n, float rgb[3]);
 int mtsamd_spd_file_to_rgb(const char *path, float rgb[3]);
 
+/* The spectral values of a scene file, as SceneHandler converts them in the three-sample build
+   (src/librender/scenehandler.cpp:534-620): <spectrum value="l1:v1, l2:v2, ..."> and <spectrum filename=...> are
+   InterpolatedSpectrum::zeroExtend (src/libcore/spectrum.cpp:630-648; needs two entries), the conversion above, and a
+   clamp of negative channels to zero; <blackbody temperature= scale=> integrates Planck's law
+   (BlackBodySpectrum::eval, spectrum.cpp:483-495) the same way, clamps, then scales. MTSAMD_EINVAL as above, for
+   fewer than two entries and for a temperature that is not positive. Need no device. */
+int mtsamd_spectrum_value_to_rgb(const float *wavelengths, const float *values, uint32_t n, float rgb[3]);
+int mtsamd_spectrum_file_to_rgb(const char *path, float rgb[3]);
+int mtsamd_blackbody_to_rgb(float temperature, float scale, float rgb[3]);
+
 /* Bitmap(EAuto, stream) followed by the conversion BitmapTexture's MIP map applies (src/libcore/bitmap.cpp:2534-2541
    and :284-286 for the gamma of a file, src/libcore/fmtconv.cpp:1093-1160 for undoing it; src/textures/bitmap.cpp:246-278):
    reads an image file into linear floats, 1 channel (luminance and luminance-alpha files) or 3 (RGB and RGBA files;

@@ -110,7 +110,8 @@ EXPORTS = ["mtsamd_last_error", "mtsamd_init", "mtsamd_scene_create", "mtsamd_sc
            "mtsamd_sample_emitter_direct", "mtsamd_camera_rays", "mtsamd_li", "mtsamd_film_put", "mtsamd_film_develop_ldr", "mtsamd_abi_version", "mtsamd_sizeof", "mtsamd_filter_table", "mtsamd_rng_stream",
            "mtsamd_rtrans_reduce", "mtsamd_filter_gaussian", "mtsamd_filter_box", "mtsamd_bvh_host_info", "mtsamd_bvh_max_depth",
            "mtsamd_trace_device_static", "mtsamd_trace_device_static_max", "mtsamd_render_multi", "mtsamd_spd_to_rgb",
-           "mtsamd_spd_file_to_rgb", "mtsamd_bsdf_query_uv", "mtsamd_texture_eval", "mtsamd_image_load", "mtsamd_image_free", "mtsamd_env_eval"]
+           "mtsamd_spd_file_to_rgb", "mtsamd_bsdf_query_uv", "mtsamd_texture_eval", "mtsamd_image_load", "mtsamd_image_free", "mtsamd_env_eval",
+           "mtsamd_spectrum_value_to_rgb", "mtsamd_spectrum_file_to_rgb", "mtsamd_blackbody_to_rgb"]
 
 _lib = None
 ABI_VERSION = 12    # MTSAMD_ABI_VERSION of include/mtsamd.h
@@ -465,21 +466,33 @@ def bvh_max_depth() -> int:
     return int(lib().mtsamd_bvh_max_depth())
 
 
-def spd_to_rgb(wavelengths, values):
-    """Linear RGB of a measured spectrum (see mtsamd_spd_to_rgb); host code only, no device needed."""
+def spd_to_rgb(wavelengths, values, scene_value=False):
+    """Linear RGB of a measured spectrum (see mtsamd_spd_to_rgb); host code only, no device needed. `scene_value`:
+    convert as a <spectrum> element of a scene file is converted (mtsamd_spectrum_value_to_rgb)."""
     w = np.ascontiguousarray(wavelengths, np.float32)
     v = np.ascontiguousarray(values, np.float32)
     if w.shape != v.shape or w.ndim != 1:
         raise ValueError("wavelengths and values must be 1-D arrays of one length")
     out = np.zeros(3, np.float32)
-    _check(lib().mtsamd_spd_to_rgb(_fp(w), _fp(v), C.c_uint32(len(w)), _fp(out)))
+    fn = lib().mtsamd_spectrum_value_to_rgb if scene_value else lib().mtsamd_spd_to_rgb
+    if fn(_fp(w), _fp(v), C.c_uint32(len(w)), _fp(out)) != 0:
+        raise MtsamdError("spectrum: wavelengths must increase%s" % (", and at least two entries are needed" if scene_value else ""))
     return out
 
 
-def spd_file_to_rgb(path):
+def spd_file_to_rgb(path, scene_value=False):
     out = np.zeros(3, np.float32)
-    if lib().mtsamd_spd_file_to_rgb(os.fsencode(path), _fp(out)) != 0:
+    fn = lib().mtsamd_spectrum_file_to_rgb if scene_value else lib().mtsamd_spd_file_to_rgb
+    if fn(os.fsencode(path), _fp(out)) != 0:
         raise MtsamdError('InterpolatedSpectrum: could not read "%s"' % path)
+    return out
+
+
+def blackbody_to_rgb(temperature, scale=1.0):
+    """mtsamd_blackbody_to_rgb: a <blackbody> element as linear RGB."""
+    out = np.zeros(3, np.float32)
+    if lib().mtsamd_blackbody_to_rgb(C.c_float(temperature), C.c_float(scale), _fp(out)) != 0:
+        raise MtsamdError("blackbody: the temperature must be positive")
     return out
 
 

@@ -160,6 +160,11 @@ typedef std::map<std::string, Value> Props;
 
 float srgbToLinear(float c) { return c <= 0.04045f ? c / 12.92f : std::pow((c + 0.055f) / 1.055f, 2.4f); }
 
+// Directory against which <spectrum filename=...> is resolved: the scene file's (set by loadSceneXml)
+thread_local std::string g_spectrumDir;
+
+// scenehandler.cpp:503-624 in the three-sample build (where Spectrum::getD65() is 1, so that both intents of a single
+// value give the same constant)
 void parseSpectrum(const Element &n, float out[3]) {
     const std::string v = n.get("value");
     if (n.tag == "rgb") {
@@ -179,12 +184,55 @@ void parseSpectrum(const Element &n, float out[3]) {
             for (int i = 0; i < 3; ++i) f[i] = (float) g[i];
         }
         for (int i = 0; i < 3; ++i) out[i] = srgbToLinear(f[i]);
+    } else if (n.tag == "blackbody") {
+        std::string t = n.get("temperature");
+        while (!t.empty() && isspace((unsigned char) t.back())) t.pop_back();
+        if (!t.empty() && toupper((unsigned char) t.back()) == 'K') t.pop_back();
+        if (t.empty()) throw Fail("<blackbody> needs a temperature");
+        const float scale = n.has("scale") ? (float) std::stod(n.get("scale")) : 1.0f;
+        if (mtsamd_blackbody_to_rgb((float) std::stod(t), scale, out) != MTSAMD_OK) throw Fail("<blackbody>: the temperature must be positive");
     } else if (n.tag == "spectrum") {
-        std::vector<double> f = numbers(v);
-        if (v.find(':') != std::string::npos || f.size() != 1)
-            throw Fail("wavelength-sampled <spectrum> values need the spectral-to-RGB conversion of src/libcore/spectrum.cpp, "
-                       "which this loader does not implement");
-        out[0] = out[1] = out[2] = (float) f[0];     // a constant spectrum has the same value in every RGB channel
+        if (n.has("value") == n.has("filename")) throw Fail("<spectrum>: please provide one of 'value' or 'filename'");
+        if (n.has("filename")) {
+            if (n.has("intent")) throw Fail("<spectrum>: 'intent' and 'filename' cannot be specified at the same time!");
+            std::string file = n.get("filename");
+            if (!file.empty() && file[0] != '/' && !g_spectrumDir.empty()) file = g_spectrumDir + "/" + file;
+            if (mtsamd_spectrum_file_to_rgb(file.c_str(), out) != MTSAMD_OK) throw Fail("InterpolatedSpectrum: could not read \"" + file + "\"");
+            return;
+        }
+        if (v.find(':') == std::string::npos) {
+            const std::vector<double> f = numbers(v);
+            if (f.size() == 1) {
+                if (n.has("intent")) {
+                    const std::string intent = lower(n.get("intent"));
+                    if (intent != "reflectance" && intent != "illuminant")
+                        throw Fail("Invalid intent \"" + intent + "\", must be \"reflectance\" or \"illuminant\"");
+                }
+                out[0] = out[1] = out[2] = (float) f[0];
+                return;
+            }
+            if (n.has("intent")) throw Fail("<spectrum>: 'intent' can only be specified when given a single-valued argument.");
+            if (f.size() != 3) throw Fail("Invalid spectrum value specified (length does not match the current spectral discretization!)");
+            for (int i = 0; i < 3; ++i) out[i] = (float) f[i];
+            return;
+        }
+        if (n.has("intent")) throw Fail("<spectrum>: 'intent' can only be specified when given a single-valued argument.");
+        std::vector<float> lambda, value;       // wavelength:value pairs separated by commas and / or blanks
+        std::string token;
+        auto flush = [&]() {
+            if (token.empty()) return;
+            const size_t colon = token.find(':');
+            if (colon == std::string::npos || token.find(':', colon + 1) != std::string::npos || colon == 0 || colon + 1 == token.size())
+                throw Fail("Invalid spectrum->value mapping specified");
+            lambda.push_back((float) std::stod(token.substr(0, colon)));
+            value.push_back((float) std::stod(token.substr(colon + 1)));
+            token.clear();
+        };
+        for (char c : v) { if (c == ',' || c == ' ' || c == '\t' || c == '\n') flush(); else token.push_back(c); }
+        flush();
+        if (lambda.size() < 2) throw Fail("InterpolatedSpectrum::zeroExtend() -- at least 2 entries are needed!");
+        if (mtsamd_spectrum_value_to_rgb(lambda.data(), value.data(), (uint32_t) lambda.size(), out) != MTSAMD_OK)
+            throw Fail("InterpolatedSpectrum: spectral power distribution values must be provided in order of increasing wavelength!");
     } else {
         throw Fail("unsupported spectrum tag <" + n.tag + ">");
     }
@@ -200,7 +248,7 @@ Props parseProps(const Element &node) {
         else if (c.tag == "integer") { v.kind = Value::Int; v.i = std::stol(c.get("value")); v.f = (double) v.i; }
         else if (c.tag == "boolean") { v.kind = Value::Bool; v.b = lower(c.get("value")) == "true"; }
         else if (c.tag == "string") { v.kind = Value::String; v.s = c.get("value"); }
-        else if (c.tag == "rgb" || c.tag == "srgb" || c.tag == "spectrum") { v.kind = Value::Rgb; parseSpectrum(c, v.rgb); }
+        else if (c.tag == "rgb" || c.tag == "srgb" || c.tag == "spectrum" || c.tag == "blackbody") { v.kind = Value::Rgb; parseSpectrum(c, v.rgb); }
         else if (c.tag == "transform") { v.kind = Value::Transform; v.t = parseTransform(c); }
         else if (c.tag == "point" || c.tag == "vector") {   // scenehandler.cpp:443-459
             v.kind = Value::Vec3;
@@ -1409,6 +1457,7 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
         expandIncludes(*root, base, params, 0);
         std::map<std::string, uint32_t> namedBsdfs;
         out.sceneDir = base;
+        g_spectrumDir = base;
         for (const auto &el : root->children)       // textures first: BSDFs refer to them by id
             if (el->tag == "texture") {
                 const uint32_t idx = makeTexture(*el, out);

@@ -6,6 +6,8 @@
 //   src/libcore/spectrum.cpp:575-602   InterpolatedSpectrum file format
 //   src/libcore/spectrum.cpp:650-714   InterpolatedSpectrum::average / eval
 //   src/libcore/quad.cpp:305-409       GaussLobattoIntegrator
+// and the <spectrum> / <blackbody> values of a scene file (src/librender/scenehandler.cpp:534-620), which add
+// InterpolatedSpectrum::zeroExtend (spectrum.cpp:630-648), BlackBodySpectrum::eval (:483-495) and a clamp at zero.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -64,9 +66,21 @@ Spd matchingFunction(int column) {
     return s;
 }
 
+// Planck's law in the reference's units and operation order (BlackBodySpectrum::eval, spectrum.cpp:483-495)
+struct BlackBody {
+    float temperature;
+    float eval(float l) const {
+        const double c = 299792458, k = 1.3806488e-23, h = 6.62606957e-34;
+        const double lambda = l * 1e-9;
+        const double I = (2 * h * c * c) * std::pow(lambda, -5.0) / ((std::exp((h / k) * c / (lambda * temperature)) - 1.0) * 1e9);
+        return (float) I;
+    }
+};
+
 // Adaptive Gauss-Lobatto quadrature of a product of two spectra (quad.cpp:305-409, without the convergence estimate).
-struct Lobatto {
-    const Spd &s1, &s2;
+template <typename First> struct Lobatto {
+    const First &s1;
+    const Spd &s2;
     size_t maxEvals = 10000, evals = 0;
     float absError = 1e-4f, relError = 1e-4f;   // the reference's Epsilon
 
@@ -118,9 +132,9 @@ struct Lobatto {
     }
 };
 
-float productAverage(const Spd &s1, const Spd &s2, float lo, float hi) {
+template <typename First> float productAverage(const First &s1, const Spd &s2, float lo, float hi) {
     if (hi <= lo) return 0.0f;
-    Lobatto q{s1, s2};
+    Lobatto<First> q{s1, s2};
     float integral = 0;
     const size_t nSteps = std::max((size_t) 1, (size_t) std::ceil((hi - lo) / 50));
     const float stepSize = (hi - lo) / nSteps;
@@ -132,7 +146,7 @@ float productAverage(const Spd &s1, const Spd &s2, float lo, float hi) {
     return integral / (hi - lo);
 }
 
-void toRgb(const Spd &s, float *rgb) {
+template <typename Spectrum> void toRgb(const Spectrum &s, float *rgb) {
     static const Spd cieX = matchingFunction(1), cieY = matchingFunction(2), cieZ = matchingFunction(3);
     const float start = kCie[0][0], end = kCie[kCieSamples - 1][0];
     float X = productAverage(s, cieX, start, end), Y = productAverage(s, cieY, start, end), Z = productAverage(s, cieZ, start, end);
@@ -143,9 +157,25 @@ void toRgb(const Spd &s, float *rgb) {
     rgb[2] =  0.055648f * X + -0.204043f * Y +  1.057311f * Z;
 }
 
-}  // namespace
+// InterpolatedSpectrum::zeroExtend (spectrum.cpp:630-648): one entry of value zero at the average spacing before a
+// non-zero first entry and after a non-zero last one
+bool zeroExtend(Spd &s) {
+    if (s.lambda.size() < 2) return false;
+    float avgSpacing = 0;
+    for (size_t i = 0; i + 1 < s.lambda.size(); ++i) avgSpacing += s.lambda[i + 1] - s.lambda[i];
+    avgSpacing /= s.lambda.size() - 1;
+    if (s.value.front() != 0) {
+        s.lambda.insert(s.lambda.begin(), s.lambda.front() - avgSpacing);
+        s.value.insert(s.value.begin(), 0.0f);
+    }
+    if (s.value.back() != 0) {
+        s.lambda.push_back(s.lambda.back() + avgSpacing);
+        s.value.push_back(0.0f);
+    }
+    return true;
+}
 
-extern "C" int mtsamd_spd_to_rgb(const float *wavelengths, const float *values, uint32_t n, float *rgb) {
+int convert(const float *wavelengths, const float *values, uint32_t n, bool sceneValue, float *rgb) {
     if (!wavelengths || !values || !rgb) return MTSAMD_EINVAL;
     Spd s;
     for (uint32_t i = 0; i < n; ++i) {
@@ -153,11 +183,36 @@ extern "C" int mtsamd_spd_to_rgb(const float *wavelengths, const float *values, 
         s.lambda.push_back(wavelengths[i]);
         s.value.push_back(values[i]);
     }
+    if (sceneValue && !zeroExtend(s)) return MTSAMD_EINVAL;
     toRgb(s, rgb);
+    if (sceneValue) for (int i = 0; i < 3; ++i) rgb[i] = std::max(0.0f, rgb[i]);       // Spectrum::clampNegative
     return MTSAMD_OK;
 }
 
-extern "C" int mtsamd_spd_file_to_rgb(const char *path, float *rgb) {
+int convertFile(const char *path, bool sceneValue, float *rgb);
+
+}  // namespace
+
+extern "C" int mtsamd_spd_to_rgb(const float *wavelengths, const float *values, uint32_t n, float *rgb) {
+    return convert(wavelengths, values, n, false, rgb);
+}
+
+extern "C" int mtsamd_spectrum_value_to_rgb(const float *wavelengths, const float *values, uint32_t n, float *rgb) {
+    return convert(wavelengths, values, n, true, rgb);
+}
+
+extern "C" int mtsamd_blackbody_to_rgb(float temperature, float scale, float *rgb) {
+    if (!rgb || !(temperature > 0)) return MTSAMD_EINVAL;
+    toRgb(BlackBody{temperature}, rgb);
+    for (int i = 0; i < 3; ++i) rgb[i] = std::max(0.0f, rgb[i]) * scale;
+    return MTSAMD_OK;
+}
+
+extern "C" int mtsamd_spd_file_to_rgb(const char *path, float *rgb) { return convertFile(path, false, rgb); }
+extern "C" int mtsamd_spectrum_file_to_rgb(const char *path, float *rgb) { return convertFile(path, true, rgb); }
+
+namespace {
+int convertFile(const char *path, bool sceneValue, float *rgb) {
     if (!path || !rgb) return MTSAMD_EINVAL;
     std::ifstream is(path);
     if (!is) return MTSAMD_EINVAL;
@@ -173,5 +228,6 @@ extern "C" int mtsamd_spd_file_to_rgb(const char *path, float *rgb) {
         value.push_back(v);
     }
     if (lambda.empty()) return MTSAMD_EINVAL;
-    return mtsamd_spd_to_rgb(lambda.data(), value.data(), (uint32_t) lambda.size(), rgb);
+    return convert(lambda.data(), value.data(), (uint32_t) lambda.size(), sceneValue, rgb);
 }
+}  // namespace

@@ -165,7 +165,12 @@ def _srgb_to_linear(c):
     return c / 12.92 if c <= 0.04045 else ((c + 0.055) / 1.055) ** 2.4
 
 
+_spectrum_dir = [None]      # directory against which <spectrum filename=...> is resolved: the scene file's (set by load_xml)
+
+
 def _spectrum(node) -> tuple:
+    """scenehandler.cpp:503-624 in the three-sample build (where Spectrum::getD65() is 1, so that both intents of a
+    single value give the same constant)"""
     tag, v = node.tag, node.get("value")
     if tag == "rgb":
         f = _floats(v)
@@ -177,13 +182,60 @@ def _spectrum(node) -> tuple:
             f = [int(v[i:i + 2], 16) / 255.0 for i in (1, 3, 5)]
         else:
             f = _floats(v)
+            if len(f) == 1:
+                f = f * 3
         return tuple(_srgb_to_linear(c) for c in f[:3])
+    from . import capi      # the conversions below are the library's (host code, no device needed)
+    if tag == "blackbody":
+        t = (node.get("temperature") or "").strip()
+        if t[-1:].upper() == "K":
+            t = t[:-1]
+        if not t:
+            raise SceneFormatError("<blackbody> needs a temperature")
+        try:
+            return tuple(float(c) for c in capi.blackbody_to_rgb(float(t), float(node.get("scale", 1.0))))
+        except capi.MtsamdError as e:
+            raise SceneFormatError("<blackbody>: %s" % e)
     if tag == "spectrum":
-        f = _floats(v) if ":" not in v else None
-        if f is not None and len(f) == 1:
-            return (f[0],) * 3      # a constant spectrum maps to the same value in every RGB channel
-        raise SceneFormatError("wavelength-sampled <spectrum> values need the spectral-to-RGB conversion of "
-                               "src/libcore/spectrum.cpp, which this loader does not implement")
+        has_file, has_intent = node.get("filename") is not None, node.get("intent") is not None
+        if (v is not None) == has_file:
+            raise SceneFormatError("<spectrum>: please provide one of 'value' or 'filename'")
+        if has_file:
+            if has_intent:
+                raise SceneFormatError("<spectrum>: 'intent' and 'filename' cannot be specified at the same time!")
+            path = node.get("filename")
+            if not os.path.isabs(path) and _spectrum_dir[0]:
+                path = os.path.join(_spectrum_dir[0], path)
+            try:
+                return tuple(float(c) for c in capi.spd_file_to_rgb(path, scene_value=True))
+            except capi.MtsamdError as e:
+                raise SceneFormatError(str(e))
+        if ":" not in v:
+            f = _floats(v)
+            if len(f) == 1:
+                if has_intent and node.get("intent").lower() not in ("reflectance", "illuminant"):
+                    raise SceneFormatError('Invalid intent "%s", must be "reflectance" or "illuminant"' % node.get("intent").lower())
+                return (f[0],) * 3
+            if has_intent:
+                raise SceneFormatError("<spectrum>: 'intent' can only be specified when given a single-valued argument.")
+            if len(f) != 3:
+                raise SceneFormatError("Invalid spectrum value specified (length does not match the current spectral discretization!)")
+            return tuple(f)
+        if has_intent:
+            raise SceneFormatError("<spectrum>: 'intent' can only be specified when given a single-valued argument.")
+        lam, val = [], []
+        for token in v.replace(",", " ").split():
+            parts = token.split(":")
+            if len(parts) != 2 or not parts[0] or not parts[1]:
+                raise SceneFormatError("Invalid spectrum->value mapping specified")
+            lam.append(float(parts[0])), val.append(float(parts[1]))
+        if len(lam) < 2:
+            raise SceneFormatError("InterpolatedSpectrum::zeroExtend() -- at least 2 entries are needed!")
+        try:
+            return tuple(float(c) for c in capi.spd_to_rgb(lam, val, scene_value=True))
+        except capi.MtsamdError:
+            raise SceneFormatError("InterpolatedSpectrum: spectral power distribution values must be provided in order of "
+                                   "increasing wavelength!")
     raise SceneFormatError("unsupported spectrum tag <%s>" % tag)
 
 
@@ -235,7 +287,7 @@ def _props(node) -> Dict:
             out[n] = c.get("value").lower() == "true"
         elif c.tag == "string":
             out[n] = c.get("value")
-        elif c.tag in ("rgb", "srgb", "spectrum"):
+        elif c.tag in ("rgb", "srgb", "spectrum", "blackbody"):
             out[n] = _spectrum(c)
         elif c.tag == "transform":
             out[n] = _transform(c)
@@ -503,6 +555,7 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
     if root.tag != "scene":
         raise SceneFormatError("root element must be <scene>")
     base = os.path.dirname(os.path.abspath(path))
+    _spectrum_dir[0] = base
     b = S.SceneBuilder()
     named_bsdfs: Dict[str, int] = {}
     info = dict(integrator_type=None, sample_count=4)

@@ -7,6 +7,9 @@ every rounding happens where the reference's `Float` arithmetic rounds. Nothing 
   src/libcore/spectrum.cpp:575-602   InterpolatedSpectrum(path)
   src/libcore/spectrum.cpp:650-714   InterpolatedSpectrum::average, ::eval
   src/libcore/quad.cpp:305-409       GaussLobattoIntegrator::integrate / calculateAbsTolerance / adaptiveGaussLobattoStep
+  src/libcore/spectrum.cpp:630-648   InterpolatedSpectrum::zeroExtend
+  src/libcore/spectrum.cpp:483-495   BlackBodySpectrum::eval
+  src/librender/scenehandler.cpp:534-620   <blackbody> and <spectrum> values of a scene file
 
 Parity unpinned: the reference holds no expected RGB triple for any of its spectra (no test, no fixture, no log), so
 this restatement is checked only against an independent dense Riemann sum of the same integrand.
@@ -76,6 +79,43 @@ class Spd:
                 result = result + F(0.5) * (((F(1) - ta) * fa + ta * fb) + ((F(1) - tb) * fa + tb * fb)) * (cb - ca)
             e += 1
         return result / (hi - lo)
+
+
+    def zero_extended(self):
+        """spectrum.cpp:630-648"""
+        assert len(self.lam) >= 2
+        spacing = F(0)
+        for i in range(len(self.lam) - 1):
+            spacing = spacing + (self.lam[i + 1] - self.lam[i])
+        spacing = spacing / F(len(self.lam) - 1)
+        lam, val = list(self.lam), list(self.val)
+        if val[0] != 0:
+            lam.insert(0, lam[0] - spacing), val.insert(0, F(0))
+        if val[-1] != 0:
+            lam.append(lam[-1] + spacing), val.append(F(0))
+        return Spd(lam, val)
+
+
+class BlackBody:
+    """spectrum.cpp:483-495: Planck's law in double precision, W m^-2 nm^-1 sr^-1, rounded to single on return"""
+
+    def __init__(self, temperature):
+        self.temperature = F(temperature)
+
+    def eval(self, l):
+        c, k, h = 299792458.0, 1.3806488e-23, 6.62606957e-34
+        lam = float(F(l)) * 1e-9
+        x = (h / k) * c / (lam * float(self.temperature))
+        e = math.exp(x) if x < 709 else math.inf
+        return F((2 * h * c * c) * lam ** -5.0 / ((e - 1.0) * 1e9))
+
+
+def scene_value(spectrum, scale=1.0):
+    """What SceneHandler stores for a <spectrum> / <blackbody> element (scenehandler.cpp:534-620): conversion, clamp at
+    zero, scale. `spectrum` is a BlackBody or an Spd (which is zero-extended first)."""
+    if isinstance(spectrum, Spd):
+        spectrum = spectrum.zero_extended()
+    return np.maximum(to_rgb(spectrum), F(0)) * F(scale)
 
 
 _ALPHA, _BETA = F(math.sqrt(2.0 / 3.0)), F(1.0 / math.sqrt(5.0))
@@ -164,8 +204,6 @@ def to_rgb_dense(spd, samples_per_nm=200):
     """The same quantity by a midpoint Riemann sum in double precision (no adaptive quadrature): what the adaptive
     rule converges to, up to its 1e-4 tolerances."""
     cie = cie_tables().astype(np.float64)
-    lam = np.asarray(spd.lam, np.float64)
-    val = np.asarray(spd.val, np.float64)
 
     def reversed_lerp(xs, vs, l):
         i = np.clip(np.searchsorted(xs, l, side="left"), 1, len(xs) - 1)
@@ -175,7 +213,11 @@ def to_rgb_dense(spd, samples_per_nm=200):
 
     n = int((cie[-1, 0] - cie[0, 0]) * samples_per_nm)
     l = cie[0, 0] + (np.arange(n) + 0.5) / samples_per_nm
-    s = reversed_lerp(lam, val, l)
+    if isinstance(spd, BlackBody):
+        c, k, h = 299792458.0, 1.3806488e-23, 6.62606957e-34
+        s = (2 * h * c * c) * (l * 1e-9) ** -5.0 / (np.expm1((h / k) * c / (l * 1e-9 * float(spd.temperature))) * 1e9)
+    else:
+        s = reversed_lerp(np.asarray(spd.lam, np.float64), np.asarray(spd.val, np.float64), l)
     xyz = [np.mean(s * reversed_lerp(cie[:, 0], cie[:, c], l)) for c in (1, 2, 3)]
     ynorm = np.trapezoid(cie[:, 2], cie[:, 0]) / (cie[-1, 0] - cie[0, 0])
     X, Y, Z = (v / ynorm for v in xyz)

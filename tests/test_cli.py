@@ -2,6 +2,7 @@
 and one end-to-end render on the GPU compared with the same scene rendered through the ctypes binding."""
 import json
 import os
+import re
 import struct
 import subprocess
 import zlib
@@ -823,3 +824,54 @@ def test_cli_obj_groups_and_material_library(scene_dir, tmp_path):
     f.write_text(SCENE % (shape % '<boolean name="loadMaterials" value="false"/>'))
     d = _describe(f)
     assert [d["material_types"][m] for m in d["shape_materials"][n0:]] == [0, 0, 0, 0]
+
+
+def test_cli_spectral_values(scene_dir, tmp_path):
+    """<spectrum value="l:v, ...">, <spectrum filename=...>, <spectrum value="a b c">, single values with an intent and
+    <blackbody> (scenehandler.cpp:534-620): both loaders store what the library's conversions return."""
+    from mitsuba_amd import capi
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    (tmp_path / "paint.spd").write_text("# measured\n400 0.1\n500 0.3\n600 0.6\n700 0.4\n")
+    body = ('<bsdf type="diffuse"><spectrum name="reflectance" value="400:0.2, 500:0.7 600:0.3,700:0.1"/></bsdf>'
+            '<bsdf type="diffuse"><spectrum name="reflectance" filename="paint.spd"/></bsdf>'
+            '<bsdf type="diffuse"><spectrum name="reflectance" value="0.1 0.2 0.3"/></bsdf>'
+            '<bsdf type="diffuse"><spectrum name="reflectance" value="0.4" intent="Reflectance"/></bsdf>'
+            '<shape type="serialized"><string name="filename" value="meshes.serialized"/><integer name="shapeIndex" value="1"/>'
+            '<emitter type="area"><blackbody name="radiance" temperature="3200K" scale="1e-3"/></emitter></shape>'
+            '<emitter type="point"><blackbody name="intensity" temperature=" 6504 "/></emitter>'
+            '<emitter type="constant"><spectrum name="radiance" value="0.25"/></emitter>')
+    f = tmp_path / "spectral.xml"
+    f.write_text(SCENE % body)
+    base = _describe(scene_dir / "scene.xml")
+    d = _describe(f)
+    sd, _ = loader.load_xml(str(f))
+    m0, e0 = 2, base["emitters"]        # after the two named BSDFs of the fixture; the shapes' default BSDF comes last
+    want = [capi.spd_to_rgb([400, 500, 600, 700], [0.2, 0.7, 0.3, 0.1], scene_value=True),
+            capi.spd_file_to_rgb(str(tmp_path / "paint.spd"), scene_value=True), np.float32([0.1, 0.2, 0.3]), np.float32([0.4] * 3)]
+    for k, w in enumerate(want):
+        assert np.array_equal(np.float32(d["diffuse"][m0 + k]), w), k
+        assert np.array_equal(np.float32(sd.materials[m0 + k]["diffuse_reflectance"]), w), k
+    assert want[0][1] > want[0][0] > 0 and want[0][1] > want[0][2]       # a spectrum that peaks at 500 nm is green
+    lights = [capi.blackbody_to_rgb(3200.0, 1e-3), capi.blackbody_to_rgb(6504.0), np.float32([0.25] * 3)]
+    got = [np.float32(e["radiance"]) for e in d["emitter_records"][e0:]]
+    assert len(got) == 3
+    for k, w in enumerate(lights):
+        assert np.array_equal(got[k], w), k
+        assert np.array_equal(np.float32(sd.emitters[e0 + k]["radiance"]), w), k
+    assert lights[0][0] > lights[0][1] > lights[0][2] > 0
+    for body, msg in (('<bsdf type="diffuse"><spectrum name="reflectance" value="500:1"/></bsdf>', "at least 2 entries"),
+                      ('<bsdf type="diffuse"><spectrum name="reflectance" value="500:1, 400:1"/></bsdf>', "increasing wavelength"),
+                      ('<bsdf type="diffuse"><spectrum name="reflectance" value="500:1:2, 600:1"/></bsdf>', "Invalid spectrum->value mapping"),
+                      ('<bsdf type="diffuse"><spectrum name="reflectance" value="1 2"/></bsdf>', "length does not match"),
+                      ('<bsdf type="diffuse"><spectrum name="reflectance" value="1" filename="paint.spd"/></bsdf>', "one of 'value' or 'filename'"),
+                      ('<bsdf type="diffuse"><spectrum name="reflectance" filename="paint.spd" intent="reflectance"/></bsdf>', "cannot be specified at the same time"),
+                      ('<bsdf type="diffuse"><spectrum name="reflectance" value="1" intent="warm"/></bsdf>', 'Invalid intent "warm"'),
+                      ('<bsdf type="diffuse"><spectrum name="reflectance" value="400:1, 500:1" intent="reflectance"/></bsdf>', "single-valued argument"),
+                      ('<bsdf type="diffuse"><spectrum name="reflectance" filename="missing.spd"/></bsdf>', "missing.spd"),
+                      ('<bsdf type="diffuse"><blackbody name="reflectance" temperature="K"/></bsdf>', "needs a temperature")):
+        g = tmp_path / "bad.xml"
+        g.write_text(SCENE % body)
+        out = subprocess.run([CLI, str(g), "--describe"], capture_output=True, text=True, timeout=60)
+        assert out.returncode != 0 and msg in out.stderr, (msg, out.stderr)
+        with pytest.raises(loader.SceneFormatError, match=re.escape(msg)):
+            loader.load_xml(str(g))
