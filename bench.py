@@ -107,13 +107,13 @@ def measured_counters(args):
     """Hardware counters of the closest-hit launches (tools/profile_round.sh runs the separate rocprofv3 --pmc passes
     and writes profiles/*_extend_pmc.json). Only a profile taken on THIS build (same hash of the device sources) of this
     workload and pass size is used; otherwise None."""
-    if args.workload != "config3" or (args.width, args.height) != (1920, 1080):
+    if (args.width, args.height) != (1920, 1080):
         return None, None
     want = kernel_source_hash()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_extend_pmc.json")), reverse=True):
         with open(path) as f:
             d = json.load(f)
-        if d.get("source_hash") == want and d.get("spp_step") == args.spp_step:
+        if d.get("source_hash") == want and d.get("spp_step") == args.spp_step and d.get("workload", "config3") == args.workload:
             return d, "profiles/" + os.path.basename(path)
     return None, None
 
@@ -276,8 +276,10 @@ def main():
                            "launches": int(launches), "avg_launch_ms": avg_ms, "rays_per_launch": wave_rays / launches,
                            "algorithmic_bytes_per_launch": alg,
                            "counters": {k: pmc[k] for k in ("l1_hit", "l2_hit", "valu_lane_utilisation", "wait_fraction", "valu_issue_bound_ms") if pmc and k in pmc} or None,
-                           "note": "the structure (BVH %.1f MB + triangle records %.1f MB) lives in the L2s and the Infinity Cache, so HBM is not the ceiling of this kernel: "
-                                   "frac_of_hbm_peak is printed for reference only" % (info.node_bytes / 1e6, info.triangle_bytes / 1e6)}
+                           "note": ("the structure (BVH %.1f MB + triangle records %.1f MB) lives in the L2s and the Infinity Cache, so HBM is not the ceiling of this kernel: "
+                                    "frac_of_hbm_peak is printed for reference only" if structure <= INFINITY_CACHE_BYTES * 3 // 4 else
+                                    "the structure (BVH %.1f MB + triangle records %.1f MB) exceeds the Infinity Cache: what leaves the L2s is served by HBM at its "
+                                    "measured rate for dependent record fetches") % (info.node_bytes / 1e6, info.triangle_bytes / 1e6)}
         del scratch
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-launch hardware-counter figures of one kernel from rocprofv3 --pmc passes, as JSON for bench.py.
 
-  python tools/pmc_json.py <kernel key> <spp per step> <dir> [<dir> ...] > profiles/rNN_extend_pmc.json
+  python tools/pmc_json.py <kernel key>[@<workload>] <spp per step> <dir> [<dir> ...] > profiles/rNN_extend_pmc.json
 
 <kernel key>: "extend" (closest-hit instantiation of k_trace), "shadow" (any-hit), "shade" (k_shade).
 Every directory is one pass; counters are summed over the dispatches of the kernel and divided by their number.
@@ -32,6 +32,7 @@ def matches(kernel, key):
 
 def main():
     key, spp = sys.argv[1], int(sys.argv[2])
+    key, _, workload = key.partition("@")
     sums, counts = defaultdict(float), defaultdict(int)
     for d in sys.argv[3:]:
         for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -42,7 +43,7 @@ def main():
                         counts[row["Counter_Name"]] += 1
     per = {c: sums[c] / counts[c] for c in sums}
     import bench
-    out = {"kernel": key, "spp_step": spp, "source_hash": bench.kernel_source_hash(), "launches": max(counts.values()) if counts else 0,
+    out = {"kernel": key, "workload": workload or "config3", "spp_step": spp, "source_hash": bench.kernel_source_hash(), "launches": max(counts.values()) if counts else 0,
            "per_launch": per}
     if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
         out["fabric_bytes_per_launch"] = (2.0 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024.0
