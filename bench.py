@@ -46,6 +46,10 @@ INFINITY_CACHE_BYTES = 256 << 20
 def build_scene(args):
     if args.workload == "config3":
         return S.config3(args.width, args.height), "synthetic 1M-triangle microfacet scene (roughconductor GGX + roughplastic GGX + dielectric), %dx%d, path integrator" % (args.width, args.height)
+    if args.workload.startswith("config3tex"):       # config3tex, config3tex:trilinear, ...
+        flt = args.workload.partition(":")[2] or "ewa"
+        return S.config3_textured(args.width, args.height, flt), ("config 3 with 1024x1024 bitmap textures (%s) on ground, plastic and conductor colours and a "
+                                                                  "bump-mapped ground, %dx%d, path integrator" % (flt, args.width, args.height))
     if args.workload == "config5":
         return S.config5(args.width, args.height), "synthetic 10M-triangle many-emitter scene, max depth 16, %dx%d" % (args.width, args.height)
     if args.workload == "cornell":

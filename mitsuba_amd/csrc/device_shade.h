@@ -847,24 +847,29 @@ __device__ __attribute__((noinline)) inline void bitmapGradient(const DevScene *
 }
 
 // ---- Texture2D::eval(its, filter = true) (src/librender/texture.cpp:112-121) ------------------------------------------
-MTS_DEV V3 textureEval(const DevScene &sc, const DevTexture &t, const SurfUV &q) {
-    const float x = q.u * t.uScale + t.uOffset, y = q.v * t.vScale + t.vOffset;
+// checkerboard / gridtexture at transformed coordinates, before the texture's scale factor
+MTS_DEV V3 proceduralEval(const DevTexture &t, float x, float y) {
     bool second;
     if (t.type == 1) {      // Checkerboard::eval (src/textures/checkerboard.cpp:66-75); math::modulo of a truncated int
         int xi = (int) (x * 2) % 2, yi = (int) (y * 2) % 2;
         if (xi < 0) xi += 2;
         if (yi < 0) yi += 2;
         second = (2 * xi - 1) * (2 * yi - 1) != 1;
-    } else if (t.type == 2) {   // GridTexture::eval (src/textures/gridtexture.cpp:75-88)
+    } else {                // GridTexture::eval (src/textures/gridtexture.cpp:75-88)
         float fx = x - (float) (int) floorf(x), fy = y - (float) (int) floorf(y);
         if (fx > 0.5f) fx -= 1;
         if (fy > 0.5f) fy -= 1;
         second = fabsf(fx) < t.lineWidth || fabsf(fy) < t.lineWidth;
-    } else {
-        const float4 r = bitmapEval(&sc, &t, x, y, make_float4(q.dudx * t.uScale, q.dvdx * t.vScale, q.dudy * t.uScale, q.dvdy * t.vScale), q.filtered);
+    }
+    return second ? ld3(t.color1) : ld3(t.color0);
+}
+MTS_DEV V3 textureEval(const DevScene &sc, const DevTexture &t, const SurfUV &q) {
+    const float x = q.u * t.uScale + t.uOffset, y = q.v * t.vScale + t.vOffset;
+    if (t.type == 3) {
+        const float4 r = bitmapEval(sc.self, &t, x, y, make_float4(q.dudx * t.uScale, q.dvdx * t.vScale, q.dudy * t.uScale, q.dvdy * t.vScale), q.filtered);
         return mk(r.x, r.y, r.z) * t.scale;
     }
-    return (second ? ld3(t.color1) : ld3(t.color0)) * t.scale;
+    return proceduralEval(t, x, y) * t.scale;
 }
 
 // Texture2D::evalGradient(its, gradient) (texture.cpp:123-141): the bitmap's bilinear gradient (bitmap.cpp:456-480) or
@@ -873,16 +878,12 @@ MTS_DEV void textureGradient(const DevScene &sc, const DevTexture &t, float u, f
     const float x = u * t.uScale + t.uOffset, y = v * t.vScale + t.vOffset;
     if (t.type == 3) {
         float g[6];
-        bitmapGradient(&sc, &t, x, y, g);
+        bitmapGradient(sc.self, &t, x, y, g);
         const V3 f = ld3(t.color0);
         gu = mk(g[0], g[1], g[2]) * f; gv = mk(g[3], g[4], g[5]) * f;
     } else {
-        // the lookups below apply the uv transform themselves: hand them coordinates whose transform is (x, y), (x + eps, y), (x, y + eps)
-        DevTexture plain = t;
-        plain.uScale = plain.vScale = 1.0f; plain.uOffset = plain.vOffset = 0.0f; plain.scale = 1.0f;
         const float eps = kEpsilon;
-        const V3 value = textureEval(sc, plain, surfUV(x, y)), valueU = textureEval(sc, plain, surfUV(x + eps, y)),
-                 valueV = textureEval(sc, plain, surfUV(x, y + eps));
+        const V3 value = proceduralEval(t, x, y), valueU = proceduralEval(t, x + eps, y), valueV = proceduralEval(t, x, y + eps);
         gu = (valueU - value) * (1 / eps); gv = (valueV - value) * (1 / eps);
     }
     gu = gu * t.uScale * t.scale; gv = gv * t.vScale * t.scale;    // Texture2D::evalGradient, then ScaleTexture::evalGradient
@@ -1109,21 +1110,66 @@ MTS_DEV V3 mixSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, 
     return result / pdf;
 }
 
+// The three mixture functions are real calls: each holds a copy of every BSDF model, and inlined into the shading
+// kernels they would triple the code there and spill hundreds of registers. What they need of the mixture record travels by
+// value (13 words), the rest of the arguments likewise, so nothing of the caller has to live in memory.
+struct MixRec { int n; float w0, w1, w2, w3, c1, c2, c3, c4; uint32_t k0, k1, k2, k3, types; };
+MTS_DEV MixRec mixRec(const DevMaterial &m) {
+    MixRec r;
+    r.n = m.variant; r.w0 = m.diffuse[0]; r.w1 = m.diffuse[1]; r.w2 = m.diffuse[2]; r.w3 = __uint_as_float(m.rtransOffset);
+    r.c1 = m.specular[0]; r.c2 = m.specular[1]; r.c3 = m.specular[2]; r.c4 = __uint_as_float(m.rtransN);
+    r.k0 = __float_as_uint(m.condEta[0]); r.k1 = __float_as_uint(m.condEta[1]); r.k2 = __float_as_uint(m.condEta[2]); r.k3 = __float_as_uint(m.condK[0]);
+    r.types = (uint32_t) m.distribution;
+    return r;
+}
+MTS_DEV void mixMaterial(const MixRec &r, DevMaterial &m) {
+    m.type = 8; m.variant = r.n; m.diffuse[0] = r.w0; m.diffuse[1] = r.w1; m.diffuse[2] = r.w2; m.rtransOffset = __float_as_uint(r.w3);
+    m.specular[0] = r.c1; m.specular[1] = r.c2; m.specular[2] = r.c3; m.rtransN = __float_as_uint(r.c4);
+    m.condEta[0] = __uint_as_float(r.k0); m.condEta[1] = __uint_as_float(r.k1); m.condEta[2] = __uint_as_float(r.k2); m.condK[0] = __uint_as_float(r.k3);
+    m.distribution = (decltype(m.distribution)) r.types;
+}
+__device__ __attribute__((noinline)) inline float4 mixEvalCall(const DevScene *scp, MixRec r, V3 wi, V3 wo, SurfUV uv) {
+    DevMaterial m;
+    mixMaterial(r, m);
+    const V3 v = mixEval(*scp, m, wi, wo, uv);
+    return make_float4(v.x, v.y, v.z, 0.0f);
+}
+__device__ __attribute__((noinline)) inline float mixPdfCall(const DevScene *scp, MixRec r, V3 wi, V3 wo, SurfUV uv) {
+    DevMaterial m;
+    mixMaterial(r, m);
+    return mixPdf(*scp, m, wi, wo, uv);
+}
+struct MixSampled { float4 weightPdf, woEta; uint32_t sampledType; };
+__device__ __attribute__((noinline)) inline void mixSampleCall(const DevScene *scp, MixRec r, V3 wi, float sx, float sy, float su, SurfUV uv, MixSampled *out) {
+    DevMaterial m;
+    mixMaterial(r, m);
+    V3 wo; float pdf, eta; uint32_t sampledType;
+    const V3 w = mixSample(*scp, m, wi, sx, sy, su, wo, pdf, eta, sampledType, uv);
+    out->weightPdf = make_float4(w.x, w.y, w.z, pdf);
+    out->woEta = make_float4(wo.x, wo.y, wo.z, eta);
+    out->sampledType = sampledType;
+}
+
 // What the integrator calls on the record that answers for this side: a mixture (only compiled in with MIX) or a plain model
 template <bool RD = true, bool MIX = true>
 MTS_DEV V3 bsdfEvalAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, const SurfUV &uv = surfUV(0, 0)) {
-    if (MIX && m.type == 8) return mixEval(sc, m, wi, wo, uv);
+    if (MIX && m.type == 8) { const float4 r = mixEvalCall(sc.self, mixRec(m), wi, wo, uv); return mk(r.x, r.y, r.z); }
     return bsdfEval<RD>(sc, m, wi, wo);
 }
 template <bool RD = true, bool MIX = true>
 MTS_DEV float bsdfPdfAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, const SurfUV &uv = surfUV(0, 0)) {
-    if (MIX && m.type == 8) return mixPdf(sc, m, wi, wo, uv);
+    if (MIX && m.type == 8) return mixPdfCall(sc.self, mixRec(m), wi, wo, uv);
     return bsdfPdf<RD>(sc, m, wi, wo);
 }
 template <bool RD = true, bool MIX = true>
 MTS_DEV V3 bsdfSampleAny(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, float su, V3 &wo, float &pdf, float &eta, uint32_t &sampledType,
                          const SurfUV &uv = surfUV(0, 0)) {
-    if (MIX && m.type == 8) return mixSample(sc, m, wi, sx, sy, su, wo, pdf, eta, sampledType, uv);
+    if (MIX && m.type == 8) {
+        MixSampled r;
+        mixSampleCall(sc.self, mixRec(m), wi, sx, sy, su, uv, &r);
+        wo = mk(r.woEta.x, r.woEta.y, r.woEta.z); pdf = r.weightPdf.w; eta = r.woEta.w; sampledType = r.sampledType;
+        return mk(r.weightPdf.x, r.weightPdf.y, r.weightPdf.z);
+    }
     return bsdfSample<RD>(sc, m, wi, sx, sy, su, wo, pdf, eta, sampledType);
 }
 
@@ -1169,7 +1215,7 @@ __device__ __attribute__((noinline)) inline float4 envSampleDirect(const DevScen
 MTS_DEV V3 sampleEnvironmentDirect(const DevScene &sc, V3 ref, V3 refN, float sx, float sy, float emPdf, DirectRec &dRec) {
     if (sc.envIsMap) {
         float4 dd;
-        const float4 r = envSampleDirect(&sc, ref, sx, sy, emPdf, &dd);
+        const float4 r = envSampleDirect(sc.self, ref, sx, sy, emPdf, &dd);
         dRec.d = mk(dd.x, dd.y, dd.z); dRec.dist = dd.w; dRec.pdf = r.w;
         return mk(r.x, r.y, r.z);
     }
@@ -1213,7 +1259,7 @@ MTS_DEV V3 envToLocal(const DevScene &sc, V3 v) {
 }
 MTS_DEV MipRef envMipRef(const DevScene &sc) {
     MipRef m;
-    m.sc = &sc; m.first = sc.envFirstLevel; m.levels = sc.envLevels; m.bcu = 1u; m.bcv = 0u; m.maxAnisotropy = 10.0f;    // repeat / clamp (envmap.cpp:141-146)
+    m.sc = sc.self; m.first = sc.envFirstLevel; m.levels = sc.envLevels; m.bcu = 1u; m.bcv = 0u; m.maxAnisotropy = 10.0f;    // repeat / clamp (envmap.cpp:141-146)
     return m;
 }
 MTS_DEV float intervalToTent(float sample) {        // src/libcore/warp.cpp:151-163
@@ -1302,13 +1348,13 @@ __device__ __attribute__((noinline)) inline float4 envSampleDirect(const DevScen
 // sampling would have produced its direction (pdfEmitterDirect), for the constant emitter or the map
 MTS_DEV V3 environmentRadiance(const DevScene &sc, V3 rayD) {
     if (!sc.envIsMap) return ld3(sc.envRadiance);
-    const float4 r = envEvalMap(&sc, rayD, false, rayD, rayD);
+    const float4 r = envEvalMap(sc.self, rayD, false, rayD, rayD);
     return mk(r.x, r.y, r.z);
 }
 MTS_DEV float environmentPdf(const DevScene &sc, V3 rayD, float refCos) {
     if (!sc.envIsMap) return environmentPdfDirect(sc, refCos);
     const V3 v = envToLocal(sc, rayD);
-    return envPdfDirection(&sc, v.x, v.y, v.z) * sc.envPdfDiscrete;     // EnvironmentMap::pdfDirect (envmap.cpp:545-551)
+    return envPdfDirection(sc.self, v.x, v.y, v.z) * sc.envPdfDiscrete;     // EnvironmentMap::pdfDirect (envmap.cpp:545-551)
 }
 
 // PointEmitter::sampleDirect (src/emitters/point.cpp:131-147), SpotEmitter::sampleDirect with falloffCurve
@@ -1442,7 +1488,7 @@ MTS_DEV void cameraOffsetRays(const DevScene &sc, const PassParams &pp, float2 p
 MTS_DEV V3 cameraEnvironmentRadiance(const DevScene &sc, const PassParams &pp, float2 pos, V3 d) {
     V3 rxD, ryD;
     cameraOffsetRays(sc, pp, pos, d, rxD, ryD);
-    const float4 r = envEvalMap(&sc, d, true, rxD, ryD);
+    const float4 r = envEvalMap(sc.self, d, true, rxD, ryD);
     return mk(r.x, r.y, r.z);
 }
 

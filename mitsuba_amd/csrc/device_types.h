@@ -139,6 +139,9 @@ struct DevScene {
     const float *envCdfRows;    // envH + 1
     const float *envCdfCols;    // envH rows of envW + 1
     const float *envRowWeights; // envH
+    // This record in device memory: what the device functions that are real calls receive instead of the address of the
+    // kernel argument (taking that address makes every lane keep a private copy of the whole record).
+    const DevScene *self;
 };
 
 // Wavefront queue of live paths (structure of arrays, one float4/uint4 stream each)

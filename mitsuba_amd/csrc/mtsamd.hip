@@ -109,7 +109,7 @@ struct mtsamd_scene {
     DevScene dev;
     int device = 0;
     DeviceBuffer nodes, tris, shadeTris, shadeUV, shapes, materials, emitters, deltaEmitters,
-        emitterCdf, areaCdf, rtrans, textures, materialTextures, plainTextures, mipLevels, texels, ewaLut, envCdfRows, envCdfCols, envRowWeights;
+        emitterCdf, areaCdf, rtrans, textures, materialTextures, plainTextures, mipLevels, texels, ewaLut, envCdfRows, envCdfCols, envRowWeights, devSelf;
     // work buffers of the wavefront loop
     DeviceBuffer fetchHeads, qbuf[2][6], hits, sbuf[3], sampleL, samplePos, shadowFlags, counters, scratch[8];
     size_t capacity = 0;
@@ -303,6 +303,9 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
     d.envCdfRows = h.envCdfRows.empty() ? nullptr : s->envCdfRows.as<float>();
     d.envCdfCols = h.envCdfRows.empty() ? nullptr : s->envCdfCols.as<float>();
     d.envRowWeights = h.envRowWeights.empty() ? nullptr : s->envRowWeights.as<float>();
+    if (s->devSelf.ensure(sizeof(DevScene)) != hipSuccess) { delete s; return fail(MTSAMD_EDEVICE, "out of device memory"); }
+    d.self = s->devSelf.as<DevScene>();
+    if (hipMemcpy(s->devSelf.ptr, &d, sizeof(DevScene), hipMemcpyHostToDevice) != hipSuccess) { delete s; return fail(MTSAMD_EDEVICE, "upload of the scene record failed"); }
     s->dev = d;
     const char *ct = getenv("MTSAMD_COUNT_TRAVERSAL");
     s->countTraversal = ct && *ct == '1';

@@ -634,10 +634,13 @@ def cornell_mixed(width=256, height=256, max_depth=-1) -> SceneData:
 
 
 def microfacet_field(n_objects=64, subdiv=5, ground_res=90, width=1920, height=1080, seed=42,
-                     max_depth=-1, n_lights=4, light_radiance=20.0, emitters_grid=0) -> SceneData:
+                     max_depth=-1, n_lights=4, light_radiance=20.0, emitters_grid=0, textured=None) -> SceneData:
     """Configs 3-5: a field of displaced icosphere "blobs" over a tessellated ground plane.
     Objects cycle through roughconductor (GGX), roughplastic (GGX) and dielectric; the ground is
-    diffuse; quad area lights hang above. subdiv=5 gives 20480 triangles per object."""
+    diffuse; quad area lights hang above. subdiv=5 gives 20480 triangles per object.
+    `textured` (a MIP filter name: "ewa", "trilinear", "bilinear", "nearest"): the same geometry with texture
+    coordinates, 1024 x 1024 bitmap textures on the ground's and the plastic's diffuse colour and on the conductor's
+    specular colour, and a bump map on the ground."""
     rng = np.random.default_rng(seed)
     b = SceneBuilder()
     m_cond = b.add_material(roughconductor(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), alpha=0.15, distribution="ggx"))
@@ -657,10 +660,29 @@ def microfacet_field(n_objects=64, subdiv=5, ground_res=90, width=1920, height=1
             p, f, n = blob(subdiv, rng)
             c = np.array([(gx + 0.5) * spacing - ext + rng.uniform(-0.2, 0.2),
                           (gy + 0.5) * spacing - ext + rng.uniform(-0.2, 0.2), 1.25], np.float32)
-            b.add_mesh(p + c, f, (m_cond, m_plast, m_glass)[k % 3], normals=n)
+            uv = None
+            if textured:        # latitude-longitude coordinates of the undisplaced direction
+                d = p / np.linalg.norm(p, axis=1, keepdims=True)
+                uv = np.stack([np.arctan2(d[:, 1], d[:, 0]) / (2 * np.pi) + 0.5, np.arccos(np.clip(d[:, 2], -1, 1)) / np.pi], -1)
+            b.add_mesh(p + c, f, (m_cond, m_plast, m_glass)[k % 3], normals=n, texcoords=uv)
             k += 1
     gp, gf = grid(ground_res, ground_res, (-ext - 4, -ext - 4), (ext + 4, ext + 4), 0.0)
-    b.add_mesh(gp, gf, m_ground)
+    b.add_mesh(gp, gf, m_ground, texcoords=(gp[:, :2] + (ext + 4)) / (2 * (ext + 4)) if textured else None)
+    if textured:
+        trng = np.random.default_rng(seed + 1)
+        yy, xx = np.mgrid[0:1024, 0:1024]
+
+        def image(freq, lo, hi):       # band-limited pattern plus texel noise, three channels
+            base = 0.5 + 0.5 * np.sin(xx * (2 * np.pi * freq / 1024))[..., None] * np.cos(yy * (2 * np.pi * freq / 1024))[..., None]
+            img = lo + (hi - lo) * (0.75 * base + 0.25 * trng.random((1024, 1024, 3)))
+            return img.astype(np.float32)
+
+        M = b.materials
+        M[m_ground]["diffuse_texture"] = b.add_texture(bitmap(image(24, 0.15, 0.75), filter_type=textured, uscale=6.0, vscale=6.0))
+        M[m_plast]["diffuse_texture"] = b.add_texture(bitmap(image(7, 0.1, 0.7), filter_type=textured, uscale=2.0))
+        M[m_cond]["specular_texture"] = b.add_texture(bitmap(image(5, 0.6, 1.0), filter_type=textured))
+        bump_tex = b.add_texture(bitmap(image(40, 0.0, 1.0)[..., 0], filter_type=textured, uscale=6.0, vscale=6.0, scale=0.02))
+        M[m_ground].update(frame_kind=FRAME_BUMPMAP, frame_texture=bump_tex)
     H = 9.0
     if emitters_grid:
         g = emitters_grid
@@ -686,6 +708,11 @@ def microfacet_field(n_objects=64, subdiv=5, ground_res=90, width=1920, height=1
 def config3(width=1920, height=1080) -> SceneData:
     """~1.0 M triangles: 48 objects x 20480 + 2 x 90^2 ground."""
     return microfacet_field(n_objects=48, subdiv=5, ground_res=90, width=width, height=height)
+
+
+def config3_textured(width=1920, height=1080, filter_type="ewa") -> SceneData:
+    """config3 with bitmap textures on three of its four surface materials and a bump-mapped ground."""
+    return microfacet_field(n_objects=48, subdiv=5, ground_res=90, width=width, height=height, textured=filter_type)
 
 
 def config5(width=3840, height=2160) -> SceneData:

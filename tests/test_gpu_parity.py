@@ -23,7 +23,9 @@ def _scenes():
             "textured_blend": S.small_test_scene(textured=True, blend=True, sky=(0.3, 0.3, 0.4)),
             "bitmap": S.small_test_scene(textured="bitmap"), "bitmap_blend": S.small_test_scene(textured="bitmap", blend=True, lamps=True),
             "bump": S.small_test_scene(textured="bitmap", bumps=True, sky=(0.3, 0.3, 0.4)),
-            "envmap": S.small_test_scene(sky="map", sky_weight=2.0), "envmap_only": S.small_test_scene(sky="map", area_lights=False, blend=True)}
+            "envmap": S.small_test_scene(sky="map", sky_weight=2.0), "envmap_only": S.small_test_scene(sky="map", area_lights=False, blend=True),
+            # the benchmark's textured workload in small: spherical uv on the blobs, 1024 x 1024 EWA-filtered bitmaps, a bump-mapped ground
+            "field_tex": S.microfacet_field(n_objects=6, subdiv=2, ground_res=8, width=96, height=54, textured="ewa", max_depth=5)}
 
 
 @pytest.fixture(scope="module")
@@ -359,7 +361,7 @@ def test_bump_and_normal_mapped_bsdf_parity(pairs):
 
 
 @pytest.mark.parametrize("name", ["small", "cornell", "veach", "mixed", "sky", "sky_hidden", "lamps", "lamps_only", "blend", "textured",
-                                  "textured_blend", "bitmap", "bitmap_blend", "bump", "envmap", "envmap_only"])
+                                  "textured_blend", "bitmap", "bitmap_blend", "bump", "envmap", "envmap_only", "field_tex"])
 def test_per_sample_radiance_parity(pairs, name):
     """MIPathTracer::Li per camera sample with the shared sample stream: same ray counts, same radiance."""
     sd, g, o = pairs[name]
@@ -367,10 +369,14 @@ def test_per_sample_radiance_parity(pairs, name):
     Lg, pg, sg = g.li(4, rect=rect, seed=3)
     Lo, pos, so = o.li(4, rect=rect, seed=3)
     assert np.array_equal(pg, pos)
-    if name == "bump":
+    if name in ("bump", "field_tex"):
         # the perturbed frames add normalisations and products whose last bits can differ between the two sides, and a
-        # path whose sampled direction differs in the last bit may find another triangle: a few paths in ten thousand
-        assert abs(int(sg.normal_rays) - int(so.normal_rays)) <= 3 and abs(int(sg.shadow_rays) - int(so.shadow_rays)) <= 3
+        # path whose sampled direction differs in the last bit may find another triangle: a few paths in ten thousand.
+        # In the field scene the same happens WITHOUT any texture on the long chains of internal reflections in its
+        # coarse glass blobs (at maxDepth 2 and 3 its ray counts are identical, unbounded 17 of 12 288 samples part ways):
+        # the test bounds its depth at 5
+        slack = 3 if name == "bump" else 8
+        assert abs(int(sg.normal_rays) - int(so.normal_rays)) <= slack and abs(int(sg.shadow_rays) - int(so.shadow_rays)) <= slack
     else:
         assert sg.normal_rays == so.normal_rays and sg.shadow_rays == so.shadow_rays
     assert np.array_equal(Lg[..., 3], Lo[..., 3])
