@@ -1113,6 +1113,9 @@ MTS_DEV V3 mixSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, 
 // The three mixture functions are real calls: each holds a copy of every BSDF model, and inlined into the shading
 // kernels they would triple the code there and spill hundreds of registers. What they need of the mixture record travels by
 // value (13 words), the rest of the arguments likewise, so nothing of the caller has to live in memory.
+#ifndef MTS_DIAG_MIXTURES
+#define MTS_DIAG_MIXTURES 1
+#endif
 struct MixRec { int n; float w0, w1, w2, w3, c1, c2, c3, c4; uint32_t k0, k1, k2, k3, types; };
 MTS_DEV MixRec mixRec(const DevMaterial &m) {
     MixRec r;
@@ -1128,18 +1131,21 @@ MTS_DEV void mixMaterial(const MixRec &r, DevMaterial &m) {
     m.condEta[0] = __uint_as_float(r.k0); m.condEta[1] = __uint_as_float(r.k1); m.condEta[2] = __uint_as_float(r.k2); m.condK[0] = __uint_as_float(r.k3);
     m.distribution = (decltype(m.distribution)) r.types;
 }
+template <int TAG>      // see resolveSurfaceCall
 __device__ __attribute__((noinline)) inline float4 mixEvalCall(const DevScene *scp, MixRec r, V3 wi, V3 wo, SurfUV uv) {
     DevMaterial m;
     mixMaterial(r, m);
     const V3 v = mixEval(*scp, m, wi, wo, uv);
     return make_float4(v.x, v.y, v.z, 0.0f);
 }
+template <int TAG>
 __device__ __attribute__((noinline)) inline float mixPdfCall(const DevScene *scp, MixRec r, V3 wi, V3 wo, SurfUV uv) {
     DevMaterial m;
     mixMaterial(r, m);
     return mixPdf(*scp, m, wi, wo, uv);
 }
 struct MixSampled { float4 weightPdf, woEta; uint32_t sampledType; };
+template <int TAG>
 __device__ __attribute__((noinline)) inline void mixSampleCall(const DevScene *scp, MixRec r, V3 wi, float sx, float sy, float su, SurfUV uv, MixSampled *out) {
     DevMaterial m;
     mixMaterial(r, m);
@@ -1151,22 +1157,22 @@ __device__ __attribute__((noinline)) inline void mixSampleCall(const DevScene *s
 }
 
 // What the integrator calls on the record that answers for this side: a mixture (only compiled in with MIX) or a plain model
-template <bool RD = true, bool MIX = true>
+template <bool RD = true, bool MIX = true, int TAG = 0>
 MTS_DEV V3 bsdfEvalAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, const SurfUV &uv = surfUV(0, 0)) {
-    if (MIX && m.type == 8) { const float4 r = mixEvalCall(sc.self, mixRec(m), wi, wo, uv); return mk(r.x, r.y, r.z); }
+    if (MIX && MTS_DIAG_MIXTURES && m.type == 8) { const float4 r = mixEvalCall<TAG>(sc.self, mixRec(m), wi, wo, uv); return mk(r.x, r.y, r.z); }
     return bsdfEval<RD>(sc, m, wi, wo);
 }
-template <bool RD = true, bool MIX = true>
+template <bool RD = true, bool MIX = true, int TAG = 0>
 MTS_DEV float bsdfPdfAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, const SurfUV &uv = surfUV(0, 0)) {
-    if (MIX && m.type == 8) return mixPdfCall(sc.self, mixRec(m), wi, wo, uv);
+    if (MIX && MTS_DIAG_MIXTURES && m.type == 8) return mixPdfCall<TAG>(sc.self, mixRec(m), wi, wo, uv);
     return bsdfPdf<RD>(sc, m, wi, wo);
 }
-template <bool RD = true, bool MIX = true>
+template <bool RD = true, bool MIX = true, int TAG = 0>
 MTS_DEV V3 bsdfSampleAny(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, float su, V3 &wo, float &pdf, float &eta, uint32_t &sampledType,
                          const SurfUV &uv = surfUV(0, 0)) {
-    if (MIX && m.type == 8) {
+    if (MIX && MTS_DIAG_MIXTURES && m.type == 8) {
         MixSampled r;
-        mixSampleCall(sc.self, mixRec(m), wi, sx, sy, su, uv, &r);
+        mixSampleCall<TAG>(sc.self, mixRec(m), wi, sx, sy, su, uv, &r);
         wo = mk(r.woEta.x, r.woEta.y, r.woEta.z); pdf = r.weightPdf.w; eta = r.woEta.w; sampledType = r.sampledType;
         return mk(r.weightPdf.x, r.weightPdf.y, r.weightPdf.z);
     }
@@ -1516,6 +1522,49 @@ MTS_DEV void cameraUVPartials(const DevScene &sc, const PassParams &pp, float2 p
     const float inverse = 1.0f / det;
     uv.dudx = (a11 * bx0 - a01 * bx1) * inverse; uv.dvdx = (a00 * bx1 - a10 * bx0) * inverse;
     uv.dudy = (a11 * by0 - a01 * by1) * inverse; uv.dvdy = (a00 * by1 - a10 * by0) * inverse;
+}
+
+// Everything a hit needs from the texture machinery, behind ONE real call: the uv partials of a camera vertex, the
+// textured colours of the answering record and the frame of a bumpmap / normalmap around it. Inlined into the shading
+// kernel these pieces cost every path a few hundred register spills whether or not its material has a texture; as a
+// call they cost the paths that need them a trip through memory (the query record) and the others one test.
+struct SurfaceQuery {
+    // in
+    V3 p, geoN, dpdu, dpdv, rayO, rayD;
+    Frame3 sh;
+    float u, v;
+    float2 pos;
+    int32_t sppTotal;
+    uint32_t material, first;
+    // out
+    SurfUV uv;
+    float colour[9];        // diffuse, specular, transmittance
+    uint32_t textured;      // bit i: colour[3 i ..] is set
+    uint32_t framed;
+    Frame3 pf;
+};
+// TAG: one instance per register budget of the calling kernels (a function shared by kernels with different launch
+// bounds is compiled for the largest budget, and its register count then becomes that of every kernel that calls it)
+template <int TAG>
+__device__ __attribute__((noinline)) inline void resolveSurfaceCall(const DevScene *scp, SurfaceQuery *q) {
+    const DevScene &sc = *scp;
+    SurfUV uv = surfUV(q->u, q->v);
+    if (q->first) {
+        Isect its;
+        its.p = q->p; its.geoN = q->geoN; its.dpdu = q->dpdu; its.dpdv = q->dpdv;
+        PassParams pp;
+        pp.sppTotal = q->sppTotal;
+        cameraUVPartials(sc, pp, q->pos, its, make_float4(q->rayO.x, q->rayO.y, q->rayO.z, 0.0f), q->rayD, uv);
+    }
+    q->uv = uv;
+    const uint4 b = sc.materialTextures[q->material];
+    uint32_t textured = 0;
+    if (b.x) { const V3 c = textureEval(sc, sc.textures[b.x - 1], uv); q->colour[0] = c.x; q->colour[1] = c.y; q->colour[2] = c.z; textured |= 1u; }
+    if (b.y) { const V3 c = textureEval(sc, sc.textures[b.y - 1], uv); q->colour[3] = c.x; q->colour[4] = c.y; q->colour[5] = c.z; textured |= 2u; }
+    if (b.z) { const V3 c = textureEval(sc, sc.textures[b.z - 1], uv); q->colour[6] = c.x; q->colour[7] = c.y; q->colour[8] = c.z; textured |= 4u; }
+    q->textured = textured;
+    q->framed = 0;
+    if (b.w & 6u) { q->framed = 1; q->pf = perturbedFrame(sc, b.w, q->sh, q->geoN, q->dpdu, q->dpdv, q->u, q->v); }
 }
 
 }  // namespace mtsamd

@@ -134,29 +134,52 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
 
         Isect its;
         fillIntersection(sc, tri, hit.y, hit.z, rayD, its);
-        // the material record comes in as seven 16-byte loads issued together, not field by field
-        DevMaterial bsdf;
-        loadMaterial(sc, its.material, bsdf);
-        // what the integrator asks of the BSDF as a whole (for a two-sided record: the adapter's type) ...
-        const uint32_t bsdfType = bsdf.typeFlags;
         const float wiZ = its.wi.z;
-        // its.getBSDF(ray) (path.cpp:145, records.inl:69-75): uv partials for the vertex a camera ray reaches, if its BSDF
-        // filters its textures
-        SurfUV uv = surfUV(its.uvx, its.uvy);
-        if (MIX && prevDepth == 0 && sc.materialTextures && (sc.materialTextures[its.material].w & 1u))
-            cameraUVPartials(sc, pp, samplePos[slot], its, in.rayO(), rayD, uv);
-        // ... and the BRDF that answers on this side (twosided.cpp:108-183)
-        const bool flipped = resolveTwoSided(sc, its.material, wiZ, bsdf);
-        const V3 wiLocal = flipped ? mirrorZ(its.wi) : its.wi;
-        // textured colours of the answering record, at this hit (only scenes with textures run the MIX kernels with a table)
-        if (MIX) applyTextures(sc, its.material, uv, bsdf);
-        // bumpmap / normalmap around the answering record: it is asked in a perturbed frame (bumpmap.cpp:161-237)
-        bool framed = false;
+        DevMaterial bsdf;
+        uint32_t bsdfType;      // what the integrator asks of the BSDF as a whole (for a two-sided record: the adapter's type)
+        bool flipped, framed = false;
         Frame3 pf;
+        SurfUV uv = surfUV(its.uvx, its.uvy);
         if (MIX && sc.materialTextures) {
-            const uint32_t fw = sc.materialTextures[its.material].w;
-            if (fw & 6u) { framed = true; pf = perturbedFrame(sc, fw, its.sh, its.geoN, its.dpdu, its.dpdv, its.uvx, its.uvy); }
+            // Scenes with textures. Who answers on this side (twosided.cpp:108-183) is read from three words of the hit's
+            // record, so that the texture call below is made BEFORE the answering record is loaded: whatever is live
+            // across a real call has to sit in the few registers a callee preserves, or in memory.
+            const DevMaterial *rec = sc.materials + its.material;
+            bsdfType = rec->typeFlags;
+            // its.getBSDF(ray) (path.cpp:145, records.inl:69-75): uv partials for the vertex a camera ray reaches, if its
+            // BSDF filters its textures
+            const bool first = prevDepth == 0 && (sc.materialTextures[its.material].w & 1u);
+            flipped = rec->twoSided && wiZ < 0;
+            if (flipped) its.material = (uint32_t) rec->backMaterial;
+            // textured colours of the answering record at this hit, and the frame of a bumpmap / normalmap around it, in
+            // which it is asked (bumpmap.cpp:161-237): one call, made only for records that have any of it
+            const uint4 tw = sc.materialTextures[its.material];
+            const bool resolve = first || (tw.x | tw.y | tw.z | (tw.w & 6u)) != 0;
+            SurfaceQuery q;
+            if (resolve) {
+                q.p = its.p; q.geoN = its.geoN; q.dpdu = its.dpdu; q.dpdv = its.dpdv; q.sh = its.sh; q.u = its.uvx; q.v = its.uvy;
+                const float4 ro = in.rayO();
+                q.rayO = mk(ro.x, ro.y, ro.z); q.rayD = rayD;
+                q.pos = first ? samplePos[slot] : make_float2(0.0f, 0.0f);
+                q.sppTotal = pp.sppTotal; q.material = its.material; q.first = first ? 1u : 0u;
+                resolveSurfaceCall<PARK ? 1 : 0>(sc.self, &q);
+            }
+            loadMaterial(sc, its.material, bsdf);
+            if (resolve) {
+                uv = q.uv;
+                if (q.textured & 1u) { bsdf.diffuse[0] = q.colour[0]; bsdf.diffuse[1] = q.colour[1]; bsdf.diffuse[2] = q.colour[2]; }
+                if (q.textured & 2u) { bsdf.specular[0] = q.colour[3]; bsdf.specular[1] = q.colour[4]; bsdf.specular[2] = q.colour[5]; }
+                if (q.textured & 4u) { bsdf.transmittance[0] = q.colour[6]; bsdf.transmittance[1] = q.colour[7]; bsdf.transmittance[2] = q.colour[8]; }
+                if (q.framed) { framed = true; pf = q.pf; }
+            }
+        } else {
+            // the material record comes in as seven 16-byte loads issued together, not field by field
+            loadMaterial(sc, its.material, bsdf);
+            bsdfType = bsdf.typeFlags;
+            // ... and the BRDF that answers on this side (twosided.cpp:108-183)
+            flipped = resolveTwoSided(sc, its.material, wiZ, bsdf);
         }
+        const V3 wiLocal = flipped ? mirrorZ(its.wi) : its.wi;
         const V3 wiB = framed ? toLocal(pf, toWorld(its.sh, wiLocal)) : wiLocal;
         // The sample's radiance is only fetched where something is added to it: at the camera vertex it still is
         // what k_raygen wrote (zero), later only paths that hit an emitter touch it.
@@ -226,10 +249,10 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                     const V3 woSide = flipped ? mirrorZ(wo) : wo;
                     const V3 woB = framed ? toLocal(pf, toWorld(its.sh, woSide)) : woSide;
                     const bool sameSide = !framed || woSide.z * woB.z > 0;
-                    const V3 bsdfVal = sameSide ? bsdfEvalAny<RD, MIX>(sc, bsdf, wiB, woB, uv) : mk(0.0f);
+                    const V3 bsdfVal = sameSide ? bsdfEvalAny<RD, MIX, PARK ? 1 : 0>(sc, bsdf, wiB, woB, uv) : mk(0.0f);
                     if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
                         // path.cpp:192-193: only emitters with a surface, sampled in the solid-angle measure, compete with BSDF sampling
-                        const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX>(sc, bsdf, wiB, woB, uv);
+                        const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX, PARK ? 1 : 0>(sc, bsdf, wiB, woB, uv);
                         c = throughput * value * bsdfVal * miWeight(dRec.pdf, bPdf);
                     }
                     o.wantShadow = true;
@@ -245,7 +268,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             const float bx = rng.next1D(), by = rng.next1D();
             V3 woLocal; float bPdf, bEta; uint32_t sampledType;
             const float bu = RD && bsdfDrawsFromSampler<MIX>(bsdf, bx) ? rng.next1D() : 0.0f;     // bRec.sampler->next1D() inside BSDF::sample
-            V3 bsdfWeight = bsdfSampleAny<RD, MIX>(sc, bsdf, wiB, bx, by, bu, woLocal, bPdf, bEta, sampledType, uv);
+            V3 bsdfWeight = bsdfSampleAny<RD, MIX, PARK ? 1 : 0>(sc, bsdf, wiB, bx, by, bu, woLocal, bPdf, bEta, sampledType, uv);
             if (framed && !isZero(bsdfWeight)) {        // back into the unperturbed frame (bumpmap.cpp:227-234)
                 const V3 pwo = woLocal;
                 woLocal = toLocal(its.sh, toWorld(pf, pwo));

@@ -211,6 +211,12 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
 
     HostScene &h = s->host;
     for (const DevMaterial &m : h.materials) s->roughDielectric |= m.type == MTSAMD_BSDF_ROUGHDIELECTRIC;
+    // kernel A/B runs: make a scene run a more general variant of the shading kernels than it needs
+    if (const char *e = getenv("MTSAMD_SHADE_VARIANT")) {
+        if (strstr(e, "env")) s->host.extEmitters = true;
+        if (strstr(e, "rd")) s->roughDielectric = true;
+        if (strstr(e, "mix")) s->host.mixture = true;
+    }
     if (const char *e = getenv("MTSAMD_NODE_STRIDE")) s->nodeStride = (uint32_t) std::min(16, std::max(5, atoi(e)));
     if (const char *e = getenv("MTSAMD_TRI_STRIDE")) s->triStride = (uint32_t) std::min(16, std::max(3, atoi(e)));
     // nodes and triangle records as raw float4 streams, each record padded to its stride
