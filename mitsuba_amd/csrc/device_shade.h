@@ -1113,9 +1113,6 @@ MTS_DEV V3 mixSample(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, 
 // The three mixture functions are real calls: each holds a copy of every BSDF model, and inlined into the shading
 // kernels they would triple the code there and spill hundreds of registers. What they need of the mixture record travels by
 // value (13 words), the rest of the arguments likewise, so nothing of the caller has to live in memory.
-#ifndef MTS_DIAG_MIXTURES
-#define MTS_DIAG_MIXTURES 1
-#endif
 struct MixRec { int n; float w0, w1, w2, w3, c1, c2, c3, c4; uint32_t k0, k1, k2, k3, types; };
 MTS_DEV MixRec mixRec(const DevMaterial &m) {
     MixRec r;
@@ -1157,20 +1154,42 @@ __device__ __attribute__((noinline)) inline void mixSampleCall(const DevScene *s
 }
 
 // What the integrator calls on the record that answers for this side: a mixture (only compiled in with MIX) or a plain model
+// (the overloads that take the uv record by address read it only for a mixture: callers keep it in memory, not in registers)
+template <bool RD = true, bool MIX = true, int TAG = 0>
+MTS_DEV V3 bsdfEvalAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, const SurfUV *uv) {
+    if (MIX && m.type == 8) { const float4 r = mixEvalCall<TAG>(sc.self, mixRec(m), wi, wo, *uv); return mk(r.x, r.y, r.z); }
+    return bsdfEval<RD>(sc, m, wi, wo);
+}
+template <bool RD = true, bool MIX = true, int TAG = 0>
+MTS_DEV float bsdfPdfAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, const SurfUV *uv) {
+    if (MIX && m.type == 8) return mixPdfCall<TAG>(sc.self, mixRec(m), wi, wo, *uv);
+    return bsdfPdf<RD>(sc, m, wi, wo);
+}
 template <bool RD = true, bool MIX = true, int TAG = 0>
 MTS_DEV V3 bsdfEvalAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, const SurfUV &uv = surfUV(0, 0)) {
-    if (MIX && MTS_DIAG_MIXTURES && m.type == 8) { const float4 r = mixEvalCall<TAG>(sc.self, mixRec(m), wi, wo, uv); return mk(r.x, r.y, r.z); }
+    if (MIX && m.type == 8) { const float4 r = mixEvalCall<TAG>(sc.self, mixRec(m), wi, wo, uv); return mk(r.x, r.y, r.z); }
     return bsdfEval<RD>(sc, m, wi, wo);
 }
 template <bool RD = true, bool MIX = true, int TAG = 0>
 MTS_DEV float bsdfPdfAny(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo, const SurfUV &uv = surfUV(0, 0)) {
-    if (MIX && MTS_DIAG_MIXTURES && m.type == 8) return mixPdfCall<TAG>(sc.self, mixRec(m), wi, wo, uv);
+    if (MIX && m.type == 8) return mixPdfCall<TAG>(sc.self, mixRec(m), wi, wo, uv);
     return bsdfPdf<RD>(sc, m, wi, wo);
 }
 template <bool RD = true, bool MIX = true, int TAG = 0>
 MTS_DEV V3 bsdfSampleAny(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, float su, V3 &wo, float &pdf, float &eta, uint32_t &sampledType,
+                         const SurfUV *uv) {
+    if (MIX && m.type == 8) {
+        MixSampled r;
+        mixSampleCall<TAG>(sc.self, mixRec(m), wi, sx, sy, su, *uv, &r);
+        wo = mk(r.woEta.x, r.woEta.y, r.woEta.z); pdf = r.weightPdf.w; eta = r.woEta.w; sampledType = r.sampledType;
+        return mk(r.weightPdf.x, r.weightPdf.y, r.weightPdf.z);
+    }
+    return bsdfSample<RD>(sc, m, wi, sx, sy, su, wo, pdf, eta, sampledType);
+}
+template <bool RD = true, bool MIX = true, int TAG = 0>
+MTS_DEV V3 bsdfSampleAny(const DevScene &sc, const DevMaterial &m, V3 wi, float sx, float sy, float su, V3 &wo, float &pdf, float &eta, uint32_t &sampledType,
                          const SurfUV &uv = surfUV(0, 0)) {
-    if (MIX && MTS_DIAG_MIXTURES && m.type == 8) {
+    if (MIX && m.type == 8) {
         MixSampled r;
         mixSampleCall<TAG>(sc.self, mixRec(m), wi, sx, sy, su, uv, &r);
         wo = mk(r.woEta.x, r.woEta.y, r.woEta.z); pdf = r.weightPdf.w; eta = r.woEta.w; sampledType = r.sampledType;

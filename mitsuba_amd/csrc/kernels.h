@@ -138,8 +138,9 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
         DevMaterial bsdf;
         uint32_t bsdfType;      // what the integrator asks of the BSDF as a whole (for a two-sided record: the adapter's type)
         bool flipped, framed = false;
-        Frame3 pf;
-        SurfUV uv = surfUV(its.uvx, its.uvy);
+        // Side storage in memory for what only textured, framed or mixture records use (the uv partials, the perturbed
+        // frame): kept here instead of in registers, it costs the other paths nothing.
+        SurfaceQuery q;
         if (MIX && sc.materialTextures) {
             // Scenes with textures. Who answers on this side (twosided.cpp:108-183) is read from three words of the hit's
             // record, so that the texture call below is made BEFORE the answering record is loaded: whatever is live
@@ -155,7 +156,6 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             // which it is asked (bumpmap.cpp:161-237): one call, made only for records that have any of it
             const uint4 tw = sc.materialTextures[its.material];
             const bool resolve = first || (tw.x | tw.y | tw.z | (tw.w & 6u)) != 0;
-            SurfaceQuery q;
             if (resolve) {
                 q.p = its.p; q.geoN = its.geoN; q.dpdu = its.dpdu; q.dpdv = its.dpdv; q.sh = its.sh; q.u = its.uvx; q.v = its.uvy;
                 const float4 ro = in.rayO();
@@ -165,22 +165,23 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                 resolveSurfaceCall<PARK ? 1 : 0>(sc.self, &q);
             }
             loadMaterial(sc, its.material, bsdf);
+            if (!resolve && bsdf.type == 8) q.uv = surfUV(its.uvx, its.uvy);       // a mixture's textured children look here
             if (resolve) {
-                uv = q.uv;
                 if (q.textured & 1u) { bsdf.diffuse[0] = q.colour[0]; bsdf.diffuse[1] = q.colour[1]; bsdf.diffuse[2] = q.colour[2]; }
                 if (q.textured & 2u) { bsdf.specular[0] = q.colour[3]; bsdf.specular[1] = q.colour[4]; bsdf.specular[2] = q.colour[5]; }
                 if (q.textured & 4u) { bsdf.transmittance[0] = q.colour[6]; bsdf.transmittance[1] = q.colour[7]; bsdf.transmittance[2] = q.colour[8]; }
-                if (q.framed) { framed = true; pf = q.pf; }
+                framed = q.framed != 0;
             }
         } else {
             // the material record comes in as seven 16-byte loads issued together, not field by field
             loadMaterial(sc, its.material, bsdf);
+            if (MIX && bsdf.type == 8) q.uv = surfUV(its.uvx, its.uvy);
             bsdfType = bsdf.typeFlags;
             // ... and the BRDF that answers on this side (twosided.cpp:108-183)
             flipped = resolveTwoSided(sc, its.material, wiZ, bsdf);
         }
         const V3 wiLocal = flipped ? mirrorZ(its.wi) : its.wi;
-        const V3 wiB = framed ? toLocal(pf, toWorld(its.sh, wiLocal)) : wiLocal;
+        const V3 wiB = framed ? toLocal(q.pf, toWorld(its.sh, wiLocal)) : wiLocal;
         // The sample's radiance is only fetched where something is added to it: at the camera vertex it still is
         // what k_raygen wrote (zero), later only paths that hit an emitter touch it.
         float4 L = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -247,12 +248,12 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                     V3 c = mk(0.0f);
                     const V3 wo = toLocal(its.sh, dRec.d);
                     const V3 woSide = flipped ? mirrorZ(wo) : wo;
-                    const V3 woB = framed ? toLocal(pf, toWorld(its.sh, woSide)) : woSide;
+                    const V3 woB = framed ? toLocal(q.pf, toWorld(its.sh, woSide)) : woSide;
                     const bool sameSide = !framed || woSide.z * woB.z > 0;
-                    const V3 bsdfVal = sameSide ? bsdfEvalAny<RD, MIX, PARK ? 1 : 0>(sc, bsdf, wiB, woB, uv) : mk(0.0f);
+                    const V3 bsdfVal = sameSide ? bsdfEvalAny<RD, MIX, PARK ? 1 : 0>(sc, bsdf, wiB, woB, &q.uv) : mk(0.0f);
                     if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
                         // path.cpp:192-193: only emitters with a surface, sampled in the solid-angle measure, compete with BSDF sampling
-                        const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX, PARK ? 1 : 0>(sc, bsdf, wiB, woB, uv);
+                        const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX, PARK ? 1 : 0>(sc, bsdf, wiB, woB, &q.uv);
                         c = throughput * value * bsdfVal * miWeight(dRec.pdf, bPdf);
                     }
                     o.wantShadow = true;
@@ -268,10 +269,10 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             const float bx = rng.next1D(), by = rng.next1D();
             V3 woLocal; float bPdf, bEta; uint32_t sampledType;
             const float bu = RD && bsdfDrawsFromSampler<MIX>(bsdf, bx) ? rng.next1D() : 0.0f;     // bRec.sampler->next1D() inside BSDF::sample
-            V3 bsdfWeight = bsdfSampleAny<RD, MIX, PARK ? 1 : 0>(sc, bsdf, wiB, bx, by, bu, woLocal, bPdf, bEta, sampledType, uv);
+            V3 bsdfWeight = bsdfSampleAny<RD, MIX, PARK ? 1 : 0>(sc, bsdf, wiB, bx, by, bu, woLocal, bPdf, bEta, sampledType, &q.uv);
             if (framed && !isZero(bsdfWeight)) {        // back into the unperturbed frame (bumpmap.cpp:227-234)
                 const V3 pwo = woLocal;
-                woLocal = toLocal(its.sh, toWorld(pf, pwo));
+                woLocal = toLocal(its.sh, toWorld(q.pf, pwo));
                 if (woLocal.z * pwo.z <= 0) bsdfWeight = mk(0.0f);
             }
             if (flipped && !isZero(bsdfWeight) && bPdf != 0) woLocal.z = -woLocal.z;      // twosided.cpp:172-181
