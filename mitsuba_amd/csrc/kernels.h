@@ -70,6 +70,9 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(64, 1024), amdgpu_wav
 #define MTS_SHADE_BLOCK 256
 #endif
 static constexpr int kShadeBlock = MTS_SHADE_BLOCK;
+#ifndef MTS_SHADE_WAVES_MIX
+#define MTS_SHADE_WAVES_MIX 3
+#endif
 #ifndef MTS_SHADE_PARK
 #define MTS_SHADE_PARK 1
 #endif
@@ -394,7 +397,7 @@ MTS_DEV void sortByBsdfType(const float4 *hits, uint32_t first, uint32_t n, uint
 // too, one more queue stream), point, spot or directional lights.
 // RD: the scene has a rough dielectric material.
 template <int ROUNDS, bool ENV, bool RD, bool MIX>
-__global__ void __launch_bounds__(kShadeBlock, MTS_SHADE_WAVES) k_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out,
+__global__ void __launch_bounds__(kShadeBlock, MIX ? MTS_SHADE_WAVES_MIX : MTS_SHADE_WAVES) k_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out,
                                                        ShadowQueue sq, float4 *sampleL, const float2 *samplePos, uint32_t *counters, uint32_t n) {
     constexpr int kWaves = kShadeBlock / 64;
     __shared__ uint32_t sCount[kShadeSortKeys * ROUNDS * kWaves];

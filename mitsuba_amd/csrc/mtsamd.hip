@@ -548,8 +548,8 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
             HIP_TRY(hipMemsetAsync(tailCounts, 0, 2 * sizeof(unsigned long long), st));
             timer.begin(T_TAIL);
 #define MTS_LAUNCH_TAIL(E, R, M) hipLaunchKernelGGL((k_tail<E, R, M>), dim3(blocksFor(n, kTailBlock)), dim3(kTailBlock), 0, st, sc, pp, s->queue(cur), sampleL, samplePos, n, s->triShare, tailCounts)
-            // scenes with a mixturebsdf run the variant that knows every feature
-            if (s->host.mixture) MTS_LAUNCH_TAIL(true, true, true);
+            // scenes with mixtures, textures or frame adapters run the variants that know them (with or without the other emitter kinds and the rough dielectric)
+            if (s->host.mixture) { if (s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_TAIL(true, true, true); else MTS_LAUNCH_TAIL(false, false, true); }
             else if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_TAIL(true, true, false); else MTS_LAUNCH_TAIL(true, false, false); }
             else { if (s->roughDielectric) MTS_LAUNCH_TAIL(false, true, false); else MTS_LAUNCH_TAIL(false, false, false); }
 #undef MTS_LAUNCH_TAIL
@@ -581,7 +581,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         const int rounds = n >= s->shadeRoundsAbove ? s->shadeRounds : 1;
 #define MTS_LAUNCH_SHADE_AS(R, E, D, M) hipLaunchKernelGGL((k_shade<R, E, D, M>), dim3(blocksFor(n, kShadeBlock * R)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, samplePos, cnt, n)
 #define MTS_LAUNCH_SHADE(R) do { \
-            if (s->host.mixture) MTS_LAUNCH_SHADE_AS(R, true, true, true); \
+            if (s->host.mixture) { if (s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true, true); else MTS_LAUNCH_SHADE_AS(R, false, false, true); } \
             else if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true, false); else MTS_LAUNCH_SHADE_AS(R, true, false, false); } \
             else { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, false, true, false); else MTS_LAUNCH_SHADE_AS(R, false, false, false); } } while (0)
         // (sweeps per workgroup: 16 for large queues, 1 for small ones; MTSAMD_SHADE_ROUNDS=1 switches the sweeps off.
