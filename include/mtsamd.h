@@ -174,8 +174,12 @@ typedef struct {
 
 /* MonteCarloIntegrator parameters (src/librender/integrator.cpp:190-225). type MTSAMD_INTEGRATOR_PATH is the `path`
    integrator (src/integrators/path/path.cpp); MTSAMD_INTEGRATOR_DIRECT is `direct` (src/integrators/direct/direct.cpp:
-   emitter_samples / bsdf_samples per camera sample, not both zero; max_depth and rr_depth are not used by it). */
-enum { MTSAMD_INTEGRATOR_PATH = 0, MTSAMD_INTEGRATOR_DIRECT = 1 };
+   emitter_samples / bsdf_samples per camera sample, not both zero; max_depth and rr_depth are not used by it);
+   MTSAMD_INTEGRATOR_VOLPATH_SIMPLE is `volpath_simple` (src/integrators/path/volpath_simple.cpp:88-297) on a scene
+   without participating media, which is the only kind this library takes: a path tracer without multiple importance
+   sampling (emitters are seen by the camera ray and after Dirac bounces; every other vertex samples an emitter at full
+   weight, with the visibility ray of Scene::sampleAttenuatedEmitterDirect, src/librender/scene.cpp:876-898). */
+enum { MTSAMD_INTEGRATOR_PATH = 0, MTSAMD_INTEGRATOR_DIRECT = 1, MTSAMD_INTEGRATOR_VOLPATH_SIMPLE = 2 };
 typedef struct {
     int32_t max_depth, rr_depth, strict_normals, hide_emitters;
     int32_t type, emitter_samples, bsdf_samples;

@@ -246,7 +246,7 @@ def fill_desc(sd):
                     setattr(texs[i], k, t[k])
         keep.append(texs)
         d.n_textures, d.textures = len(tex_list), texs
-    d.integrator.type = {"path": 0, "direct": 1}[sd.integrator.get("type", "path")]
+    d.integrator.type = {"path": 0, "direct": 1, "volpath_simple": 2}[sd.integrator.get("type", "path")]
     d.integrator.emitter_samples = sd.integrator.get("emitter_samples", 1)
     d.integrator.bsdf_samples = sd.integrator.get("bsdf_samples", 1)
     return d, keep

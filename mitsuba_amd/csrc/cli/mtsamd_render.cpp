@@ -37,10 +37,10 @@ static void describe(const LoadedScene &s) {
     printf("{\"vertices\": %zu, \"triangles\": %zu, \"shapes\": %zu, \"materials\": %zu, \"emitters\": %zu, \"has_normals\": %s, "
            "\"has_texcoords\": %s, \"sum_positions\": %.9g, \"sum_normals\": %.9g, \"sum_texcoords\": %.9g, \"sum_indices\": %llu, "
            "\"width\": %d, \"height\": %d, \"crop\": [%d, %d, %d, %d], \"x_fov\": %.9g, \"filter_radius\": %.9g, \"max_depth\": %d, \"rr_depth\": %d, "
-           "\"sample_count\": %d, \"integrator\": \"%s\", \"emitter_samples\": %d, \"bsdf_samples\": %d, \"to_world\": [",
+           "\"sample_count\": %d, \"integrator\": \"%s\", \"integrator_kind\": %d, \"emitter_samples\": %d, \"bsdf_samples\": %d, \"to_world\": [",
            s.positions.size() / 3, s.indices.size() / 3, s.shapes.size(), s.materials.size(), s.emitters.size(),
            s.anyNormals ? "true" : "false", s.anyTexcoords ? "true" : "false", sp, sn, st, si, s.film.width, s.film.height,
-           s.film.crop_x, s.film.crop_y, s.film.crop_w, s.film.crop_h, s.camera.x_fov, s.film.filter_radius, s.integrator.max_depth, s.integrator.rr_depth, s.sampleCount, s.integratorType.c_str(),
+           s.film.crop_x, s.film.crop_y, s.film.crop_w, s.film.crop_h, s.camera.x_fov, s.film.filter_radius, s.integrator.max_depth, s.integrator.rr_depth, s.sampleCount, s.integratorType.c_str(), s.integrator.type,
            s.integrator.emitter_samples, s.integrator.bsdf_samples);
     for (int i = 0; i < 16; ++i) printf("%s%.9g", i ? ", " : "", s.camera.to_world[i]);
     printf("], \"material_types\": [");
@@ -163,7 +163,7 @@ int main(int argc, char **argv) {
     LoadedScene scene;
     const std::string err = loadSceneXml(scenePath, opts, scene);
     if (!err.empty()) { fprintf(stderr, "mtsamd-render: %s\n", err.c_str()); return 1; }
-    if (!scene.integratorType.empty() && scene.integratorType != "path" && scene.integratorType != "direct")
+    if (!scene.integratorType.empty() && scene.integratorType != "path" && scene.integratorType != "direct" && scene.integratorType != "volpath_simple")
         fprintf(stderr, "mtsamd-render: the scene asks for integrator '%s'; rendering with 'path'\n", scene.integratorType.c_str());
     if (describeOnly) { describe(scene); return 0; }
     if (spp <= 0) spp = scene.sampleCount;

@@ -1501,6 +1501,8 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
                     const int shading = (int) getF(p, "shadingSamples", 1);
                     out.integrator.emitter_samples = (int32_t) getF(p, "emitterSamples", shading);
                     out.integrator.bsdf_samples = (int32_t) getF(p, "bsdfSamples", shading);
+                } else if (out.integratorType == "volpath_simple") {       // media are not loaded: the surface-only form of it
+                    out.integrator.type = MTSAMD_INTEGRATOR_VOLPATH_SIMPLE;
                 }
             } else if (el.tag == "sensor") {
                 if (el.get("type") != "perspective") return "only the perspective sensor is supported";

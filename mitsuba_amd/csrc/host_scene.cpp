@@ -498,7 +498,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         if (d->integrator.emitter_samples < 0 || d->integrator.bsdf_samples < 0 || d->integrator.emitter_samples + d->integrator.bsdf_samples <= 0)
             return "direct: the numbers of emitter and BSDF samples must not be negative and not both zero";
         if (d->integrator.emitter_samples > 1024 || d->integrator.bsdf_samples > 1024) return "direct: at most 1024 emitter and BSDF samples";
-    } else if (d->integrator.type != MTSAMD_INTEGRATOR_PATH) {
+    } else if (d->integrator.type != MTSAMD_INTEGRATOR_PATH && d->integrator.type != MTSAMD_INTEGRATOR_VOLPATH_SIMPLE) {
         return "unknown integrator type";
     }
 

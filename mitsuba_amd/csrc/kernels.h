@@ -113,7 +113,9 @@ struct HeldPath {
 // Radiance gathered at this vertex goes to sampleL[slot] directly; the rest comes back in `o`.
 // `park` (workgroup memory, two float4 per thread of the workgroup) or nullptr: where the shadow ray's direction and
 // contribution wait while the BSDF is sampled, instead of in eight registers.
-template <bool ENV, bool RD, bool MIX, bool PARK, typename Path>
+// VS: the estimator of volpath_simple on a scene without media (src/integrators/path/volpath_simple.cpp:88-297) in place
+// of path's: no multiple importance sampling; emitters are seen by the camera ray and after Dirac bounces only.
+template <bool ENV, bool RD, bool MIX, bool PARK, typename Path, bool VS = false>
 MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &in, const float4 hit, float4 *sampleL, const float2 *samplePos,
                          ShadeOut &o, float4 *park = nullptr) {
     const uint32_t triWord = __float_as_uint(hit.w);
@@ -201,6 +203,23 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                     L.x += c.x; L.y += c.y; L.z += c.z;
                 }
             }
+        } else if (VS) {
+            // roulette closes the previous iteration before anything is gathered here (volpath_simple.cpp:282-292) ...
+            if ((int) prevDepth >= sc.rrDepth) {
+                const float q = fminf(maxComp(throughput) * eta * eta, 0.95f);
+                if (rng.next1D() >= q) terminate = true;
+                throughput = throughput / q;
+            }
+            // ... then the emitter counts only after a Dirac bounce (:243-263, :184-186), at full weight
+            if (!terminate && its.emitter >= 0 && (flags & PF_PREV_DELTA) && dot(its.sh.n, -rayD) > 0) {
+                const V3 c = throughput * ld3(sc.emitters[its.emitter].radiance);
+                if (c.x != 0 || c.y != 0 || c.z != 0) {
+                    L = sampleL[slot];
+                    L.x += c.x; L.y += c.y; L.z += c.z; Lchanged = true;
+                }
+            }
+            depth = (int) prevDepth + 1;
+            if (!(depth <= sc.maxDepth || sc.maxDepth < 0)) terminate = true;      // volpath_simple.cpp:112
         } else {
             // emitter reached by BSDF sampling: MIS against the emitter-sampling pdf (path.cpp:228-232,257-264)
             if (its.emitter >= 0) {
@@ -232,9 +251,9 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
 
         // written here, not at the end: nothing below adds to it, and L would occupy four registers until then
         if (Lchanged) sampleL[slot] = L;
-        // path.cpp:156-165
+        // path.cpp:156-165; volpath_simple.cpp:193-196 lets a product of exactly zero pass
         if (!terminate && ((depth >= sc.maxDepth && sc.maxDepth > 0) ||
-                           (sc.strictNormals && dot(rayD, its.geoN) * wiZ >= 0)))
+                           (sc.strictNormals && (VS ? dot(rayD, its.geoN) * wiZ > 0 : dot(rayD, its.geoN) * wiZ >= 0))))
             terminate = true;
 
         if (!terminate) {
@@ -256,12 +275,16 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                     const V3 bsdfVal = sameSide ? bsdfEvalAny<RD, MIX, PARK ? 1 : 0>(sc, bsdf, wiB, woB, &q.uv) : mk(0.0f);
                     if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
                         // path.cpp:192-193: only emitters with a surface, sampled in the solid-angle measure, compete with BSDF sampling
-                        const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX, PARK ? 1 : 0>(sc, bsdf, wiB, woB, &q.uv);
-                        c = throughput * value * bsdfVal * miWeight(dRec.pdf, bPdf);
+                        if (VS) c = throughput * value * bsdfVal;       // volpath_simple.cpp:224: no weighting against BSDF sampling
+                        else {
+                            const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX, PARK ? 1 : 0>(sc, bsdf, wiB, woB, &q.uv);
+                            c = throughput * value * bsdfVal * miWeight(dRec.pdf, bPdf);
+                        }
                     }
                     o.wantShadow = true;
                     o.sRayO = make_float4(its.p.x, its.p.y, its.p.z, kEpsilon);
-                    const float4 sRayD = make_float4(dRec.d.x, dRec.d.y, dRec.d.z, dRec.dist * (1 - kShadowEpsilon));   // scene.cpp:840-841
+                    // scene.cpp:840-841; Scene::evalTransmittance (scene.cpp:619-626) shortens the ray only towards a point on a surface
+                    const float4 sRayD = make_float4(dRec.d.x, dRec.d.y, dRec.d.z, (VS && ENV && dRec.delta) ? dRec.dist : dRec.dist * (1 - kShadowEpsilon));
                     const float4 sContrib = make_float4(c.x, c.y, c.z, __uint_as_float(slot));
                     if (PARK) { park[threadIdx.x] = sRayD; park[kShadeBlock + threadIdx.x] = sContrib; }
                     else { o.sRayD = sRayD; o.sContrib = sContrib; }
@@ -283,7 +306,9 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                 if (sampledType != ENull) flags |= PF_SCATTERED;
                 const V3 wo = toWorld(its.sh, woLocal);
                 const float woDotGeoN = dot(its.geoN, wo);
-                if (!(sc.strictNormals && woDotGeoN * woLocal.z <= 0)) {
+                // volpath_simple.cpp:243-263: the path goes on only if the next vertex may gather something
+                const bool goesOn = !VS || depth + 1 < sc.maxDepth || sc.maxDepth < 0 || ((sampledType & EDelta) && depth < sc.maxDepth);
+                if (goesOn && !(sc.strictNormals && woDotGeoN * woLocal.z <= 0)) {
                     o.alive = true;
                     throughput = throughput * bsdfWeight;   // path.cpp:252-253
                     eta *= bEta;
@@ -313,6 +338,28 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             if (!sc.hideEmitters) {
                 const V3 c = throughput * (sc.envIsMap ? cameraEnvironmentRadiance(sc, pp, samplePos[slot], rayD) : ld3(sc.envRadiance));
                 sampleL[slot] = make_float4(c.x, c.y, c.z, 0.0f);
+            }
+        } else if (VS) {
+            // volpath_simple.cpp:282-292, then :170-181: roulette first, then the environment after a Dirac bounce only
+            V3 thr = throughput;
+            bool dead = false;
+            if ((int) prevDepth >= sc.rrDepth) {
+                Rng rng;
+                int px, py, s;
+                const uint64_t key = sampleKey(sc, pp, slot, px, py, s);
+                rng.inc = (key << 1) | 1u;
+                rng.state = (uint64_t) misc.z | ((uint64_t) misc.w << 32);
+                const float q = fminf(maxComp(thr) * th.w * th.w, 0.95f);
+                if (rng.next1D() >= q) dead = true;
+                thr = thr / q;
+            }
+            if (!dead && (flags & PF_PREV_DELTA)) {
+                const V3 c = thr * environmentRadiance(sc, rayD);
+                if (c.x != 0 || c.y != 0 || c.z != 0) {
+                    float4 L = sampleL[slot];
+                    L.x += c.x; L.y += c.y; L.z += c.z;
+                    sampleL[slot] = L;
+                }
             }
         } else if (!(sc.hideEmitters && !(flags & PF_SCATTERED))) {
             // ray from BSDF sampling (path.cpp:233-247,257-264): MIS against the environment emitter's pdfDirect
@@ -396,7 +443,7 @@ MTS_DEV void sortByBsdfType(const float4 *hits, uint32_t first, uint32_t n, uint
 // ENV: the scene has emitters other than area lights: an environment emitter (rays that leave the scene are shaded
 // too, one more queue stream), point, spot or directional lights.
 // RD: the scene has a rough dielectric material.
-template <int ROUNDS, bool ENV, bool RD, bool MIX>
+template <int ROUNDS, bool ENV, bool RD, bool MIX, bool VS = false>
 __global__ void __launch_bounds__(kShadeBlock, MIX ? MTS_SHADE_WAVES_MIX : MTS_SHADE_WAVES) k_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out,
                                                        ShadowQueue sq, float4 *sampleL, const float2 *samplePos, uint32_t *counters, uint32_t n) {
     constexpr int kWaves = kShadeBlock / 64;
@@ -415,7 +462,7 @@ __global__ void __launch_bounds__(kShadeBlock, MIX ? MTS_SHADE_WAVES_MIX : MTS_S
     asm volatile("" : "+v"(tidS));
     const uint32_t i = first + sOrder[round * kShadeBlock + tidS];
     ShadeOut o;
-    if (i < n) shadeVertex<ENV, RD, MIX, kShadePark>(sc, pp, QueuedPath{ in, i }, hits[i], sampleL, samplePos, o, sPark);
+    if (i < n) shadeVertex<ENV, RD, MIX, kShadePark, QueuedPath, VS>(sc, pp, QueuedPath{ in, i }, hits[i], sampleL, samplePos, o, sPark);
     const bool alive = o.alive, wantShadow = o.wantShadow;
     uint32_t tidL = threadIdx.x;
     asm volatile("" : "+v"(tidL));
@@ -460,7 +507,7 @@ __global__ void __launch_bounds__(kShadeBlock, MIX ? MTS_SHADE_WAVES_MIX : MTS_S
 // functions as the wavefront kernels, hence the same results. counts[0] / counts[1] receive the closest-hit and
 // shadow rays traced (the reference's two ray counters).
 static constexpr int kTailBlock = 64;
-template <bool ENV, bool RD, bool MIX>
+template <bool ENV, bool RD, bool MIX, bool VS = false>
 __global__ void __launch_bounds__(kTailBlock) k_tail(DevScene sc, PassParams pp, PathQueue in, float4 *sampleL, const float2 *samplePos, uint32_t n,
                                                      uint32_t triShare, unsigned long long *counts) {
     __shared__ uint2 sStack[kLdsStack * kTailBlock];
@@ -491,7 +538,7 @@ __global__ void __launch_bounds__(kTailBlock) k_tail(DevScene sc, PassParams pp,
         traceHeldRays<false>(sc, r, busy, ldsStack, kTailBlock, triShare);
         // shade
         ShadeOut o;
-        if (active) shadeVertex<ENV, RD, MIX, false>(sc, pp, path, make_float4(r.hit.t, r.hit.u, r.hit.v, __uint_as_float(r.hit.tri)), sampleL, samplePos, o);
+        if (active) shadeVertex<ENV, RD, MIX, false, HeldPath, VS>(sc, pp, path, make_float4(r.hit.t, r.hit.u, r.hit.v, __uint_as_float(r.hit.tri)), sampleL, samplePos, o);
         // shadow ray of the emitter sample (scene.cpp:839-843), then path.cpp:196-198
         const bool wantShadow = active && o.wantShadow;
         busy = false;

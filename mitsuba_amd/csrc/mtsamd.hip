@@ -147,7 +147,7 @@ struct mtsamd_scene {
         PathQueue q;
         q.rayO = qbuf[i][0].as<float4>(); q.rayD = qbuf[i][1].as<float4>(); q.thr = qbuf[i][2].as<float4>();
         q.misc = qbuf[i][3].as<uint4>(); q.bsdfPdf = qbuf[i][4].as<float>();
-        q.refCos = (host.extEmitters || host.mixture || host.desc.integrator.type == MTSAMD_INTEGRATOR_DIRECT) ? qbuf[i][5].as<float>() : nullptr;
+        q.refCos = (host.extEmitters || host.mixture || host.desc.integrator.type != MTSAMD_INTEGRATOR_PATH) ? qbuf[i][5].as<float>() : nullptr;
         return q;
     }
     ShadowQueue shadowQueue() const {
@@ -168,7 +168,7 @@ struct mtsamd_scene {
         for (int i = 0; i < 2; ++i) {
             for (int j = 0; j < 4; ++j) HIP_TRY(qbuf[i][j].ensure(n * 16));
             HIP_TRY(qbuf[i][4].ensure(n * 4));
-            if (host.extEmitters || host.mixture || host.desc.integrator.type == MTSAMD_INTEGRATOR_DIRECT) HIP_TRY(qbuf[i][5].ensure(n * 4));
+            if (host.extEmitters || host.mixture || host.desc.integrator.type != MTSAMD_INTEGRATOR_PATH) HIP_TRY(qbuf[i][5].ensure(n * 4));
         }
         HIP_TRY(hits.ensure(n * 16));
         for (int j = 0; j < 3; ++j) HIP_TRY(sbuf[j].ensure(n * 16));
@@ -496,6 +496,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
     bool shadowPending = false;
     const bool traceIters = getenv("MTSAMD_TRACE_ITERS") != nullptr;
     const mtsamd_integrator &ig = s->host.desc.integrator;
+    const bool simple = ig.type == MTSAMD_INTEGRATOR_VOLPATH_SIMPLE;       // runs the every-feature kernels with its own estimator
     if (ig.type == MTSAMD_INTEGRATOR_DIRECT) {
         // camera rays -> shade the camera vertex into nEmitter shadow rays and nBsdf BSDF-sampled rays per sample -> both
         // traversals -> gather. The queues keep a fixed place for every ray of a sample.
@@ -547,9 +548,10 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
             unsigned long long *tailCounts = cnt64 + CNT64_TAIL_NORMAL;
             HIP_TRY(hipMemsetAsync(tailCounts, 0, 2 * sizeof(unsigned long long), st));
             timer.begin(T_TAIL);
-#define MTS_LAUNCH_TAIL(E, R, M) hipLaunchKernelGGL((k_tail<E, R, M>), dim3(blocksFor(n, kTailBlock)), dim3(kTailBlock), 0, st, sc, pp, s->queue(cur), sampleL, samplePos, n, s->triShare, tailCounts)
+#define MTS_LAUNCH_TAIL(...) hipLaunchKernelGGL((k_tail<__VA_ARGS__>), dim3(blocksFor(n, kTailBlock)), dim3(kTailBlock), 0, st, sc, pp, s->queue(cur), sampleL, samplePos, n, s->triShare, tailCounts)
             // scenes with mixtures, textures or frame adapters run the variants that know them (with or without the other emitter kinds and the rough dielectric)
-            if (s->host.mixture) { if (s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_TAIL(true, true, true); else MTS_LAUNCH_TAIL(false, false, true); }
+            if (simple) MTS_LAUNCH_TAIL(true, true, true, true);
+            else if (s->host.mixture) { if (s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_TAIL(true, true, true); else MTS_LAUNCH_TAIL(false, false, true); }
             else if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_TAIL(true, true, false); else MTS_LAUNCH_TAIL(true, false, false); }
             else { if (s->roughDielectric) MTS_LAUNCH_TAIL(false, true, false); else MTS_LAUNCH_TAIL(false, false, false); }
 #undef MTS_LAUNCH_TAIL
@@ -579,9 +581,11 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         timer.begin(T_SHADE);
         // large queues: several sweeps per workgroup (purer wavefronts); small ones: one, to keep every CU busy
         const int rounds = n >= s->shadeRoundsAbove ? s->shadeRounds : 1;
-#define MTS_LAUNCH_SHADE_AS(R, E, D, M) hipLaunchKernelGGL((k_shade<R, E, D, M>), dim3(blocksFor(n, kShadeBlock * R)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, samplePos, cnt, n)
+#define MTS_LAUNCH_SHADE_AS(...) hipLaunchKernelGGL((k_shade<__VA_ARGS__>), dim3(blocksFor(n, kShadeBlock * rounds16)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, samplePos, cnt, n)
 #define MTS_LAUNCH_SHADE(R) do { \
-            if (s->host.mixture) { if (s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true, true); else MTS_LAUNCH_SHADE_AS(R, false, false, true); } \
+            const int rounds16 = R; \
+            if (simple) MTS_LAUNCH_SHADE_AS(R, true, true, true, true); \
+            else if (s->host.mixture) { if (s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true, true); else MTS_LAUNCH_SHADE_AS(R, false, false, true); } \
             else if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true, false); else MTS_LAUNCH_SHADE_AS(R, true, false, false); } \
             else { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, false, true, false); else MTS_LAUNCH_SHADE_AS(R, false, false, false); } } while (0)
         // (sweeps per workgroup: 16 for large queues, 1 for small ones; MTSAMD_SHADE_ROUNDS=1 switches the sweeps off.

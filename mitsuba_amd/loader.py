@@ -592,6 +592,8 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
             if el.get("type") == "direct":      # src/integrators/direct/direct.cpp:93-107
                 shading = p.get("shadingSamples", 1)
                 integ.update(type="direct", emitter_samples=p.get("emitterSamples", shading), bsdf_samples=p.get("bsdfSamples", shading))
+            elif el.get("type") == "volpath_simple":    # media are not loaded: the surface-only form of it
+                integ.update(type="volpath_simple")
         elif el.tag == "sensor":
             if el.get("type") != "perspective":
                 raise SceneFormatError("only the perspective sensor is supported")

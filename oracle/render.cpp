@@ -261,7 +261,7 @@ std::string Scene::build(const orc_scene_desc *d) {
     if (d->integrator.type == 1) {      // MIDirectIntegrator (direct.cpp:96-107)
         if (d->integrator.emitter_samples < 0 || d->integrator.bsdf_samples < 0 || d->integrator.emitter_samples + d->integrator.bsdf_samples <= 0)
             return "direct: the numbers of emitter and BSDF samples must not be negative and not both zero";
-    } else if (d->integrator.type != 0) {
+    } else if (d->integrator.type != 0 && d->integrator.type != 2) {
         return "unknown integrator type";
     }
     deltaEmitters.assign(d->n_emitters, DeltaEmitter());
@@ -749,6 +749,103 @@ static Spectrum Li(const Scene &sc, const Ray &r, const RayDifferentials &rd0, P
     return Li;
 }
 
+// ---- SimpleVolumetricPathTracer::Li (src/integrators/path/volpath_simple.cpp:88-297) for scenes without participating
+// media (rRec.medium is always NULL, no BSDF has a null component): a path tracer without multiple importance sampling.
+// Emitters are seen by the camera ray and after Dirac bounces only; every other vertex gathers direct light by emitter
+// sampling at full weight, with the visibility test of Scene::sampleAttenuatedEmitterDirect (scene.cpp:876-898,
+// evalTransmittance :619-676: a ray from the surface to the sampled point, shortened by ShadowEpsilon only where that
+// point lies on a surface).
+static Spectrum LiSimple(const Scene &sc, const Ray &r, const RayDifferentials &rd0, Pcg32 &rng, float &alpha, RayCounters &cnt) {
+    const orc_integrator &ig = sc.desc.integrator;
+    Intersection its;
+    Ray ray(r);
+    RayDifferentials rd = rd0;
+    Spectrum Li(0.0f);
+    bool scattered = false;
+    bool emitted = true, direct = true;         // rRec.type & EEmittedRadiance, & EDirectSurfaceRadiance
+    float eta = 1.0f;
+    int depth = 1;
+
+    cnt.normal++;
+    sc.rayIntersect(ray, its, &cnt.trav);
+    alpha = its.isValid() ? 1.0f : 0.0f;
+    ray.mint = Epsilon;
+    Spectrum throughput(1.0f);
+    if (ig.max_depth == 1) direct = false;      // :103-104
+
+    while (depth <= ig.max_depth || ig.max_depth < 0) {
+        if (!its.isValid()) {                   // :170-181
+            if (sc.envEmitter >= 0 && emitted && (!ig.hide_emitters || scattered))
+                Li += throughput * envRadiance(sc, ray.d, rd);
+            break;
+        }
+        const orc_shape &shape = sc.shapes[its.shape];
+        const Material &bsdf = sc.materials[shape.material];
+        g_textureUV = its.uv;
+        g_bsdfIts = &its;
+        g_texturePartials = partialsFor(bsdf, its, ray, rd);
+        rd.has = false;
+
+        if (shape.emitter >= 0 && emitted && (!ig.hide_emitters || scattered)) {     // :184-186
+            const orc_emitter &em = sc.emitters[shape.emitter];
+            if (dot(its.shFrame.n, -ray.d) > 0)
+                Li += throughput * Spectrum(em.radiance[0], em.radiance[1], em.radiance[2]);
+        }
+        // :193-196: strictly negative, unlike path.cpp's test
+        if (ig.strict_normals && (-dot(its.geoFrame.n, ray.d)) * Frame::cosTheta(its.wi) < 0) break;
+
+        Vec3 refN(0.0f);
+        if ((bsdf.type_flags & (ETransmission | EBackSide)) == 0) refN = its.shFrame.n;
+
+        if (direct && (bsdf.type_flags & ESmooth)) {        // :205-226
+            DirectSample dRec;
+            Vec2 s = rng.next2D();
+            Spectrum value = sampleEmitterDirect(sc, its.p, refN, s, dRec);
+            if (dRec.pdf != 0) {
+                cnt.shadow++;
+                Ray shadowRay(its.p, dRec.d, Epsilon, dRec.delta ? dRec.dist : dRec.dist * (1 - ShadowEpsilon));
+                if (sc.rayIntersectShadow(shadowRay, &cnt.trav)) value = Spectrum(0.0f);
+            }
+            if (!value.isZero()) {
+                Vec3 wo = its.toLocal(dRec.d);
+                if (!ig.strict_normals || dot(its.geoFrame.n, dRec.d) * Frame::cosTheta(wo) > 0)
+                    Li += throughput * value * bsdfEval(bsdf, its.wi, wo);
+            }
+        }
+
+        float bsdfPdf_;
+        BSDFSample bs;
+        struct StreamTap : Sampler1D { Pcg32 &r; explicit StreamTap(Pcg32 &r_) : r(r_) {} float next1D() override { return r.next1D(); } } tap(rng);
+        const Vec2 bsdfSample2D = rng.next2D();
+        Spectrum bsdfVal = bsdfSample(bsdf, its.wi, bsdfSample2D, bs, bsdfPdf_, &tap);
+        if (bsdfVal.isZero()) break;
+
+        // :243-263 (no null components: nullChain plays no part)
+        bool nextDirect = false, nextEmitted = false;
+        if (depth + 1 < ig.max_depth || ig.max_depth < 0) nextDirect = true;
+        if ((depth < ig.max_depth || ig.max_depth < 0) && (bs.sampledType & EDelta)) nextEmitted = true;
+        if (!nextDirect && !nextEmitted) break;
+        direct = nextDirect; emitted = nextEmitted;
+
+        const Vec3 wo = its.toWorld(bs.wo);
+        if (dot(its.geoFrame.n, wo) * Frame::cosTheta(bs.wo) <= 0 && ig.strict_normals) break;
+
+        throughput *= bsdfVal;
+        eta *= bs.eta;
+        ray = Ray(its.p, wo);
+        cnt.normal++;
+        sc.rayIntersect(ray, its, &cnt.trav);
+        scattered |= bs.sampledType != ENull;
+
+        if (depth++ >= ig.rr_depth) {           // :282-292
+            float q = std::min(throughput.max() * eta * eta, 0.95f);
+            if (rng.next1D() >= q) break;
+            throughput /= q;
+        }
+    }
+    return Li;
+}
+
 // ---- MIDirectIntegrator::Li (src/integrators/direct/direct.cpp:146-309) -----------------------------------
 // Sample order per camera sample: the emitter samples' 2-D numbers, then for every BSDF sample its 2-D number
 // followed by what the BSDF itself takes from the sampler.
@@ -1100,7 +1197,8 @@ static inline void renderSample(const Scene &sc, const orc_render_opts *o, int x
     RayDifferentials rd;
     Ray ray = sc.anyRayDifferentials ? cameraRay(sc, pos[0], pos[1], &rd, 1.0f / std::sqrt((float) o->spp_total)) : cameraRay(sc, pos[0], pos[1]);
     float alpha;
-    Spectrum L = sc.desc.integrator.type == 1 ? LiDirect(sc, ray, rd, rng, alpha, cnt) : Li(sc, ray, rd, rng, alpha, cnt);
+    const int integrator = sc.desc.integrator.type;
+    Spectrum L = integrator == 1 ? LiDirect(sc, ray, rd, rng, alpha, cnt) : integrator == 2 ? LiSimple(sc, ray, rd, rng, alpha, cnt) : Li(sc, ray, rd, rng, alpha, cnt);
     rgba[0] = L.x; rgba[1] = L.y; rgba[2] = L.z; rgba[3] = alpha;
 }
 

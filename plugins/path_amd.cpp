@@ -40,6 +40,10 @@ public:
 		m_refreshSamples = props.getInteger("refreshSamples", 0);
 		/* "direct" = true: MIDirectIntegrator's estimator (src/integrators/direct/direct.cpp) with its sample counts */
 		m_direct = props.getBoolean("direct", false);
+		/* "simple" = true: the estimator of volpath_simple (src/integrators/path/volpath_simple.cpp) for scenes without media */
+		m_simple = props.getBoolean("simple", false);
+		if (m_direct && m_simple)
+			Log(EError, "path_amd: 'direct' and 'simple' exclude each other");
 		int shadingSamples = props.getInteger("shadingSamples", 1);
 		m_emitterSamples = props.getInteger("emitterSamples", shadingSamples);
 		m_bsdfSamples = props.getInteger("bsdfSamples", shadingSamples);
@@ -51,6 +55,7 @@ public:
 		m_seed = stream->readUInt();
 		m_refreshSamples = stream->readInt();
 		m_direct = stream->readBool();
+		m_simple = stream->readBool();
 		m_emitterSamples = stream->readInt();
 		m_bsdfSamples = stream->readInt();
 	}
@@ -62,6 +67,7 @@ public:
 		stream->writeUInt(m_seed);
 		stream->writeInt(m_refreshSamples);
 		stream->writeBool(m_direct);
+		stream->writeBool(m_simple);
 		stream->writeInt(m_emitterSamples);
 		stream->writeInt(m_bsdfSamples);
 	}
@@ -357,7 +363,7 @@ private:
 
 		d.integrator.max_depth = m_maxDepth; d.integrator.rr_depth = m_rrDepth;
 		d.integrator.strict_normals = m_strictNormals; d.integrator.hide_emitters = m_hideEmitters;
-		d.integrator.type = m_direct ? MTSAMD_INTEGRATOR_DIRECT : MTSAMD_INTEGRATOR_PATH;
+		d.integrator.type = m_direct ? MTSAMD_INTEGRATOR_DIRECT : m_simple ? MTSAMD_INTEGRATOR_VOLPATH_SIMPLE : MTSAMD_INTEGRATOR_PATH;
 		d.integrator.emitter_samples = m_emitterSamples; d.integrator.bsdf_samples = m_bsdfSamples;
 
 		/* one replica of the scene per GPU (Scene::initialize + kd-tree build happen once per worker node in the
@@ -383,7 +389,7 @@ private:
 	std::string m_deviceList;
 	uint32_t m_seed;
 	int m_refreshSamples;
-	bool m_direct;
+	bool m_direct, m_simple;
 	int m_emitterSamples, m_bsdfSamples;
 };
 

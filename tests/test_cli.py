@@ -361,6 +361,21 @@ def test_cli_direct_integrator(scene_dir, tmp_path):
         assert (d["emitter_samples"], d["bsdf_samples"]) == want == (sd.integrator["emitter_samples"], sd.integrator["bsdf_samples"])
 
 
+def test_cli_volpath_simple_integrator(scene_dir, tmp_path):
+    """<integrator type="volpath_simple"> on a scene without media: both loaders hand the estimator over with path's
+    parameters; an integrator neither of them knows is named."""
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    text = (scene_dir / "scene.xml").read_text()
+    head = text[text.index("<integrator"):text.index("</integrator>") + len("</integrator>")]
+    f = tmp_path / "simple.xml"
+    f.write_text(text.replace(head, '<integrator type="volpath_simple"><integer name="maxDepth" value="7"/><integer name="rrDepth" value="2"/></integrator>'))
+    d = _describe(f)
+    sd, info = loader.load_xml(str(f))
+    assert d["integrator"] == info["integrator_type"] == "volpath_simple" and d["integrator_kind"] == 2 and sd.integrator["type"] == "volpath_simple"
+    assert (d["max_depth"], d["rr_depth"]) == (7, 2) == (sd.integrator["max_depth"], sd.integrator["rr_depth"])
+    assert _describe(scene_dir / "scene.xml")["integrator_kind"] == 0
+
+
 def test_cli_mixturebsdf(scene_dir, tmp_path):
     """mixturebsdf.cpp:66-85,279-287: nested BSDFs are appended before the mixture's own record, by both loaders alike."""
     (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())

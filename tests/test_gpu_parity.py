@@ -432,6 +432,36 @@ def test_direct_integrator_parity(gpu, oracle_mod, ne, nb):
     assert np.allclose(f2, fg, rtol=1e-5, atol=1e-6)
 
 
+def test_volpath_simple_parity(gpu, oracle_mod):
+    """SimpleVolumetricPathTracer::Li without media (volpath_simple.cpp:88-297) per camera sample: same ray counts, same
+    radiance, for bounded and unbounded depth, early roulette, strict normals, hidden emitters, every emitter kind,
+    mixtures and textures."""
+    cases = [(S.small_test_scene(), {}), (S.small_test_scene(max_depth=2), {}), (S.small_test_scene(max_depth=3), dict(rr_depth=1)),
+             (S.small_test_scene(sky=(0.6, 0.8, 1.2), lamps=True, blend=True, max_depth=6), dict(rr_depth=2)),
+             (S.cornell_mixed(64, 64, max_depth=5), {}), (S.small_test_scene(sky=(0.2, 0.2, 0.3), max_depth=4), dict(hide_emitters=1, strict_normals=1)),
+             (S.small_test_scene(textured="bitmap", max_depth=4), {}), (S.small_test_scene(sky="map", max_depth=5), {}),
+             (S.small_test_scene(sky="map", area_lights=False, lamps=True, max_depth=3), {})]
+    for sd, extra in cases:
+        sd.integrator.update(type="volpath_simple", **extra)
+        g, o = gpu.Scene(sd), oracle_mod.OracleScene(sd)
+        Lg, pg, sg = g.li(4, seed=7)
+        Lo, po_, so = o.li(4, seed=7)
+        assert np.array_equal(pg, po_)
+        assert (sg.normal_rays, sg.shadow_rays) == (so.normal_rays, so.shadow_rays), (sd.integrator, sg.normal_rays, so.normal_rays, sg.shadow_rays, so.shadow_rays)
+        assert np.array_equal(Lg[..., 3], Lo[..., 3])
+        rel = np.abs(Lg[..., :3] - Lo[..., :3]).max(-1) / (np.abs(Lo[..., :3]).max(-1) + 1e-3)
+        assert np.mean(rel < 1e-3) > 0.995, (sd.integrator, np.mean(rel < 1e-3))
+        assert abs(Lg[..., :3].mean() - Lo[..., :3].mean()) < 2e-3 * Lo[..., :3].mean() + 1e-6
+    # film; the launch that finishes a pass (the unbounded case has long tails) against the wavefront loop alone
+    sd = S.small_test_scene(sky=(0.3, 0.3, 0.4))
+    sd.integrator.update(type="volpath_simple")
+    g, o = gpu.Scene(sd), oracle_mod.OracleScene(sd)
+    fg, _ = g.render(8, seed=3)
+    fo, _ = o.render(8, seed=3)
+    dg, do = g.develop(fg), o.develop(fo)
+    assert np.mean((dg[..., :3] - do[..., :3]) ** 2 / (do[..., :3] ** 2 + 1e-2)) < 1e-6
+
+
 def test_max_depth_and_rr_variants(gpu, oracle_mod):
     for md, rr in ((1, 5), (2, 5), (3, 1), (6, 2)):
         sd = S.small_test_scene(max_depth=md)
