@@ -102,6 +102,8 @@ static void describe(const LoadedScene &s) {
     printf("], \"diffuse\": [");
     for (size_t i = 0; i < s.materials.size(); ++i)
         printf("%s[%.9g, %.9g, %.9g]", i ? ", " : "", s.materials[i].diffuse_reflectance[0], s.materials[i].diffuse_reflectance[1], s.materials[i].diffuse_reflectance[2]);
+    printf("], \"annotations\": [");
+    for (size_t i = 0; i < s.annotations.size(); ++i) printf("%s[\"%s\", %d]", i ? ", " : "", s.annotations[i].key.c_str(), s.annotations[i].kind);
     printf("], \"emitter_records\": [");
     for (size_t i = 0; i < s.emitters.size(); ++i) {
         const mtsamd_emitter &e = s.emitters[i];
@@ -206,13 +208,16 @@ int main(int argc, char **argv) {
     // its defaults), .exr -> OpenEXR, anything else -> PFM
     auto endsWith = [&](const char *ext) { return outPath.size() >= 4 && outPath.compare(outPath.size() - 4, 4, ext) == 0; };
     std::string werr;
+    std::vector<Metadata> metadata;     // the film's annotations (PNG and OpenEXR carry them; PFM has no place for them)
+    const std::string merr = resolveAnnotations(scene, outPath, st.seconds, (int) handles.size(), metadata);
+    if (!merr.empty()) { fprintf(stderr, "mtsamd-render: %s\n", merr.c_str()); return 1; }
     if (endsWith(".png")) {
         const int channels[4] = { 1, 2, 3, 4 };
         std::vector<uint8_t> ldr((size_t) W * H * 4);
         if (mtsamd_film_develop_ldr(film.data(), W, H, &scene.ldr, ldr.data()) != MTSAMD_OK) { fprintf(stderr, "mtsamd-render: %s\n", mtsamd_last_error()); return 1; }
-        werr = writePng(outPath, ldr.data(), W, H, channels[scene.ldr.pixel_format]);
+        werr = writePng(outPath, ldr.data(), W, H, channels[scene.ldr.pixel_format], &metadata);
     } else {
-        werr = endsWith(".exr") ? writeExr(outPath, rgba.data(), W, H, scene.hdrPixelFormat, scene.hdrHalf) : writePfm(outPath, rgba.data(), W, H);
+        werr = endsWith(".exr") ? writeExr(outPath, rgba.data(), W, H, scene.hdrPixelFormat, scene.hdrHalf, &metadata) : writePfm(outPath, rgba.data(), W, H);
     }
     for (mtsamd_scene *h : handles) mtsamd_scene_destroy(h);
     if (!werr.empty()) { fprintf(stderr, "mtsamd-render: %s\n", werr.c_str()); return 1; }

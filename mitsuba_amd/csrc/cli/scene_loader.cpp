@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <iomanip>
 #include <map>
 #include <sstream>
 #include <tuple>
@@ -1132,7 +1133,7 @@ std::string writePfm(const std::string &path, const float *rgba, int width, int 
 }
 
 // PNG: signature, IHDR, one IDAT holding the zlib stream of the unfiltered rows, IEND
-std::string writePng(const std::string &path, const uint8_t *pixels, int width, int height, int channels) {
+std::string writePng(const std::string &path, const uint8_t *pixels, int width, int height, int channels, const std::vector<Metadata> *metadata) {
     if (channels < 1 || channels > 4) return "PNG output needs 1 to 4 channels";
     const size_t row = (size_t) width * channels;
     std::vector<uint8_t> raw((row + 1) * (size_t) height);
@@ -1164,6 +1165,15 @@ std::string writePng(const std::string &path, const uint8_t *pixels, int width, 
     const uint8_t colourType[5] = { 0, 0, 4, 2, 6 };    // grey, grey + alpha, RGB, RGBA
     ihdr[8] = 8; ihdr[9] = colourType[channels]; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
     chunk("IHDR", ihdr, 13);
+    if (metadata)
+        for (const Metadata &m : *metadata) {       // keyword, a zero byte, the text
+            std::ostringstream value;
+            if (m.kind == 0) value << m.s; else if (m.kind == 1) value << m.i; else value << m.f;
+            std::string body = m.key.substr(0, 79);
+            body.push_back('\0');
+            body += value.str();
+            chunk("tEXt", (const uint8_t *) body.data(), body.size());
+        }
     chunk("IDAT", z.data(), zlen);
     chunk("IEND", nullptr, 0);
     const bool ok = !ferror(f);
@@ -1198,7 +1208,7 @@ static uint16_t floatToHalf(float f) {
     return (uint16_t) (sign | h);
 }
 
-std::string writeExr(const std::string &path, const float *rgba, int width, int height, int pixelFormat, bool half) {
+std::string writeExr(const std::string &path, const float *rgba, int width, int height, int pixelFormat, bool half, const std::vector<Metadata> *metadata) {
     FILE *f = fopen(path.c_str(), "wb");
     if (!f) return "cannot write " + path;
     std::vector<uint8_t> h;
@@ -1216,7 +1226,9 @@ std::string writeExr(const std::string &path, const float *rgba, int width, int 
     if (colour) { channels.push_back({ "B", 2 }); channels.push_back({ "G", 1 }); channels.push_back({ "R", 0 }); }
     else channels.push_back({ "Y", 4 });
     const size_t nc = channels.size(), bpc = half ? 2 : 4;
-    putI(20000630); putI(2);
+    bool longNames = false;         // attribute names above 31 characters need the long-names bit of the version field
+    if (metadata) for (const Metadata &m : *metadata) longNames |= m.key.size() > 31;
+    putI(20000630); putI(2 | (longNames ? 0x400 : 0));
     attr("channels", "chlist", (int32_t) (nc * 18 + 1));
     for (const Channel &c : channels) { putStr(c.name); putI(half ? 1 /* HALF */ : 2 /* FLOAT */); putI(0); putI(1); putI(1); }
     h.push_back(0);
@@ -1227,6 +1239,13 @@ std::string writeExr(const std::string &path, const float *rgba, int width, int 
     attr("pixelAspectRatio", "float", 4); putF(1.0f);
     attr("screenWindowCenter", "v2f", 8); putF(0.0f); putF(0.0f);
     attr("screenWindowWidth", "float", 4); putF(1.0f);
+    if (metadata)
+        for (const Metadata &m : *metadata) {
+            if (m.key.empty() || m.key.size() > 255) { fclose(f); return "metadata key '" + m.key + "' cannot be an OpenEXR attribute name"; }
+            if (m.kind == 0) { attr(m.key.c_str(), "string", (int32_t) m.s.size()); put(m.s.data(), m.s.size()); }
+            else if (m.kind == 1) { attr(m.key.c_str(), "int", 4); putI(m.i); }
+            else { attr(m.key.c_str(), "float", 4); putF(m.f); }
+        }
     h.push_back(0);
     const uint64_t dataBytes = (uint64_t) width * nc * bpc, rowBytes = 8 + dataBytes;
     uint64_t offset = h.size() + (uint64_t) height * 8;
@@ -1247,6 +1266,88 @@ std::string writeExr(const std::string &path, const float *rgba, int width, int 
         fwrite(row.data(), 1, row.size(), f);
     }
     fclose(f);
+    return "";
+}
+
+// timeString / memString (src/libcore/util.cpp:864-905)
+static std::string timeString(double seconds, bool precise) {
+    float time = (float) seconds;
+    if (std::isnan(time) || std::isinf(time)) return "inf";
+    char suffix = 's';
+    if (time > 60) { time /= 60; suffix = 'm'; if (time > 60) { time /= 60; suffix = 'h'; if (time > 12) { time /= 12; suffix = 'd'; } } }
+    std::ostringstream os;
+    os << std::setprecision(precise ? 4 : 1) << std::fixed << time << suffix;
+    return os.str();
+}
+static std::string memString(size_t size, bool precise) {
+    float value = (float) size;
+    const char *suffixes[] = { "B", "KiB", "MiB", "GiB", "TiB", "PiB" };
+    int suffix = 0;
+    while (suffix < 5 && value > 1024.0f) { value /= 1024.0f; ++suffix; }
+    std::ostringstream os;
+    os << std::setprecision(suffix == 0 ? 0 : (precise ? 4 : 1)) << std::fixed << value << " " << suffixes[suffix];
+    return os.str();
+}
+static size_t residentBytes() {     // what getPrivateMemoryUsage reports on Linux: the resident set
+    FILE *f = fopen("/proc/self/statm", "r");
+    if (!f) return 0;
+    unsigned long total = 0, resident = 0;
+    const int n = fscanf(f, "%lu %lu", &total, &resident);
+    fclose(f);
+    return n == 2 ? (size_t) resident * 4096u : 0;
+}
+
+std::string resolveAnnotations(const LoadedScene &scene, const std::string &destFile, double renderSeconds, int coreCount, std::vector<Metadata> &out) {
+    out.clear();
+    bool generatedBy = false;
+    auto strip = [](std::string v) { v.erase(std::remove_if(v.begin(), v.end(), [](unsigned char c) { return std::isspace(c); }), v.end()); return v; };
+    for (const LoadedScene::Annotation &a : scene.annotations) {
+        Metadata m;
+        m.key = a.key; m.kind = a.kind; m.i = (int32_t) a.i; m.f = (float) a.f;
+        if (a.kind == 0) {
+            std::string value = a.text;
+            while (true) {      // annotations.h:76-141: replace the first $source['key'] until none is left
+                const size_t strt = value.find('$');
+                if (strt == std::string::npos) break;
+                const size_t par1 = value.find('[', strt);
+                if (par1 == std::string::npos) break;
+                const size_t par2 = value.find(']', par1);
+                if (par2 == std::string::npos) break;
+                const std::string source = strip(value.substr(strt + 1, par1 - strt - 1));
+                std::string key = strip(value.substr(par1 + 1, par2 - par1 - 1));
+                if (key.size() < 2 || key.front() != '\'' || key.back() != '\'') return "Encountered invalid key '" + key + "'";
+                key = key.substr(1, key.size() - 2);
+                std::string replacement;
+                if (source == "scene") {
+                    if (key == "renderTime") replacement = timeString(renderSeconds, false);
+                    else if (key == "renderTimePrecise") replacement = timeString(renderSeconds, true);
+                    else if (key == "memUsage") replacement = memString(residentBytes(), false);
+                    else if (key == "memUsagePrecise") replacement = memString(residentBytes(), true);
+                    else if (key == "coreCount") replacement = std::to_string(coreCount);
+                    else if (key == "blockSize") replacement = std::to_string(scene.blockSize);
+                    else if (key == "sourceFile") replacement = scene.sourceFile;
+                    else if (key == "destFile") replacement = destFile;
+                    else return "Property \"" + key + "\" has not been specified!";
+                } else {
+                    auto el = scene.elements.find(source);
+                    if (source != "film" && source != "sampler" && source != "sensor" && source != "integrator")
+                        return "Unknown data source '" + source + "' (must be film/sampler/sensor/integrator)";
+                    if (el == scene.elements.end() || !el->second.count(key)) return "Property \"" + key + "\" has not been specified!";
+                    replacement = el->second.at(key);
+                }
+                value.replace(strt, par2 - strt + 1, replacement);
+            }
+            m.s = value;
+        }
+        generatedBy |= m.key == "generatedBy";
+        out.push_back(m);
+    }
+    if (!generatedBy) {     // Bitmap::write adds it (bitmap.cpp:2610-2611, 3192-3193); this caller names itself
+        Metadata m;
+        m.key = "generatedBy"; m.s = "mtsamd-render (libmtsamd, interface version " + std::to_string(MTSAMD_ABI_VERSION) + ")";
+        out.push_back(m);
+    }
+    std::sort(out.begin(), out.end(), [](const Metadata &a, const Metadata &b) { return a.key < b.key; });     // Properties keeps its names ordered
     return "";
 }
 
@@ -1443,6 +1544,45 @@ void expandIncludes(Element &scene, const std::string &base, std::map<std::strin
     }
     scene.children = std::move(flat);
 }
+// The scalar properties of an element as Properties::getAsString prints them (src/libcore/properties.cpp:184-201): what
+// $film['...'] and its siblings of a metadata annotation expand to; "type" is the plugin's name.
+std::map<std::string, std::string> propertyStrings(const Element &el) {
+    std::map<std::string, std::string> out;
+    out["type"] = el.get("type");
+    for (const auto &cp : el.children) {
+        const Element &c = *cp;
+        const std::string name = c.get("name");
+        std::ostringstream oss;
+        if (c.tag == "float") oss << (float) std::stod(c.get("value"));
+        else if (c.tag == "integer") oss << std::stol(c.get("value"));
+        else if (c.tag == "boolean") oss << (lower(c.get("value")) == "true" ? "true" : "false");
+        else if (c.tag == "string") oss << c.get("value");
+        else continue;
+        if (name != "type") out[name] = oss.str();
+    }
+    return out;
+}
+
+// annotations.h:41-68,143-150: the film properties named metadata['key']; labels need a bitmap font this caller does not carry
+void collectAnnotations(const Element &film, LoadedScene &out) {
+    for (const auto &cp : film.children) {
+        const Element &c = *cp;
+        std::string key = c.get("name");
+        key.erase(std::remove_if(key.begin(), key.end(), [](unsigned char ch) { return std::isspace(ch); }), key.end());
+        const std::string lkey = lower(key);
+        if (lkey.compare(0, 6, "label[") == 0 && lkey.back() == ']')
+            throw Fail("label annotations (" + c.get("name") + ") are not supported: they are drawn with the renderer's built-in bitmap font; metadata['...'] annotations are");
+        if (!(lkey.size() >= 12 && lkey.compare(0, 10, "metadata['") == 0 && lkey.compare(lkey.size() - 2, 2, "']") == 0)) continue;
+        LoadedScene::Annotation a;
+        a.key = key.substr(10, key.size() - 12);
+        if (c.tag == "string") { a.kind = 0; a.text = c.get("value"); }
+        else if (c.tag == "integer") { a.kind = 1; a.i = std::stol(c.get("value")); }
+        else if (c.tag == "float") { a.kind = 2; a.f = std::stod(c.get("value")); }
+        else if (c.tag == "boolean") { a.kind = 0; a.text = lower(c.get("value")) == "true" ? "true" : "false"; }
+        else throw Fail("metadata annotation '" + a.key + "': only string, integer, float and boolean values are supported");
+        out.annotations.push_back(a);
+    }
+}
 }  // namespace
 
 std::string loadSceneXml(const std::string &path, const LoadOptions &opts, LoadedScene &out) {
@@ -1457,6 +1597,7 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
         expandIncludes(*root, base, params, 0);
         std::map<std::string, uint32_t> namedBsdfs;
         out.sceneDir = base;
+        out.sourceFile = path;
         g_spectrumDir = base;
         for (const auto &el : root->children)       // textures first: BSDFs refer to them by id
             if (el->tag == "texture") {
@@ -1489,6 +1630,7 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
             const Element &el = *elp;
             if (el.tag == "integrator") {
                 const Props p = parseProps(el);
+                out.elements["integrator"] = propertyStrings(el);
                 out.integratorType = el.get("type");
                 out.integrator.max_depth = (int32_t) getF(p, "maxDepth", -1);
                 out.integrator.rr_depth = (int32_t) getF(p, "rrDepth", 5);
@@ -1507,12 +1649,15 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
             } else if (el.tag == "sensor") {
                 if (el.get("type") != "perspective") return "only the perspective sensor is supported";
                 const Props p = parseProps(el);
+                out.elements["sensor"] = propertyStrings(el);
                 int fw = 768, fh = 576;         // Film defaults (src/librender/film.cpp:25-55)
                 int cropX = 0, cropY = 0, cropW = fw, cropH = fh;
                 const Element *rf = nullptr;
                 for (const auto &c : el.children) {
                     if (c->tag == "film") {
                         const Props fp = parseProps(*c);
+                        out.elements["film"] = propertyStrings(*c);
+                        collectAnnotations(*c, out);
                         fw = (int) getF(fp, "width", 768); fh = (int) getF(fp, "height", 576);
                         // crop window in pixels, by default the whole film (src/librender/film.cpp:35-48)
                         cropX = (int) getF(fp, "cropOffsetX", 0); cropY = (int) getF(fp, "cropOffsetY", 0);
@@ -1551,6 +1696,7 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
                             out.ldr.burn = (float) getF(fp, "burn", 0.0);
                         }
                     } else if (c->tag == "sampler") {
+                        out.elements["sampler"] = propertyStrings(*c);
                         out.sampleCount = (int) getF(parseProps(*c), "sampleCount", 4);
                     }
                 }

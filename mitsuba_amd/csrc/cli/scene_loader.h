@@ -44,6 +44,15 @@ struct LoadedScene {
     std::string filmType;               // "hdrfilm", "ldrfilm", ... as the scene file names it
     int hdrPixelFormat = MTSAMD_PIXEL_RGB;      // HDRFilm parameters (src/films/hdrfilm.cpp:213-260): channels ...
     bool hdrHalf = true;                        // ... and component format of the OpenEXR output (float16 is HDRFilm's default)
+    // Render-time annotations of hdrfilm / ldrfilm (src/films/annotations.h:32-155): the film's metadata['key'] properties.
+    // kind 0: a string that may refer to $scene['...'], $film['...'], $sampler['...'], $sensor['...'], $integrator['...'];
+    // 1: an integer, 2: a float (copied as they are). `elements` holds the properties of those four scene elements as
+    // Properties::getAsString prints them (src/libcore/properties.cpp:184-201, 298-309), "type" = the plugin name.
+    struct Annotation { std::string key; int kind = 0; std::string text; long i = 0; double f = 0; };
+    std::vector<Annotation> annotations;
+    std::map<std::string, std::map<std::string, std::string>> elements;
+    std::string sourceFile;
+    int blockSize = 32;                         // Scene's blockSize property (src/librender/scene.cpp), only reported
     mtsamd_ldr_opts ldr = { MTSAMD_PIXEL_RGB, MTSAMD_TONEMAP_GAMMA, -1.0f, 0.0f, 0.18f, 0.0f };     // LDRFilm parameters (src/films/ldrfilm.cpp:131-183)
 
     // The returned description points into this object; keep it alive until mtsamd_scene_create has returned.
@@ -75,12 +84,19 @@ std::string loadPly(const std::string &path, Mesh &out);
 void makeCube(Mesh &out);
 std::string loadSceneXml(const std::string &path, const LoadOptions &opts, LoadedScene &out);
 
+// Metadata of an output image (Bitmap::getMetadata): kind 0 string, 1 integer, 2 float
+struct Metadata { std::string key; int kind = 0; std::string s; int32_t i = 0; float f = 0; };
+// The scene's annotations with their references resolved (annotations.h:76-141), plus "generatedBy" unless the scene sets it
+std::string resolveAnnotations(const LoadedScene &scene, const std::string &destFile, double renderSeconds, int coreCount, std::vector<Metadata> &out);
+
 // Portable float map, the format HDRFilm writes for ".pfm" (src/films/hdrfilm.cpp:226-227): RGB, bottom row first.
 std::string writePfm(const std::string &path, const float *rgba, int width, int height);
 // OpenEXR (HDRFilm's default container): luminance / luminance-alpha / RGB / RGBA channels (MTSAMD_PIXEL_*), 16- or
 // 32-bit float, uncompressed scan lines, top row first.
-std::string writeExr(const std::string &path, const float *rgba, int width, int height, int pixelFormat, bool half);
+// Metadata becomes header attributes of type string / int / float (Bitmap::writeOpenEXR, src/libcore/bitmap.cpp:3191-3228).
+std::string writeExr(const std::string &path, const float *rgba, int width, int height, int pixelFormat, bool half, const std::vector<Metadata> *metadata = nullptr);
 // PNG, LDRFilm's default container (src/films/ldrfilm.cpp:141-142): 8 bits per channel, 1-4 channels, top row first.
-std::string writePng(const std::string &path, const uint8_t *pixels, int width, int height, int channels);
+// Metadata becomes tEXt chunks (Bitmap::writePNG, src/libcore/bitmap.cpp:2609-2628).
+std::string writePng(const std::string &path, const uint8_t *pixels, int width, int height, int channels, const std::vector<Metadata> *metadata = nullptr);
 
 }  // namespace mtsamd_host

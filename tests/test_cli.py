@@ -591,7 +591,8 @@ def _read_exr(path):
     """Minimal reader for uncompressed single-part scan-line OpenEXR files with 16- or 32-bit float channels:
     returns ({channel name: (h, w) array}, numpy dtype of the stored components)."""
     b = open(path, "rb").read()
-    assert struct.unpack_from("<ii", b, 0) == (20000630, 2)
+    magic, version = struct.unpack_from("<ii", b, 0)
+    assert magic == 20000630 and version & ~0x400 == 2        # 0x400: attribute names may be longer than 31 characters
     pos, attrs = 8, {}
     while b[pos] != 0:
         e = b.index(b"\0", pos); name = b[pos:e].decode(); pos = e + 1
@@ -890,3 +891,94 @@ def test_cli_spectral_values(scene_dir, tmp_path):
         assert out.returncode != 0 and msg in out.stderr, (msg, out.stderr)
         with pytest.raises(loader.SceneFormatError, match=re.escape(msg)):
             loader.load_xml(str(g))
+
+
+def _exr_attributes(path):
+    b = open(path, "rb").read()
+    magic, version = struct.unpack_from("<ii", b, 0)
+    assert magic == 20000630
+    pos, attrs = 8, {}
+    while b[pos] != 0:
+        e = b.index(b"\0", pos); name = b[pos:e].decode(); pos = e + 1
+        e = b.index(b"\0", pos); typ = b[pos:e].decode(); pos = e + 1
+        size, = struct.unpack_from("<i", b, pos); pos += 4
+        attrs[name] = (typ, b[pos:pos + size]); pos += size
+    return version, attrs
+
+
+def _png_text(path):
+    b = open(path, "rb").read()
+    pos, out = 8, {}
+    while pos < len(b):
+        n, = struct.unpack_from(">I", b, pos)
+        typ, data = b[pos + 4:pos + 8], b[pos + 8:pos + 8 + n]
+        assert struct.unpack_from(">I", b, pos + 8 + n)[0] == zlib.crc32(typ + data)
+        if typ == b"tEXt":
+            k, v = data.split(b"\0", 1)
+            out[k.decode()] = v.decode()
+        pos += 12 + n
+    return out
+
+
+ANNOTATED_FILM = ('<film type="%s"><integer name="width" value="64"/><integer name="height" value="48"/><rfilter type="gaussian"/>'
+                  '<string name="metadata[\'note\']" value="a $film[\'width\']x$film[ \'height\' ] $film[\'type\'] of $scene[\'sourceFile\'], '
+                  '$sampler[\'sampleCount\'] spp ($sampler[\'type\']), fov $sensor[\'fov\'], depth $integrator[\'maxDepth\'], '
+                  'blocks of $scene[\'blockSize\'] on $scene[\'coreCount\'] device(s), written to $scene[\'destFile\']"/>'
+                  '<string name=" Metadata[\'time taken\'] " value="$scene[\'renderTime\'] / $scene[\'renderTimePrecise\'] / $scene[\'memUsage\']"/>'
+                  '<integer name="metadata[\'revision\']" value="42"/><float name="metadata[\'a name that is longer than thirty-one characters\']" value="0.25"/>'
+                  '</film>')
+
+
+def test_cli_annotations(scene_dir, tmp_path):
+    """Render-time annotations (src/films/annotations.h:32-155): metadata['key'] properties of the film are collected
+    (white space and the case of the prefix do not matter), labels are refused by name, a bad reference is reported."""
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    text = (scene_dir / "scene.xml").read_text()
+    film = text[text.index("<film"):text.index("</film>") + len("</film>")]
+    f = tmp_path / "annotated.xml"
+    f.write_text(text.replace(film, ANNOTATED_FILM % "hdrfilm"))
+    d = _describe(f)
+    assert d["annotations"] == [["note", 0], ["timetaken", 0], ["revision", 1], ["anamethatislongerthanthirty-onecharacters", 2]]
+    loader.load_xml(str(f))         # the Python loader reads past them
+    g = tmp_path / "label.xml"
+    g.write_text(text.replace(film, film.replace("</film>", '<string name="label[10, 10]" value="hello"/></film>')))
+    out = subprocess.run([CLI, str(g), "--describe"], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "label annotations" in out.stderr
+
+
+@pytest.mark.gpu
+def test_cli_annotations_in_the_output(scene_dir, tmp_path):
+    """The annotations arrive in the image files: string / int / float attributes of the OpenEXR header (with the
+    long-names bit when a key needs it), tEXt chunks of the PNG; references to film / sampler / sensor / integrator
+    properties and to the scene's run-time values are replaced; generatedBy is added."""
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    text = (scene_dir / "scene.xml").read_text()
+    film = text[text.index("<film"):text.index("</film>") + len("</film>")]
+    for kind, name in (("hdrfilm", "out.exr"), ("ldrfilm", "out.png")):
+        f = tmp_path / ("annotated_%s.xml" % kind)
+        f.write_text(text.replace(film, ANNOTATED_FILM % kind))
+        dest = tmp_path / name
+        out = subprocess.run([CLI, str(f), "-o", str(dest), "--spp", "2"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        want_note = ("a 64x48 %s of %s, 8 spp (independent), fov 45, depth 5, blocks of 32 on 1 device(s), written to %s" % (kind, f, dest))
+        if kind == "hdrfilm":
+            version, attrs = _exr_attributes(str(dest))
+            assert version & 0x400
+            assert attrs["note"] == ("string", want_note.encode())
+            assert attrs["revision"] == ("int", struct.pack("<i", 42))
+            assert attrs["anamethatislongerthanthirty-onecharacters"] == ("float", struct.pack("<f", 0.25))
+            assert attrs["generatedBy"][0] == "string" and attrs["generatedBy"][1].startswith(b"mtsamd-render")
+            taken = attrs["timetaken"][1].decode()
+            chans, _ = _read_exr(str(dest))         # still a readable image
+            assert chans["R"].shape == (48, 64)
+        else:
+            t = _png_text(str(dest))
+            assert t["note"] == want_note and t["revision"] == "42" and t["anamethatislongerthanthirty-onecharacters"] == "0.25"
+            assert t["generatedBy"].startswith("mtsamd-render")
+            taken = t["timetaken"]
+            assert _read_png(str(dest)).shape == (48, 64, 3)
+        assert re.fullmatch(r"\d+\.\ds / \d+\.\d{4}s / \d+\.\d [KMG]iB", taken), taken
+    bad = tmp_path / "bad.xml"
+    bad.write_text(text.replace(film, film.replace("</film>", '<string name="metadata[\'x\']" value="$film[\'nope\']"/></film>')))
+    out = subprocess.run([CLI, str(bad), "-o", str(tmp_path / "bad.exr"), "--spp", "1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and 'Property "nope" has not been specified!' in out.stderr
