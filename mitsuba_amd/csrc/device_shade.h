@@ -1198,6 +1198,9 @@ MTS_DEV V3 bsdfSampleAny(const DevScene &sc, const DevMaterial &m, V3 wi, float 
     return bsdfSample<RD>(sc, m, wi, sx, sy, su, wo, pdf, eta, sampledType);
 }
 
+#ifndef MTS_ENV_SCENE
+#define MTS_ENV_SCENE(sc) (sc).self
+#endif
 struct DirectRec { V3 d; float dist, pdf; bool delta; };
 
 // warp::squareToUniformSphere (src/libcore/warp.cpp:25-31)
@@ -1240,7 +1243,7 @@ __device__ __attribute__((noinline)) inline float4 envSampleDirect(const DevScen
 MTS_DEV V3 sampleEnvironmentDirect(const DevScene &sc, V3 ref, V3 refN, float sx, float sy, float emPdf, DirectRec &dRec) {
     if (sc.envIsMap) {
         float4 dd;
-        const float4 r = envSampleDirect(sc.self, ref, sx, sy, emPdf, &dd);
+        const float4 r = envSampleDirect(MTS_ENV_SCENE(sc), ref, sx, sy, emPdf, &dd);
         dRec.d = mk(dd.x, dd.y, dd.z); dRec.dist = dd.w; dRec.pdf = r.w;
         return mk(r.x, r.y, r.z);
     }
@@ -1284,7 +1287,7 @@ MTS_DEV V3 envToLocal(const DevScene &sc, V3 v) {
 }
 MTS_DEV MipRef envMipRef(const DevScene &sc) {
     MipRef m;
-    m.sc = sc.self; m.first = sc.envFirstLevel; m.levels = sc.envLevels; m.bcu = 1u; m.bcv = 0u; m.maxAnisotropy = 10.0f;    // repeat / clamp (envmap.cpp:141-146)
+    m.sc = MTS_ENV_SCENE(sc); m.first = sc.envFirstLevel; m.levels = sc.envLevels; m.bcu = 1u; m.bcv = 0u; m.maxAnisotropy = 10.0f;    // repeat / clamp (envmap.cpp:141-146)
     return m;
 }
 MTS_DEV float intervalToTent(float sample) {        // src/libcore/warp.cpp:151-163
@@ -1373,13 +1376,13 @@ __device__ __attribute__((noinline)) inline float4 envSampleDirect(const DevScen
 // sampling would have produced its direction (pdfEmitterDirect), for the constant emitter or the map
 MTS_DEV V3 environmentRadiance(const DevScene &sc, V3 rayD) {
     if (!sc.envIsMap) return ld3(sc.envRadiance);
-    const float4 r = envEvalMap(sc.self, rayD, false, rayD, rayD);
+    const float4 r = envEvalMap(MTS_ENV_SCENE(sc), rayD, false, rayD, rayD);
     return mk(r.x, r.y, r.z);
 }
 MTS_DEV float environmentPdf(const DevScene &sc, V3 rayD, float refCos) {
     if (!sc.envIsMap) return environmentPdfDirect(sc, refCos);
     const V3 v = envToLocal(sc, rayD);
-    return envPdfDirection(sc.self, v.x, v.y, v.z) * sc.envPdfDiscrete;     // EnvironmentMap::pdfDirect (envmap.cpp:545-551)
+    return envPdfDirection(MTS_ENV_SCENE(sc), v.x, v.y, v.z) * sc.envPdfDiscrete;     // EnvironmentMap::pdfDirect (envmap.cpp:545-551)
 }
 
 // PointEmitter::sampleDirect (src/emitters/point.cpp:131-147), SpotEmitter::sampleDirect with falloffCurve
@@ -1418,15 +1421,37 @@ MTS_DEV V3 sampleDeltaDirect(const DevScene &sc, const DevEmitter &em, V3 ref, f
 // (src/emitters/area.cpp:158-173) -> Shape::sampleDirect (src/librender/shape.cpp:102-115) -> TriMesh::samplePosition
 // (src/librender/trimesh.cpp:412-423) -> Triangle::sample (src/libcore/triangle.cpp:24-59)
 // EXT: the scene has emitters that are not area lights.
-template <bool EXT = true>
+// The emitters that are not area lights (the environment, point / spot / directional lights) behind one real call:
+// inlined, their sampling code costs every vertex of a scene that has such an emitter a hundred spilled registers.
+// Returns value.rgb and the pdf; dOut receives the direction and the distance. TAG: see resolveSurfaceCall.
+template <int TAG>
+__device__ __attribute__((noinline)) inline float4 sampleOtherEmitterCall(const DevScene *scp, uint32_t index, V3 ref, V3 refN, float sx, float sy, float emPdf,
+                                                                         float4 *dOut) {
+    const DevScene &sc = *scp;
+    DirectRec dRec;
+    dRec.pdf = 0; dRec.dist = 0; dRec.d = mk(0.0f); dRec.delta = false;
+    const V3 value = (int32_t) index == sc.envEmitter ? sampleEnvironmentDirect(sc, ref, refN, sx, sy, emPdf, dRec)
+                                                      : sampleDeltaDirect(sc, sc.emitters[index], ref, emPdf, dRec);
+    *dOut = make_float4(dRec.d.x, dRec.d.y, dRec.d.z, dRec.dist);
+    return make_float4(value.x, value.y, value.z, dRec.pdf);
+}
+
+template <bool EXT = true, int TAG = 0>
 MTS_DEV V3 sampleEmitterDirect(const DevScene &sc, V3 ref, V3 refN, float sx, float sy, DirectRec &dRec) {
     dRec.pdf = 0; dRec.dist = 0; dRec.d = mk(0.0f); dRec.delta = false;
     if (sc.nEmitters == 0) return mk(0.0f);
     float emPdf;
     const uint32_t index = cdfSampleReuse(sc.emitterCdf, sc.nEmitters, sx, &emPdf);
-    if (EXT && (int32_t) index == sc.envEmitter) return sampleEnvironmentDirect(sc, ref, refN, sx, sy, emPdf, dRec);
+    if (EXT) {
+        const bool environment = (int32_t) index == sc.envEmitter;
+        if (environment || sc.emitters[index].kind >= 2) {
+            float4 dd;
+            const float4 r = sampleOtherEmitterCall<TAG>(sc.self, index, ref, refN, sx, sy, emPdf, &dd);
+            dRec.d = mk(dd.x, dd.y, dd.z); dRec.dist = dd.w; dRec.pdf = r.w; dRec.delta = !environment;
+            return mk(r.x, r.y, r.z);
+        }
+    }
     const DevEmitter em = sc.emitters[index];
-    if (EXT && em.kind >= 2) return sampleDeltaDirect(sc, em, ref, emPdf, dRec);
     const uint32_t triIdx = cdfSampleReuse(sc.areaCdf + em.cdfOffset, em.nTris, sy, nullptr);
     const uint32_t t = em.firstTri + triIdx;
     const float4 *g = sc.shadeTris + kShadeTriStride * (size_t) t;
@@ -1513,7 +1538,7 @@ MTS_DEV void cameraOffsetRays(const DevScene &sc, const PassParams &pp, float2 p
 MTS_DEV V3 cameraEnvironmentRadiance(const DevScene &sc, const PassParams &pp, float2 pos, V3 d) {
     V3 rxD, ryD;
     cameraOffsetRays(sc, pp, pos, d, rxD, ryD);
-    const float4 r = envEvalMap(sc.self, d, true, rxD, ryD);
+    const float4 r = envEvalMap(MTS_ENV_SCENE(sc), d, true, rxD, ryD);
     return mk(r.x, r.y, r.z);
 }
 

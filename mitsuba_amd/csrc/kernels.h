@@ -118,6 +118,8 @@ struct HeldPath {
 template <bool ENV, bool RD, bool MIX, bool PARK, typename Path, bool VS = false>
 MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &in, const float4 hit, float4 *sampleL, const float2 *samplePos,
                          ShadeOut &o, float4 *park = nullptr) {
+    // one instance of every real call per register budget of the kernels that share this function
+    constexpr int kTag = PARK ? (MIX ? 2 : 1) : 0;
     const uint32_t triWord = __float_as_uint(hit.w);
     if (triWord != kMiss) {
         const uint32_t tri = triWord & kTriIndexMask;
@@ -167,7 +169,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                 q.rayO = mk(ro.x, ro.y, ro.z); q.rayD = rayD;
                 q.pos = first ? samplePos[slot] : make_float2(0.0f, 0.0f);
                 q.sppTotal = pp.sppTotal; q.material = its.material; q.first = first ? 1u : 0u;
-                resolveSurfaceCall<PARK ? 1 : 0>(sc.self, &q);
+                resolveSurfaceCall<kTag>(sc.self, &q);
             }
             loadMaterial(sc, its.material, bsdf);
             if (!resolve && bsdf.type == 8) q.uv = surfUV(its.uvx, its.uvy);       // a mixture's textured children look here
@@ -265,19 +267,19 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             if (bsdfType & ESmooth) {
                 const float sx = rng.next1D(), sy = rng.next1D();
                 DirectRec dRec;
-                const V3 value = sampleEmitterDirect<ENV>(sc, its.p, refN, sx, sy, dRec);
+                const V3 value = sampleEmitterDirect<ENV, kTag>(sc, its.p, refN, sx, sy, dRec);
                 if (dRec.pdf != 0) {
                     V3 c = mk(0.0f);
                     const V3 wo = toLocal(its.sh, dRec.d);
                     const V3 woSide = flipped ? mirrorZ(wo) : wo;
                     const V3 woB = framed ? toLocal(q.pf, toWorld(its.sh, woSide)) : woSide;
                     const bool sameSide = !framed || woSide.z * woB.z > 0;
-                    const V3 bsdfVal = sameSide ? bsdfEvalAny<RD, MIX, PARK ? 1 : 0>(sc, bsdf, wiB, woB, &q.uv) : mk(0.0f);
+                    const V3 bsdfVal = sameSide ? bsdfEvalAny<RD, MIX, kTag>(sc, bsdf, wiB, woB, &q.uv) : mk(0.0f);
                     if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
                         // path.cpp:192-193: only emitters with a surface, sampled in the solid-angle measure, compete with BSDF sampling
                         if (VS) c = throughput * value * bsdfVal;       // volpath_simple.cpp:224: no weighting against BSDF sampling
                         else {
-                            const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX, PARK ? 1 : 0>(sc, bsdf, wiB, woB, &q.uv);
+                            const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX, kTag>(sc, bsdf, wiB, woB, &q.uv);
                             c = throughput * value * bsdfVal * miWeight(dRec.pdf, bPdf);
                         }
                     }
@@ -295,7 +297,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             const float bx = rng.next1D(), by = rng.next1D();
             V3 woLocal; float bPdf, bEta; uint32_t sampledType;
             const float bu = RD && bsdfDrawsFromSampler<MIX>(bsdf, bx) ? rng.next1D() : 0.0f;     // bRec.sampler->next1D() inside BSDF::sample
-            V3 bsdfWeight = bsdfSampleAny<RD, MIX, PARK ? 1 : 0>(sc, bsdf, wiB, bx, by, bu, woLocal, bPdf, bEta, sampledType, &q.uv);
+            V3 bsdfWeight = bsdfSampleAny<RD, MIX, kTag>(sc, bsdf, wiB, bx, by, bu, woLocal, bPdf, bEta, sampledType, &q.uv);
             if (framed && !isZero(bsdfWeight)) {        // back into the unperturbed frame (bumpmap.cpp:227-234)
                 const V3 pwo = woLocal;
                 woLocal = toLocal(its.sh, toWorld(q.pf, pwo));
