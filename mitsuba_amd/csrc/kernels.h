@@ -592,7 +592,10 @@ __global__ void __launch_bounds__(256) k_shadow_accumulate(uint32_t n, const uin
 static constexpr uint32_t PF_IDLE = 0x8000u;
 
 static constexpr int kDirectRounds = 16;    // sweeps per workgroup, sorted by BSDF type like k_shade
-__global__ void __launch_bounds__(kShadeBlock) k_direct_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out, ShadowQueue sq,
+#ifndef MTS_DIRECT_WAVES
+#define MTS_DIRECT_WAVES 1
+#endif
+__global__ void __launch_bounds__(kShadeBlock, MTS_DIRECT_WAVES) k_direct_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out, ShadowQueue sq,
                                                              float4 *sampleL, const float2 *samplePos, unsigned long long *counts, uint32_t n, int nEmitter, int nBsdf) {
     __shared__ uint32_t sCount[kShadeSortKeys * kDirectRounds * (kShadeBlock / 64)];
     __shared__ uint32_t sOrder[kShadeBlock * kDirectRounds];
