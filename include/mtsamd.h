@@ -100,6 +100,12 @@ typedef struct {
        (MTSAMD_FRAME_NORMALMAP); frame_texture is that texture (1-based). Any record but a mixture may be wrapped, a wrapped
        record may in turn sit in a `twosided` adapter; wrapped records cannot be nested in a mixture. */
     int32_t frame_kind, frame_texture;
+    /* Textured roughness of roughconductor and roughdielectric (a <texture> child named alpha, or alphaU / alphaV): 1-based
+       texture indices, 0 = the constants alpha_u / alpha_v. The BSDF takes `m_alphaU->eval(bRec.its).average()` at every
+       query (src/bsdfs/roughconductor.cpp:257-270, src/bsdfs/roughdielectric.cpp:296-316), with the texture's own
+       colours and scale (no energy-conservation factor). roughplastic is not taken with a textured roughness: it would
+       need the whole three-dimensional transmittance table instead of its slice at one roughness. */
+    int32_t alpha_u_texture, alpha_v_texture;
 } mtsamd_material;
 enum { MTSAMD_FRAME_NONE = 0, MTSAMD_FRAME_BUMPMAP = 1, MTSAMD_FRAME_NORMALMAP = 2 };
 
@@ -267,7 +273,7 @@ const char *mtsamd_last_error(void);
    are never reordered). A caller compiled against another version must not pass them in: compare MTSAMD_ABI_VERSION with
    mtsamd_abi_version(), and where records are mirrored by hand (FFI bindings) their sizes with mtsamd_sizeof(). No
    counterpart in the reference, whose plugins are compiled against its own headers. */
-#define MTSAMD_ABI_VERSION 12
+#define MTSAMD_ABI_VERSION 13
 enum { MTSAMD_SIZEOF_SCENE_DESC = 0, MTSAMD_SIZEOF_MATERIAL = 1, MTSAMD_SIZEOF_EMITTER = 2, MTSAMD_SIZEOF_SHAPE = 3,
        MTSAMD_SIZEOF_RENDER_OPTS = 4, MTSAMD_SIZEOF_STATS = 5, MTSAMD_SIZEOF_LDR_OPTS = 6, MTSAMD_SIZEOF_TEXTURE = 7 };
 int mtsamd_abi_version(void);

@@ -31,7 +31,8 @@ class Material(C.Structure):
                 ("rtrans_diffuse_int", C.c_float), ("two_sided", C.c_int32), ("back_material", C.c_int32),
                 ("mix_count", C.c_int32), ("mix_material", C.c_int32 * 4), ("mix_weight", C.c_float * 4),
                 ("diffuse_texture", C.c_int32), ("specular_texture", C.c_int32), ("transmittance_texture", C.c_int32),
-                ("frame_kind", C.c_int32), ("frame_texture", C.c_int32)]
+                ("frame_kind", C.c_int32), ("frame_texture", C.c_int32),
+                ("alpha_u_texture", C.c_int32), ("alpha_v_texture", C.c_int32)]
 
 
 class Texture(C.Structure):
@@ -114,7 +115,7 @@ EXPORTS = ["mtsamd_last_error", "mtsamd_init", "mtsamd_scene_create", "mtsamd_sc
            "mtsamd_spectrum_value_to_rgb", "mtsamd_spectrum_file_to_rgb", "mtsamd_blackbody_to_rgb"]
 
 _lib = None
-ABI_VERSION = 12    # MTSAMD_ABI_VERSION of include/mtsamd.h
+ABI_VERSION = 13    # MTSAMD_ABI_VERSION of include/mtsamd.h
 
 
 class MtsamdError(RuntimeError):
@@ -194,7 +195,7 @@ def fill_desc(sd):
             setattr(c, k, m[k])
         for k in ("diffuse_reflectance", "specular_reflectance", "specular_transmittance", "eta", "k"):
             setattr(c, k, (C.c_float * 3)(*[float(x) for x in m[k]]))
-        for k in ("diffuse_texture", "specular_texture", "transmittance_texture", "frame_kind", "frame_texture"):
+        for k in ("diffuse_texture", "specular_texture", "transmittance_texture", "frame_kind", "frame_texture", "alpha_u_texture", "alpha_v_texture"):
             setattr(c, k, int(m.get(k, 0)))
         mix = m.get("mix", ())
         c.mix_count = len(mix)

@@ -69,6 +69,8 @@ static void describe(const LoadedScene &s) {
     printf("], \"material_textures\": [");
     for (size_t i = 0; i < s.materials.size(); ++i)
         printf("%s[%d, %d, %d]", i ? ", " : "", s.materials[i].diffuse_texture, s.materials[i].specular_texture, s.materials[i].transmittance_texture);
+    printf("], \"alpha_textures\": [");
+    for (size_t i = 0; i < s.materials.size(); ++i) printf("%s[%d, %d]", i ? ", " : "", s.materials[i].alpha_u_texture, s.materials[i].alpha_v_texture);
     printf("], \"envmaps\": [");
     bool firstEnv = true;
     for (size_t i = 0; i < s.emitters.size(); ++i) {

@@ -391,9 +391,14 @@ void attachTextures(const Element &node, LoadedScene &out, mtsamd_material &m) {
         const bool diffuseName = name == "diffuseReflectance" || (name == "reflectance" && m.type == MTSAMD_BSDF_DIFFUSE);
         const bool usesDiffuse = m.type == MTSAMD_BSDF_DIFFUSE || m.type == MTSAMD_BSDF_ROUGHPLASTIC || m.type == MTSAMD_BSDF_PLASTIC || m.type == MTSAMD_BSDF_WARD;
         const bool usesTransmittance = m.type == MTSAMD_BSDF_DIELECTRIC || m.type == MTSAMD_BSDF_ROUGHDIELECTRIC;
+        const bool usesRoughnessTexture = m.type == MTSAMD_BSDF_ROUGHCONDUCTOR || m.type == MTSAMD_BSDF_ROUGHDIELECTRIC;
         if (diffuseName && usesDiffuse) m.diffuse_texture = (int32_t) index;
         else if (name == "specularReflectance" && m.type != MTSAMD_BSDF_DIFFUSE) m.specular_texture = (int32_t) index;
         else if (name == "specularTransmittance" && usesTransmittance) m.transmittance_texture = (int32_t) index;
+        // roughconductor.cpp:207-221, roughdielectric.cpp:224-243: alpha sets both directions
+        else if (name == "alpha" && usesRoughnessTexture) m.alpha_u_texture = m.alpha_v_texture = (int32_t) index;
+        else if (name == "alphaU" && usesRoughnessTexture) m.alpha_u_texture = (int32_t) index;
+        else if (name == "alphaV" && usesRoughnessTexture) m.alpha_v_texture = (int32_t) index;
         else throw Fail("a texture for the parameter '" + name + "' of <bsdf type=\"" + node.get("type") + "\"> is not supported");
     }
 }

@@ -913,6 +913,14 @@ MTS_DEV Frame3 perturbedFrame(const DevScene &sc, uint32_t frameWord, const Fram
     return r;
 }
 
+// m_alphaU->eval(bRec.its).average() (roughconductor.cpp:264-268; Spectrum::average sums the channels, then multiplies by 1 / 3)
+MTS_DEV float texturedRoughness(const DevScene &sc, uint32_t texture /* 1-based in plainTextures */, const SurfUV &q) {
+    const V3 c = textureEval(sc, sc.plainTextures[texture - 1], q);
+    float r = 0.0f;
+    r += c.x; r += c.y; r += c.z;
+    return r * (1.0f / 3.0f);
+}
+
 // The colours of record `index` that are textured, evaluated at the intersection's uv and written over the constants
 // in m: what m_reflectance->eval(bRec.its) etc. return inside the BSDF (e.g. src/bsdfs/diffuse.cpp:110-118)
 MTS_DEV void applyTextures(const DevScene &sc, uint32_t index, const SurfUV &q, DevMaterial &m) {
@@ -921,6 +929,11 @@ MTS_DEV void applyTextures(const DevScene &sc, uint32_t index, const SurfUV &q, 
     if (b.x) { const V3 c = textureEval(sc, sc.textures[b.x - 1], q); m.diffuse[0] = c.x; m.diffuse[1] = c.y; m.diffuse[2] = c.z; }
     if (b.y) { const V3 c = textureEval(sc, sc.textures[b.y - 1], q); m.specular[0] = c.x; m.specular[1] = c.y; m.specular[2] = c.z; }
     if (b.z) { const V3 c = textureEval(sc, sc.textures[b.z - 1], q); m.transmittance[0] = c.x; m.transmittance[1] = c.y; m.transmittance[2] = c.z; }
+    if (b.w & 8u) {
+        const uint2 a = sc.materialAlphaTextures[index];
+        if (a.x) m.alphaU = texturedRoughness(sc, a.x, q);
+        if (a.y) m.alphaV = texturedRoughness(sc, a.y, q);
+    }
 }
 MTS_DEV void loadMaterialAt(const DevScene &sc, uint32_t index, const SurfUV &uv, DevMaterial &m) {
     loadMaterial(sc, index, m);
@@ -1583,7 +1596,8 @@ struct SurfaceQuery {
     // out
     SurfUV uv;
     float colour[9];        // diffuse, specular, transmittance
-    uint32_t textured;      // bit i: colour[3 i ..] is set
+    float alpha[2];         // roughness along u, v
+    uint32_t textured;      // bit i: colour[3 i ..] is set; bits 3, 4: alpha[0], alpha[1]
     uint32_t framed;
     Frame3 pf;
 };
@@ -1606,6 +1620,11 @@ __device__ __attribute__((noinline)) inline void resolveSurfaceCall(const DevSce
     if (b.x) { const V3 c = textureEval(sc, sc.textures[b.x - 1], uv); q->colour[0] = c.x; q->colour[1] = c.y; q->colour[2] = c.z; textured |= 1u; }
     if (b.y) { const V3 c = textureEval(sc, sc.textures[b.y - 1], uv); q->colour[3] = c.x; q->colour[4] = c.y; q->colour[5] = c.z; textured |= 2u; }
     if (b.z) { const V3 c = textureEval(sc, sc.textures[b.z - 1], uv); q->colour[6] = c.x; q->colour[7] = c.y; q->colour[8] = c.z; textured |= 4u; }
+    if (b.w & 8u) {
+        const uint2 a = sc.materialAlphaTextures[q->material];
+        if (a.x) { q->alpha[0] = texturedRoughness(sc, a.x, uv); textured |= 8u; }
+        if (a.y) { q->alpha[1] = texturedRoughness(sc, a.y, uv); textured |= 16u; }
+    }
     q->textured = textured;
     q->framed = 0;
     if (b.w & 6u) { q->framed = 1; q->pf = perturbedFrame(sc, b.w, q->sh, q->geoN, q->dpdu, q->dpdv, q->u, q->v); }

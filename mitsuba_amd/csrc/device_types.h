@@ -108,8 +108,11 @@ struct DevScene {
     // Only when some material has a texture: per material the 1-based texture of its diffuse, specular and
     // transmittance colour (0 = the constant in the record), and the textures. w: bit 0 = the BSDF the shape holds wants
     // uv partials at the first vertex of a path (BSDF::usesRayDifferentials); bits 1-2 = the record sits in a bumpmap (1) or
-    // normalmap (2) adapter whose texture is entry (w >> 8) - 1 of plainTextures
+    // normalmap (2) adapter whose texture is entry (w >> 8) - 1 of plainTextures; bit 3 = the record's roughness is textured
     const uint4 *materialTextures;
+    // Only when some roughness is textured: per material the 1-based entries of plainTextures that give alphaU and alphaV
+    // (0 = the record's constant)
+    const uint2 *materialAlphaTextures;
     const DevTexture *textures;
     const DevTexture *plainTextures;    // the description's textures on their own (scale factor applied), in its order
     // Only with bitmap textures: the levels of all MIP pyramids, their texels, and the 64-entry weight table of the

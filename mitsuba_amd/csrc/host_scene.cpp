@@ -246,7 +246,23 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
                 default: break;
             }
         }
-        const unsigned aniso = m.alpha_u != m.alpha_v ? EAnisotropic : 0u;
+        // roughness textures (roughconductor.cpp:228-250, roughdielectric.cpp:245-274): evaluated per query; they count
+        // for the anisotropy flag and for usesRayDifferentials like the colours
+        if (m.alpha_u_texture || m.alpha_v_texture) {
+            if (m.type != MTSAMD_BSDF_ROUGHCONDUCTOR && m.type != MTSAMD_BSDF_ROUGHDIELECTRIC)
+                return "a textured roughness is supported for roughconductor and roughdielectric only (roughplastic would need the whole transmittance table)";
+            for (int32_t t : { m.alpha_u_texture, m.alpha_v_texture }) {
+                if (t < 0 || (uint32_t) t > d->n_textures || (t && !d->textures)) return "roughness texture index out of range";
+                if (t && d->textures[t - 1].type == MTSAMD_TEX_BITMAP) wantsPartials[i] = 1;       // bitmap.cpp:541-543
+            }
+            if (hs.materialTextures.empty()) hs.materialTextures.assign((size_t) d->n_materials * 4, 0u);
+            if (hs.materialAlphaTextures.empty()) hs.materialAlphaTextures.assign((size_t) d->n_materials * 2, 0u);
+            hs.materialAlphaTextures[(size_t) i * 2] = (uint32_t) m.alpha_u_texture;
+            hs.materialAlphaTextures[(size_t) i * 2 + 1] = (uint32_t) m.alpha_v_texture;
+            hs.materialTextures[(size_t) i * 4 + 3] |= 8u;
+            hs.mixture = true;
+        }
+        const unsigned aniso = (m.alpha_u != m.alpha_v || m.alpha_u_texture != m.alpha_v_texture) ? EAnisotropic : 0u;
         if (m.type == MTSAMD_BSDF_ROUGHCONDUCTOR || m.type == MTSAMD_BSDF_ROUGHPLASTIC || m.type == MTSAMD_BSDF_ROUGHDIELECTRIC) {
             if (m.distribution != MTSAMD_DISTR_BECKMANN && m.distribution != MTSAMD_DISTR_GGX)
                 return "Specified an invalid distribution, must be \"beckmann\" or \"ggx\"";

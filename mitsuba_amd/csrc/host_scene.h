@@ -19,6 +19,7 @@ struct HostScene {
     std::vector<float> emitterCdf, areaCdf, rtrans;
     std::vector<DevTexture> textures;           // one per (material, colour) that is textured
     std::vector<uint32_t> materialTextures;     // 4 per material (see DevScene), empty without textures
+    std::vector<uint32_t> materialAlphaTextures;    // 2 per material (see DevScene), empty without textured roughness
     std::vector<DevTexture> plainTextures;      // the description's textures on their own, in its order (mtsamd_texture_eval)
     std::vector<DevMipLevel> mipLevels;         // levels of all bitmap textures' pyramids
     std::vector<uint16_t> texels;               // their texels, four halves each

@@ -162,7 +162,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             // textured colours of the answering record at this hit, and the frame of a bumpmap / normalmap around it, in
             // which it is asked (bumpmap.cpp:161-237): one call, made only for records that have any of it
             const uint4 tw = sc.materialTextures[its.material];
-            const bool resolve = first || (tw.x | tw.y | tw.z | (tw.w & 6u)) != 0;
+            const bool resolve = first || (tw.x | tw.y | tw.z | (tw.w & 14u)) != 0;
             if (resolve) {
                 q.p = its.p; q.geoN = its.geoN; q.dpdu = its.dpdu; q.dpdv = its.dpdv; q.sh = its.sh; q.u = its.uvx; q.v = its.uvy;
                 const float4 ro = in.rayO();
@@ -177,6 +177,8 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                 if (q.textured & 1u) { bsdf.diffuse[0] = q.colour[0]; bsdf.diffuse[1] = q.colour[1]; bsdf.diffuse[2] = q.colour[2]; }
                 if (q.textured & 2u) { bsdf.specular[0] = q.colour[3]; bsdf.specular[1] = q.colour[4]; bsdf.specular[2] = q.colour[5]; }
                 if (q.textured & 4u) { bsdf.transmittance[0] = q.colour[6]; bsdf.transmittance[1] = q.colour[7]; bsdf.transmittance[2] = q.colour[8]; }
+                if (q.textured & 8u) bsdf.alphaU = q.alpha[0];
+                if (q.textured & 16u) bsdf.alphaV = q.alpha[1];
                 framed = q.framed != 0;
             }
         } else {

@@ -109,7 +109,7 @@ struct mtsamd_scene {
     DevScene dev;
     int device = 0;
     DeviceBuffer nodes, tris, shadeTris, shadeUV, shapes, materials, emitters, deltaEmitters,
-        emitterCdf, areaCdf, rtrans, textures, materialTextures, plainTextures, mipLevels, texels, ewaLut, envCdfRows, envCdfCols, envRowWeights, devSelf;
+        emitterCdf, areaCdf, rtrans, textures, materialTextures, materialAlphaTextures, plainTextures, mipLevels, texels, ewaLut, envCdfRows, envCdfCols, envRowWeights, devSelf;
     // work buffers of the wavefront loop
     DeviceBuffer fetchHeads, qbuf[2][6], hits, sbuf[3], sampleL, samplePos, shadowFlags, counters, scratch[8];
     size_t capacity = 0;
@@ -247,6 +247,7 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
         HIP_TRY(upload(s->areaCdf, h.areaCdf));
         if (!h.textures.empty()) HIP_TRY(upload(s->textures, h.textures));
         if (!h.materialTextures.empty()) HIP_TRY(upload(s->materialTextures, h.materialTextures));
+        if (!h.materialAlphaTextures.empty()) HIP_TRY(upload(s->materialAlphaTextures, h.materialAlphaTextures));
         if (!h.plainTextures.empty()) HIP_TRY(upload(s->plainTextures, h.plainTextures));
         if (!h.mipLevels.empty()) {
             HIP_TRY(upload(s->mipLevels, h.mipLevels));
@@ -302,6 +303,7 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
     d.emitterCdf = s->emitterCdf.as<float>(); d.areaCdf = s->areaCdf.as<float>(); d.rtrans = s->rtrans.as<float>();
     d.textures = h.textures.empty() ? nullptr : s->textures.as<DevTexture>();
     d.materialTextures = h.materialTextures.empty() ? nullptr : s->materialTextures.as<uint4>();
+    d.materialAlphaTextures = h.materialAlphaTextures.empty() ? nullptr : s->materialAlphaTextures.as<uint2>();
     d.plainTextures = h.plainTextures.empty() ? nullptr : s->plainTextures.as<DevTexture>();
     d.mipLevels = h.mipLevels.empty() ? nullptr : s->mipLevels.as<DevMipLevel>();
     d.texels = h.mipLevels.empty() ? nullptr : s->texels.as<uint2>();

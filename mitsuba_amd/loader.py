@@ -398,6 +398,12 @@ def _attach_textures(node, m: Dict, ctx) -> None:
             m["specular_texture"] = index
         elif name == "specularTransmittance" and ty in (S.BSDF_DIELECTRIC, S.BSDF_ROUGHDIELECTRIC):
             m["transmittance_texture"] = index
+        elif name in ("alpha", "alphaU", "alphaV") and ty in (S.BSDF_ROUGHCONDUCTOR, S.BSDF_ROUGHDIELECTRIC):
+            # roughconductor.cpp:207-221, roughdielectric.cpp:224-243: alpha sets both directions
+            if name != "alphaV":
+                m["alpha_u_texture"] = index
+            if name != "alphaU":
+                m["alpha_v_texture"] = index
         else:
             raise SceneFormatError("a texture for the parameter '%s' of <bsdf type=\"%s\"> is not supported" % (name, node.get("type")))
 

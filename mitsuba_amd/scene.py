@@ -178,7 +178,8 @@ def _mat(**kw) -> Dict:
              specular_transmittance=(1.0, 1.0, 1.0), eta=(0.0, 0.0, 0.0), k=(1.0, 1.0, 1.0),
              ext_eta=1.000277, ensure_energy_conservation=1,
              rtrans=None, rtrans_diffuse_ext=0.0, rtrans_diffuse_int=0.0, two_sided=0, back_material=-1,
-             diffuse_texture=0, specular_texture=0, transmittance_texture=0, frame_kind=0, frame_texture=0)
+             diffuse_texture=0, specular_texture=0, transmittance_texture=0, frame_kind=0, frame_texture=0,
+             alpha_u_texture=0, alpha_v_texture=0)
     m.update(kw)
     return m
 
@@ -748,12 +749,13 @@ def test_environment_map(width=64, height=32, seed=5) -> np.ndarray:
 
 
 def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_weight=1.0, hide_emitters=0, lamps=False, area_lights=True,
-                     blend=False, textured=False, bumps=False) -> SceneData:
+                     blend=False, textured=False, bumps=False, rough_maps=False) -> SceneData:
     """A few hundred triangles with every BSDF type present; used by the parity tests. `sky` adds a constant
     environment emitter of that radiance next to the two area lights; `lamps` adds a point, a spot and a directional light;
     `blend` makes the ground and two of the blobs mixtures of the other materials; `textured` puts checkerboard and grid
     textures on colours of most materials (meshes with and without texture coordinates, colours above one, a scale
-    texture, two textures in one energy check)."""
+    texture, two textures in one energy check); `rough_maps` textures the roughness of the rough conductors and of a rough
+    dielectric."""
     rng = np.random.default_rng(7)
     b = SceneBuilder()
     mats = [b.add_material(diffuse((0.6, 0.5, 0.4))),
@@ -809,6 +811,19 @@ def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_
             M[mats[2]] = bumpmap(M[mats[2]], t_grid)
             M[mats[3]] = bumpmap(M[mats[3]], t_height)
             M[mats[5]] = twosided(normalmap(M[mats[5]], t_normal))
+    if rough_maps:
+        # textured roughness: a checkerboard on both directions of the GGX conductor, an image on alphaU alone of the
+        # Beckmann one (anisotropic), an image on a rough dielectric that takes the smooth dielectric's place
+        M = b.materials
+        t_check = b.add_texture(checkerboard((0.05, 0.05, 0.05), (0.4, 0.4, 0.4), uscale=3.0, vscale=3.0))
+        # (a smooth image: the roughness decides where a path goes next, and a value that jumps from texel to texel would
+        # turn last-bit differences of a hit position into different paths within a few bounces inside the glass)
+        ry, rx = np.mgrid[0:24, 0:24]
+        rough = (0.275 + 0.225 * np.sin(rx * (2 * np.pi / 24)) * np.cos(ry * (4 * np.pi / 24))).astype(np.float32)
+        t_image = b.add_texture(bitmap(rough, "trilinear"))
+        M[mats[1]].update(alpha_u_texture=t_check, alpha_v_texture=t_check)
+        M[mats[5]].update(alpha_u_texture=t_image)
+        mats[3] = b.add_material(dict(roughdielectric(alpha=0.2, distribution="ggx", int_ior=1.5, ext_ior=1.0), alpha_u_texture=t_image, alpha_v_texture=t_image))
     if blend:
         m_ground = b.add_material(twosided(mixture([m_ground, mats[1]], [0.75, 0.25])))
         mats[0] = b.add_material(mixture([mats[0], mats[2], mats[4]], [0.6, 0.5, 0.4]))      # weights above one: rescaled

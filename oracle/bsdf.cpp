@@ -508,6 +508,15 @@ void Material::configure(const std::vector<Texture> &textures) {
                              makeTexture(m.specular_reflectance, m.specular_texture, textures, specular),
                              makeTexture(m.specular_transmittance, m.transmittance_texture, textures, transmittance) })
         if (err) throw std::runtime_error(err);
+    alphaUTextured = m.alpha_u_texture != 0; alphaVTextured = m.alpha_v_texture != 0;
+    if (alphaUTextured || alphaVTextured) {
+        if (m.type != ORC_BSDF_ROUGHCONDUCTOR && m.type != ORC_BSDF_ROUGHDIELECTRIC)
+            throw std::runtime_error("a textured roughness is supported for roughconductor and roughdielectric only");
+        for (int32_t t : { m.alpha_u_texture, m.alpha_v_texture })
+            if (t < 0 || (size_t) t > textures.size()) throw std::runtime_error("roughness texture index out of range");
+        if (alphaUTextured) alphaUTex = textures[m.alpha_u_texture - 1];
+        if (alphaVTextured) alphaVTex = textures[m.alpha_v_texture - 1];
+    }
     frameKind = m.frame_kind;
     if (frameKind < 0 || frameKind > 2) throw std::runtime_error("unknown frame adapter");
     if (frameKind) {
@@ -519,13 +528,15 @@ void Material::configure(const std::vector<Texture> &textures) {
         const bool d = diffuse.usesRayDifferentials(), sp = specular.usesRayDifferentials(), tr = transmittance.usesRayDifferentials();
         switch (m.type) {
             case ORC_BSDF_DIFFUSE: usesRayDifferentials = d; break;
-            case ORC_BSDF_ROUGHCONDUCTOR: case ORC_BSDF_CONDUCTOR: usesRayDifferentials = sp; break;
+            case ORC_BSDF_ROUGHCONDUCTOR: case ORC_BSDF_CONDUCTOR: usesRayDifferentials = sp; break;      // + the roughness textures, below
             case ORC_BSDF_ROUGHPLASTIC: case ORC_BSDF_PLASTIC: case ORC_BSDF_WARD: usesRayDifferentials = d || sp; break;
             case ORC_BSDF_DIELECTRIC: case ORC_BSDF_ROUGHDIELECTRIC: usesRayDifferentials = sp || tr; break;
             default: usesRayDifferentials = false;
         }
     }
-    unsigned aniso = (m.alpha_u != m.alpha_v) ? EAnisotropic : 0;
+    // roughconductor.cpp:240-244, roughdielectric.cpp:264-268: the roughness textures count as well
+    if ((alphaUTextured && alphaUTex.usesRayDifferentials()) || (alphaVTextured && alphaVTex.usesRayDifferentials())) usesRayDifferentials = true;
+    unsigned aniso = (m.alpha_u != m.alpha_v || m.alpha_u_texture != m.alpha_v_texture) ? EAnisotropic : 0;
     switch (m.type) {
         case ORC_BSDF_DIFFUSE:   // src/bsdfs/diffuse.cpp:93-104
             ensureEnergy(ee, diffuse);
@@ -681,7 +692,7 @@ static Spectrum evalOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo
         case ORC_BSDF_ROUGHCONDUCTOR: {   // roughconductor.cpp:257-294
             if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0) return Spectrum(0.0f);
             Vec3 H = normalize(wo + wi);
-            MicrofacetDistribution distr(m.distribution, m.alpha_u, m.alpha_v, m.sample_visible != 0);
+            MicrofacetDistribution distr(m.distribution, mat.AU(), mat.AV(), m.sample_visible != 0);
             const float D = distr.eval(H);
             if (D == 0) return Spectrum(0.0f);
             const Spectrum F = fresnelConductorExact(dot(wi, H), mat.condEta, mat.condK) * mat.S();
@@ -744,7 +755,7 @@ static Spectrum evalOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo
                 H = normalize(wi + wo * eta_);
             }
             H = H * signum(Frame::cosTheta(H));
-            MicrofacetDistribution distr(m.distribution, m.alpha_u, m.alpha_v, m.sample_visible != 0);
+            MicrofacetDistribution distr(m.distribution, mat.AU(), mat.AV(), m.sample_visible != 0);
             const float D = distr.eval(H);
             if (D == 0) return Spectrum(0.0f);
             const float F = fresnelDielectricExt(dot(wi, H), mat.eta);
@@ -786,7 +797,7 @@ static float pdfOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
         case ORC_BSDF_ROUGHCONDUCTOR: {   // roughconductor.cpp:296-321
             if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0) return 0.0f;
             Vec3 H = normalize(wo + wi);
-            MicrofacetDistribution distr(m.distribution, m.alpha_u, m.alpha_v, m.sample_visible != 0);
+            MicrofacetDistribution distr(m.distribution, mat.AU(), mat.AV(), m.sample_visible != 0);
             if (distr.sampleVisible)
                 return distr.eval(H) * distr.smithG1(wi, H) / (4.0f * Frame::cosTheta(wi));
             else
@@ -833,7 +844,7 @@ static float pdfOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
                 dwh_dwo = (eta_ * eta_ * dot(wo, H)) / (sqrtDenom * sqrtDenom);
             }
             H = H * signum(Frame::cosTheta(H));
-            MicrofacetDistribution sampleDistr(m.distribution, m.alpha_u, m.alpha_v, m.sample_visible != 0);
+            MicrofacetDistribution sampleDistr(m.distribution, mat.AU(), mat.AV(), m.sample_visible != 0);
             if (!sampleDistr.sampleVisible) sampleDistr.scaleAlpha(1.2f - 0.2f * std::sqrt(std::abs(Frame::cosTheta(wi))));
             float prob = sampleDistr.pdf(wi * signum(Frame::cosTheta(wi)), H);
             float F = fresnelDielectricExt(dot(wi, H), mat.eta);
@@ -870,7 +881,7 @@ static Spectrum sampleOneSided(const Material &mat, const Vec3 &wi, const Vec2 &
         }
         case ORC_BSDF_ROUGHCONDUCTOR: {   // roughconductor.cpp:369-415
             if (Frame::cosTheta(wi) < 0) return Spectrum(0.0f);
-            MicrofacetDistribution distr(m.distribution, m.alpha_u, m.alpha_v, m.sample_visible != 0);
+            MicrofacetDistribution distr(m.distribution, mat.AU(), mat.AV(), m.sample_visible != 0);
             Vec3 mm = distr.sample(wi, _sample, pdf);
             if (pdf == 0) return Spectrum(0.0f);
             out.wo = reflect(wi, mm);
@@ -962,7 +973,7 @@ static Spectrum sampleOneSided(const Material &mat, const Vec3 &wi, const Vec2 &
             return evalOneSided(mat, wi, out.wo) / pdf;
         }
         case ORC_BSDF_ROUGHDIELECTRIC: {   // roughdielectric.cpp:511-613 (both lobes enabled, ERadiance)
-            MicrofacetDistribution distr(m.distribution, m.alpha_u, m.alpha_v, m.sample_visible != 0);
+            MicrofacetDistribution distr(m.distribution, mat.AU(), mat.AV(), m.sample_visible != 0);
             MicrofacetDistribution sampleDistr(distr);
             if (!distr.sampleVisible) sampleDistr.scaleAlpha(1.2f - 0.2f * std::sqrt(std::abs(Frame::cosTheta(wi))));
             float microfacetPDF;

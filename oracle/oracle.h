@@ -53,6 +53,7 @@ typedef struct {
     /* the record is the BSDF nested in a bumpmap (1, src/bsdfs/bumpmap.cpp) or normalmap (2, src/bsdfs/normalmap.cpp)
        adapter with that displacement / normal texture (1-based) */
     int32_t frame_kind, frame_texture;
+    int32_t alpha_u_texture, alpha_v_texture;   /* textured roughness (roughconductor, roughdielectric), 1-based, 0 = constant */
 } orc_material;
 
 /* type 1: checkerboard (src/textures/checkerboard.cpp), 2: gridtexture (src/textures/gridtexture.cpp), 3: bitmap

@@ -82,6 +82,13 @@ struct Material {
     Spectrum D() const { return diffuseTex.eval(g_textureUV); }
     Spectrum S() const { return specularTex.eval(g_textureUV); }
     Spectrum T() const { return transmittanceTex.eval(g_textureUV); }
+    // roughness of roughconductor / roughdielectric: m_alphaU->eval(bRec.its).average() where it is textured
+    // (roughconductor.cpp:264-268, roughdielectric.cpp:303-308; Spectrum::average sums, then multiplies by 1 / 3)
+    bool alphaUTextured = false, alphaVTextured = false;
+    Texture alphaUTex, alphaVTex;
+    static float average(const Spectrum &v) { float r = 0; r += v.x; r += v.y; r += v.z; return r * (1.0f / 3.0f); }
+    float AU() const { return alphaUTextured ? average(alphaUTex.eval(g_textureUV)) : m.alpha_u; }
+    float AV() const { return alphaVTextured ? average(alphaVTex.eval(g_textureUV)) : m.alpha_v; }
     Spectrum condEta, condK;                     // divided by extEta
     float eta = 1, invEta = 1, invEta2 = 1;
     float specularSamplingWeight = 0;

@@ -982,3 +982,27 @@ def test_cli_annotations_in_the_output(scene_dir, tmp_path):
     bad.write_text(text.replace(film, film.replace("</film>", '<string name="metadata[\'x\']" value="$film[\'nope\']"/></film>')))
     out = subprocess.run([CLI, str(bad), "-o", str(tmp_path / "bad.exr"), "--spp", "1"], capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and 'Property "nope" has not been specified!' in out.stderr
+
+
+def test_cli_textured_roughness(scene_dir, tmp_path):
+    """A <texture> named alpha / alphaU / alphaV under roughconductor and roughdielectric (roughconductor.cpp:207-221,
+    roughdielectric.cpp:224-243): both loaders fill the same slots; other models refuse it."""
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    body = ('<texture type="checkerboard" id="rough"><rgb name="color0" value="0.05"/><rgb name="color1" value="0.4"/></texture>'
+            '<bsdf type="roughconductor"><string name="material" value="none"/><ref name="alpha" id="rough"/></bsdf>'
+            '<bsdf type="roughconductor"><string name="material" value="none"/><float name="alpha" value="0.2"/>'
+            '<texture type="gridtexture" name="alphaV"><rgb name="color0" value="0.1"/><rgb name="color1" value="0.3"/></texture></bsdf>'
+            '<bsdf type="roughdielectric"><ref name="alphaU" id="rough"/><float name="alphaV" value="0.15"/></bsdf>')
+    f = tmp_path / "rough.xml"
+    f.write_text(SCENE % body)
+    d = _describe(f)
+    sd, _ = loader.load_xml(str(f))
+    assert d["alpha_textures"] == [[m["alpha_u_texture"], m["alpha_v_texture"]] for m in sd.materials]
+    assert d["alpha_textures"][2:5] == [[1, 1], [0, 2], [1, 0]]
+    assert sd.materials[3]["alpha_u"] == np.float32(0.2) and sd.materials[4]["alpha_v"] == np.float32(0.15)
+    g = tmp_path / "bad.xml"
+    g.write_text(SCENE % '<bsdf type="ward"><texture type="checkerboard" name="alpha"/></bsdf>')        # only the two models above take one
+    out = subprocess.run([CLI, str(g), "--describe"], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "parameter 'alpha'" in out.stderr
+    with pytest.raises(loader.SceneFormatError, match="parameter 'alpha'"):
+        loader.load_xml(str(g))

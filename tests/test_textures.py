@@ -376,3 +376,59 @@ def test_bump_and_normal_map_frames(oracle_mod):
     bad.materials = list(bad.materials)[:-2] + [S.bumpmap(base, 9)]
     with pytest.raises(RuntimeError, match="out of range"):
         oracle_mod.OracleScene(bad)
+
+
+def test_textured_roughness(oracle_mod):
+    """m_alphaU->eval(bRec.its).average() (roughconductor.cpp:264-268, roughdielectric.cpp:303-308): a roughness texture
+    gives, at every uv, what the record with that constant roughness gives; `alpha` sets both directions, alphaU alone
+    makes the record anisotropic; the texture's own colours count (no energy-conservation factor: values above one stay);
+    records that cannot take one say so."""
+    b = S.SceneBuilder()
+    t_check = b.add_texture(S.checkerboard((0.0625, 0.0625, 0.0625), (0.5, 0.5, 0.5), uscale=2.0, vscale=2.0))
+    t_flat = b.add_texture(S.bitmap(np.full((4, 4), 0.25, np.float32), "bilinear"))
+    t_big = b.add_texture(S.bitmap(np.full((4, 4, 3), (1.5, 1.5, 1.5), np.float32), "nearest"))
+    cond = dict(eta=(0.2, 0.92, 1.1), k=(3.9, 2.45, 2.14), distribution="ggx")
+    rec = {}
+    rec["check"] = b.add_material(dict(S.roughconductor(alpha=0.3, **cond), alpha_u_texture=t_check, alpha_v_texture=t_check))
+    rec["lo"] = b.add_material(S.roughconductor(alpha=0.0625, **cond))
+    rec["hi"] = b.add_material(S.roughconductor(alpha=0.5, **cond))
+    rec["flat_u"] = b.add_material(dict(S.roughconductor(alpha=0.1, **cond), alpha_u_texture=t_flat))
+    aniso = S.roughconductor(alpha=0.1, **cond)
+    aniso.update(alpha_u=0.25, alpha_v=0.1)
+    rec["aniso"] = b.add_material(aniso)
+    rec["glass_tex"] = b.add_material(dict(S.roughdielectric(alpha=0.1, distribution="beckmann", int_ior=1.5, ext_ior=1.0), alpha_u_texture=t_flat, alpha_v_texture=t_flat))
+    rec["glass"] = b.add_material(S.roughdielectric(alpha=0.25, distribution="beckmann", int_ior=1.5, ext_ior=1.0))
+    rec["big_tex"] = b.add_material(dict(S.roughconductor(alpha=0.1, **cond), alpha_u_texture=t_big, alpha_v_texture=t_big))
+    rec["big"] = b.add_material(S.roughconductor(alpha=1.5, **cond))
+    b.add_quad([-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0], rec["check"], radiance=(1, 1, 1))
+    sd = b.finish(S.make_camera([0, -3, 2], [0, 0, 0], [0, 0, 1], 40), S.make_film(8, 8))
+    o = oracle_mod.OracleScene(sd)
+    rng = np.random.default_rng(3)
+    n = 4000
+    d = rng.normal(size=(2, n, 3))
+    d /= np.linalg.norm(d, axis=2, keepdims=True)
+    wi, wo = d[0].astype(np.float32), d[1].astype(np.float32)
+    smp, extra = rng.random((n, 2)).astype(np.float32), rng.random(n).astype(np.float32)
+
+    def same(a, c, uv):
+        o.bsdf_query_uv(*uv)
+        assert np.allclose(o.bsdf_eval(rec[a], wi, wo), o.bsdf_eval(rec[c], wi, wo), rtol=2e-5, atol=1e-7), (a, c, uv)
+        assert np.allclose(o.bsdf_pdf(rec[a], wi, wo), o.bsdf_pdf(rec[c], wi, wo), rtol=2e-5, atol=1e-7), (a, c, uv)
+        sa, sc = o.bsdf_sample(rec[a], wi, smp, extra), o.bsdf_sample(rec[c], wi, smp, extra)
+        for x, y in zip(sa, sc):
+            assert np.allclose(x, y, rtol=2e-4, atol=1e-5), (a, c, uv)
+    same("check", "lo", (0.1, 0.1))         # first colour of the checkerboard ...
+    same("check", "hi", (0.1, 0.35))        # ... and the second
+    same("check", "lo", (0.35, 0.35))
+    same("flat_u", "aniso", (0.4, 0.6))
+    same("glass_tex", "glass", (0.7, 0.2))
+    same("big_tex", "big", (0.5, 0.5))
+    o.bsdf_query_uv(0.0, 0.0)
+    assert np.abs(o.bsdf_eval(rec["lo"], wi, wo) - o.bsdf_eval(rec["hi"], wi, wo)).max() > 0.1
+    for bad in (S.roughplastic(alpha=0.1, distribution="ggx", int_ior=1.49), S.diffuse()):
+        b2 = S.SceneBuilder()
+        t = b2.add_texture(S.checkerboard())
+        m = b2.add_material(dict(bad, alpha_u_texture=t, alpha_v_texture=t))
+        b2.add_quad([-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0], m, radiance=(1, 1, 1))
+        with pytest.raises(RuntimeError, match="roughconductor and roughdielectric only"):
+            oracle_mod.OracleScene(b2.finish(S.make_camera([0, -3, 2], [0, 0, 0], [0, 0, 1], 40), S.make_film(8, 8)))
