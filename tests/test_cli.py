@@ -703,7 +703,7 @@ def test_cli_textures(scene_dir, tmp_path):
     assert sd.textures[3]["scale"] == 0.5 and sd.textures[3]["type"] == 2 and sd.textures[3]["line_width"] == np.float32(0.1)
     # what is not supported says so
     for body, msg in (('<bsdf type="diffuse"><texture type="wood" name="reflectance"/></bsdf>', "texture type 'wood'"),
-                      ('<bsdf type="roughconductor"><string name="material" value="none"/><texture type="checkerboard" name="alpha"/></bsdf>', "parameter 'alpha'"),
+                      ('<bsdf type="ward"><texture type="checkerboard" name="alphaU"/></bsdf>', "parameter 'alphaU'"),
                       ('<bsdf type="diffuse"><texture type="bitmap" name="reflectance"><string name="filename" value="nope.png"/></texture></bsdf>', "nope.png"),
                       ('<bsdf type="bumpmap"><bsdf type="diffuse"/><texture type="bitmap"><string name="filename" value="wood.png"/></texture></bsdf>', "'gamma' parameter"),
                       ('<bsdf type="bumpmap"><bsdf type="diffuse"/></bsdf>', "displacement texture must be specified"),
