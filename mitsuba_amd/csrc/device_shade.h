@@ -1601,6 +1601,19 @@ struct SurfaceQuery {
     uint32_t framed;
     Frame3 pf;
 };
+// the textured colours and roughness of record `material` at uv, into the query record
+MTS_DEV void resolveColours(const DevScene &sc, uint32_t material, const uint4 b, const SurfUV &uv, SurfaceQuery *q) {
+    uint32_t textured = 0;
+    if (b.x) { const V3 c = textureEval(sc, sc.textures[b.x - 1], uv); q->colour[0] = c.x; q->colour[1] = c.y; q->colour[2] = c.z; textured |= 1u; }
+    if (b.y) { const V3 c = textureEval(sc, sc.textures[b.y - 1], uv); q->colour[3] = c.x; q->colour[4] = c.y; q->colour[5] = c.z; textured |= 2u; }
+    if (b.z) { const V3 c = textureEval(sc, sc.textures[b.z - 1], uv); q->colour[6] = c.x; q->colour[7] = c.y; q->colour[8] = c.z; textured |= 4u; }
+    if (b.w & 8u) {
+        const uint2 a = sc.materialAlphaTextures[material];
+        if (a.x) { q->alpha[0] = texturedRoughness(sc, a.x, uv); textured |= 8u; }
+        if (a.y) { q->alpha[1] = texturedRoughness(sc, a.y, uv); textured |= 16u; }
+    }
+    q->textured = textured;
+}
 // TAG: one instance per register budget of the calling kernels (a function shared by kernels with different launch
 // bounds is compiled for the largest budget, and its register count then becomes that of every kernel that calls it)
 template <int TAG>
@@ -1616,18 +1629,16 @@ __device__ __attribute__((noinline)) inline void resolveSurfaceCall(const DevSce
     }
     q->uv = uv;
     const uint4 b = sc.materialTextures[q->material];
-    uint32_t textured = 0;
-    if (b.x) { const V3 c = textureEval(sc, sc.textures[b.x - 1], uv); q->colour[0] = c.x; q->colour[1] = c.y; q->colour[2] = c.z; textured |= 1u; }
-    if (b.y) { const V3 c = textureEval(sc, sc.textures[b.y - 1], uv); q->colour[3] = c.x; q->colour[4] = c.y; q->colour[5] = c.z; textured |= 2u; }
-    if (b.z) { const V3 c = textureEval(sc, sc.textures[b.z - 1], uv); q->colour[6] = c.x; q->colour[7] = c.y; q->colour[8] = c.z; textured |= 4u; }
-    if (b.w & 8u) {
-        const uint2 a = sc.materialAlphaTextures[q->material];
-        if (a.x) { q->alpha[0] = texturedRoughness(sc, a.x, uv); textured |= 8u; }
-        if (a.y) { q->alpha[1] = texturedRoughness(sc, a.y, uv); textured |= 16u; }
-    }
-    q->textured = textured;
+    resolveColours(sc, q->material, b, uv, q);
     q->framed = 0;
     if (b.w & 6u) { q->framed = 1; q->pf = perturbedFrame(sc, b.w, q->sh, q->geoN, q->dpdu, q->dpdv, q->u, q->v); }
+}
+// The common case of the above, a vertex after the first of a record without a frame adapter: nothing goes in through
+// memory, only the colours and the roughness come back through it.
+template <int TAG>
+__device__ __attribute__((noinline)) inline void resolveColoursCall(const DevScene *scp, uint32_t material, float u, float v, SurfaceQuery *q) {
+    const DevScene &sc = *scp;
+    resolveColours(sc, material, sc.materialTextures[material], surfUV(u, v), q);
 }
 
 }  // namespace mtsamd

@@ -163,13 +163,16 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             // which it is asked (bumpmap.cpp:161-237): one call, made only for records that have any of it
             const uint4 tw = sc.materialTextures[its.material];
             const bool resolve = first || (tw.x | tw.y | tw.z | (tw.w & 14u)) != 0;
-            if (resolve) {
+            const bool heavy = first || (tw.w & 6u) != 0;      // partials or a frame: the query goes through memory
+            if (resolve && heavy) {
                 q.p = its.p; q.geoN = its.geoN; q.dpdu = its.dpdu; q.dpdv = its.dpdv; q.sh = its.sh; q.u = its.uvx; q.v = its.uvy;
                 const float4 ro = in.rayO();
                 q.rayO = mk(ro.x, ro.y, ro.z); q.rayD = rayD;
                 q.pos = first ? samplePos[slot] : make_float2(0.0f, 0.0f);
                 q.sppTotal = pp.sppTotal; q.material = its.material; q.first = first ? 1u : 0u;
                 resolveSurfaceCall<kTag>(sc.self, &q);
+            } else if (resolve) {
+                resolveColoursCall<kTag>(sc.self, its.material, its.uvx, its.uvy, &q);
             }
             loadMaterial(sc, its.material, bsdf);
             if (!resolve && bsdf.type == 8) q.uv = surfUV(its.uvx, its.uvy);       // a mixture's textured children look here
@@ -179,7 +182,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                 if (q.textured & 4u) { bsdf.transmittance[0] = q.colour[6]; bsdf.transmittance[1] = q.colour[7]; bsdf.transmittance[2] = q.colour[8]; }
                 if (q.textured & 8u) bsdf.alphaU = q.alpha[0];
                 if (q.textured & 16u) bsdf.alphaV = q.alpha[1];
-                framed = q.framed != 0;
+                framed = heavy && q.framed != 0;
             }
         } else {
             // the material record comes in as seven 16-byte loads issued together, not field by field
