@@ -1123,6 +1123,22 @@ void makeCube(Mesh &out) {
     }
 }
 
+// The `rectangle` shape (src/shapes/rectangle.cpp:80-110,150-165): the square [-1, 1]^2 of the xy plane, normal +z,
+// uv = (x + 1) / 2, (y + 1) / 2, as two triangles with face normals. The same surface, area and uv; the shading frame
+// follows dp/du like the reference's (for a mirroring toWorld or flipNormals its second tangent points the other way,
+// which only an anisotropic BSDF would notice).
+void makeRectangle(Mesh &out) {
+    static const float P[4][2] = { { -1, -1 }, { 1, -1 }, { 1, 1 }, { -1, 1 } };
+    out.name = "rectangle";
+    out.faceNormals = true;
+    for (int v = 0; v < 4; ++v) {
+        out.positions.push_back(P[v][0]); out.positions.push_back(P[v][1]); out.positions.push_back(0.0f);
+        out.texcoords.push_back(0.5f * (P[v][0] + 1)); out.texcoords.push_back(0.5f * (P[v][1] + 1));
+    }
+    const uint32_t tri[6] = { 0, 1, 2, 2, 3, 0 };
+    out.indices.assign(tri, tri + 6);
+}
+
 std::string writePfm(const std::string &path, const float *rgba, int width, int height) {
     FILE *f = fopen(path.c_str(), "wb");
     if (!f) return "cannot write " + path;
@@ -1814,6 +1830,7 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
                     if (type == "serialized") err = loadSerialized(joinPath(base, getS(p, "filename", "")), (int) getF(p, "shapeIndex", 0), mesh);
                     else if (type == "ply") err = loadPly(joinPath(base, getS(p, "filename", "")), mesh);
                     else if (type == "cube") makeCube(mesh);
+                    else if (type == "rectangle") makeRectangle(mesh);
                     else return "shape type '" + type + "' is not supported (triangle meshes only)";
                     if (!err.empty()) return err;
                     meshes.emplace_back(std::move(mesh), mat >= 0 ? mat : defaultMaterial());

@@ -82,6 +82,7 @@ std::string loadObjParts(const std::string &path, bool flipTexCoords, bool colla
 std::string loadMtl(const std::string &path, std::map<std::string, MtlMaterial> &out);
 std::string loadPly(const std::string &path, Mesh &out);
 void makeCube(Mesh &out);
+void makeRectangle(Mesh &out);
 std::string loadSceneXml(const std::string &path, const LoadOptions &opts, LoadedScene &out);
 
 // Metadata of an output image (Bitmap::getMetadata): kind 0 string, 1 integer, 2 float

@@ -1006,3 +1006,24 @@ def test_cli_textured_roughness(scene_dir, tmp_path):
     assert out.returncode != 0 and "parameter 'alpha'" in out.stderr
     with pytest.raises(loader.SceneFormatError, match="parameter 'alpha'"):
         loader.load_xml(str(g))
+
+
+def test_cli_rectangle_shape(scene_dir, tmp_path):
+    """<shape type="rectangle"> (src/shapes/rectangle.cpp:80-110,150-165): two triangles over [-1, 1]^2 with uv
+    (x + 1) / 2, (y + 1) / 2 under toWorld; it may carry an area emitter; other analytic shapes are still refused."""
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    body = ('<shape type="rectangle"><transform name="toWorld"><scale x="2" y="0.5"/><translate x="1" y="2" z="3"/></transform>'
+            '<emitter type="area"><rgb name="radiance" value="5"/></emitter></shape>'
+            '<shape type="rectangle"><boolean name="flipNormals" value="true"/><ref id="grey"/></shape>')
+    f = tmp_path / "rect.xml"
+    f.write_text(SCENE % body)
+    base, d = _describe(scene_dir / "scene.xml"), _describe(f)
+    assert d["shapes"] == base["shapes"] + 2 and d["shape_triangles"][-2:] == [2, 2] and d["vertices"] == base["vertices"] + 8
+    assert d["emitters"] == base["emitters"] + 1 and d["emitter_records"][-1]["radiance"] == [5, 5, 5]
+    # first rectangle: corners (+-2, +-0.5, 0) + (1, 2, 3) sum to 4 * 6; the second sums to zero; uv sums are 4 each
+    assert abs(d["sum_positions"] - base["sum_positions"] - 24.0) < 1e-4
+    assert abs(d["sum_texcoords"] - base.get("sum_texcoords", 0.0) - 8.0) < 1e-5
+    g = tmp_path / "sphere.xml"
+    g.write_text(SCENE % '<shape type="sphere"/>')
+    out = subprocess.run([CLI, str(g), "--describe"], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "shape type 'sphere' is not supported" in out.stderr
