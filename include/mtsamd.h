@@ -436,7 +436,7 @@ int mtsamd_blackbody_to_rgb(float temperature, float scale, float rgb[3]);
    reads an image file into linear floats, 1 channel (luminance and luminance-alpha files) or 3 (RGB and RGBA files;
    alpha is dropped), first row = top. `gamma`: 0 = the file's own (sRGB for 8- and 16-bit files unless a PNG says
    otherwise, linear for floating-point ones), else the value of the texture's `gamma` property (-1 = sRGB). Formats: PNG
-   (not interlaced), PFM, OpenEXR scan-line files with no, ZIPS or ZIP compression (R, G, B or Y channels). The pixels
+   (not interlaced), PFM, OpenEXR scan-line files with no, ZIPS, ZIP or PIZ compression (R, G, B or Y channels). The pixels
    belong to the library until mtsamd_image_free. Needs no device. */
 typedef struct { int32_t width, height, channels; float *pixels; } mtsamd_image;
 int mtsamd_image_load(const char *path, float gamma, mtsamd_image *out);

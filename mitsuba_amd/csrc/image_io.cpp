@@ -177,7 +177,7 @@ std::string decodePfm(const std::vector<uint8_t> &f, Raw &img) {
     return "";
 }
 
-// ---- OpenEXR, scan-line files without or with ZIP compression ------------------------------------------------------------
+// ---- OpenEXR, scan-line files without compression or with ZIPS / ZIP / PIZ ------------------------------------------------------------
 float halfBitsToFloat(uint16_t h) {
     const uint32_t sign = ((uint32_t) h & 0x8000u) << 16;
     int e = (h >> 10) & 0x1f;
@@ -190,6 +190,200 @@ float halfBitsToFloat(uint16_t h) {
     float out;
     memcpy(&out, &x, 4);
     return out;
+}
+
+// ---- PIZ: the compression Mitsuba's own OpenEXR files and most others use. A block of 32 scan lines is stored as the
+// range of 16-bit values that occur (a bitmap), then the Huffman-coded Haar-like wavelet transform of the values'
+// ranks, channel after channel (the OpenEXR file format: ImfPizCompressor, ImfHuf, ImfWav).
+struct BitReader {
+    const uint8_t *p, *end;
+    uint64_t c = 0;
+    int lc = 0;
+    bool ok = true;
+    uint32_t bits(int n) {
+        while (lc < n) {
+            if (p >= end) { ok = false; c <<= 8; } else c = (c << 8) | *p++;
+            lc += 8;
+        }
+        lc -= n;
+        return (uint32_t) ((c >> lc) & ((1ull << n) - 1ull));
+    }
+};
+
+bool pizHuffman(const uint8_t *src, size_t n, std::vector<uint16_t> &out) {
+    constexpr int kEncSize = (1 << 16) + 1, kShortRun = 59, kLongRun = 63, kShortestLongRun = 2 + kLongRun - kShortRun;
+    if (n == 0) return out.empty();
+    if (n < 20) return false;
+    const uint32_t im = le32(src), iM = le32(src + 4), nBits = le32(src + 12);
+    if (im >= (uint32_t) kEncSize || iM >= (uint32_t) kEncSize || im > iM) return false;
+    // code lengths, six bits each, runs of zeros packed
+    std::vector<uint8_t> length(kEncSize, 0);
+    BitReader r{ src + 20, src + n };
+    for (uint32_t i = im; i <= iM; ++i) {
+        const uint32_t l = r.bits(6);
+        if (!r.ok) return false;
+        if (l == (uint32_t) kLongRun) {
+            uint32_t run = r.bits(8) + kShortestLongRun;
+            if (i + run > iM + 1) return false;
+            i += run - 1;
+        } else if (l >= (uint32_t) kShortRun) {
+            uint32_t run = l - kShortRun + 2;
+            if (i + run > iM + 1) return false;
+            i += run - 1;
+        } else length[i] = (uint8_t) l;
+    }
+    const uint8_t *data = r.p;      // the coded values start at the next byte
+    if ((uint64_t) nBits > 8ull * (uint64_t) (src + n - data)) return false;
+    // canonical codes: within a length in order of the symbol, the longest lengths first
+    uint64_t first[60] = { 0 }, count[60] = { 0 };
+    for (int i = 0; i < kEncSize; ++i) ++count[length[i]];
+    {
+        uint64_t c = 0;
+        for (int l = 58; l > 0; --l) { const uint64_t nc = (c + count[l]) >> 1; first[l] = c; c = nc; }
+    }
+    uint32_t offset[60] = { 0 };
+    for (int l = 1, acc = 0; l <= 58; ++l) { offset[l] = (uint32_t) acc; acc += (int) count[l]; }
+    std::vector<uint32_t> symbols(kEncSize), fill(offset, offset + 60);
+    for (int i = 0; i < kEncSize; ++i) if (length[i]) symbols[fill[length[i]]++] = (uint32_t) i;
+    // a table for the codes of up to 12 bits; longer ones are walked bit by bit
+    constexpr int kFast = 12;
+    std::vector<uint32_t> fast(1u << kFast, 0u);    // symbol << 8 | length, 0 = not a short code
+    for (int l = 1; l <= kFast; ++l)
+        for (uint64_t k = 0; k < count[l]; ++k) {
+            const uint64_t code = first[l] + k;
+            if (code >> l) return false;
+            const uint32_t entry = (symbols[offset[l] + k] << 8) | (uint32_t) l;
+            for (uint32_t pad = 0; pad < (1u << (kFast - l)); ++pad) fast[(code << (kFast - l)) | pad] = entry;
+        }
+    BitReader d{ data, src + n };
+    uint64_t used = 0;
+    size_t o = 0;
+    while (o < out.size()) {
+        uint32_t symbol = 0;
+        int len = 0;
+        // peek
+        while (d.lc < kFast) { d.c = (d.c << 8) | (d.p < d.end ? *d.p++ : 0); d.lc += 8; }
+        const uint32_t entry = fast[(d.c >> (d.lc - kFast)) & ((1u << kFast) - 1u)];
+        if (entry) { len = (int) (entry & 0xffu); symbol = entry >> 8; d.lc -= len; }
+        else {
+            uint64_t code = 0;
+            bool found = false;
+            while (len < 58) {
+                code = (code << 1) | d.bits(1);
+                ++len;
+                if (count[len] && code >= first[len] && code - first[len] < count[len]) { symbol = symbols[offset[len] + (code - first[len])]; found = true; break; }
+            }
+            if (!found) return false;
+        }
+        used += (uint64_t) len;
+        if (used > nBits) return false;
+        if (symbol == iM) {         // run-length code: repeat the last value
+            const uint32_t run = d.bits(8);
+            used += 8;
+            if (used > nBits || o == 0 || o + run > out.size()) return false;
+            const uint16_t v = out[o - 1];
+            for (uint32_t k = 0; k < run; ++k) out[o++] = v;
+        } else out[o++] = (uint16_t) symbol;
+    }
+    return true;
+}
+
+inline void wdec14(uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) {
+    const int ls = (int16_t) l, hi = (int16_t) h;
+    const int ai = ls + (hi & 1) + (hi >> 1);
+    a = (uint16_t) (int16_t) ai;
+    b = (uint16_t) (int16_t) (ai - hi);
+}
+inline void wdec16(uint16_t l, uint16_t h, uint16_t &a, uint16_t &b) {
+    const int m = l, d = h;
+    const int bb = (m - (d >> 1)) & 0xffff;
+    const int aa = (d + bb - 0x8000) & 0xffff;
+    b = (uint16_t) bb; a = (uint16_t) aa;
+}
+void pizWaveletDecode(uint16_t *in, int nx, int ox, int ny, int oy, uint16_t mx) {
+    const bool w14 = mx < (1 << 14);
+    const int n = nx > ny ? ny : nx;
+    int p = 1, p2;
+    while (p <= n) p <<= 1;
+    p >>= 1; p2 = p; p >>= 1;
+    while (p >= 1) {
+        uint16_t *py = in;
+        uint16_t *const ey = in + (ptrdiff_t) oy * (ny - p2);
+        const ptrdiff_t oy1 = (ptrdiff_t) oy * p, oy2 = (ptrdiff_t) oy * p2, ox1 = (ptrdiff_t) ox * p, ox2 = (ptrdiff_t) ox * p2;
+        uint16_t i00, i01, i10, i11;
+        for (; py <= ey; py += oy2) {
+            uint16_t *px = py;
+            uint16_t *const ex = py + (ptrdiff_t) ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t *p01 = px + ox1, *p10 = px + oy1, *p11 = p10 + ox1;
+                if (w14) { wdec14(*px, *p10, i00, i10); wdec14(*p01, *p11, i01, i11); wdec14(i00, i01, *px, *p01); wdec14(i10, i11, *p10, *p11); }
+                else { wdec16(*px, *p10, i00, i10); wdec16(*p01, *p11, i01, i11); wdec16(i00, i01, *px, *p01); wdec16(i10, i11, *p10, *p11); }
+            }
+            if (nx & p) {
+                uint16_t *p10 = px + oy1;
+                if (w14) wdec14(*px, *p10, i00, *p10); else wdec16(*px, *p10, i00, *p10);
+                *px = i00;
+            }
+        }
+        if (ny & p) {
+            uint16_t *px = py;
+            uint16_t *const ex = py + (ptrdiff_t) ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t *p01 = px + ox1;
+                if (w14) wdec14(*px, *p01, i00, *p01); else wdec16(*px, *p01, i00, *p01);
+                *px = i00;
+            }
+        }
+        p2 = p; p >>= 1;
+    }
+}
+
+// One PIZ block -> the bytes of its scan lines as an uncompressed file stores them. sizes[c] = 16-bit words per sample of
+// channel c (1 for half, 2 for float / uint), all channels `w` samples wide.
+bool pizDecodeBlock(const uint8_t *src, size_t n, const std::vector<int> &sizes, int w, int lines, std::vector<uint8_t> &out) {
+    constexpr int kBitmapSize = 8192;
+    if (n < 4) return false;
+    const uint32_t minNonZero = src[0] | (src[1] << 8), maxNonZero = src[2] | (src[3] << 8);
+    if (maxNonZero >= (uint32_t) kBitmapSize) return false;
+    std::vector<uint8_t> bitmap(kBitmapSize, 0);
+    size_t p = 4;
+    if (minNonZero <= maxNonZero) {
+        const size_t k = maxNonZero - minNonZero + 1;
+        if (p + k > n) return false;
+        memcpy(&bitmap[minNonZero], src + p, k);
+        p += k;
+    }
+    std::vector<uint16_t> lut(65536, 0);
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < 65536; ++i)
+        if (i == 0 || (bitmap[i >> 3] & (1 << (i & 7)))) lut[k++] = (uint16_t) i;
+    const uint16_t maxValue = (uint16_t) (k - 1);
+    if (p + 4 > n) return false;
+    const uint32_t length = le32(src + p);
+    p += 4;
+    if (p + length > n) return false;
+    size_t total = 0;
+    for (int sz : sizes) total += (size_t) w * lines * sz;
+    std::vector<uint16_t> tmp(total);
+    if (!pizHuffman(src + p, length, tmp)) return false;
+    size_t start = 0;
+    std::vector<size_t> starts;
+    for (int sz : sizes) {
+        starts.push_back(start);
+        for (int j = 0; j < sz; ++j) pizWaveletDecode(&tmp[start + j], w, sz, lines, w * sz, maxValue);
+        start += (size_t) w * lines * sz;
+    }
+    for (uint16_t &v : tmp) v = lut[v];
+    out.resize(total * 2);
+    size_t o = 0;
+    std::vector<size_t> cursor = starts;
+    for (int y = 0; y < lines; ++y)
+        for (size_t c = 0; c < sizes.size(); ++c)
+            for (int x = 0; x < w * sizes[c]; ++x) {
+                const uint16_t v = tmp[cursor[c]++];
+                out[o++] = (uint8_t) (v & 0xffu); out[o++] = (uint8_t) (v >> 8);
+            }
+    return true;
 }
 
 std::string decodeExr(const std::vector<uint8_t> &f, Raw &img) {
@@ -225,9 +419,9 @@ std::string decodeExr(const std::vector<uint8_t> &f, Raw &img) {
     }
     ++p;
     if (channels.empty() || x1 < x0 || y1 < y0) return "OpenEXR header without channels or data window";
-    if (compression != 0 && compression != 2 && compression != 3)
-        return "OpenEXR compression other than none, ZIPS and ZIP is not supported";
-    const int w = x1 - x0 + 1, h = y1 - y0 + 1, linesPerBlock = compression == 3 ? 16 : 1;
+    if (compression != 0 && compression != 2 && compression != 3 && compression != 4)
+        return "OpenEXR compression other than none, ZIPS, ZIP and PIZ is not supported";
+    const int w = x1 - x0 + 1, h = y1 - y0 + 1, linesPerBlock = compression == 3 ? 16 : compression == 4 ? 32 : 1;
     auto find = [&](const char *n) { for (size_t i = 0; i < channels.size(); ++i) if (channels[i].name == n) return (int) i; return -1; };
     int src[3] = { find("R"), find("G"), find("B") };
     img.channels = 3;
@@ -258,7 +452,11 @@ std::string decodeExr(const std::vector<uint8_t> &f, Raw &img) {
         const size_t rawSize = lineBytes * lines;
         buf.resize(rawSize);
         if (compression == 0 || dataSize == rawSize) memcpy(buf.data(), &f[off + 8], std::min<size_t>(dataSize, rawSize));
-        else {
+        else if (compression == 4) {
+            std::vector<int> sizes;
+            for (const Channel &c : channels) sizes.push_back(c.type == 1 ? 1 : 2);
+            if (!pizDecodeBlock(&f[off + 8], dataSize, sizes, w, lines, buf) || buf.size() != rawSize) return "OpenEXR PIZ block could not be decoded";
+        } else {
             tmp.resize(rawSize);
             if (!inflateAll(&f[off + 8], dataSize, tmp)) return "OpenEXR block could not be inflated";
             for (size_t i = 1; i < rawSize; ++i) tmp[i] = (uint8_t) (tmp[i - 1] + tmp[i] - 128);    // predictor

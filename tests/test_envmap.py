@@ -1,8 +1,10 @@
-"""The environment map emitter on the CPU: the oracle's restatement of src/emitters/envmap.cpp against closed forms.
-The reference holds one environment map (testScene/testScenes/envmap.exr) but it is PIZ-compressed, which the image
-reader here does not decode, and no expected values for it: parity unpinned; the restatement is checked by the
-properties below (normalisation, sample = eval / pdf consistency, orientation, the constant map against the constant
-emitter), the GPU against the restatement (tests/test_gpu_parity.py)."""
+"""The environment map emitter on the CPU: the oracle's restatement of src/emitters/envmap.cpp against closed forms
+(normalisation, sample = eval / pdf consistency, orientation, the constant map against the constant emitter) and
+against the one thing the reference holds of it: the background of the renders kept beside its matpreview-style test
+scenes (the last test; it reads those files where they lie and is skipped where the reference is absent). The GPU is
+held to the restatement by tests/test_gpu_parity.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -174,3 +176,60 @@ def test_invalid_maps_are_refused(oracle_mod):
     b.add_constant_emitter((1, 1, 1))
     with pytest.raises(RuntimeError, match="only contain one environment emitter"):
         oracle_mod.OracleScene(_empty_scene(b))
+
+
+REFERENCE_TEST_SCENES = "/root/reference/testScene/testScenes"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_TEST_SCENES), reason="the reference's test scenes are not on this machine")
+def test_background_of_the_reference_held_renders(oracle_mod):
+    """The only images of an `envmap` emitter the reference holds: its matpreview-style test scenes
+    (testScene/testScenes/*_sphere.xml) show a sphere with one of the fork's BRDFs in front of envmap.exr, and the renders
+    are kept beside them. The BRDFs are outside this library; the BACKGROUND is the environment emitter seen through the
+    perspective camera, the same in all four files. Rendered here from the scene files' camera and emitter parameters, it
+    agrees with every one of them in every 32 x 32-pixel cell that the object does not touch (50 of 256): within 4 %
+    (observed: 1.0 to 2.9 % darker, median 1.8 %, varying smoothly over the frame; the cause of that residue was not found -
+    a spectral build of the reference, which converts the map's RGB to spectra and back, would leave one of this size). A flipped or
+    rotated map, a wrong scale or field of view, or a wrong decode of the PIZ-compressed map would be off by tens of
+    per cent. The files are read where they lie (nothing of them is kept in this repository), so the test runs only where
+    the reference is present; it pins the oracle's environment map and the library's OpenEXR reader, the GPU path is
+    held to the oracle by tests/test_gpu_parity.py."""
+    from mitsuba_amd import capi
+    env = capi.image_load(os.path.join(REFERENCE_TEST_SCENES, "envmap.exr"))          # PIZ
+    assert env.shape == (256, 512, 3) and np.isfinite(env).all() and env.min() > 0 and 15 < env.max() < 25
+    lum = env.sum(-1)
+    assert np.median(np.abs(np.diff(lum, axis=1)) / (lum[:, 1:] + lum[:, :-1])) < 0.02     # a photograph, not noise
+    names = ["smooth_sphere", "sgd_sphere", "measured_sphere", "ctd_sphere"]
+    refs = np.stack([capi.image_load(os.path.join(REFERENCE_TEST_SCENES, n + ".exr")) for n in names])      # ZIP
+    assert refs.shape == (4, 512, 512, 3)
+    cells = lambda a: a.reshape(16, 32, 16, 32, 3).mean((1, 3))
+    ref_cells = np.stack([cells(r) for r in refs])
+    spread = (ref_cells.max(0) - ref_cells.min(0)).max(-1) / ref_cells.mean(0).mean(-1)
+    # the four BRDFs differ on the object and where its edge crosses a cell (spread 1e-3 and up), not behind it (1e-4:
+    # the half-precision rounding of the files)
+    background = spread < 3e-4
+    assert 40 <= background.sum() <= 120 and background[:, 0].sum() >= 6 and background[0, :6].all() and background[-1, -5:].all() \
+        and not background[5:11, 5:11].any()
+
+    b = S.SceneBuilder()
+    m = b.add_material(S.diffuse((0.0, 0.0, 0.0)))
+    b.add_mesh(np.float32([[100, 100, 100], [100.001, 100, 100], [100, 100.001, 100]]), np.uint32([[0, 1, 2]]), m)      # out of sight
+    matrix = np.float64([[-0.224951, -0.000001, -0.974370, 0.0], [-0.974370, 0.0, 0.224951, 0.0], [0.0, 1.0, -0.000001, 8.87], [0.0, 0.0, 0.0, 1.0]])
+    to_world = (matrix @ S.rotation_about([0, 1, 0], -180.0).astype(np.float64)).astype(np.float32)     # <rotate y="1" angle="-180"/>, then <matrix>
+    b.add_envmap_emitter(env, to_world=to_world, scale=3.0)
+    cam = S.make_camera([3.69558, -3.46243, 3.25463], [3.04072, -2.85176, 2.80939], [-0.317366, 0.312466, 0.895346], 28.8415,
+                        near_clip=0.01, far_clip=1e4)
+    o = oracle_mod.OracleScene(b.finish(cam, S.make_film(512, 512), dict(max_depth=2)))
+    film, _ = o.render(4, seed=1, n_threads=os.cpu_count() or 1)
+    ours = cells(o.develop(film)[..., :3])
+    ratio = ours[None, background] / ref_cells[:, background]
+    assert np.all(np.abs(ratio - 0.98) < 0.02), (ratio.min(), ratio.max())
+    assert 0.975 < np.median(ratio) < 0.99
+    # the orientation matters: the same map turned by a quarter about the vertical is far off
+    b2 = S.SceneBuilder()
+    b2.add_mesh(np.float32([[100, 100, 100], [100.001, 100, 100], [100, 100.001, 100]]), np.uint32([[0, 1, 2]]), b2.add_material(S.diffuse((0.0, 0.0, 0.0))))
+    b2.add_envmap_emitter(env, to_world=(matrix @ S.rotation_about([0, 1, 0], -90.0).astype(np.float64)).astype(np.float32), scale=3.0)
+    o2 = oracle_mod.OracleScene(b2.finish(cam, S.make_film(512, 512), dict(max_depth=2)))
+    film2, _ = o2.render(1, seed=1, n_threads=os.cpu_count() or 1)
+    turned = cells(o2.develop(film2)[..., :3])[None, background] / ref_cells[:, background]
+    assert np.median(np.abs(turned - 1)) > 0.2
