@@ -249,6 +249,119 @@ def test_image_load_png(tmp_path):
         capi.image_load(p)
 
 
+def _piz_block(planes_rows, word_sizes, width):
+    """One PIZ block the way an OpenEXR writer stores it (the published format: ImfPizCompressor, ImfWav, ImfHuf; test
+    data only, no run-length codes): planes_rows[c] = the block's rows of channel c as uint16 words."""
+    import heapq
+    data = [np.concatenate(rows).astype(np.int64) for rows in planes_rows]
+    everything = np.concatenate(data)
+    present = np.zeros(65536, bool)
+    present[everything] = True
+    bitmap = np.packbits(present, bitorder="little")
+    bitmap[0] &= 0xfe
+    nz = np.nonzero(bitmap)[0]
+    lo, hi = (int(nz[0]), int(nz[-1])) if len(nz) else (8191, 0)
+    present[0] = True
+    rank = np.cumsum(present) - 1
+    max_value = int(rank[-1])
+    w14 = max_value < (1 << 14)
+
+    def enc(a, b):
+        if w14:
+            a = a - 65536 if a >= 32768 else a
+            b = b - 65536 if b >= 32768 else b
+            return ((a + b) >> 1) & 0xffff, (a - b) & 0xffff
+        ao = (a + 0x8000) & 0xffff
+        m, d = (ao + b) >> 1, ao - b
+        if d < 0:
+            m = (m + 0x8000) & 0xffff
+        return m, d & 0xffff
+
+    coded = []
+    for c, words in enumerate(data):
+        a = [int(v) for v in rank[words]]
+        sz, ny = word_sizes[c], len(planes_rows[c])
+        for j in range(sz):
+            nx, ox, oy = width, sz, width * sz
+            pw, p2 = 1, 2
+            while p2 <= min(nx, ny):
+                py = j
+                while py <= j + oy * (ny - p2):
+                    px = py
+                    while px <= py + ox * (nx - p2):
+                        p01, p10 = px + ox * pw, px + oy * pw
+                        p11 = p10 + ox * pw
+                        i00, i01 = enc(a[px], a[p01])
+                        i10, i11 = enc(a[p10], a[p11])
+                        a[px], a[p10] = enc(i00, i10)
+                        a[p01], a[p11] = enc(i01, i11)
+                        px += ox * p2
+                    if nx & pw:
+                        a[px], a[px + oy * pw] = enc(a[px], a[px + oy * pw])
+                    py += oy * p2
+                if ny & pw:
+                    px = py
+                    while px <= py + ox * (nx - p2):
+                        a[px], a[px + ox * pw] = enc(a[px], a[px + ox * pw])
+                        px += ox * p2
+                pw, p2 = p2, p2 << 1
+        coded += a
+    freq = {}
+    for v in coded:
+        freq[v] = freq.get(v, 0) + 1
+    im, iM = min(freq), max(freq) + 1
+    freq[iM] = 1                                    # the run-length symbol (never used below)
+    heap = [(f, s, (s,)) for s, f in freq.items()]
+    heapq.heapify(heap)
+    length = dict.fromkeys(freq, 0)
+    while len(heap) > 1:
+        f1, s1, m1 = heapq.heappop(heap)
+        f2, s2, m2 = heapq.heappop(heap)
+        for sym in m1 + m2:
+            length[sym] += 1
+        heapq.heappush(heap, (f1 + f2, min(s1, s2), m1 + m2))
+    assert max(length.values()) <= 58
+    count = [0] * 59
+    for l in length.values():
+        count[l] += 1
+    first, c = [0] * 59, 0
+    for l in range(58, 0, -1):                      # canonical codes, the longest first
+        first[l], c = c, (c + count[l]) >> 1
+    code, nxt = {}, list(first)
+    for sym in sorted(length):
+        code[sym] = nxt[length[sym]]
+        nxt[length[sym]] += 1
+    bits = []
+    i = im
+    while i <= iM:                                  # six bits per code length, runs of zeros packed
+        l = length.get(i, 0)
+        if l:
+            bits.append((l, 6)); i += 1
+            continue
+        run = 1
+        while i + run <= iM and length.get(i + run, 0) == 0 and run < 255 + 6:
+            run += 1
+        if run >= 6:
+            bits.append((63, 6)); bits.append((run - 6, 8))
+        elif run >= 2:
+            bits.append((59 + run - 2, 6))
+        else:
+            bits.append((0, 6))
+        i += run
+
+    def pack(pairs):
+        acc, n = 0, 0
+        for v, k in pairs:
+            acc, n = (acc << k) | v, n + k
+        pad = -n % 8
+        return ((acc << pad).to_bytes((n + pad) // 8, "big") if n else b""), n
+    table, _ = pack(bits)
+    payload, n_bits = pack([(code[v], length[v]) for v in coded])
+    huf = struct.pack("<IIIII", im, iM, len(table), n_bits, 0) + table + payload
+    head = struct.pack("<HH", lo, hi) + (bytes(bitmap[lo:hi + 1]) if lo <= hi else b"")
+    return head + struct.pack("<I", len(huf)) + huf, w14
+
+
 def test_image_load_pfm_and_openexr(tmp_path):
     from mitsuba_amd import capi
     rng = np.random.default_rng(6)
@@ -264,6 +377,8 @@ def test_image_load_pfm_and_openexr(tmp_path):
         f.write(lum[::-1].astype(">f4").tobytes())
     assert np.array_equal(capi.image_load(p), lum)
 
+    wavelets = []
+
     def exr(path, planes, names, types, compression):
         h, w = planes[0].shape
         order = np.argsort(names)
@@ -277,7 +392,7 @@ def test_image_load_pfm_and_openexr(tmp_path):
         hdr += attr(b"dataWindow", b"box2i", box) + attr(b"displayWindow", b"box2i", box)
         hdr += attr(b"lineOrder", b"lineOrder", b"\0") + attr(b"pixelAspectRatio", b"float", struct.pack("<f", 1))
         hdr += attr(b"screenWindowCenter", b"v2f", struct.pack("<ff", 0, 0)) + attr(b"screenWindowWidth", b"float", struct.pack("<f", 1)) + b"\0"
-        lines = {0: 1, 1: 1, 2: 1, 3: 16}[compression]
+        lines = {0: 1, 1: 1, 2: 1, 3: 16, 4: 32}[compression]
         blocks = []
         for y0 in range(0, h, lines):
             raw = b""
@@ -285,7 +400,13 @@ def test_image_load_pfm_and_openexr(tmp_path):
                 for i in order:
                     raw += planes[i][y].astype("<f2" if types[i] == 1 else "<f4").tobytes()
             data = raw
-            if compression:
+            if compression == 4:
+                rows = [[np.frombuffer(planes[i][y].astype("<f2" if types[i] == 1 else "<f4").tobytes(), "<u2")
+                         for y in range(y0, min(h, y0 + lines))] for i in order]
+                comp, w14 = _piz_block(rows, [1 if types[i] == 1 else 2 for i in order], w)
+                data = comp if len(comp) < len(raw) else raw        # what a writer does
+                wavelets.append(w14 if data is comp else None)
+            elif compression:
                 a = np.frombuffer(raw, np.uint8)
                 t = np.concatenate([a[0::2], a[1::2]]).astype(np.int64)
                 t[1:] = (t[1:] - t[:-1] + 128 + 256) % 256
@@ -311,6 +432,19 @@ def test_image_load_pfm_and_openexr(tmp_path):
     assert np.array_equal(capi.image_load(p), expect)
     exr(p, [big[..., 1]], ["Y"], [2], 3)
     assert np.array_equal(capi.image_load(p), big[..., 1])
+    # PIZ: half and float channels, odd sizes, a second block stored as it is; few distinct values (the 14-bit wavelet)
+    yy, xx = np.mgrid[0:37, 0:45]
+    smooth = (np.round(8 * np.sin(xx / 7.0) * np.cos(yy / 5.0)) / 8 + 2).astype(np.float32)
+    steps = np.stack([smooth, smooth.T[:37, :37].mean() + 0 * smooth, np.round(smooth * 3) / 4], -1).astype(np.float32)
+    exr(p, [steps[..., 0], steps[..., 1], steps[..., 2], steps[..., 0]], ["R", "G", "B", "A"], [1, 2, 1, 2], 4)
+    assert np.array_equal(capi.image_load(p), steps)
+    # ... and more than 2^14 distinct 16-bit words in a block (the 16-bit wavelet): full-precision floats of a smooth image
+    yy, xx = np.mgrid[0:33, 0:400]
+    fine = np.stack([np.sin(xx / 40.0 + c) * np.cos(yy / 30.0) + 1.5 for c in range(3)], -1)
+    fine = (fine + rng.uniform(0, 1e-3, fine.shape)).astype(np.float32)
+    exr(p, [fine[..., 0], fine[..., 1], fine[..., 2]], ["R", "G", "B"], [2, 2, 2], 4)
+    assert np.array_equal(capi.image_load(p), fine)
+    assert wavelets == [True, None, False, None]      # the short last blocks are smaller as they are
     # run-length compression is not read: refused with a message that says so (PIZ, which the reference's own files
     # use, is: tests/test_envmap.py reads one)
     exr(p, [big[..., 1]], ["Y"], [2], 1)
