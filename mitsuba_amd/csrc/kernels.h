@@ -77,6 +77,9 @@ static constexpr int kShadeBlock = MTS_SHADE_BLOCK;
 #define MTS_SHADE_PARK 1
 #endif
 static constexpr bool kShadePark = MTS_SHADE_PARK != 0;
+#ifndef MTS_ENV_LATE_MATERIAL
+#define MTS_ENV_LATE_MATERIAL 1
+#endif
 
 struct ShadeOut {
     bool alive = false, wantShadow = false;
@@ -120,6 +123,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                          ShadeOut &o, float4 *park = nullptr) {
     // one instance of every real call per register budget of the kernels that share this function
     constexpr int kTag = PARK ? (MIX ? 2 : 1) : 0;
+    constexpr bool kLateMaterial = ENV && MTS_ENV_LATE_MATERIAL != 0;
     const uint32_t triWord = __float_as_uint(hit.w);
     if (triWord != kMiss) {
         const uint32_t tri = triWord & kTriIndexMask;
@@ -148,6 +152,19 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
         // Side storage in memory for what only textured, framed or mixture records use (the uv partials, the perturbed
         // frame): kept here instead of in registers, it costs the other paths nothing.
         SurfaceQuery q;
+        bool texResolve = false;        // the call that resolves the textures of the answering record was made
+        // the answering record, with the textured colours and roughness the call found (a mixture's textured children look up q.uv)
+        auto loadAnswering = [&]() {
+            loadMaterial(sc, its.material, bsdf);
+            if (MIX && !texResolve && bsdf.type == 8) q.uv = surfUV(its.uvx, its.uvy);
+            if (MIX && texResolve) {
+                if (q.textured & 1u) { bsdf.diffuse[0] = q.colour[0]; bsdf.diffuse[1] = q.colour[1]; bsdf.diffuse[2] = q.colour[2]; }
+                if (q.textured & 2u) { bsdf.specular[0] = q.colour[3]; bsdf.specular[1] = q.colour[4]; bsdf.specular[2] = q.colour[5]; }
+                if (q.textured & 4u) { bsdf.transmittance[0] = q.colour[6]; bsdf.transmittance[1] = q.colour[7]; bsdf.transmittance[2] = q.colour[8]; }
+                if (q.textured & 8u) bsdf.alphaU = q.alpha[0];
+                if (q.textured & 16u) bsdf.alphaV = q.alpha[1];
+            }
+        };
         if (MIX && sc.materialTextures) {
             // Scenes with textures. Who answers on this side (twosided.cpp:108-183) is read from three words of the hit's
             // record, so that the texture call below is made BEFORE the answering record is loaded: whatever is live
@@ -174,16 +191,16 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             } else if (resolve) {
                 resolveColoursCall<kTag>(sc.self, its.material, its.uvx, its.uvy, &q);
             }
-            loadMaterial(sc, its.material, bsdf);
-            if (!resolve && bsdf.type == 8) q.uv = surfUV(its.uvx, its.uvy);       // a mixture's textured children look here
-            if (resolve) {
-                if (q.textured & 1u) { bsdf.diffuse[0] = q.colour[0]; bsdf.diffuse[1] = q.colour[1]; bsdf.diffuse[2] = q.colour[2]; }
-                if (q.textured & 2u) { bsdf.specular[0] = q.colour[3]; bsdf.specular[1] = q.colour[4]; bsdf.specular[2] = q.colour[5]; }
-                if (q.textured & 4u) { bsdf.transmittance[0] = q.colour[6]; bsdf.transmittance[1] = q.colour[7]; bsdf.transmittance[2] = q.colour[8]; }
-                if (q.textured & 8u) bsdf.alphaU = q.alpha[0];
-                if (q.textured & 16u) bsdf.alphaV = q.alpha[1];
-                framed = heavy && q.framed != 0;
-            }
+            texResolve = resolve;
+            framed = resolve && heavy && q.framed != 0;
+            if (!kLateMaterial) loadAnswering();
+        } else if (kLateMaterial) {
+            // Scenes with emitters that are sampled through a real call: the answering record is loaded after that call
+            // (below), so that its 28 words are not live across it; who answers is read from three words of the hit's record.
+            const DevMaterial *rec = sc.materials + its.material;
+            bsdfType = rec->typeFlags;
+            flipped = rec->twoSided && wiZ < 0;
+            if (flipped) its.material = (uint32_t) rec->backMaterial;
         } else {
             // the material record comes in as seven 16-byte loads issued together, not field by field
             loadMaterial(sc, its.material, bsdf);
@@ -269,10 +286,16 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             if ((bsdfType & (ETransmission | EBackSide)) == 0) refN = its.sh.n;
 
             // direct illumination sampling (path.cpp:172-200)
-            if (bsdfType & ESmooth) {
+            const bool smooth = (bsdfType & ESmooth) != 0;
+            DirectRec dRec;
+            dRec.pdf = 0;
+            V3 value = mk(0.0f);
+            if (smooth) {
                 const float sx = rng.next1D(), sy = rng.next1D();
-                DirectRec dRec;
-                const V3 value = sampleEmitterDirect<ENV, kTag>(sc, its.p, refN, sx, sy, dRec);
+                value = sampleEmitterDirect<ENV, kTag>(sc, its.p, refN, sx, sy, dRec);
+            }
+            if (kLateMaterial) loadAnswering();
+            if (smooth) {
                 if (dRec.pdf != 0) {
                     V3 c = mk(0.0f);
                     const V3 wo = toLocal(its.sh, dRec.d);
