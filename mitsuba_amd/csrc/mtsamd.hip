@@ -514,7 +514,10 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         unsigned long long *counts = cnt64 + CNT64_TAIL_NORMAL;
         HIP_TRY(hipMemsetAsync(counts, 0, 2 * sizeof(unsigned long long), st));
         timer.begin(T_SHADE);
-        hipLaunchKernelGGL(k_direct_shade, dim3(blocksFor(n, kShadeBlock * kDirectRounds)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, samplePos, counts, n, nE, nB);
+        if (s->host.mixture || s->host.extEmitters || s->roughDielectric)
+            hipLaunchKernelGGL((k_direct_shade<true>), dim3(blocksFor(n, kShadeBlock * kDirectRounds)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, samplePos, counts, n, nE, nB);
+        else
+            hipLaunchKernelGGL((k_direct_shade<false>), dim3(blocksFor(n, kShadeBlock * kDirectRounds)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, samplePos, counts, n, nE, nB);
         timer.end(T_SHADE);
         if (nE > 0) {
             TraceArgs sa;
