@@ -153,7 +153,8 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
         // frame): kept here instead of in registers, it costs the other paths nothing.
         SurfaceQuery q;
         bool texResolve = false;        // the call that resolves the textures of the answering record was made
-        // the answering record, with the textured colours and roughness the call found (a mixture's textured children look up q.uv)
+        // Variants that load the answering record late: the record, with the textured colours and roughness the call found
+        // (a mixture's textured children look up q.uv)
         auto loadAnswering = [&]() {
             loadMaterial(sc, its.material, bsdf);
             if (MIX && !texResolve && bsdf.type == 8) q.uv = surfUV(its.uvx, its.uvy);
@@ -191,9 +192,21 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             } else if (resolve) {
                 resolveColoursCall<kTag>(sc.self, its.material, its.uvx, its.uvy, &q);
             }
-            texResolve = resolve;
-            framed = resolve && heavy && q.framed != 0;
-            if (!kLateMaterial) loadAnswering();
+            if (kLateMaterial) {
+                texResolve = resolve;
+                framed = resolve && heavy && q.framed != 0;
+            } else {
+                loadMaterial(sc, its.material, bsdf);
+                if (!resolve && bsdf.type == 8) q.uv = surfUV(its.uvx, its.uvy);       // a mixture's textured children look here
+                if (resolve) {
+                    if (q.textured & 1u) { bsdf.diffuse[0] = q.colour[0]; bsdf.diffuse[1] = q.colour[1]; bsdf.diffuse[2] = q.colour[2]; }
+                    if (q.textured & 2u) { bsdf.specular[0] = q.colour[3]; bsdf.specular[1] = q.colour[4]; bsdf.specular[2] = q.colour[5]; }
+                    if (q.textured & 4u) { bsdf.transmittance[0] = q.colour[6]; bsdf.transmittance[1] = q.colour[7]; bsdf.transmittance[2] = q.colour[8]; }
+                    if (q.textured & 8u) bsdf.alphaU = q.alpha[0];
+                    if (q.textured & 16u) bsdf.alphaV = q.alpha[1];
+                    framed = heavy && q.framed != 0;
+                }
+            }
         } else if (kLateMaterial) {
             // Scenes with emitters that are sampled through a real call: the answering record is loaded after that call
             // (below), so that its 28 words are not live across it; who answers is read from three words of the hit's record.
@@ -287,15 +300,26 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
 
             // direct illumination sampling (path.cpp:172-200)
             const bool smooth = (bsdfType & ESmooth) != 0;
-            DirectRec dRec;
-            dRec.pdf = 0;
-            V3 value = mk(0.0f);
-            if (smooth) {
-                const float sx = rng.next1D(), sy = rng.next1D();
-                value = sampleEmitterDirect<ENV, kTag>(sc, its.p, refN, sx, sy, dRec);
+            DirectRec earlyRec;         // used by the variants that load the answering record late only
+            V3 earlyValue;
+            if (kLateMaterial) {
+                // the emitter is sampled first, the answering record loaded after that call
+                earlyRec.pdf = 0;
+                earlyValue = mk(0.0f);
+                if (smooth) {
+                    const float sx = rng.next1D(), sy = rng.next1D();
+                    earlyValue = sampleEmitterDirect<ENV, kTag>(sc, its.p, refN, sx, sy, earlyRec);
+                }
+                loadAnswering();
             }
-            if (kLateMaterial) loadAnswering();
             if (smooth) {
+                DirectRec dRec;
+                V3 value;
+                if (kLateMaterial) { dRec = earlyRec; value = earlyValue; }
+                else {
+                    const float sx = rng.next1D(), sy = rng.next1D();
+                    value = sampleEmitterDirect<ENV, kTag>(sc, its.p, refN, sx, sy, dRec);
+                }
                 if (dRec.pdf != 0) {
                     V3 c = mk(0.0f);
                     const V3 wo = toLocal(its.sh, dRec.d);
