@@ -46,6 +46,10 @@ INFINITY_CACHE_BYTES = 256 << 20
 def build_scene(args):
     if args.workload == "config3":
         return S.config3(args.width, args.height), "synthetic 1M-triangle microfacet scene (roughconductor GGX + roughplastic GGX + dielectric), %dx%d, path integrator" % (args.width, args.height)
+    if args.workload == "config3simple":    # the same scene under volpath_simple's estimator (no media)
+        sd = S.config3(args.width, args.height)
+        sd.integrator["type"] = "volpath_simple"
+        return sd, "synthetic 1M-triangle microfacet scene, %dx%d, volpath_simple integrator" % (args.width, args.height)
     if args.workload.startswith("config3tex"):       # config3tex, config3tex:trilinear, ...
         flt = args.workload.partition(":")[2] or "ewa"
         return S.config3_textured(args.width, args.height, flt), ("config 3 with 1024x1024 bitmap textures (%s) on ground, plastic and conductor colours and a "

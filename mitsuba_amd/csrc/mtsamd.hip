@@ -498,7 +498,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
     bool shadowPending = false;
     const bool traceIters = getenv("MTSAMD_TRACE_ITERS") != nullptr;
     const mtsamd_integrator &ig = s->host.desc.integrator;
-    const bool simple = ig.type == MTSAMD_INTEGRATOR_VOLPATH_SIMPLE;       // runs the every-feature kernels with its own estimator
+    const bool simple = ig.type == MTSAMD_INTEGRATOR_VOLPATH_SIMPLE;       // its own estimator, in the plain or the every-feature kernels
     if (ig.type == MTSAMD_INTEGRATOR_DIRECT) {
         // camera rays -> shade the camera vertex into nEmitter shadow rays and nBsdf BSDF-sampled rays per sample -> both
         // traversals -> gather. The queues keep a fixed place for every ray of a sample.
@@ -555,7 +555,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
             timer.begin(T_TAIL);
 #define MTS_LAUNCH_TAIL(...) hipLaunchKernelGGL((k_tail<__VA_ARGS__>), dim3(blocksFor(n, kTailBlock)), dim3(kTailBlock), 0, st, sc, pp, s->queue(cur), sampleL, samplePos, n, s->triShare, tailCounts)
             // scenes with mixtures, textures or frame adapters run the variants that know them (with or without the other emitter kinds and the rough dielectric)
-            if (simple) MTS_LAUNCH_TAIL(true, true, true, true);
+            if (simple) { if (s->host.mixture || s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_TAIL(true, true, true, true); else MTS_LAUNCH_TAIL(false, false, false, true); }
             else if (s->host.mixture) { if (s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_TAIL(true, true, true); else MTS_LAUNCH_TAIL(false, false, true); }
             else if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_TAIL(true, true, false); else MTS_LAUNCH_TAIL(true, false, false); }
             else { if (s->roughDielectric) MTS_LAUNCH_TAIL(false, true, false); else MTS_LAUNCH_TAIL(false, false, false); }
@@ -589,7 +589,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
 #define MTS_LAUNCH_SHADE_AS(...) hipLaunchKernelGGL((k_shade<__VA_ARGS__>), dim3(blocksFor(n, kShadeBlock * rounds16)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, samplePos, cnt, n)
 #define MTS_LAUNCH_SHADE(R) do { \
             const int rounds16 = R; \
-            if (simple) MTS_LAUNCH_SHADE_AS(R, true, true, true, true); \
+            if (simple) { if (s->host.mixture || s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true, true, true); else MTS_LAUNCH_SHADE_AS(R, false, false, false, true); } \
             else if (s->host.mixture) { if (s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true, true); else MTS_LAUNCH_SHADE_AS(R, false, false, true); } \
             else if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true, false); else MTS_LAUNCH_SHADE_AS(R, true, false, false); } \
             else { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, false, true, false); else MTS_LAUNCH_SHADE_AS(R, false, false, false); } } while (0)
