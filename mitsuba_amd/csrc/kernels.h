@@ -650,10 +650,10 @@ static constexpr int kDirectRounds = 16;    // sweeps per workgroup, sorted by B
 #ifndef MTS_DIRECT_WAVES_PLAIN
 #define MTS_DIRECT_WAVES_PLAIN 1
 #endif
-// ALL = false: for scenes with area lights only, without rough dielectrics, mixtures, textures and frame adapters (the
-// same split as k_shade's variants: the code of those features costs registers whether or not a scene uses them)
-template <bool ALL>
-__global__ void __launch_bounds__(kShadeBlock, ALL ? MTS_DIRECT_WAVES : MTS_DIRECT_WAVES_PLAIN) k_direct_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out, ShadowQueue sq,
+// ENV, RD, MIX: the same split as k_shade's variants (the code of those features costs registers whether or not a scene
+// uses them); the variant without any of them runs at whatever occupancy its registers allow
+template <bool ENV, bool RD, bool MIX>
+__global__ void __launch_bounds__(kShadeBlock, (ENV || RD || MIX) ? MTS_DIRECT_WAVES : MTS_DIRECT_WAVES_PLAIN) k_direct_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out, ShadowQueue sq,
                                                              float4 *sampleL, const float2 *samplePos, unsigned long long *counts, uint32_t n, int nEmitter, int nBsdf) {
     __shared__ uint32_t sCount[kShadeSortKeys * kDirectRounds * (kShadeBlock / 64)];
     __shared__ uint32_t sOrder[kShadeBlock * kDirectRounds];
@@ -675,7 +675,7 @@ __global__ void __launch_bounds__(kShadeBlock, ALL ? MTS_DIRECT_WAVES : MTS_DIRE
         Rng rng;
         if (triWord == kMiss) {
             // direct.cpp:156-163: the environment seen directly, alpha 0
-            if (ALL && sc.envEmitter >= 0 && !sc.hideEmitters) {
+            if (ENV && sc.envEmitter >= 0 && !sc.hideEmitters) {
                 const V3 e = sc.envIsMap ? cameraEnvironmentRadiance(sc, pp, samplePos[slot], rayD) : ld3(sc.envRadiance);
                 L.x = e.x; L.y = e.y; L.z = e.z;
             }
@@ -704,12 +704,12 @@ __global__ void __launch_bounds__(kShadeBlock, ALL ? MTS_DIRECT_WAVES : MTS_DIRE
         if (shade) {
             bsdfType = bsdf.typeFlags;
             uv = surfUV(its.uvx, its.uvy);
-            if (ALL && sc.materialTextures && (sc.materialTextures[its.material].w & 1u))     // its.getBSDF(ray) (direct.cpp:176)
+            if (MIX && sc.materialTextures && (sc.materialTextures[its.material].w & 1u))     // its.getBSDF(ray) (direct.cpp:176)
                 cameraUVPartials(sc, pp, samplePos[slot], its, in.rayO[i], rayD, uv);
             flipped = resolveTwoSided(sc, its.material, its.wi.z, bsdf);
             wiLocal = flipped ? mirrorZ(its.wi) : its.wi;
-            if (ALL) applyTextures(sc, its.material, uv, bsdf);
-            if (ALL && sc.materialTextures) {      // bumpmap / normalmap around the answering record
+            if (MIX) applyTextures(sc, its.material, uv, bsdf);
+            if (MIX && sc.materialTextures) {      // bumpmap / normalmap around the answering record
                 const uint32_t fw = sc.materialTextures[its.material].w;
                 if (fw & 6u) { framed = true; pf = perturbedFrame(sc, fw, its.sh, its.geoN, its.dpdu, its.dpdv, its.uvx, its.uvy); }
             }
@@ -728,16 +728,16 @@ __global__ void __launch_bounds__(kShadeBlock, ALL ? MTS_DIRECT_WAVES : MTS_DIRE
                 const float sx = rng.next1D(), sy = rng.next1D();
                 if (bsdfType & ESmooth) {
                     DirectRec dRec;
-                    const V3 value = sampleEmitterDirect<ALL>(sc, its.p, refN, sx, sy, dRec);
+                    const V3 value = sampleEmitterDirect<ENV>(sc, its.p, refN, sx, sy, dRec);
                     if (dRec.pdf != 0) {
                         V3 c = mk(0.0f);
                         const V3 wo = toLocal(its.sh, dRec.d);
                         const V3 woSide = flipped ? mirrorZ(wo) : wo;
                         const V3 woB = framed ? toLocal(pf, toWorld(its.sh, woSide)) : woSide;
                         const bool sameSide = !framed || woSide.z * woB.z > 0;
-                        const V3 bsdfVal = sameSide ? bsdfEvalAny<ALL, ALL>(sc, bsdf, wiB, woB, uv) : mk(0.0f);
+                        const V3 bsdfVal = sameSide ? bsdfEvalAny<RD, MIX>(sc, bsdf, wiB, woB, uv) : mk(0.0f);
                         if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
-                            const float bPdf = ALL && dRec.delta ? 0.0f : bsdfPdfAny<ALL, ALL>(sc, bsdf, wiB, woB, uv);
+                            const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX>(sc, bsdf, wiB, woB, uv);
                             c = value * bsdfVal * (miWeight(dRec.pdf * fracLum, bPdf * fracBSDF) * weightLum);
                         }
                         ++nShadow;
@@ -758,9 +758,9 @@ __global__ void __launch_bounds__(kShadeBlock, ALL ? MTS_DIRECT_WAVES : MTS_DIRE
             float oPdf = 0.0f, oRefCos = -2.0f;
             if (shade) {
                 const float bx = rng.next1D(), by = rng.next1D();
-                const float bu = ALL && bsdfDrawsFromSampler(bsdf, bx) ? rng.next1D() : 0.0f;
+                const float bu = RD && bsdfDrawsFromSampler<MIX>(bsdf, bx) ? rng.next1D() : 0.0f;
                 V3 woLocal; float bPdf, bEta; uint32_t sampledType;
-                V3 bsdfVal = bsdfSampleAny<ALL, ALL>(sc, bsdf, wiB, bx, by, bu, woLocal, bPdf, bEta, sampledType, uv);
+                V3 bsdfVal = bsdfSampleAny<RD, MIX>(sc, bsdf, wiB, bx, by, bu, woLocal, bPdf, bEta, sampledType, uv);
                 if (framed && !isZero(bsdfVal)) {
                     const V3 pwo = woLocal;
                     woLocal = toLocal(its.sh, toWorld(pf, pwo));

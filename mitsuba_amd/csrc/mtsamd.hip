@@ -514,10 +514,11 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         unsigned long long *counts = cnt64 + CNT64_TAIL_NORMAL;
         HIP_TRY(hipMemsetAsync(counts, 0, 2 * sizeof(unsigned long long), st));
         timer.begin(T_SHADE);
-        if (s->host.mixture || s->host.extEmitters || s->roughDielectric)
-            hipLaunchKernelGGL((k_direct_shade<true>), dim3(blocksFor(n, kShadeBlock * kDirectRounds)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, samplePos, counts, n, nE, nB);
-        else
-            hipLaunchKernelGGL((k_direct_shade<false>), dim3(blocksFor(n, kShadeBlock * kDirectRounds)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, samplePos, counts, n, nE, nB);
+#define MTS_LAUNCH_DIRECT(...) hipLaunchKernelGGL((k_direct_shade<__VA_ARGS__>), dim3(blocksFor(n, kShadeBlock * kDirectRounds)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, samplePos, counts, n, nE, nB)
+        if (s->host.mixture) { if (s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_DIRECT(true, true, true); else MTS_LAUNCH_DIRECT(false, false, true); }
+        else if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_DIRECT(true, true, false); else MTS_LAUNCH_DIRECT(true, false, false); }
+        else { if (s->roughDielectric) MTS_LAUNCH_DIRECT(false, true, false); else MTS_LAUNCH_DIRECT(false, false, false); }
+#undef MTS_LAUNCH_DIRECT
         timer.end(T_SHADE);
         if (nE > 0) {
             TraceArgs sa;
