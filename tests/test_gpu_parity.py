@@ -443,7 +443,8 @@ def test_direct_integrator_parity(gpu, oracle_mod, ne, nb):
     for sd in (S.small_test_scene(sky=(0.6, 0.8, 1.2), lamps=True, blend=True), S.cornell_mixed(64, 64),
                S.small_test_scene(hide_emitters=1, sky=(0.2, 0.2, 0.3)), S.small_test_scene(textured=True, blend=True),
                S.small_test_scene(textured="bitmap"), S.small_test_scene(textured="bitmap", bumps=True),
-               S.small_test_scene(sky="map", hide_emitters=0), S.small_test_scene(sky="map", area_lights=False, hide_emitters=1)):
+               S.small_test_scene(sky="map", hide_emitters=0), S.small_test_scene(sky="map", area_lights=False, hide_emitters=1),
+               S.small_test_scene(), S.cornell_box(64, 64)):     # the last two: area lights only, the kernel built without the optional features
         sd.integrator.update(type="direct", emitter_samples=ne, bsdf_samples=nb)
         g, o = gpu.Scene(sd), oracle_mod.OracleScene(sd)
         Lg, pg, sg = g.li(4, seed=7)
@@ -473,7 +474,7 @@ def test_volpath_simple_parity(gpu, oracle_mod):
              (S.small_test_scene(sky=(0.6, 0.8, 1.2), lamps=True, blend=True, max_depth=6), dict(rr_depth=2)),
              (S.cornell_mixed(64, 64, max_depth=5), {}), (S.small_test_scene(sky=(0.2, 0.2, 0.3), max_depth=4), dict(hide_emitters=1, strict_normals=1)),
              (S.small_test_scene(textured="bitmap", max_depth=4), {}), (S.small_test_scene(sky="map", max_depth=5), {}),
-             (S.small_test_scene(sky="map", area_lights=False, lamps=True, max_depth=3), {})]
+             (S.small_test_scene(sky="map", area_lights=False, lamps=True, max_depth=3), {}), (S.cornell_box(64, 64, max_depth=5), dict(rr_depth=3))]
     for sd, extra in cases:
         sd.integrator.update(type="volpath_simple", **extra)
         g, o = gpu.Scene(sd), oracle_mod.OracleScene(sd)
