@@ -425,6 +425,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         memcpy(dm.condEta, child, 12); memcpy(&dm.condK[0], &child[3], 4);
         dm.typeFlags = dm.ownFlags = flags;
         hs.mixture = true;
+        hs.blend = true;
     }
     // TwoSidedBRDF::configure (twosided.cpp:84-106): the adapter shows the front BRDF's components on the front side
     // and the back BRDF's on the back side

@@ -31,6 +31,7 @@ struct HostScene {
     int32_t envEmitter = -1;    // index of the constant environment emitter in `emitters`, if any
     std::vector<DevDeltaEmitter> deltaEmitters;     // point, spot and directional emitters
     bool mixture = false;       // some material is a mixturebsdf or textured (selects the kernels that know every feature)
+    bool blend = false;         // some material is a mixturebsdf (the kernels with the mixture code)
     bool extEmitters = false;   // some emitter is not an area light (selects the kernels that know the other kinds)
 };
 

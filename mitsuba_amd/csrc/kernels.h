@@ -118,7 +118,8 @@ struct HeldPath {
 // contribution wait while the BSDF is sampled, instead of in eight registers.
 // VS: the estimator of volpath_simple on a scene without media (src/integrators/path/volpath_simple.cpp:88-297) in place
 // of path's: no multiple importance sampling; emitters are seen by the camera ray and after Dirac bounces only.
-template <bool ENV, bool RD, bool MIX, bool PARK, typename Path, bool VS = false>
+// BLEND: some record of the scene is a mixture (MIX alone: textures and frame adapters only, no mixture code).
+template <bool ENV, bool RD, bool MIX, bool PARK, typename Path, bool VS = false, bool BLEND = MIX>
 MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &in, const float4 hit, float4 *sampleL, const float2 *samplePos,
                          ShadeOut &o, float4 *park = nullptr) {
     // one instance of every real call per register budget of the kernels that share this function
@@ -157,7 +158,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
         // (a mixture's textured children look up q.uv)
         auto loadAnswering = [&]() {
             loadMaterial(sc, its.material, bsdf);
-            if (MIX && !texResolve && bsdf.type == 8) q.uv = surfUV(its.uvx, its.uvy);
+            if (BLEND && !texResolve && bsdf.type == 8) q.uv = surfUV(its.uvx, its.uvy);
             if (MIX && texResolve) {
                 if (q.textured & 1u) { bsdf.diffuse[0] = q.colour[0]; bsdf.diffuse[1] = q.colour[1]; bsdf.diffuse[2] = q.colour[2]; }
                 if (q.textured & 2u) { bsdf.specular[0] = q.colour[3]; bsdf.specular[1] = q.colour[4]; bsdf.specular[2] = q.colour[5]; }
@@ -197,7 +198,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                 framed = resolve && heavy && q.framed != 0;
             } else {
                 loadMaterial(sc, its.material, bsdf);
-                if (!resolve && bsdf.type == 8) q.uv = surfUV(its.uvx, its.uvy);       // a mixture's textured children look here
+                if (BLEND && !resolve && bsdf.type == 8) q.uv = surfUV(its.uvx, its.uvy);       // a mixture's textured children look here
                 if (resolve) {
                     if (q.textured & 1u) { bsdf.diffuse[0] = q.colour[0]; bsdf.diffuse[1] = q.colour[1]; bsdf.diffuse[2] = q.colour[2]; }
                     if (q.textured & 2u) { bsdf.specular[0] = q.colour[3]; bsdf.specular[1] = q.colour[4]; bsdf.specular[2] = q.colour[5]; }
@@ -217,7 +218,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
         } else {
             // the material record comes in as seven 16-byte loads issued together, not field by field
             loadMaterial(sc, its.material, bsdf);
-            if (MIX && bsdf.type == 8) q.uv = surfUV(its.uvx, its.uvy);
+            if (BLEND && bsdf.type == 8) q.uv = surfUV(its.uvx, its.uvy);
             bsdfType = bsdf.typeFlags;
             // ... and the BRDF that answers on this side (twosided.cpp:108-183)
             flipped = resolveTwoSided(sc, its.material, wiZ, bsdf);
@@ -326,12 +327,12 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                     const V3 woSide = flipped ? mirrorZ(wo) : wo;
                     const V3 woB = framed ? toLocal(q.pf, toWorld(its.sh, woSide)) : woSide;
                     const bool sameSide = !framed || woSide.z * woB.z > 0;
-                    const V3 bsdfVal = sameSide ? bsdfEvalAny<RD, MIX, kTag>(sc, bsdf, wiB, woB, &q.uv) : mk(0.0f);
+                    const V3 bsdfVal = sameSide ? bsdfEvalAny<RD, BLEND, kTag>(sc, bsdf, wiB, woB, &q.uv) : mk(0.0f);
                     if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
                         // path.cpp:192-193: only emitters with a surface, sampled in the solid-angle measure, compete with BSDF sampling
                         if (VS) c = throughput * value * bsdfVal;       // volpath_simple.cpp:224: no weighting against BSDF sampling
                         else {
-                            const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX, kTag>(sc, bsdf, wiB, woB, &q.uv);
+                            const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, BLEND, kTag>(sc, bsdf, wiB, woB, &q.uv);
                             c = throughput * value * bsdfVal * miWeight(dRec.pdf, bPdf);
                         }
                     }
@@ -348,8 +349,8 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
             // BSDF sampling (path.cpp:206-226)
             const float bx = rng.next1D(), by = rng.next1D();
             V3 woLocal; float bPdf, bEta; uint32_t sampledType;
-            const float bu = RD && bsdfDrawsFromSampler<MIX>(bsdf, bx) ? rng.next1D() : 0.0f;     // bRec.sampler->next1D() inside BSDF::sample
-            V3 bsdfWeight = bsdfSampleAny<RD, MIX, kTag>(sc, bsdf, wiB, bx, by, bu, woLocal, bPdf, bEta, sampledType, &q.uv);
+            const float bu = RD && bsdfDrawsFromSampler<BLEND>(bsdf, bx) ? rng.next1D() : 0.0f;     // bRec.sampler->next1D() inside BSDF::sample
+            V3 bsdfWeight = bsdfSampleAny<RD, BLEND, kTag>(sc, bsdf, wiB, bx, by, bu, woLocal, bPdf, bEta, sampledType, &q.uv);
             if (framed && !isZero(bsdfWeight)) {        // back into the unperturbed frame (bumpmap.cpp:227-234)
                 const V3 pwo = woLocal;
                 woLocal = toLocal(its.sh, toWorld(q.pf, pwo));
@@ -497,7 +498,7 @@ MTS_DEV void sortByBsdfType(const float4 *hits, uint32_t first, uint32_t n, uint
 // ENV: the scene has emitters other than area lights: an environment emitter (rays that leave the scene are shaded
 // too, one more queue stream), point, spot or directional lights.
 // RD: the scene has a rough dielectric material.
-template <int ROUNDS, bool ENV, bool RD, bool MIX, bool VS = false>
+template <int ROUNDS, bool ENV, bool RD, bool MIX, bool VS = false, bool BLEND = MIX>
 __global__ void __launch_bounds__(kShadeBlock, MIX ? MTS_SHADE_WAVES_MIX : MTS_SHADE_WAVES) k_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out,
                                                        ShadowQueue sq, float4 *sampleL, const float2 *samplePos, uint32_t *counters, uint32_t n) {
     constexpr int kWaves = kShadeBlock / 64;
@@ -516,7 +517,7 @@ __global__ void __launch_bounds__(kShadeBlock, MIX ? MTS_SHADE_WAVES_MIX : MTS_S
     asm volatile("" : "+v"(tidS));
     const uint32_t i = first + sOrder[round * kShadeBlock + tidS];
     ShadeOut o;
-    if (i < n) shadeVertex<ENV, RD, MIX, kShadePark, QueuedPath, VS>(sc, pp, QueuedPath{ in, i }, hits[i], sampleL, samplePos, o, sPark);
+    if (i < n) shadeVertex<ENV, RD, MIX, kShadePark, QueuedPath, VS, BLEND>(sc, pp, QueuedPath{ in, i }, hits[i], sampleL, samplePos, o, sPark);
     const bool alive = o.alive, wantShadow = o.wantShadow;
     uint32_t tidL = threadIdx.x;
     asm volatile("" : "+v"(tidL));
@@ -561,7 +562,7 @@ __global__ void __launch_bounds__(kShadeBlock, MIX ? MTS_SHADE_WAVES_MIX : MTS_S
 // functions as the wavefront kernels, hence the same results. counts[0] / counts[1] receive the closest-hit and
 // shadow rays traced (the reference's two ray counters).
 static constexpr int kTailBlock = 64;
-template <bool ENV, bool RD, bool MIX, bool VS = false>
+template <bool ENV, bool RD, bool MIX, bool VS = false, bool BLEND = MIX>
 __global__ void __launch_bounds__(kTailBlock) k_tail(DevScene sc, PassParams pp, PathQueue in, float4 *sampleL, const float2 *samplePos, uint32_t n,
                                                      uint32_t triShare, unsigned long long *counts) {
     __shared__ uint2 sStack[kLdsStack * kTailBlock];
@@ -592,7 +593,7 @@ __global__ void __launch_bounds__(kTailBlock) k_tail(DevScene sc, PassParams pp,
         traceHeldRays<false>(sc, r, busy, ldsStack, kTailBlock, triShare);
         // shade
         ShadeOut o;
-        if (active) shadeVertex<ENV, RD, MIX, false, HeldPath, VS>(sc, pp, path, make_float4(r.hit.t, r.hit.u, r.hit.v, __uint_as_float(r.hit.tri)), sampleL, samplePos, o);
+        if (active) shadeVertex<ENV, RD, MIX, false, HeldPath, VS, BLEND>(sc, pp, path, make_float4(r.hit.t, r.hit.u, r.hit.v, __uint_as_float(r.hit.tri)), sampleL, samplePos, o);
         // shadow ray of the emitter sample (scene.cpp:839-843), then path.cpp:196-198
         const bool wantShadow = active && o.wantShadow;
         busy = false;

@@ -215,7 +215,8 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
     if (const char *e = getenv("MTSAMD_SHADE_VARIANT")) {
         if (strstr(e, "env")) s->host.extEmitters = true;
         if (strstr(e, "rd")) s->roughDielectric = true;
-        if (strstr(e, "mix")) s->host.mixture = true;
+        if (strstr(e, "mix")) s->host.mixture = s->host.blend = true;
+        if (strstr(e, "tex")) s->host.mixture = true;       // the kernels with textures and frame adapters but no mixtures
     }
     if (const char *e = getenv("MTSAMD_NODE_STRIDE")) s->nodeStride = (uint32_t) std::min(16, std::max(5, atoi(e)));
     if (const char *e = getenv("MTSAMD_TRI_STRIDE")) s->triStride = (uint32_t) std::min(16, std::max(3, atoi(e)));
@@ -557,6 +558,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
 #define MTS_LAUNCH_TAIL(...) hipLaunchKernelGGL((k_tail<__VA_ARGS__>), dim3(blocksFor(n, kTailBlock)), dim3(kTailBlock), 0, st, sc, pp, s->queue(cur), sampleL, samplePos, n, s->triShare, tailCounts)
             // scenes with mixtures, textures or frame adapters run the variants that know them (with or without the other emitter kinds and the rough dielectric)
             if (simple) { if (s->host.mixture || s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_TAIL(true, true, true, true); else MTS_LAUNCH_TAIL(false, false, false, true); }
+            else if (s->host.mixture && !s->host.blend) { if (s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_TAIL(true, true, true, false, false); else MTS_LAUNCH_TAIL(false, false, true, false, false); }
             else if (s->host.mixture) { if (s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_TAIL(true, true, true); else MTS_LAUNCH_TAIL(false, false, true); }
             else if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_TAIL(true, true, false); else MTS_LAUNCH_TAIL(true, false, false); }
             else { if (s->roughDielectric) MTS_LAUNCH_TAIL(false, true, false); else MTS_LAUNCH_TAIL(false, false, false); }
@@ -591,6 +593,7 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
 #define MTS_LAUNCH_SHADE(R) do { \
             const int rounds16 = R; \
             if (simple) { if (s->host.mixture || s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true, true, true); else MTS_LAUNCH_SHADE_AS(R, false, false, false, true); } \
+            else if (s->host.mixture && !s->host.blend) { if (s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true, true, false, false); else MTS_LAUNCH_SHADE_AS(R, false, false, true, false, false); } \
             else if (s->host.mixture) { if (s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true, true); else MTS_LAUNCH_SHADE_AS(R, false, false, true); } \
             else if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, true, true, false); else MTS_LAUNCH_SHADE_AS(R, true, false, false); } \
             else { if (s->roughDielectric) MTS_LAUNCH_SHADE_AS(R, false, true, false); else MTS_LAUNCH_SHADE_AS(R, false, false, false); } } while (0)
