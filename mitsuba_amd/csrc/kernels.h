@@ -651,9 +651,9 @@ static constexpr int kDirectRounds = 16;    // sweeps per workgroup, sorted by B
 #ifndef MTS_DIRECT_WAVES_PLAIN
 #define MTS_DIRECT_WAVES_PLAIN 1
 #endif
-// ENV, RD, MIX: the same split as k_shade's variants (the code of those features costs registers whether or not a scene
+// ENV, RD, MIX, BLEND: the same split as k_shade's variants (the code of those features costs registers whether or not a scene
 // uses them); the variant without any of them runs at whatever occupancy its registers allow
-template <bool ENV, bool RD, bool MIX>
+template <bool ENV, bool RD, bool MIX, bool BLEND = MIX>
 __global__ void __launch_bounds__(kShadeBlock, (ENV || RD || MIX) ? MTS_DIRECT_WAVES : MTS_DIRECT_WAVES_PLAIN) k_direct_shade(DevScene sc, PassParams pp, PathQueue in, const float4 *hits, PathQueue out, ShadowQueue sq,
                                                              float4 *sampleL, const float2 *samplePos, unsigned long long *counts, uint32_t n, int nEmitter, int nBsdf) {
     __shared__ uint32_t sCount[kShadeSortKeys * kDirectRounds * (kShadeBlock / 64)];
@@ -736,9 +736,9 @@ __global__ void __launch_bounds__(kShadeBlock, (ENV || RD || MIX) ? MTS_DIRECT_W
                         const V3 woSide = flipped ? mirrorZ(wo) : wo;
                         const V3 woB = framed ? toLocal(pf, toWorld(its.sh, woSide)) : woSide;
                         const bool sameSide = !framed || woSide.z * woB.z > 0;
-                        const V3 bsdfVal = sameSide ? bsdfEvalAny<RD, MIX>(sc, bsdf, wiB, woB, uv) : mk(0.0f);
+                        const V3 bsdfVal = sameSide ? bsdfEvalAny<RD, BLEND>(sc, bsdf, wiB, woB, uv) : mk(0.0f);
                         if (!isZero(bsdfVal) && (!sc.strictNormals || dot(its.geoN, dRec.d) * wo.z > 0)) {
-                            const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, MIX>(sc, bsdf, wiB, woB, uv);
+                            const float bPdf = ENV && dRec.delta ? 0.0f : bsdfPdfAny<RD, BLEND>(sc, bsdf, wiB, woB, uv);
                             c = value * bsdfVal * (miWeight(dRec.pdf * fracLum, bPdf * fracBSDF) * weightLum);
                         }
                         ++nShadow;
@@ -759,9 +759,9 @@ __global__ void __launch_bounds__(kShadeBlock, (ENV || RD || MIX) ? MTS_DIRECT_W
             float oPdf = 0.0f, oRefCos = -2.0f;
             if (shade) {
                 const float bx = rng.next1D(), by = rng.next1D();
-                const float bu = RD && bsdfDrawsFromSampler<MIX>(bsdf, bx) ? rng.next1D() : 0.0f;
+                const float bu = RD && bsdfDrawsFromSampler<BLEND>(bsdf, bx) ? rng.next1D() : 0.0f;
                 V3 woLocal; float bPdf, bEta; uint32_t sampledType;
-                V3 bsdfVal = bsdfSampleAny<RD, MIX>(sc, bsdf, wiB, bx, by, bu, woLocal, bPdf, bEta, sampledType, uv);
+                V3 bsdfVal = bsdfSampleAny<RD, BLEND>(sc, bsdf, wiB, bx, by, bu, woLocal, bPdf, bEta, sampledType, uv);
                 if (framed && !isZero(bsdfVal)) {
                     const V3 pwo = woLocal;
                     woLocal = toLocal(its.sh, toWorld(pf, pwo));

@@ -516,7 +516,8 @@ int renderPass(mtsamd_scene *s, const PassParams &pp, float *filmDev, float *liO
         HIP_TRY(hipMemsetAsync(counts, 0, 2 * sizeof(unsigned long long), st));
         timer.begin(T_SHADE);
 #define MTS_LAUNCH_DIRECT(...) hipLaunchKernelGGL((k_direct_shade<__VA_ARGS__>), dim3(blocksFor(n, kShadeBlock * kDirectRounds)), dim3(kShadeBlock), 0, st, sc, pp, qin, hits, qout, sq, sampleL, samplePos, counts, n, nE, nB)
-        if (s->host.mixture) { if (s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_DIRECT(true, true, true); else MTS_LAUNCH_DIRECT(false, false, true); }
+        if (s->host.mixture && !s->host.blend) { if (s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_DIRECT(true, true, true, false); else MTS_LAUNCH_DIRECT(false, false, true, false); }
+        else if (s->host.mixture) { if (s->host.extEmitters || s->roughDielectric) MTS_LAUNCH_DIRECT(true, true, true); else MTS_LAUNCH_DIRECT(false, false, true); }
         else if (s->host.extEmitters) { if (s->roughDielectric) MTS_LAUNCH_DIRECT(true, true, false); else MTS_LAUNCH_DIRECT(true, false, false); }
         else { if (s->roughDielectric) MTS_LAUNCH_DIRECT(false, true, false); else MTS_LAUNCH_DIRECT(false, false, false); }
 #undef MTS_LAUNCH_DIRECT
