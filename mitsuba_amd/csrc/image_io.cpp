@@ -10,12 +10,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
 namespace mtsamd {
 
 void setLastError(const std::string &msg);     // mtsamd.hip
+// Largest image the readers accept: what a header claims is checked against this before anything is allocated.
+constexpr int64_t kMaxImageSide = 65536, kMaxImagePixels = 1ll << 28;
 
 namespace {
 
@@ -70,6 +73,7 @@ std::string decodePng(const std::vector<uint8_t> &f, Raw &img) {
         p += 12 + (size_t) len;
     }
     if (width == 0 || height == 0 || colour < 0) return "PNG without a header";
+    if ((int64_t) width > kMaxImageSide || (int64_t) height > kMaxImageSide || (int64_t) width * (int64_t) height > kMaxImagePixels) return "PNG size out of range";
     if (interlace) return "interlaced PNG files are not supported";
     const int samples = colour == 0 ? 1 : colour == 2 ? 3 : colour == 3 ? 1 : colour == 4 ? 2 : colour == 6 ? 4 : 0;
     if (!samples || (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16)) return "unsupported PNG colour type or bit depth";
@@ -421,7 +425,11 @@ std::string decodeExr(const std::vector<uint8_t> &f, Raw &img) {
     if (channels.empty() || x1 < x0 || y1 < y0) return "OpenEXR header without channels or data window";
     if (compression != 0 && compression != 2 && compression != 3 && compression != 4)
         return "OpenEXR compression other than none, ZIPS, ZIP and PIZ is not supported";
-    const int w = x1 - x0 + 1, h = y1 - y0 + 1, linesPerBlock = compression == 3 ? 16 : compression == 4 ? 32 : 1;
+    // a damaged header must not turn into a gigantic allocation
+    const int64_t w64 = (int64_t) x1 - x0 + 1, h64 = (int64_t) y1 - y0 + 1;
+    if (w64 > kMaxImageSide || h64 > kMaxImageSide || w64 * h64 > kMaxImagePixels) return "OpenEXR data window out of range";
+    const int w = (int) w64, h = (int) h64, linesPerBlock = compression == 3 ? 16 : compression == 4 ? 32 : 1;
+    if (p + (size_t) ((h + linesPerBlock - 1) / linesPerBlock) * 8 > f.size()) return "truncated OpenEXR offset table";
     auto find = [&](const char *n) { for (size_t i = 0; i < channels.size(); ++i) if (channels[i].name == n) return (int) i; return -1; };
     int src[3] = { find("R"), find("G"), find("B") };
     img.channels = 3;
@@ -521,7 +529,9 @@ extern "C" int mtsamd_image_load(const char *path, float gamma, mtsamd_image *ou
     out->width = out->height = out->channels = 0; out->pixels = nullptr;
     std::vector<float> px;
     int w, h, c;
-    const std::string err = mtsamd::loadImage(path, gamma, w, h, c, px);
+    std::string err;
+    try { err = mtsamd::loadImage(path, gamma, w, h, c, px); }
+    catch (const std::exception &e) { err = std::string(path ? path : "") + ": " + e.what(); }       // nothing is thrown across the C boundary
     if (!err.empty()) { mtsamd::setLastError(err); return MTSAMD_EINVAL; }
     out->pixels = (float *) malloc(px.size() * sizeof(float));
     if (!out->pixels) { mtsamd::setLastError("mtsamd_image_load: out of memory"); return MTSAMD_EINVAL; }

@@ -445,6 +445,14 @@ def test_image_load_pfm_and_openexr(tmp_path):
     exr(p, [fine[..., 0], fine[..., 1], fine[..., 2]], ["R", "G", "B"], [2, 2, 2], 4)
     assert np.array_equal(capi.image_load(p), fine)
     assert wavelets == [True, None, False, None]      # the short last blocks are smaller as they are
+    # a header that claims a gigantic image is refused before anything is allocated
+    exr(p, [big[..., 1]], ["Y"], [2], 0)
+    data = bytearray(open(p, "rb").read())
+    at = data.index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0") + 4
+    data[at + 8:at + 12] = struct.pack("<i", 1 << 30)
+    open(p, "wb").write(bytes(data))
+    with pytest.raises(capi.MtsamdError, match="out of range"):
+        capi.image_load(p)
     # run-length compression is not read: refused with a message that says so (PIZ, which the reference's own files
     # use, is: tests/test_envmap.py reads one)
     exr(p, [big[..., 1]], ["Y"], [2], 1)
