@@ -1,6 +1,7 @@
 #include "scene_loader.h"
 #include "xml_lite.h"
 
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -35,11 +36,14 @@ std::string joinPath(const std::string &dir, const std::string &file) {
 }
 
 bool readFile(const std::string &path, std::vector<uint8_t> &out) {
+    struct stat info;
+    if (stat(path.c_str(), &info) != 0 || !S_ISREG(info.st_mode)) return false;     // a directory opens, and reports a size of 2^63 - 1
     std::ifstream f(path, std::ios::binary);
     if (!f) return false;
     f.seekg(0, std::ios::end);
     std::streamoff n = f.tellg();
     f.seekg(0);
+    if (n < 0) return false;
     out.resize((size_t) n);
     if (n) f.read((char *) out.data(), n);
     return (bool) f;

@@ -5,6 +5,7 @@
 #include "../../include/mtsamd.h"
 #include "host_scene.h"
 
+#include <sys/stat.h>
 #include <zlib.h>
 #include <cmath>
 #include <cstdio>
@@ -30,6 +31,8 @@ struct Raw {
 };
 
 bool readFile(const char *path, std::vector<uint8_t> &out) {
+    struct stat info;
+    if (!path || stat(path, &info) != 0 || !S_ISREG(info.st_mode)) return false;     // a directory opens, and reports a size of 2^63 - 1
     FILE *f = fopen(path, "rb");
     if (!f) return false;
     fseek(f, 0, SEEK_END);
