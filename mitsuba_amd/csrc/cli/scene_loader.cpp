@@ -953,10 +953,12 @@ std::string loadSerialized(const std::string &path, int shapeIndex, Mesh &out) {
         uint64_t nv, nt;
         memcpy(&nv, &raw[p], 8); memcpy(&nt, &raw[p + 8], 8); p += 16;
         const bool dbl = (flags & 0x2000u) != 0;
+        // the counts come from the file: checked against the stream's length before anything is multiplied or allocated
+        if (nv > raw.size() || nt > raw.size()) throw Fail("truncated mesh stream");
         auto take = [&](size_t n, int comps, std::vector<float> *dst) {
             const size_t count = n * comps, bytes = count * (dbl ? 8 : 4);
             need(bytes);
-            if (dst) {
+            if (dst && count) {
                 dst->resize(count);
                 if (dbl) for (size_t i = 0; i < count; ++i) { double v; memcpy(&v, &raw[p + 8 * i], 8); (*dst)[i] = (float) v; }
                 else memcpy(dst->data(), &raw[p], bytes);
@@ -970,7 +972,7 @@ std::string loadSerialized(const std::string &path, int shapeIndex, Mesh &out) {
         out.faceNormals = (flags & 0x10u) != 0;
         need(nt * 12);
         out.indices.resize(nt * 3);
-        memcpy(out.indices.data(), &raw[p], nt * 12);
+        if (nt) memcpy(out.indices.data(), &raw[p], nt * 12);
     } catch (const Fail &f) {
         return f.what();
     }
@@ -1841,6 +1843,12 @@ std::string loadSceneXml(const std::string &path, const LoadOptions &opts, Loade
                 }
                 for (auto &entry : meshes) {
                     Mesh &mesh = entry.first;
+                    // whatever the file says: no triangle may name a vertex the mesh does not have
+                    const size_t meshVertices = mesh.positions.size() / 3;
+                    for (uint32_t index : mesh.indices)
+                        if (index >= meshVertices) return "shape '" + type + "': a triangle refers to vertex " + std::to_string(index) + " of " + std::to_string(meshVertices);
+                    if ((!mesh.normals.empty() && mesh.normals.size() != mesh.positions.size()) || (!mesh.texcoords.empty() && mesh.texcoords.size() / 2 != meshVertices))
+                        return "shape '" + type + "': normals or texture coordinates do not match the vertex count";
                     const bool faceNormals = getB(p, "faceNormals", false) || mesh.faceNormals;
                     const bool flipNormals = getB(p, "flipNormals", false);
                     if (faceNormals) mesh.normals.clear();

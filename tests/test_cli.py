@@ -1027,3 +1027,30 @@ def test_cli_rectangle_shape(scene_dir, tmp_path):
     g.write_text(SCENE % '<shape type="sphere"/>')
     out = subprocess.run([CLI, str(g), "--describe"], capture_output=True, text=True, timeout=60)
     assert out.returncode != 0 and "shape type 'sphere' is not supported" in out.stderr
+
+
+def test_cli_damaged_mesh_files_are_refused(scene_dir, tmp_path):
+    """What a mesh file claims is checked before it is used: a triangle that names a vertex the mesh does not have, vertex
+    or triangle counts beyond the stream's length, and a file name that is a directory are errors, not reads out of bounds
+    or gigantic allocations."""
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    shape = '<shape type="serialized"><string name="filename" value="%s"/><ref id="grey"/></shape>'
+    p, idx = _quad(0.0, 1.0)
+    bad = idx.copy()
+    bad[1, 2] = 7                                               # four vertices
+    _serialize(str(tmp_path / "index.serialized"), [(p, None, bad)])
+    f = tmp_path / "damaged.xml"
+    f.write_text(SCENE % (shape % "index.serialized"))
+    out = subprocess.run([CLI, str(f), "--describe"], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "refers to vertex 7 of 4" in out.stderr, out.stderr
+    for nv, nt in ((1 << 62, 2), (4, (1 << 64) // 12 + 1), ((1 << 64) - 1, (1 << 64) - 1)):
+        body = struct.pack("<I", 0x1000) + b"mesh0\0" + struct.pack("<QQ", nv, nt) + p.tobytes() + idx.tobytes()
+        blob = struct.pack("<HH", 0x041C, 4) + zlib.compress(body) + struct.pack("<Q", 0) + struct.pack("<I", 1)
+        (tmp_path / "count.serialized").write_bytes(blob)
+        f.write_text(SCENE % (shape % "count.serialized"))
+        out = subprocess.run([CLI, str(f), "--describe"], capture_output=True, text=True, timeout=60)
+        assert out.returncode != 0 and "truncated mesh stream" in out.stderr, out.stderr
+    (tmp_path / "a_directory").mkdir()
+    f.write_text(SCENE % (shape % "a_directory"))
+    out = subprocess.run([CLI, str(f), "--describe"], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "cannot read" in out.stderr, out.stderr
