@@ -1466,6 +1466,9 @@ std::string loadPly(const std::string &path, Mesh &out) {
         }
         if (format < 0) return "PLY: header has no format line";
         PlyReader rd{ data, pos, format };
+        // every record of an element with properties takes at least one byte of the file: a count beyond that is damage
+        for (const PlyElement &e : elements)
+            if (!e.props.empty() && e.count > data.size()) return "PLY: element '" + e.name + "' claims more records than the file has bytes";
         out = Mesh();
         size_t slash = path.find_last_of('/');
         out.name = path.substr(slash == std::string::npos ? 0 : slash + 1);
