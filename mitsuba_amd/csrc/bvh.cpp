@@ -20,7 +20,7 @@ struct Prim { Box box; float c[3]; uint32_t tri; };
 
 float kCostNode = 1.0f, kCostTri = 0.5f;   // relative cost of visiting a wide node / testing a triangle
 const int kBins = 16;
-const uint32_t kMaxLeaf = 3;
+const uint32_t kMaxLeaf = kLeafTris;
 
 struct Builder2 {
     std::vector<Prim> prims;
@@ -348,7 +348,7 @@ const char *collapseToWide(const BinaryTree &tree, const float *positions, const
         }
         node.childBase = (uint32_t) out.nodes.size();
         node.triBase = (uint32_t) out.tris.size();
-        uint32_t nInternal = 0, triOfs = 0;
+        uint32_t nInternal = 0, leafTris = 0;
         for (int s = 0; s < 8; ++s) {
             int i = childAt[s];
             if (i < 0) continue;
@@ -368,7 +368,7 @@ const char *collapseToWide(const BinaryTree &tree, const float *positions, const
             }
             if (dp[kids[i]].leaf) {
                 uint32_t unary = (1u << c.count) - 1u;     // 1 -> 001, 2 -> 011, 3 -> 111
-                node.meta[s] = (uint8_t) ((unary << 5) | triOfs);
+                leafTris |= unary << (kLeafTris * s);
                 for (uint32_t j = 0; j < c.count; ++j) {
                     uint32_t tri = tree.primTri[c.first + j];
                     TriRecord tr;
@@ -377,14 +377,13 @@ const char *collapseToWide(const BinaryTree &tree, const float *positions, const
                     tr.tri = tri;
                     out.tris.push_back(tr);
                 }
-                triOfs += c.count;
                 sah += (double) (cb[i].area() / rootArea) * kCostTri * c.count;
             } else {
                 node.imask |= (uint8_t) (1u << s);
-                node.meta[s] = (uint8_t) (0x20 | (24 + s));
                 nInternal++;
             }
         }
+        node.leafTris = leafTris;
         out.nodes[w.wide] = node;
         // internal children are laid out contiguously in slot order
         for (int s = 0; s < 8; ++s) {

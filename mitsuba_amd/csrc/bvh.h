@@ -23,16 +23,25 @@ static_assert(kShadeTriStride >= 6, "a shading record is six float4");
 //   lo = p + qlo * 2^e,  hi = p + qhi * 2^e   (rounded outwards, so decoded boxes contain the true ones)
 // Children occupy 8 slots; slot s is visited first by rays whose direction-sign octant equals s, the other
 // slots follow in the order of (slot XOR octant) -- an approximate front-to-back order that needs no sort.
-//   meta[s] == 0            empty slot
-//   meta[s] & 0x20, low 5 bits >= 24   internal child; node index = childBase + popcount(imask & ((1<<s)-1))
-//   otherwise               leaf child: triangles [triBase + (meta & 31), +popcount(meta >> 5)) (1..3 triangles)
+//   imask bit s             internal child; node index = childBase + popcount(imask & ((1<<s)-1))
+//   leafTris bits Ls..Ls+L-1  (L = kLeafTris) leaf child with 1 .. L triangles (001, 011, 111 ...). The records of a node's leaves
+//                           lie one after the other in slot order: the record of bit b is triBase + popcount(leafTris & ((1<<b)-1))
+//   neither                 empty slot: whatever its box test says selects nothing
+// Most triangles of a leaf child: 3 (24 bits of leafTris) or 4 (all 32)
+#ifndef MTS_LEAF_TRIS
+#define MTS_LEAF_TRIS 4
+#endif
+constexpr int kLeafTris = MTS_LEAF_TRIS;
+static_assert(kLeafTris == 3 || kLeafTris == 4, "a node's triangle mask has 8 fields of 3 or 4 bits");
+
 struct alignas(16) WideNode {
     float p[3];
     uint8_t e[3];
     uint8_t imask;
     uint32_t childBase;
     uint32_t triBase;
-    uint8_t meta[8];
+    uint32_t leafTris;
+    uint32_t reserved;
     uint8_t qlo[3][8];
     uint8_t qhi[3][8];
 };

@@ -107,7 +107,7 @@ struct DNode { uint32_t left, right; float lo[3], hi[3]; uint32_t count, pad; };
 // in the best split into j roots, take bit j = splitting into j beats j-1, leaf = the node becomes a leaf of the wide tree.
 struct DDp { float c[8]; uint8_t k[9]; uint8_t take; uint8_t leaf; uint8_t pad; };
 
-constexpr uint32_t kMaxLeafTris = 3;
+constexpr uint32_t kMaxLeafTris = kLeafTris;
 
 MTS_HD inline float boxArea(const float *lo, const float *hi) {
     const float d0 = hi[0] - lo[0], d1 = hi[1] - lo[1], d2 = hi[2] - lo[2];
@@ -455,7 +455,7 @@ __global__ void __launch_bounds__(64) k_emit_level(EmitArgs a) {
     const uint32_t triBase = nLeafTris ? atomicAdd(&a.counters[1], nLeafTris) : 0u;
     if (childBase + nInternal > a.nodeCapacity) { atomicOr(&a.counters[2], 1u); return; }
     node.childBase = childBase; node.triBase = triBase;
-    uint32_t rank = 0, triOfs = 0;
+    uint32_t rank = 0, triOfs = 0, leafTris = 0;
     for (int s = 0; s < 8; ++s) {
         const int i = childAt[s];
         if (i < 0) continue;
@@ -475,9 +475,9 @@ __global__ void __launch_bounds__(64) k_emit_level(EmitArgs a) {
         }
         if (a.dp[kids[i]].leaf) {
             const uint32_t unary = (1u << c.count) - 1u;     // 1 -> 001, 2 -> 011, 3 -> 111
-            node.meta[s] = (uint8_t) ((unary << 5) | triOfs);
-            // the (at most three) triangles of the leaf: walk its little subtree, left to right
-            uint32_t st[4]; int sp = 0; uint32_t j = 0;
+            leafTris |= unary << (kLeafTris * s);
+            // the (at most kLeafTris) triangles of the leaf: walk its little subtree, left to right
+            uint32_t st[8]; int sp = 0; uint32_t j = 0;
             st[sp++] = kids[i];
             while (sp > 0) {
                 const DNode &ln = a.nodes[st[--sp]];
@@ -497,11 +497,11 @@ __global__ void __launch_bounds__(64) k_emit_level(EmitArgs a) {
             triOfs += c.count;
         } else {
             node.imask |= (uint8_t) (1u << s);
-            node.meta[s] = (uint8_t) (0x20 | (24 + s));
             a.wideBin[childBase + rank] = kids[i];      // internal children are laid out contiguously in slot order
             ++rank;
         }
     }
+    node.leafTris = leafTris;
     float4 *dst = a.outNodes + (size_t) a.nodeStride * w;
     const float4 *src = reinterpret_cast<const float4 *>(&node);
     for (int k = 0; k < 5; ++k) dst[k] = src[k];

@@ -92,10 +92,14 @@ MTS_DEV float4 toFloat4(RawFloat4 v) { return make_float4(v.x, v.y, v.z, v.w); }
 // pieces are separate variables on purpose: kept in one struct, the dynamically indexed spill array drags the stack
 // pointer and the LDS base into scratch memory with it.
 // Index of this lane's column in the LDS stack, recomputed where it is used (two VALU instructions) instead of being
-// carried in a register across the traversal loop.
-MTS_DEV uint32_t stackLane() {
-    return (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x & ~63u)) + __lane_id();
+// carried in a register across the traversal loop. `waveFirst` (wave-uniform, a scalar register) is the workgroup
+// thread index of the wave's lane 0.
+MTS_DEV uint32_t stackLane(uint32_t waveFirst) {
+    uint32_t lane;      // volatile: computed where it is used, never hoisted out of the loop into a register of its own
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    return waveFirst + lane;
 }
+MTS_DEV uint32_t waveFirstThread() { return (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x & ~63u)); }
 
 // STACK selects the layout: STACK == 0 keeps kLdsStack entries in LDS and kSpillStack more in scratch (any tree the
 // builders return); STACK = N > 0 keeps N entries in LDS and none in scratch, for trees of depth <= N + 2 -- without the
@@ -107,18 +111,18 @@ template <int STACK> struct StackLayout {
 };
 
 template <int STACK>
-MTS_DEV void stackPush(LdsUint2 *ldsStack, uint32_t stackStride, uint2 (&spill)[StackLayout<STACK>::kSpill], int &sp, uint2 e) {
+MTS_DEV void stackPush(LdsUint2 *ldsStack, uint32_t stackStride, uint32_t waveFirst, uint2 (&spill)[StackLayout<STACK>::kSpill], int &sp, uint2 e) {
     typedef StackLayout<STACK> L;
-    if (!L::kSpills || sp < L::kLds) { ldsStack[sp * stackStride + stackLane()].x = e.x; ldsStack[sp * stackStride + stackLane()].y = e.y; }
+    if (!L::kSpills || sp < L::kLds) { LdsUint2 *slot = ldsStack + (__umul24((uint32_t) sp, stackStride) + stackLane(waveFirst)); slot->x = e.x; slot->y = e.y; }
     else if (sp - L::kLds < L::kSpill) spill[sp - L::kLds] = e;
     ++sp;
 }
 
 template <int STACK>
-MTS_DEV uint2 stackPop(LdsUint2 *ldsStack, uint32_t stackStride, uint2 (&spill)[StackLayout<STACK>::kSpill], int &sp) {
+MTS_DEV uint2 stackPop(LdsUint2 *ldsStack, uint32_t stackStride, uint32_t waveFirst, uint2 (&spill)[StackLayout<STACK>::kSpill], int &sp) {
     typedef StackLayout<STACK> L;
     --sp;
-    if (!L::kSpills || sp < L::kLds) return make_uint2(ldsStack[sp * stackStride + stackLane()].x, ldsStack[sp * stackStride + stackLane()].y);
+    if (!L::kSpills || sp < L::kLds) { const LdsUint2 *slot = ldsStack + (__umul24((uint32_t) sp, stackStride) + stackLane(waveFirst)); return make_uint2(slot->x, slot->y); }
     return spill[sp - L::kLds < L::kSpill ? sp - L::kLds : L::kSpill - 1];
 }
 
@@ -129,9 +133,9 @@ struct LaneRay {
     float mint, maxt;           // maxt shrinks to the closest hit found so far
     uint32_t oct;               // sign octant of the direction
     HitRec hit;
-    bool found;
     uint2 ng;                   // node group: x = index of the first internal child, y = imask | pending (priority order) << 8
-    uint2 tg;                   // triangle group: x = first triangle record of the node, y = mask of records still to test
+    uint2 tg;                   // triangle group: x = first triangle record of the node, y = mask of triangles still to test (3 bits per slot)
+    uint32_t tv;                // triangle group: which of those 3 x 8 bits stand for a record (the node's `leafTris`)
 };
 
 MTS_DEV void laneStart(LaneRay &r, V3 o, V3 d, float mint, float maxt) {
@@ -144,20 +148,61 @@ MTS_DEV void laneStart(LaneRay &r, V3 o, V3 d, float mint, float maxt) {
     r.idz = fabsf(d.z) > 1e-30f ? __builtin_amdgcn_rcpf(d.z) : copysignf(big, d.z);
     r.oct = (r.idx < 0 ? 1u : 0u) | (r.idy < 0 ? 2u : 0u) | (r.idz < 0 ? 4u : 0u);
     r.hit.t = kInf; r.hit.u = 0; r.hit.v = 0; r.hit.tri = 0xFFFFFFFFu;
-    r.found = false;
     // Priority bit k of a node group stands for slot k ^ oct; the root is a pseudo group whose only member sits in slot 0.
     r.ng = make_uint2(0u, 1u | ((1u << r.oct) << 8));
     r.tg = make_uint2(0u, 0u);
+    r.tv = 0u;
 }
 
 #define MTS_UBYTE(w, i) ((float) (((w) >> (8 * (i))) & 0xffu))
 
-// Visits the next pending internal child of the lane's node group: box tests of its 8 children, branch free.
-// Children that are hit contribute `meta >> 5` shifted to bit `meta & 31` of a 32-bit mask: leaf children put one bit
-// per triangle record into bits 0..23, internal children one bit into 24 + (slot ^ oct), i.e. already in the
-// visiting order of this ray. Empty slots have meta == 0 and contribute nothing.
+typedef float __attribute__((ext_vector_type(2))) Float2;
+
+// Bit s of an 8-bit mask moves to bit s ^ oct: three conditional exchanges whose shift distances are 0 or 4, 2, 1.
+MTS_DEV uint32_t xorPermute8(uint32_t x, uint32_t oct) {
+    const uint32_t s4 = oct & 4u, s2 = oct & 2u, s1 = oct & 1u;
+    x = ((x << s4) & 0xf0u) | ((x >> s4) & 0x0fu);
+    x = ((x << s2) & 0xccu) | ((x >> s2) & 0x33u);
+    x = ((x << s1) & 0xaau) | ((x >> s1) & 0x55u);
+    return x;
+}
+
+// Bit s of an 8-bit mask to the kLeafTris bits from bit kLeafTris * s on
+MTS_DEV uint32_t tripleBits8(uint32_t x) {
+    if (kLeafTris == 3) {
+        x = (x | (x << 8)) & 0x00f00fu;
+        x = (x | (x << 4)) & 0x0c30c3u;
+        x = (x | (x << 2)) & 0x249249u;
+        return x * 7u;
+    }
+    x = (x | (x << 12)) & 0x000f000fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return x * 15u;
+}
+
+typedef __attribute__((address_space(3))) uint32_t LdsUint;
+
+// The record of bit b of the lane's triangle group: the node's records lie one after the other in the order of their bits
+MTS_DEV const float4 *triRecord(const DevScene &sc, const LaneRay &r, uint32_t b) {
+    return sc.tris + sc.triStride * (size_t) (r.tg.x + __popc(r.tv & ((1u << b) - 1u)));
+}
+
+// mask = 2 * mask + (a <= b): the comparison's lane mask goes straight into the carry input of an add
+#ifndef MTS_VISIT_ADDC
+#define MTS_VISIT_ADDC 1
+#endif
+MTS_DEV void shiftInLessEqual(uint32_t &mask, float a, float b) {
+    if (!MTS_VISIT_ADDC) { mask = (mask << 1) | (a <= b ? 1u : 0u); return; }
+    asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(a), "v"(b) : "vcc");
+}
+
+// Visits the next pending internal child of the lane's node group: box tests of its 8 children, branch free, two
+// children per packed multiply-add. The tests leave one bit per slot; the slots that hold internal children go into the
+// node group in this ray's visiting order (slot ^ oct), the others select their (up to three) bits of the node's
+// triangle mask. Empty slots have degenerate planes that no ray passes and no triangle bits.
 template <int STACK>
-MTS_DEV uint32_t visitNode(const DevScene &sc, LaneRay &r, LdsUint2 *ldsStack, uint32_t stackStride, uint2 (&spill)[StackLayout<STACK>::kSpill], int &sp) {
+MTS_DEV uint32_t visitNode(const DevScene &sc, LaneRay &r, LdsUint2 *ldsStack, uint32_t stackStride, uint32_t waveFirst, uint2 (&spill)[StackLayout<STACK>::kSpill], int &sp) {
     const uint32_t pending = (r.ng.y >> 8) & 0xffu;
     const uint32_t kbit = __ffs((int) pending) - 1;
     r.ng.y &= ~(0x100u << kbit);
@@ -187,56 +232,90 @@ MTS_DEV uint32_t visitNode(const DevScene &sc, LaneRay &r, LdsUint2 *ldsStack, u
     const uint32_t nearx[2] = { nx ? hix0 : lox0, nx ? hix1 : lox1 }, farx[2] = { nx ? lox0 : hix0, nx ? lox1 : hix1 };
     const uint32_t neary[2] = { ny ? hiy0 : loy0, ny ? hiy1 : loy1 }, fary[2] = { ny ? loy0 : hiy0, ny ? loy1 : hiy1 };
     const uint32_t nearz[2] = { nz ? hiz0 : loz0, nz ? hiz1 : loz1 }, farz[2] = { nz ? loz0 : hiz0, nz ? loz1 : hiz1 };
-    const uint32_t metaw[2] = { __float_as_uint(n1.z), __float_as_uint(n1.w) };
 
-    // (packing the near and far plane of an axis into one v_pk_fma_f32 was measured: 3 % slower)
-    uint32_t hitmask = 0;
+    const Float2 asx2 = { asx, asx }, apx2 = { apx, apx }, fsx2 = { fsx, fsx }, fpx2 = { fpx, fpx };
+    const Float2 asy2 = { asy, asy }, apy2 = { apy, apy }, fsy2 = { fsy, fsy }, fpy2 = { fpy, fpy };
+    const Float2 asz2 = { asz, asz }, apz2 = { apz, apz }, fsz2 = { fsz, fsz }, fpz2 = { fpz, fpz };
+    uint32_t hitSlots = 0;      // bit s: the box in slot s is entered within [mint, maxt]
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const uint32_t meta4 = metaw[h];
-        const uint32_t inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;      // internal children have bits 3 and 4 of the index set
-        const uint32_t index4 = (meta4 ^ ((inner4 >> 4) * r.oct)) & 0x1f1f1f1fu;
-        const uint32_t bits4 = (meta4 >> 5) & 0x07070707u;
+    for (int h = 1; h >= 0; --h) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float tx0 = __builtin_fmaf(MTS_UBYTE(nearx[h], i), asx, apx), tx1 = __builtin_fmaf(MTS_UBYTE(farx[h], i), fsx, fpx);
-            const float ty0 = __builtin_fmaf(MTS_UBYTE(neary[h], i), asy, apy), ty1 = __builtin_fmaf(MTS_UBYTE(fary[h], i), fsy, fpy);
-            const float tz0 = __builtin_fmaf(MTS_UBYTE(nearz[h], i), asz, apz), tz1 = __builtin_fmaf(MTS_UBYTE(farz[h], i), fsz, fpz);
-            const float tn = fmaxf(fmaxf(tx0, ty0), fmaxf(tz0, r.mint));
-            const float tf = fminf(fminf(tx1, ty1), fminf(tz1, maxtPad));
-            const uint32_t bits = ((bits4 >> (8 * i)) & 0xffu) << ((index4 >> (8 * i)) & 0xffu);
-            hitmask |= tn <= tf ? bits : 0u;
+        for (int p = 1; p >= 0; --p) {
+            const Float2 qx0 = { MTS_UBYTE(nearx[h], 2 * p), MTS_UBYTE(nearx[h], 2 * p + 1) }, qx1 = { MTS_UBYTE(farx[h], 2 * p), MTS_UBYTE(farx[h], 2 * p + 1) };
+            const Float2 qy0 = { MTS_UBYTE(neary[h], 2 * p), MTS_UBYTE(neary[h], 2 * p + 1) }, qy1 = { MTS_UBYTE(fary[h], 2 * p), MTS_UBYTE(fary[h], 2 * p + 1) };
+            const Float2 qz0 = { MTS_UBYTE(nearz[h], 2 * p), MTS_UBYTE(nearz[h], 2 * p + 1) }, qz1 = { MTS_UBYTE(farz[h], 2 * p), MTS_UBYTE(farz[h], 2 * p + 1) };
+            const Float2 tx0 = __builtin_elementwise_fma(qx0, asx2, apx2), tx1 = __builtin_elementwise_fma(qx1, fsx2, fpx2);
+            const Float2 ty0 = __builtin_elementwise_fma(qy0, asy2, apy2), ty1 = __builtin_elementwise_fma(qy1, fsy2, fpy2);
+            const Float2 tz0 = __builtin_elementwise_fma(qz0, asz2, apz2), tz1 = __builtin_elementwise_fma(qz1, fsz2, fpz2);
+            const float tnB = fmaxf(fmaxf(tx0.y, ty0.y), fmaxf(tz0.y, r.mint)), tfB = fminf(fminf(tx1.y, ty1.y), fminf(tz1.y, maxtPad));
+            const float tnA = fmaxf(fmaxf(tx0.x, ty0.x), fmaxf(tz0.x, r.mint)), tfA = fminf(fminf(tx1.x, ty1.x), fminf(tz1.x, maxtPad));
+            shiftInLessEqual(hitSlots, tnB, tfB);
+            shiftInLessEqual(hitSlots, tnA, tfA);
         }
     }
 
-    const uint32_t triMask = hitmask & 0xffffffu, childPending = hitmask >> 24;
+    const uint32_t leafTris = __float_as_uint(n1.z);        // bit 3s + j: slot s is a leaf with more than j triangles
+    const uint32_t triMask = tripleBits8(hitSlots) & leafTris;
+    const uint32_t childPending = xorPermute8(hitSlots & imask, r.oct);
     r.tg = make_uint2(__float_as_uint(n1.y), triMask);     // the lane's triangle group is empty whenever it visits a node
+    r.tv = leafTris;
     if (childPending) {
         // descend; siblings still pending in the current group wait on the stack
-        if ((r.ng.y >> 8) & 0xffu) stackPush<STACK>(ldsStack, stackStride, spill, sp, r.ng);
+        if ((r.ng.y >> 8) & 0xffu) stackPush<STACK>(ldsStack, stackStride, waveFirst, spill, sp, r.ng);
         r.ng = make_uint2(__float_as_uint(n1.x), imask | (childPending << 8));
     }
-    return hitmask;
+    return triMask | (childPending << 24);
 }
 
-// Tests the next triangle record of the lane's triangle group. Equal-t ties are resolved towards the lowest global
-// triangle index, so the result does not depend on traversal order (the reference keeps the last equal-t triangle
-// in kd-leaf order, sahkdtree3.h:286-291, which depends on its tree). Returns true when a hit was accepted.
-MTS_DEV bool testNextTriangle(const DevScene &sc, LaneRay &r) {
-    const uint32_t b = __ffs((int) r.tg.y) - 1;
-    r.tg.y &= r.tg.y - 1;
-    const float4 *tp = sc.tris + sc.triStride * (size_t) (r.tg.x + b);
-    const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
+// One triangle record against the lane's ray. Equal-t ties are resolved towards the lowest global triangle index, so
+// the result does not depend on traversal order (the reference keeps the last equal-t triangle in kd-leaf order,
+// sahkdtree3.h:286-291, which depends on its tree). Returns true when the hit was accepted.
+MTS_DEV bool testRecord(LaneRay &r, const float4 r0, const float4 r1, const float4 r2, bool enabled) {
     float t, u, v;
     // global triangle index in bits 0..27, BSDF type of its material in bits 28..30 (carried along for the shading kernel)
     const uint32_t tri = __float_as_uint(r2.z) | __float_as_uint(r2.w);
     const bool inside = triTest(r0, r1, r2, r.o, r.d, r.mint, r.maxt, t, u, v);
-    const bool accept = inside & !(r.found & (t == r.hit.t) & ((tri & kTriIndexMask) >= (r.hit.tri & kTriIndexMask)));
+    // (without a hit so far hit.t is infinite and hit.tri all ones: the tie rule cannot fire)
+    const bool accept = enabled & inside & !((t == r.hit.t) & ((tri & kTriIndexMask) >= (r.hit.tri & kTriIndexMask)));
     r.hit.t = accept ? t : r.hit.t; r.hit.u = accept ? u : r.hit.u; r.hit.v = accept ? v : r.hit.v;
     r.hit.tri = accept ? tri : r.hit.tri;
     r.maxt = accept ? t : r.maxt;
-    r.found |= accept;
     return accept;
+}
+
+// (non-temporal loads of the records were measured: the closest-hit kernel half as slow again -- it lives on the caches)
+MTS_DEV void loadTriangle(const float4 *tp, float4 &r0, float4 &r1, float4 &r2) {
+    r0 = tp[0]; r1 = tp[1]; r2 = tp[2];
+}
+
+// Tests the next triangle record of the lane's triangle group. Returns true when a hit was accepted.
+MTS_DEV bool testNextTriangle(const DevScene &sc, LaneRay &r) {
+    const uint32_t b = __ffs((int) r.tg.y) - 1;
+    r.tg.y &= r.tg.y - 1;
+    float4 r0, r1, r2;
+    loadTriangle(triRecord(sc, r, b), r0, r1, r2);
+    return testRecord(r, r0, r1, r2, true);
+}
+
+// Tests the next TWO records of the lane's triangle group (the second only if there is one) behind one wait for memory:
+// both records are requested before the first is tested. An any-hit query stops after the first accepted hit.
+#ifndef MTS_TRI_PAIRS
+#define MTS_TRI_PAIRS 1
+#endif
+template <bool ANY_HIT>
+MTS_DEV bool testNextTriangles(const DevScene &sc, LaneRay &r) {
+    if (!MTS_TRI_PAIRS) return testNextTriangle(sc, r);
+    const uint32_t b0 = __ffs((int) r.tg.y) - 1;
+    r.tg.y &= r.tg.y - 1;
+    const bool two = r.tg.y != 0;
+    const uint32_t b1 = two ? __ffs((int) r.tg.y) - 1 : b0;
+    r.tg.y &= r.tg.y - 1;       // (zero stays zero)
+    float4 p0, p1, p2, q0, q1, q2;
+    loadTriangle(triRecord(sc, r, b0), p0, p1, p2);
+    loadTriangle(triRecord(sc, r, b1), q0, q1, q2);
+    const bool first = testRecord(r, p0, p1, p2, true);
+    const bool second = testRecord(r, q0, q1, q2, two & !(ANY_HIT & first));
+    return first | second;
 }
 
 // What a traversal kernel does with a finished ray
@@ -269,8 +348,6 @@ MTS_DEV void laneFinish(const TraceArgs &a, uint32_t ray, const LaneRay &r, bool
     }
 }
 
-typedef __attribute__((address_space(3))) uint32_t LdsUint;
-
 // The traversal loop shared by the closest-hit and the any-hit kernels. Every wavefront runs until the ray counter
 // is exhausted and its own lanes have drained, so the grid may be any size >= 1.
 // Rays reach the lanes in two steps. A producer step, run by all 64 lanes together, takes the next 64 rays of the
@@ -284,11 +361,11 @@ MTS_DEV void traceLoop(const DevScene &sc, const TraceArgs &a, LdsUint2 *ldsStac
     const uint32_t lane = __lane_id();
     const unsigned long long laneBelow = (1ull << lane) - 1ull;
     // this wave's part of the ray buffer: 64 x (origin+mint, direction+maxt) and 64 ray indices
-    const uint32_t waveFirst = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x & ~63u));
+    const uint32_t waveFirst = waveFirstThread();
     LdsFloat4 *bufRay = rayBuf + 2 * waveFirst;
     LdsUint *bufIdx = rayBufIdx + waveFirst;
     LaneRay r;
-    r.tg = make_uint2(0u, 0u); r.ng = make_uint2(0u, 0u);
+    r.tg = make_uint2(0u, 0u); r.ng = make_uint2(0u, 0u); r.tv = 0u;
     uint2 spill[StackLayout<STACK>::kSpill];
     int sp = 0;
     int ray = -1;               // index of the ray this lane holds, -1 = idle
@@ -379,8 +456,8 @@ MTS_DEV void traceLoop(const DevScene &sc, const TraceArgs &a, LdsUint2 *ldsStac
             if (nTri == nBusy || nTri * 64u >= a.triShare * nBusy) {
                 // triangle phase: one record for every lane that has some
                 if (hasTri) {
-                    if (COUNT) nt++;
-                    const bool accepted = testNextTriangle(sc, r);
+                    if (COUNT) nt += (MTS_TRI_PAIRS && (r.tg.y & (r.tg.y - 1u))) ? 2u : 1u;        // records fetched
+                    const bool accepted = testNextTriangles<ANY_HIT>(sc, r);
                     if (ANY_HIT && accepted) { laneFinish<MODE>(a, (uint32_t) ray, r, true); ray = -1; r.tg.y = 0; }
                 }
             } else if (busy && !hasTri) {
@@ -388,12 +465,12 @@ MTS_DEV void traceLoop(const DevScene &sc, const TraceArgs &a, LdsUint2 *ldsStac
                 bool go = true;
                 if (!((r.ng.y >> 8) & 0xffu)) {
                     if (sp == 0) { laneFinish<MODE>(a, (uint32_t) ray, r, false); ray = -1; go = false; }
-                    else r.ng = stackPop<STACK>(ldsStack, stackStride, spill, sp);
+                    else r.ng = stackPop<STACK>(ldsStack, stackStride, waveFirst, spill, sp);
                 }
                 if (go) {
                     if (COUNT) nv++;
-                    const uint32_t hm = visitNode<STACK>(sc, r, ldsStack, stackStride, spill, sp);
-                    if (COUNT && hm == 0) { ne++; if (r.found) ns++; }
+                    const uint32_t hm = visitNode<STACK>(sc, r, ldsStack, stackStride, waveFirst, spill, sp);
+                    if (COUNT && hm == 0) { ne++; if (r.hit.tri != 0xFFFFFFFFu) ns++; }
                 }
             }
         }
@@ -414,6 +491,7 @@ MTS_DEV void traceHeldRays(const DevScene &sc, LaneRay &r, bool &busy, LdsUint2 
     uint2 spill[StackLayout<0>::kSpill];
     int sp = 0;
     bool occluded = false;
+    const uint32_t waveFirst = waveFirstThread();
     while (true) {
         const bool hasTri = busy && r.tg.y != 0;
         const uint32_t nTri = (uint32_t) __popcll(__ballot(hasTri));
@@ -421,16 +499,16 @@ MTS_DEV void traceHeldRays(const DevScene &sc, LaneRay &r, bool &busy, LdsUint2 
         if (nBusy == 0) break;
         if (nTri == nBusy || nTri * 64u >= triShare * nBusy) {
             if (hasTri) {
-                const bool accepted = testNextTriangle(sc, r);
+                const bool accepted = testNextTriangles<ANY_HIT>(sc, r);
                 if (ANY_HIT && accepted) { occluded = true; busy = false; r.tg.y = 0; }
             }
         } else if (busy && !hasTri) {
             bool go = true;
             if (!((r.ng.y >> 8) & 0xffu)) {
                 if (sp == 0) { busy = false; go = false; }
-                else r.ng = stackPop<0>(ldsStack, stackStride, spill, sp);
+                else r.ng = stackPop<0>(ldsStack, stackStride, waveFirst, spill, sp);
             }
-            if (go) visitNode<0>(sc, r, ldsStack, stackStride, spill, sp);
+            if (go) visitNode<0>(sc, r, ldsStack, stackStride, waveFirst, spill, sp);
         }
     }
     if (ANY_HIT) busy = occluded;

@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(kTailBlock) k_tail(DevScene sc, PassParams pp,
     while (__ballot(active)) {
         // extend (Scene::rayIntersect(ray, its))
         LaneRay r;
-        r.tg = make_uint2(0u, 0u); r.ng = make_uint2(0u, 0u);
+        r.tg = make_uint2(0u, 0u); r.ng = make_uint2(0u, 0u); r.tv = 0u;
         r.hit.t = kInf; r.hit.u = 0; r.hit.v = 0; r.hit.tri = 0xFFFFFFFFu;
         bool busy = false;
         if (active) {

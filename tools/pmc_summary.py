@@ -13,6 +13,11 @@ from collections import defaultdict
 
 
 def short(name):
+    flat = name.replace(" ", "").replace("(mtsamd::TraceMode)", "")
+    if "k_trace<0" in flat:
+        return "k_trace<closest-hit>"
+    if "k_trace<1" in flat:
+        return "k_trace<any-hit>"
     for ch in "(<":
         i = name.find(ch)
         if i > 0:
