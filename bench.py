@@ -8,12 +8,15 @@ One GPU: the synthetic ~1M-triangle microfacet scene (roughconductor GGX + rough
 diffuse ground, four quad area lights) at 1920x1080, `path` integrator with default parameters; a step is one
 wavefront pass of `--spp-step` (256) samples per pixel over the whole frame.
 
-N > 1 GPUs: the same scene at 3840x2160; a step is `--spp-step` samples per pixel of the WHOLE frame, dealt out as an
-image-tile partition: full-width tiles of `--band-rows` (16) rows, rank r owning tiles r, r + N, r + 2N, ... (the scene
-is replicated, every rank traces its whole share in one wavefront pass). The total work per step is fixed, so the
-scaling is strong; with the default 4 steps the job is the 1 024 samples per pixel the configuration names. After the K
-timed steps the per-rank films are summed with one reduction over RCCL inside the timed region -- Film::put(block) of
-the reference. Every rank reports the time it was busy, so that the balance of the partition is visible.
+N > 1 GPUs: the same scene at 3840x2160, dealt out as an image-tile partition: full-width tiles of `--band-rows` (16)
+rows, rank r owning tiles r, r + N, r + 2N, ... (the scene is replicated). Every rank traces wavefront passes of the
+SAME size whatever N is -- 530 841 600 paths, the 1920x1080 x 256 samples of the one-GPU run: 64 N samples per pixel
+of its 1/N share of the 4K frame -- because the traversal kernels' rate depends on the pass size; a step is
+max(256, 64 N) samples per pixel of the whole frame (one or two such passes per rank). Per-GPU work per pass is fixed
+as N grows (weak scaling); with the default 4 steps the job covers the 1 024 samples per pixel the configuration
+names. After the K timed steps the per-rank films are summed with one reduction over RCCL inside the timed region --
+Film::put(block) of the reference. Every rank reports the time it was busy, so that the balance of the partition is
+visible.
 
 All inputs (scene, BVH, film) are resident in HBM before the timed region.
 """
@@ -32,15 +35,19 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from mitsuba_amd import capi, render, scene as S
+from mitsuba_amd import capi, gates, render, scene as S
 
 NODE_BYTES, TRI_BYTES = 80, 48
+PASS_PATHS = 1920 * 1080 * 256      # paths a rank traces in one wavefront pass, on any number of GPUs
 # Ceilings of the memory system for dependent fetches of small records, chip-wide, GB/s (MI355X measurements of
 # indexed-row gathers: rows served by the XCD's L2 16.8-18.8 TB/s; rows of a table resident in the Infinity Cache
 # 8.6 TB/s at 38 MB and 7.4-7.9 TB/s at 151 MB; rows from HBM 6.0-6.3 TB/s)
 GATHER_L2_GBS = 17800.0
 GATHER_IC_SMALL_GBS, GATHER_IC_LARGE_GBS, GATHER_HBM_GBS = 8600.0, 7650.0, 6150.0
 INFINITY_CACHE_BYTES = 256 << 20
+# Dependent fetches of uniformly random 80-B records, 5 x 16 B per lane, G records/s chip-wide (tools/microbench/gather.hip,
+# MI355X): table of 2 MB (lives in every L2), 8 MB, 58 MB (Infinity Cache)
+RECORD_GATHER_GRS = {"l2": 134.0, "8MB": 79.7, "58MB": 41.1}
 
 
 def build_scene(args):
@@ -102,6 +109,35 @@ def cpu_baseline(sd, seconds_target=10.0, seconds_cap=30.0):
                        % (sd.film["crop_w"], sd.film["crop_h"], spp_done, total_rays, total_s, threads, build_s))
 
 
+def extra_workloads(steps=2, spp=256):
+    """Short runs of the configurations the headline is not quoted on: Cornell box 512x512 (config 1's scene on the GPU), veach_bidir
+    1024x768 under `path` (config 2), the 10M-triangle many-emitter scene, depth 16, at 1080p (config 5 on one GPU). One
+    untimed pass, then `steps` passes of `spp` samples per pixel; whole-job rates like the headline."""
+    res = {}
+    for name, make in (("cornell_512x512", lambda: S.cornell_box(512, 512)), ("veach_bidir_1024x768", lambda: S.veach_bidir(1024, 768)),
+                       ("config5_10M_triangles_1920x1080", lambda: S.config5(1920, 1080))):
+        sd = make()
+        g = capi.Scene(sd)
+        W, H = sd.film["crop_w"], sd.film["crop_h"]
+        film = torch.zeros(H, W, 5, device="cuda", dtype=torch.float32)
+        kw = dict(spp_total=spp * (steps + 1), seed=1, spp_per_pass=spp)
+        g.render_device(spp, film.data_ptr(), sample_offset=0, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rays = paths = 0
+        for i in range(steps):
+            st = g.render_device(spp, film.data_ptr(), sample_offset=(i + 1) * spp, **kw)
+            rays += st.normal_rays + st.shadow_rays
+            paths += st.paths
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res[name] = {"mrays_s": rays / dt / 1e6, "mpix_spp_per_s": paths / dt / 1e6, "ms_per_step": dt / steps * 1e3, "spp": spp * steps,
+                     "triangles": sd.n_triangles}
+        del g, film
+        torch.cuda.empty_cache()
+    return res
+
+
 def kernel_source_hash():
     """Identifies the build a counter profile was taken on: hash of the device sources."""
     h = hashlib.sha1()
@@ -134,7 +170,8 @@ def main():
     ap.add_argument("--workload", default="config3")
     ap.add_argument("--width", type=int, default=0, help="0: 1920x1080 on one GPU, 3840x2160 on several")
     ap.add_argument("--height", type=int, default=0)
-    ap.add_argument("--spp-step", type=int, default=256, help="samples per pixel per step")
+    ap.add_argument("--spp-step", type=int, default=0, help="samples per pixel per step (0: 256 on one GPU, max(256, 64 N) on N)")
+    ap.add_argument("--no-extra-workloads", action="store_true", help="skip the short runs of the other configurations (one GPU only)")
     ap.add_argument("--band-rows", type=int, default=16, help="rows of a tile of the multi-GPU partition")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -157,6 +194,11 @@ def main():
     coll_device = "cuda" if backend == "nccl" else "cpu"
     if args.width == 0 or args.height == 0:
         args.width, args.height = (1920, 1080) if world == 1 else (3840, 2160)
+    # Pass size: what one rank traces at once. On N GPUs a rank owns 1/N of the rows, so 64 N samples per pixel of the 4K
+    # frame are the 530 841 600 paths of the one-GPU pass (1920 x 1080 x 256).
+    if args.spp_step <= 0:
+        args.spp_step = 256 if world == 1 else max(256, 64 * world)
+    spp_pass = args.spp_step if world == 1 else max(1, min(args.spp_step, (PASS_PATHS * world) // (args.width * args.height)))
 
     sd, workload = build_scene(args)
     g = capi.Scene(sd)
@@ -168,15 +210,18 @@ def main():
     if world > 1:
         band = render.interleaved_bands(H, args.band_rows, world, rank)
         rect, bands = (0, band[0], W, H), (band[1], band[2])
-        partition = ("image tiles: full-width tiles of %d rows dealt round-robin over %d GPUs (%d tiles each), one wavefront pass per GPU and step, "
-                     "scene replicated, one film reduction over RCCL" % (args.band_rows, world, len(render.band_rects(W, H, args.band_rows, world, rank))))
+        partition = ("image tiles: full-width tiles of %d rows dealt round-robin over %d GPUs (%d tiles each); every GPU traces passes of %d samples "
+                     "per pixel of its share = %d paths, the pass size of the one-GPU run; a step is %d samples per pixel of the whole frame; scene "
+                     "replicated, one film reduction over RCCL inside the timed region"
+                     % (args.band_rows, world, len(render.band_rects(W, H, args.band_rows, world, rank)), spp_pass,
+                        spp_pass * sum(r[3] - r[1] for r in render.band_rects(W, H, args.band_rows, world, rank)) * W, args.spp_step))
     else:
         rect, bands = (0, 0, W, H), None
         partition = "one GPU: the whole frame in one wavefront pass per step"
 
     def step(i):
         st = g.render_device(args.spp_step, film.data_ptr(), spp_total=spp_total, sample_offset=i * args.spp_step, seed=1, rect=rect,
-                             bands=bands, spp_per_pass=args.spp_step)
+                             bands=bands, spp_per_pass=spp_pass)
         return dict(normal=st.normal_rays, shadow=st.shadow_rays, ext_ms=st.extend_ms, shd_ms=st.shadow_ms, shade_ms=st.shade_ms,
                     film_ms=st.film_ms, tail_ms=st.tail_ms, iters=st.bounce_iterations, paths=st.paths, busy_s=st.seconds)
 
@@ -222,10 +267,10 @@ def main():
         out = {
             "metric": "Mrays/s (camera+bounce+shadow)", "value": rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if world > 1 else "n/a", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "mpix_spp_per_s": paths / elapsed / 1e6,
             "config": {"workload": workload, "triangles": sd.n_triangles, "spp_per_step": args.spp_step, "spp_timed": args.spp_step * args.steps,
-                       "paths_per_step": int(paths / args.steps), "partition": partition,
+                       "paths_per_step": int(paths / args.steps), "partition": partition, "gates": gates.as_dict(),
                        "bvh": {"nodes": info.n_nodes, "depth": info.depth, "node_bytes": NODE_BYTES, "tri_bytes": TRI_BYTES,
                                "build_s": round(info.build_seconds, 3), "binary_tree_s": round(info.binary_seconds, 3),
                                "builder": "device" if info.builder == 1 else "host"}},
@@ -240,7 +285,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         g.set_counting(True)
         scratch = torch.zeros_like(film)
-        kw = dict(spp_total=spp_total, sample_offset=args.warmup * args.spp_step, seed=1, rect=rect, bands=bands, spp_per_pass=args.spp_step)
+        kw = dict(spp_total=spp_total, sample_offset=args.warmup * args.spp_step, seed=1, rect=rect, bands=bands, spp_per_pass=spp_pass)
         stc = g.render_device(args.spp_step, scratch.data_ptr(), **kw)
         g.set_counting(False)
         st = g.render_device(args.spp_step, scratch.data_ptr(), **kw)
@@ -272,7 +317,18 @@ def main():
             t_min = alg / (GATHER_L2_GBS * 1e9)
             basis = "no counter profile of this build: every byte priced at the L2 gather rate (the fraction is a lower bound)"
         peak = alg / t_min / 1e9
-        out["roofline"] = {"kernel": "k_trace<TRACE_CLOSEST> (extend)", "bound": "hbm",
+        # the same launches as a rate of records (80-B nodes + 48-B triangle records), next to what a kernel that does nothing
+        # but fetch uniformly random 80-B records reaches on this chip (tools/microbench/gather.hip)
+        records_per_s = (nodes_per_ray + tris_per_ray) * wave_rays / launches / (avg_ms * 1e-3)
+        micro = RECORD_GATHER_GRS["l2"] if structure <= (4 << 20) else RECORD_GATHER_GRS["8MB"] if structure <= (16 << 20) else RECORD_GATHER_GRS["58MB"]
+        out["roofline"] = {"kernel": "k_trace<TRACE_CLOSEST> (extend)",
+                           "bound": "cache hierarchy (vector-memory pipeline of the CUs: texture addresser 80 % busy, L1 99 % active; not HBM, not MFMA)",
+                           "record_rate": {"achieved_Grecords_s": records_per_s / 1e9,
+                                           "uniform_random_80B_records_Grecords_s": RECORD_GATHER_GRS,
+                                           "frac_of_uniform_random_at_this_structure_size": records_per_s / 1e9 / micro,
+                                           "frac_of_l2_resident_rate": records_per_s / 1e9 / RECORD_GATHER_GRS["l2"],
+                                           "note": "the traversal beats the uniform-random rate at its structure size because the upper levels of the tree stay in the L1s and L2s; "
+                                                   "against the rate for a table that fits the L2s it stands just below 1"},
                            "ceiling": "memory hierarchy serving dependent 80-B node / 48-B triangle fetches: bytes that stay in the L2s at %.0f GB/s, bytes beyond them at %.0f GB/s from %s"
                                       % (GATHER_L2_GBS, fabric_rate, served),
                            "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
@@ -289,6 +345,12 @@ def main():
                                     "the structure (BVH %.1f MB + triangle records %.1f MB) exceeds the Infinity Cache: what leaves the L2s is served by HBM at its "
                                     "measured rate for dependent record fetches") % (info.node_bytes / 1e6, info.triangle_bytes / 1e6)}
         del scratch
+
+    # ---- the other single-GPU configurations, two timed passes each (one GPU, default workload only) ----
+    if rank == 0 and world == 1 and args.workload == "config3" and not args.no_extra_workloads:
+        del g
+        torch.cuda.empty_cache()
+        out["extra"] = {"workloads": extra_workloads()}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sd)

@@ -238,6 +238,9 @@ typedef struct {
        the closest-hit / shadow rays it traced (already contained in normal_rays / shadow_rays, not in extend_ms) */
     double tail_ms;
     uint64_t tail_normal_rays, tail_shadow_rays;
+    /* mtsamd_render_multi only: the time this device's share of the film took to reach the host (its bands and their
+       filter borders, through page-locked memory); entry 0 also carries the host-side sum of the shares */
+    double gather_ms;
 } mtsamd_stats;
 
 typedef struct {
@@ -273,7 +276,7 @@ const char *mtsamd_last_error(void);
    are never reordered). A caller compiled against another version must not pass them in: compare MTSAMD_ABI_VERSION with
    mtsamd_abi_version(), and where records are mirrored by hand (FFI bindings) their sizes with mtsamd_sizeof(). No
    counterpart in the reference, whose plugins are compiled against its own headers. */
-#define MTSAMD_ABI_VERSION 13
+#define MTSAMD_ABI_VERSION 14
 enum { MTSAMD_SIZEOF_SCENE_DESC = 0, MTSAMD_SIZEOF_MATERIAL = 1, MTSAMD_SIZEOF_EMITTER = 2, MTSAMD_SIZEOF_SHAPE = 3,
        MTSAMD_SIZEOF_RENDER_OPTS = 4, MTSAMD_SIZEOF_STATS = 5, MTSAMD_SIZEOF_LDR_OPTS = 6, MTSAMD_SIZEOF_TEXTURE = 7 };
 int mtsamd_abi_version(void);
@@ -303,7 +306,9 @@ int mtsamd_render_device(mtsamd_scene *scene, const mtsamd_render_opts *opts, fl
    followed by mtsamd_scene_create, per device). The rectangle of opts is cut into full-width tiles of band_rows rows
    (0 = 16); GPU i renders tiles i, i + n, i + 2n, ... on a host thread of its own, and the n films are added into
    film_host (host memory, ACCUMULATED like mtsamd_render) in device order. stats, if not NULL, has n_scenes entries,
-   one per GPU (their `seconds` show the balance of the partition). opts->band_rows / band_period must be zero. */
+   one per GPU (their `seconds` show the balance of the partition, `gather_ms` what the film hand-over cost). A GPU hands
+   back only the rows of its tiles and their filter borders, through page-locked memory. opts->band_rows / band_period
+   must be zero. */
 int mtsamd_render_multi(mtsamd_scene *const *scenes, int32_t n_scenes, const mtsamd_render_opts *opts, int32_t band_rows,
                         float *film_host, mtsamd_stats *stats);
 
@@ -346,8 +351,9 @@ int mtsamd_occluded(mtsamd_scene *scene, uint64_t n, const float *rays, uint8_t 
    measured with HIP events on the library's stream. */
 int mtsamd_trace_device(mtsamd_scene *scene, uint64_t n, const float *rays_device, mtsamd_hit *hits_device, double *kernel_seconds);
 int mtsamd_occluded_device(mtsamd_scene *scene, uint64_t n, const float *rays_device, uint8_t *occluded_device, double *kernel_seconds);
-/* mtsamd_trace_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving
-   loops, harnesses that forbid hipMalloc). No counterpart in the reference. Same query, same results; its work
+/* mtsamd_trace_device for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+   hipMalloc). No counterpart in the reference. The call still sets the device, launches on the library's own stream and
+   waits for it, so it is not something to record into a caller's HIP graph; what it guarantees is that it allocates nothing. Same query, same results; its work
    memory (ray hand-out counters and the raw hits) is a static device array inside the library instead of buffers
    allocated per call, so one call takes at most mtsamd_trace_device_static_max() rays (2^20; 16 MiB of device memory
    per GPU the library runs on, held until the process ends) and fails with MTSAMD_EINVAL beyond that. The call

@@ -90,7 +90,8 @@ class Stats(C.Structure):
                 ("raygen_ms", C.c_double), ("extend_launches", C.c_uint64), ("shadow_launches", C.c_uint64),
                 ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("shadow_node_visits", C.c_uint64), ("shadow_tri_tests", C.c_uint64),
-                ("tail_ms", C.c_double), ("tail_normal_rays", C.c_uint64), ("tail_shadow_rays", C.c_uint64)]
+                ("tail_ms", C.c_double), ("tail_normal_rays", C.c_uint64), ("tail_shadow_rays", C.c_uint64),
+                ("gather_ms", C.c_double)]
 
 
 class BvhInfo(C.Structure):
@@ -115,7 +116,7 @@ EXPORTS = ["mtsamd_last_error", "mtsamd_init", "mtsamd_scene_create", "mtsamd_sc
            "mtsamd_spectrum_value_to_rgb", "mtsamd_spectrum_file_to_rgb", "mtsamd_blackbody_to_rgb"]
 
 _lib = None
-ABI_VERSION = 13    # MTSAMD_ABI_VERSION of include/mtsamd.h
+ABI_VERSION = 14    # MTSAMD_ABI_VERSION of include/mtsamd.h
 
 
 class MtsamdError(RuntimeError):

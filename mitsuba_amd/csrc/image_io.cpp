@@ -165,9 +165,10 @@ std::string decodePfm(const std::vector<uint8_t> &f, Raw &img) {
     img.w = atoi(token().c_str()); img.h = atoi(token().c_str());
     const float scaleAndOrder = (float) atof(token().c_str());
     if (img.w <= 0 || img.h <= 0 || scaleAndOrder == 0) return "invalid PFM header";
+    if ((int64_t) img.w > kMaxImageSide || (int64_t) img.h > kMaxImageSide || (int64_t) img.w * (int64_t) img.h > kMaxImagePixels) return "PFM size out of range";
     ++p;    // the single white-space byte after the header
     const size_t n = (size_t) img.w * img.h * img.channels;
-    if (p + n * 4 > f.size()) return "truncated PFM file";
+    if (p > f.size() || n > (f.size() - p) / 4) return "truncated PFM file";
     img.v.resize(n);
     const bool little = scaleAndOrder <= 0.0f;
     const float scale = std::fabs(scaleAndOrder);
@@ -420,7 +421,7 @@ std::string decodeExr(const std::vector<uint8_t> &f, Raw &img) {
                 q += 16;
                 channels.push_back(c);
             }
-        } else if (name == "compression") compression = d[0];
+        } else if (name == "compression") { if (size < 1) return "malformed OpenEXR compression attribute"; compression = d[0]; }
         else if (name == "dataWindow" && size >= 16) { x0 = (int) le32(d); y0 = (int) le32(d + 4); x1 = (int) le32(d + 8); y1 = (int) le32(d + 12); }
         p += size;
     }

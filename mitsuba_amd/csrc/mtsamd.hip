@@ -7,6 +7,7 @@
 #include "bvh_internal.h"
 
 #include <atomic>
+#include <memory>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -72,13 +73,15 @@ inline unsigned blocksFor(size_t n, unsigned bs) { return (unsigned) ((n + bs - 
 }  // namespace
 
 // ---- static device scratch of mtsamd_trace_device_static -----------------------------------------------------------------
-// Callers that may not allocate (code under graph capture, tight serving loops) get a closest-hit query whose work
+// Callers that may not allocate device memory (tight serving loops, harnesses that forbid hipMalloc) get a closest-hit query whose work
 // memory -- the ray hand-out counters and the raw (t, u, v, triangle) hits that k_hits_to_records turns into hit
 // records -- lives in this array instead of buffers from hipMalloc. Every GPU holds its own copy at its own address;
 // host code never uses the array's name as an address, only the pointer hipGetSymbolAddress returns for the device
 // that is current (g_scratchPtr, filled once per device).
 static constexpr uint64_t kStaticMaxRays = 1ull << 20;
 static constexpr size_t kStaticHeadsBytes = 768;         // 8 counters 64 bytes apart, rounded up to the array's alignment
+static_assert(kFetchHeads * kFetchHeadStride * sizeof(uint32_t) <= kStaticHeadsBytes && kStaticHeadsBytes % 256 == 0,
+              "the hand-out counters that launchTrace clears must end before the raw hits of the static array begin");
 static constexpr size_t kStaticScratchBytes = kStaticHeadsBytes + kStaticMaxRays * 16;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
@@ -197,16 +200,17 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
     *out = nullptr;
     mtsamd_scene *s = new (std::nothrow) mtsamd_scene();
     if (!s) return fail(MTSAMD_EDEVICE, "out of host memory");
+    std::unique_ptr<mtsamd_scene> owner(s);     // every early return below releases the scene and what it holds
     std::string err;
     try {
         err = prepareScene(desc, s->host);
     } catch (const std::exception &ex) {
         err = std::string("scene preparation failed: ") + ex.what();
     }
-    if (!err.empty()) { delete s; return fail(MTSAMD_EINVAL, "%s", err.c_str()); }
+    if (!err.empty()) { return fail(MTSAMD_EINVAL, "%s", err.c_str()); }
 
     int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { delete s; return fail(MTSAMD_EDEVICE, "no HIP device available"); }
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { return fail(MTSAMD_EDEVICE, "no HIP device available"); }
     (void) hipGetDevice(&s->device);
 
     HostScene &h = s->host;
@@ -292,7 +296,7 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
         return MTSAMD_OK;
     };
     int rc = up();
-    if (rc != MTSAMD_OK) { delete s; return rc; }
+    if (rc != MTSAMD_OK) { return rc; }
 
     DevScene d = h.params;
     d.nodes = s->nodes.as<float4>(); d.tris = s->tris.as<float4>();
@@ -312,9 +316,9 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
     d.envCdfRows = h.envCdfRows.empty() ? nullptr : s->envCdfRows.as<float>();
     d.envCdfCols = h.envCdfRows.empty() ? nullptr : s->envCdfCols.as<float>();
     d.envRowWeights = h.envRowWeights.empty() ? nullptr : s->envRowWeights.as<float>();
-    if (s->devSelf.ensure(sizeof(DevScene)) != hipSuccess) { delete s; return fail(MTSAMD_EDEVICE, "out of device memory"); }
+    if (s->devSelf.ensure(sizeof(DevScene)) != hipSuccess) { return fail(MTSAMD_EDEVICE, "out of device memory"); }
     d.self = s->devSelf.as<DevScene>();
-    if (hipMemcpy(s->devSelf.ptr, &d, sizeof(DevScene), hipMemcpyHostToDevice) != hipSuccess) { delete s; return fail(MTSAMD_EDEVICE, "upload of the scene record failed"); }
+    if (hipMemcpy(s->devSelf.ptr, &d, sizeof(DevScene), hipMemcpyHostToDevice) != hipSuccess) { return fail(MTSAMD_EDEVICE, "upload of the scene record failed"); }
     s->dev = d;
     const char *ct = getenv("MTSAMD_COUNT_TRAVERSAL");
     s->countTraversal = ct && *ct == '1';
@@ -330,7 +334,8 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
         s->xcdRanges = s->nodes.bytes + s->tris.bytes <= ((size_t) 128 << 20) ? 8 : 1;
         if (const char *e = getenv("MTSAMD_XCD_RANGES")) s->xcdRanges = (uint32_t) std::min(8, std::max(1, atoi(e)));
         if (const char *e = getenv("MTSAMD_TAIL_BELOW")) s->tailBelow = (uint32_t) std::max(0ll, atoll(e));
-        if (const char *e = getenv("MTSAMD_SHADE_ROUNDS")) s->shadeRounds = atoi(e);
+        // on / off only: the library holds the 16-sweep and the 1-sweep build of the shading kernels (any value >= 2 means 16)
+        if (const char *e = getenv("MTSAMD_SHADE_ROUNDS")) s->shadeRounds = atoi(e) >= 2 ? 16 : 1;
         if (const char *e = getenv("MTSAMD_SHADE_ROUNDS_ABOVE")) s->shadeRoundsAbove = (uint32_t) std::max(0ll, atoll(e));
         if (const char *e = getenv("MTSAMD_CHUNK_MAX")) s->chunkMax = (uint32_t) std::min(65536, std::max(64, atoi(e)));
         if (const char *e = getenv("MTSAMD_TRACE_BLOCK")) s->traceBlock = (unsigned) std::min(1024, std::max(64, atoi(e) / 64 * 64));
@@ -353,7 +358,7 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
         s->traceGrid = (unsigned) std::max(1, perCu) * (unsigned) std::max(1, prop.multiProcessorCount);
         if (getenv("MTSAMD_VERBOSE")) fprintf(stderr, "mtsamd: trace block %u, %d blocks/CU, %zu B LDS, stack layout %d (tree depth %u)\n", s->traceBlock, perCu, lds, s->traceStack, h.bvh.depth);
     }
-    *out = s;
+    *out = owner.release();
     return MTSAMD_OK;
 }
 
@@ -803,8 +808,13 @@ extern "C" int mtsamd_render_multi(mtsamd_scene *const *scenes, int32_t n_scenes
     if (rc != MTSAMD_OK) return rc;
     if (base.band_rows) return fail(MTSAMD_EINVAL, "mtsamd_render_multi deals the bands out itself: leave band_rows / band_period of the options zero");
     if (band_rows <= 0) band_rows = 16;
-    const size_t floats = (size_t) scenes[0]->dev.cropW * scenes[0]->dev.cropH * 5;
-    std::vector<std::vector<float>> films((size_t) n_scenes);
+    const int W = scenes[0]->dev.cropW, H = scenes[0]->dev.cropH;
+    const size_t floats = (size_t) W * H * 5, rowFloats = (size_t) W * 5;
+    // What a device hands back: only the frame rows its bands and their filter borders touch (a device's film is zero
+    // everywhere else), through page-locked memory. 8 GPUs at 3840x2160: 8 x 34 MB instead of 8 x 166 MB.
+    struct Segment { int row0, rows; size_t offset; };      // frame rows [row0, row0 + rows) at `offset` floats of the staging buffer
+    struct Share { std::vector<Segment> segments; float *staging = nullptr; size_t floats = 0; };
+    std::vector<Share> shares((size_t) n_scenes);
     std::vector<int> codes((size_t) n_scenes, MTSAMD_OK);
     std::vector<std::string> errors((size_t) n_scenes);
     auto work = [&](int i) {
@@ -819,11 +829,26 @@ extern "C" int mtsamd_render_multi(mtsamd_scene *const *scenes, int32_t n_scenes
             HIP_TRY(hipSetDevice(sc->device));
             DeviceBuffer film;
             HIP_TRY(film.ensure(floats * sizeof(float)));
-            HIP_TRY(hipMemset(film.ptr, 0, floats * sizeof(float)));
+            HIP_TRY(hipMemsetAsync(film.ptr, 0, floats * sizeof(float), sc->stream));
             int r = renderCommon(sc, &o, film.as<float>(), nullptr, nullptr, stats ? &stats[i] : nullptr);
             if (r != MTSAMD_OK) return r;
-            films[(size_t) i].resize(floats);
-            HIP_TRY(hipMemcpy(films[(size_t) i].data(), film.ptr, floats * sizeof(float), hipMemcpyDeviceToHost));
+            auto t0 = std::chrono::steady_clock::now();
+            Share &sh = shares[(size_t) i];
+            const int border = (int) std::ceil(sc->dev.filterRadius - 0.5f);
+            for (int yb = o.y0; yb < o.y1; yb += o.band_period) {
+                const int r0 = std::max(0, yb - border), r1 = std::min(H, std::min(yb + band_rows, o.y1) + border);
+                if (!sh.segments.empty() && r0 <= sh.segments.back().row0 + sh.segments.back().rows) {
+                    Segment &last = sh.segments.back();     // borders of neighbouring bands meet: one segment
+                    last.rows = std::max(last.rows, r1 - last.row0);
+                } else sh.segments.push_back({ r0, r1 - r0, 0 });
+            }
+            for (Segment &g : sh.segments) { g.offset = sh.floats; sh.floats += (size_t) g.rows * rowFloats; }
+            HIP_TRY(hipHostMalloc((void **) &sh.staging, sh.floats * sizeof(float), hipHostMallocDefault));
+            for (const Segment &g : sh.segments)
+                HIP_TRY(hipMemcpyAsync(sh.staging + g.offset, film.as<float>() + (size_t) g.row0 * rowFloats, (size_t) g.rows * rowFloats * sizeof(float),
+                                       hipMemcpyDeviceToHost, sc->stream));
+            HIP_TRY(hipStreamSynchronize(sc->stream));
+            if (stats) stats[i].gather_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             return MTSAMD_OK;
         };
         try { codes[(size_t) i] = run(); } catch (const std::exception &ex) { codes[(size_t) i] = fail(MTSAMD_EDEVICE, "%s", ex.what()); }
@@ -835,24 +860,32 @@ extern "C" int mtsamd_render_multi(mtsamd_scene *const *scenes, int32_t n_scenes
         work(0);
         for (std::thread &t : threads) t.join();
     }
-    for (int i = 0; i < n_scenes; ++i)
-        if (codes[(size_t) i] != MTSAMD_OK) return fail(codes[(size_t) i], "device %d: %s", scenes[i]->device, errors[(size_t) i].c_str());
-    // film_host += film 0 + film 1 + ... (fixed order per element; the element ranges are summed side by side)
-    {
-        const int nt = std::max(1, std::min(n_scenes, 16));
+    int failed = -1;
+    for (int i = 0; i < n_scenes && failed < 0; ++i) if (codes[(size_t) i] != MTSAMD_OK) failed = i;
+    if (failed < 0) {
+        // film_host += share 0 + share 1 + ... (fixed order per element, so the sum is reproducible; the frame's rows
+        // are cut into slabs that are summed side by side)
+        auto t0 = std::chrono::steady_clock::now();
+        const int nt = std::max(1, std::min(H, 16));
         std::vector<std::thread> threads;
         auto sum = [&](int t) {
-            const size_t a = floats * (size_t) t / nt, b = floats * (size_t) (t + 1) / nt;
-            for (int i = 0; i < n_scenes; ++i) {
-                if (films[(size_t) i].empty()) continue;
-                const float *src = films[(size_t) i].data();
-                for (size_t k = a; k < b; ++k) film_host[k] += src[k];
-            }
+            const int ra = (int) ((int64_t) H * t / nt), rb = (int) ((int64_t) H * (t + 1) / nt);
+            for (int i = 0; i < n_scenes; ++i)
+                for (const Segment &g : shares[(size_t) i].segments) {
+                    const int a = std::max(ra, g.row0), b = std::min(rb, g.row0 + g.rows);
+                    if (a >= b) continue;
+                    const float *src = shares[(size_t) i].staging + g.offset + (size_t) (a - g.row0) * rowFloats;
+                    float *dst = film_host + (size_t) a * rowFloats;
+                    for (size_t k = 0, n = (size_t) (b - a) * rowFloats; k < n; ++k) dst[k] += src[k];
+                }
         };
         for (int t = 1; t < nt; ++t) threads.emplace_back(sum, t);
         sum(0);
         for (std::thread &t : threads) t.join();
+        if (stats) stats[0].gather_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
+    for (Share &sh : shares) if (sh.staging) (void) hipHostFree(sh.staging);
+    if (failed >= 0) return fail(codes[(size_t) failed], "device %d: %s", scenes[failed]->device, errors[(size_t) failed].c_str());
     return MTSAMD_OK;
 }
 

@@ -877,6 +877,35 @@ def test_veach_room_against_the_reference_held_image(gpu):
     assert 1.55 < np.median(c["lit_plain"]) < 1.85
     q = np.percentile(c["unlit"], [10, 50, 90])
     assert 0.65 < q[0] and 0.8 < q[1] < 0.97 and q[2] < 1.1, q
+    # the gate as one number: relative mean squared error of the cell luminances against the reference-held image
+    print("relMSE vs bidir.exr: all cells %.4f, lit cells %.5f (plain render: %.4f / %.4f)" % (c["rel_mse"], c["rel_mse_lit"], c["rel_mse_plain"], c["rel_mse_lit_plain"]))
+    assert c["rel_mse"] < bidir_pin.REL_MSE_ALL_CELLS and c["rel_mse_lit"] < bidir_pin.REL_MSE_LIT_CELLS
+    assert c["rel_mse_plain"] > c["rel_mse"] and c["rel_mse_lit_plain"] > 100 * c["rel_mse_lit"]
+
+
+@pytest.mark.parametrize("name", ["cornell", "veach"])
+def test_image_rel_mse_is_within_seed_noise(gpu, oracle_mod, name):
+    """Image-level gate at matched samples per pixel: the relative mean squared error between the GPU render and a CPU
+    restatement render with ANOTHER seed is at most twice that between two CPU renders with different seeds -- the GPU
+    image is indistinguishable from seed noise. (With the same seed the two share their sample streams and the images
+    agree far below noise; that is asserted too.) relMSE = mean((a - b)^2 / (b^2 + 0.01)) over pixels and channels of
+    the images clamped to [0, 4], so that a handful of caustic fireflies does not decide the figure."""
+    sd = S.cornell_box(128, 128) if name == "cornell" else S.veach_bidir(192, 144)
+    spp = 64
+    g, o = gpu.Scene(sd), oracle_mod.OracleScene(sd, fast=True)
+
+    def rel_mse(a, b):
+        a, b = np.clip(a[..., :3].astype(np.float64), 0, 4), np.clip(b[..., :3].astype(np.float64), 0, 4)
+        return float(np.mean((a - b) ** 2 / (b ** 2 + 1e-2)))
+    gpu_a = g.develop(g.render(spp, seed=11)[0])
+    cpu = {s: o.develop(o.render(spp, seed=s, n_threads=os.cpu_count() or 1)[0]) for s in (11, 12, 13)}
+    noise = rel_mse(cpu[12], cpu[13])
+    same = rel_mse(gpu_a, cpu[11])
+    other = 0.5 * (rel_mse(gpu_a, cpu[12]) + rel_mse(gpu_a, cpu[13]))
+    print("%s: relMSE GPU vs CPU, same seed %.3g; other seeds %.4g; CPU vs CPU (seed noise) %.4g" % (name, same, other, noise))
+    from mitsuba_amd import gates
+    assert noise > 0 and other <= gates.SEED_NOISE_FACTOR * noise
+    assert same <= gates.SAME_SEED_FACTOR * noise
 
 
 def test_interleaved_band_partition_matches_the_whole_frame(gpu, pairs):
@@ -921,6 +950,7 @@ def test_render_multi_deals_one_job_over_scene_replicas(gpu):
         assert np.allclose(film, full, rtol=1e-5, atol=1e-6)
         assert sum(s.normal_rays + s.shadow_rays for s in stats) == sf.normal_rays + sf.shadow_rays
         assert sum(s.paths for s in stats) == sf.paths and all(s.paths > 0 for s in stats)
+        assert all(s.gather_ms > 0 for s in stats)
     acc, _ = gpu.render_multi([a, b], 6, film=full.copy(), seed=9)       # accumulates like mtsamd_render
     assert np.allclose(acc, 2 * full, rtol=1e-5, atol=1e-6)
     with pytest.raises(gpu.MtsamdError, match="twice"):
@@ -950,6 +980,14 @@ def test_4k_film_weight_and_band_partition(gpu):
         paths += sr.paths
     assert rays == st.normal_rays + st.shadow_rays and paths == st.paths
     assert np.allclose(parts, film, rtol=1e-5, atol=1e-6)
+    # the same job through mtsamd_render_multi with two replicas of the scene: every replica hands back only the rows
+    # of its tiles and their filter borders; the sum is the single render
+    g2 = gpu.Scene(sd)
+    multi, stats = gpu.render_multi([g, g2], 1, seed=1, band_rows=16)
+    assert np.allclose(multi, film, rtol=1e-5, atol=1e-6)
+    assert sum(s.normal_rays + s.shadow_rays for s in stats) == st.normal_rays + st.shadow_rays
+    assert [s.paths for s in stats] == [3840 * 16 * 68, 3840 * 16 * 67]
+    assert all(s.gather_ms > 0 for s in stats)
 
 
 @pytest.mark.timeout(900)
