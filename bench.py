@@ -109,10 +109,11 @@ def cpu_baseline(sd, seconds_target=10.0, seconds_cap=30.0):
                        % (sd.film["crop_w"], sd.film["crop_h"], spp_done, total_rays, total_s, threads, build_s))
 
 
-def extra_workloads(steps=2, spp=256):
+def extra_workloads(min_steps=2, min_seconds=1.5, spp=256):
     """Short runs of the configurations the headline is not quoted on: Cornell box 512x512 (config 1's scene on the GPU), veach_bidir
-    1024x768 under `path` (config 2), the 10M-triangle many-emitter scene, depth 16, at 1080p (config 5 on one GPU). One
-    untimed pass, then `steps` passes of `spp` samples per pixel; whole-job rates like the headline."""
+    1024x768 under `path` (config 2), the 10M-triangle many-emitter scene, depth 16, at 1080p (config 5 on one GPU). Two
+    untimed passes, then passes of `spp` samples per pixel until at least `min_steps` of them and `min_seconds` have been
+    timed; whole-job rates like the headline."""
     res = {}
     for name, make in (("cornell_512x512", lambda: S.cornell_box(512, 512)), ("veach_bidir_1024x768", lambda: S.veach_bidir(1024, 768)),
                        ("config5_10M_triangles_1920x1080", lambda: S.config5(1920, 1080))):
@@ -120,15 +121,17 @@ def extra_workloads(steps=2, spp=256):
         g = capi.Scene(sd)
         W, H = sd.film["crop_w"], sd.film["crop_h"]
         film = torch.zeros(H, W, 5, device="cuda", dtype=torch.float32)
-        kw = dict(spp_total=spp * (steps + 1), seed=1, spp_per_pass=spp)
-        g.render_device(spp, film.data_ptr(), sample_offset=0, **kw)
+        kw = dict(spp_total=spp * 4096, seed=1, spp_per_pass=spp)
+        for i in range(2):
+            g.render_device(spp, film.data_ptr(), sample_offset=i * spp, **kw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        rays = paths = 0
-        for i in range(steps):
-            st = g.render_device(spp, film.data_ptr(), sample_offset=(i + 1) * spp, **kw)
+        rays = paths = steps = 0
+        while steps < min_steps or time.perf_counter() - t0 < min_seconds:
+            st = g.render_device(spp, film.data_ptr(), sample_offset=(steps + 2) * spp, **kw)
             rays += st.normal_rays + st.shadow_rays
             paths += st.paths
+            steps += 1
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         res[name] = {"mrays_s": rays / dt / 1e6, "mpix_spp_per_s": paths / dt / 1e6, "ms_per_step": dt / steps * 1e3, "spp": spp * steps,

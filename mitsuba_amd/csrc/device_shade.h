@@ -1449,26 +1449,35 @@ __device__ __attribute__((noinline)) inline float4 sampleOtherEmitterCall(const 
     return make_float4(value.x, value.y, value.z, dRec.pdf);
 }
 
-template <bool EXT = true, int TAG = 0>
-MTS_DEV V3 sampleEmitterDirect(const DevScene &sc, V3 ref, V3 refN, float sx, float sy, DirectRec &dRec) {
-    dRec.pdf = 0; dRec.dist = 0; dRec.d = mk(0.0f); dRec.delta = false;
-    if (sc.nEmitters == 0) return mk(0.0f);
-    float emPdf;
-    const uint32_t index = cdfSampleReuse(sc.emitterCdf, sc.nEmitters, sx, &emPdf);
-    if (EXT) {
-        const bool environment = (int32_t) index == sc.envEmitter;
-        if (environment || sc.emitters[index].kind >= 2) {
-            float4 dd;
-            const float4 r = sampleOtherEmitterCall<TAG>(sc.self, index, ref, refN, sx, sy, emPdf, &dd);
-            dRec.d = mk(dd.x, dd.y, dd.z); dRec.dist = dd.w; dRec.pdf = r.w; dRec.delta = !environment;
-            return mk(r.x, r.y, r.z);
+// The emitter tables of a scene with few area lights, as the shading kernel holds them in workgroup memory (DevScene::emitterTris)
+struct EmitterTables {
+    float cdf[kLdsEmitters + 1];
+    float areaCdf[kLdsEmitterTris + kLdsEmitters];
+    uint32_t firstTri[kLdsEmitters];        // an emitter's first triangle in `tris`
+    DevEmitter em[kLdsEmitters];
+    float4 tris[kLdsEmitterTris * 6];       // shading records: three positions, three normals
+    // every thread of the workgroup calls this; a barrier must follow before the tables are read
+    MTS_DEV void fill(const DevScene &sc, uint32_t tid, uint32_t nThreads) {
+        for (uint32_t i = tid; i <= sc.nEmitters; i += nThreads) cdf[i] = sc.emitterCdf[i];
+        for (uint32_t i = tid; i < sc.areaCdfLen; i += nThreads) areaCdf[i] = sc.areaCdf[i];
+        for (uint32_t i = tid; i < sc.nEmitters; i += nThreads) {
+            em[i] = sc.emitters[i];
+            uint32_t first = 0;
+            for (uint32_t j = 0; j < i; ++j) first += sc.emitters[j].nTris;
+            firstTri[i] = first;
+        }
+        for (uint32_t k = tid; k < sc.emitterTris * 6u; k += nThreads) {
+            uint32_t t = k / 6u, e = 0;
+            while (t >= sc.emitters[e].nTris) { t -= sc.emitters[e].nTris; ++e; }
+            tris[k] = sc.shadeTris[kShadeTriStride * (size_t) (sc.emitters[e].firstTri + t) + k % 6u];
         }
     }
-    const DevEmitter em = sc.emitters[index];
-    const uint32_t triIdx = cdfSampleReuse(sc.areaCdf + em.cdfOffset, em.nTris, sy, nullptr);
-    const uint32_t t = em.firstTri + triIdx;
-    const float4 *g = sc.shadeTris + kShadeTriStride * (size_t) t;
-    const float4 g0 = g[0], g1 = g[1], g2 = g[2], h0 = g[3], h1 = g[4], h2 = g[5];
+};
+
+// The area-light branch of sampleEmitterDirect, given the emitter's record, its triangle (six float4) and the choice
+// probability: AreaLight::sampleDirect (src/emitters/area.cpp:158-173)
+MTS_DEV V3 sampleAreaLight(const DevEmitter &em, const float4 g0, const float4 g1, const float4 g2, const float4 h0, const float4 h1, const float4 h2,
+                           V3 ref, V3 refN, float sx, float sy, float emPdf, DirectRec &dRec) {
     const V3 p0 = mk(g0.x, g0.y, g0.z), p1 = mk(g1.x, g1.y, g1.z), p2 = mk(g2.x, g2.y, g2.z);
     const float a = safeSqrt(1.0f - sx);                  // squareToUniformTriangle (warp.cpp:84-87)
     const float baryX = 1 - a, baryY = a * sy;
@@ -1496,6 +1505,36 @@ MTS_DEV V3 sampleEmitterDirect(const DevScene &sc, V3 ref, V3 refN, float sx, fl
     }
     dRec.pdf = 0.0f;
     return mk(0.0f);
+}
+
+template <bool EXT = true, int TAG = 0>
+MTS_DEV V3 sampleEmitterDirect(const DevScene &sc, V3 ref, V3 refN, float sx, float sy, DirectRec &dRec, const EmitterTables *tables = nullptr, bool useTables = false) {
+    dRec.pdf = 0; dRec.dist = 0; dRec.d = mk(0.0f); dRec.delta = false;
+    if (sc.nEmitters == 0) return mk(0.0f);
+    float emPdf;
+    if (!EXT && useTables) {
+        // the same steps on the copies in workgroup memory
+        const uint32_t index = cdfSampleReuse(tables->cdf, sc.nEmitters, sx, &emPdf);
+        const DevEmitter em = tables->em[index];
+        const uint32_t triIdx = cdfSampleReuse(tables->areaCdf + em.cdfOffset, em.nTris, sy, nullptr);
+        const float4 *g = tables->tris + 6u * (tables->firstTri[index] + triIdx);
+        return sampleAreaLight(em, g[0], g[1], g[2], g[3], g[4], g[5], ref, refN, sx, sy, emPdf, dRec);
+    }
+    const uint32_t index = cdfSampleReuse(sc.emitterCdf, sc.nEmitters, sx, &emPdf);
+    if (EXT) {
+        const bool environment = (int32_t) index == sc.envEmitter;
+        if (environment || sc.emitters[index].kind >= 2) {
+            float4 dd;
+            const float4 r = sampleOtherEmitterCall<TAG>(sc.self, index, ref, refN, sx, sy, emPdf, &dd);
+            dRec.d = mk(dd.x, dd.y, dd.z); dRec.dist = dd.w; dRec.pdf = r.w; dRec.delta = !environment;
+            return mk(r.x, r.y, r.z);
+        }
+    }
+    const DevEmitter em = sc.emitters[index];
+    const uint32_t triIdx = cdfSampleReuse(sc.areaCdf + em.cdfOffset, em.nTris, sy, nullptr);
+    const uint32_t t = em.firstTri + triIdx;
+    const float4 *g = sc.shadeTris + kShadeTriStride * (size_t) t;
+    return sampleAreaLight(em, g[0], g[1], g[2], g[3], g[4], g[5], ref, refN, sx, sy, emPdf, dRec);
 }
 
 MTS_DEV float miWeight(float pdfA, float pdfB) {   // path.cpp:296-300

@@ -68,6 +68,9 @@ struct DevShape {
     uint32_t flags, pad[3];
 };
 
+// Limits of the emitter tables the shading kernel keeps in workgroup memory
+static constexpr uint32_t kLdsEmitters = 8, kLdsEmitterTris = 16;
+
 struct alignas(16) DevEmitter {
     float radiance[3];
     float pdfDiscrete;      // samplingWeight * normalization (scene.h:848-850)
@@ -121,6 +124,11 @@ struct DevScene {
     const uint2 *texels;
     const float *ewaLut;
     uint32_t nEmitters, nTris, nShapes, nMaterials;
+    // Scenes with a handful of area lights (and no other emitter kind): the shading kernel copies their tables --
+    // choice distribution, records, triangle distributions, triangles -- into workgroup memory once per workgroup, so that
+    // sampling an emitter costs no chain of dependent global loads. emitterTris = their triangles in all (0 = no copy),
+    // areaCdfLen = entries of areaCdf.
+    uint32_t emitterTris, areaCdfLen;
     float aabbMin[3], aabbMax[3];       // enlarged scene bounds (gkdtree.h:1213-1220)
     float sampleToCamera[16];
     float camToWorld[12];

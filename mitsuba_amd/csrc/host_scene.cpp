@@ -724,6 +724,13 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
     DevScene &p = hs.params;
     memset(&p, 0, sizeof(p));
     p.nEmitters = d->n_emitters; p.nTris = d->n_triangles; p.nShapes = d->n_shapes; p.nMaterials = d->n_materials;
+    {   // few area lights and nothing else: their tables fit the shading kernel's workgroup memory
+        uint32_t tris = 0;
+        bool areaOnly = !hs.extEmitters && !hs.emitters.empty() && hs.emitters.size() <= kLdsEmitters;
+        for (const DevEmitter &e : hs.emitters) { areaOnly = areaOnly && e.kind == 0; tris += e.nTris; }
+        p.areaCdfLen = (uint32_t) hs.areaCdf.size();
+        p.emitterTris = areaOnly && tris <= kLdsEmitterTris && p.areaCdfLen <= kLdsEmitterTris + kLdsEmitters ? tris : 0u;
+    }
     // enlarged scene bounds (gkdtree.h:1213-1220, MTS_KD_AABB_EPSILON = 1e-3f; note max grows by the already grown extent)
     {
         float lo[3], hi[3];

@@ -77,6 +77,9 @@ static constexpr int kShadeBlock = MTS_SHADE_BLOCK;
 #define MTS_SHADE_PARK 1
 #endif
 static constexpr bool kShadePark = MTS_SHADE_PARK != 0;
+#ifndef MTS_SHADE_EMITTER_LDS
+#define MTS_SHADE_EMITTER_LDS 1
+#endif
 #ifndef MTS_ENV_LATE_MATERIAL
 #define MTS_ENV_LATE_MATERIAL 1
 #endif
@@ -121,7 +124,7 @@ struct HeldPath {
 // BLEND: some record of the scene is a mixture (MIX alone: textures and frame adapters only, no mixture code).
 template <bool ENV, bool RD, bool MIX, bool PARK, typename Path, bool VS = false, bool BLEND = MIX>
 MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &in, const float4 hit, float4 *sampleL, const float2 *samplePos,
-                         ShadeOut &o, float4 *park = nullptr) {
+                         ShadeOut &o, float4 *park = nullptr, const EmitterTables *emitterTables = nullptr, bool useEmitterTables = false) {
     // one instance of every real call per register budget of the kernels that share this function
     constexpr int kTag = PARK ? (MIX ? 2 : 1) : 0;
     constexpr bool kLateMaterial = ENV && MTS_ENV_LATE_MATERIAL != 0;
@@ -309,7 +312,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                 earlyValue = mk(0.0f);
                 if (smooth) {
                     const float sx = rng.next1D(), sy = rng.next1D();
-                    earlyValue = sampleEmitterDirect<ENV, kTag>(sc, its.p, refN, sx, sy, earlyRec);
+                    earlyValue = sampleEmitterDirect<ENV, kTag>(sc, its.p, refN, sx, sy, earlyRec, emitterTables, useEmitterTables);
                 }
                 loadAnswering();
             }
@@ -319,7 +322,7 @@ MTS_DEV void shadeVertex(const DevScene &sc, const PassParams &pp, const Path &i
                 if (kLateMaterial) { dRec = earlyRec; value = earlyValue; }
                 else {
                     const float sx = rng.next1D(), sy = rng.next1D();
-                    value = sampleEmitterDirect<ENV, kTag>(sc, its.p, refN, sx, sy, dRec);
+                    value = sampleEmitterDirect<ENV, kTag>(sc, its.p, refN, sx, sy, dRec, emitterTables, useEmitterTables);
                 }
                 if (dRec.pdf != 0) {
                     V3 c = mk(0.0f);
@@ -505,6 +508,10 @@ __global__ void __launch_bounds__(kShadeBlock, MIX ? MTS_SHADE_WAVES_MIX : MTS_S
     __shared__ uint32_t sCount[kShadeSortKeys * ROUNDS * kWaves];
     __shared__ uint32_t sOrder[kShadeBlock * ROUNDS];
     const uint32_t first = blockIdx.x * (kShadeBlock * ROUNDS);
+    // few area lights: their tables come into workgroup memory (the sort's barriers stand between this and their use)
+    __shared__ EmitterTables sEmitters;
+    const bool useEmitterTables = MTS_SHADE_EMITTER_LDS && !ENV && sc.emitterTris != 0;
+    if (useEmitterTables) sEmitters.fill(sc, threadIdx.x, kShadeBlock);
     sortByBsdfType<ROUNDS>(hits, first, n, sCount, sOrder);
     // reservation cells, one set per sweep parity: a sweep's cells are rewritten two sweeps later, by when every wave has
     // passed the barriers of the sweep in between, so no barrier is needed at the end of a sweep
@@ -517,7 +524,7 @@ __global__ void __launch_bounds__(kShadeBlock, MIX ? MTS_SHADE_WAVES_MIX : MTS_S
     asm volatile("" : "+v"(tidS));
     const uint32_t i = first + sOrder[round * kShadeBlock + tidS];
     ShadeOut o;
-    if (i < n) shadeVertex<ENV, RD, MIX, kShadePark, QueuedPath, VS, BLEND>(sc, pp, QueuedPath{ in, i }, hits[i], sampleL, samplePos, o, sPark);
+    if (i < n) shadeVertex<ENV, RD, MIX, kShadePark, QueuedPath, VS, BLEND>(sc, pp, QueuedPath{ in, i }, hits[i], sampleL, samplePos, o, sPark, &sEmitters, useEmitterTables);
     const bool alive = o.alive, wantShadow = o.wantShadow;
     uint32_t tidL = threadIdx.x;
     asm volatile("" : "+v"(tidL));
