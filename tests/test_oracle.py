@@ -46,33 +46,52 @@ def _node_params(tab, pt):
 
 @pytest.mark.parametrize("distr", ["beckmann", "ggx"])
 def test_rough_transmittance_table_pin(oracle_mod, distr):
-    """E[(1-F) G1(wo)] over visible-normal samples (the transmission-only sample weight of the rough dielectric,
-    src/bsdfs/roughdielectric.cpp:453-510, which is what the tables tabulate) against raw table nodes."""
+    """Raw nodes of data/microfacet/*.dat against the quantity they tabulate, the integral over the unit square of the
+    transmission-only sample weight of the rough dielectric (src/bsdfs/roughdielectric.cpp:453-510) -- the procedure and the
+    tolerance, 1e-3, of the reference's own test (src/tests/test_rtrans.cpp:27-36,94-124,141-160). All 40 nodes of the
+    fixture, very rough and grazing ones included. Two estimators of the same integral on a 512 x 512 midpoint grid: normals
+    from the full distribution (weight (1-F) G |wi.m| / (cos_i cos_m), sampleAll) and visible normals (weight (1-F)
+    G1(wo)). The tables were made with the first: the Beckmann nodes agree with it to 1e-4, while the visible-normal
+    form sits up to 2.2e-3 away -- it divides by the rational approximation of G1 (microfacet.h:477-514) but draws from
+    the exact one. GGX has an exact G1; its heavy tail makes the full-distribution form noisy, so the visible form is
+    the one compared. Outside 1e-3, for reasons that lie in the files: one Beckmann node next to the critical angle, where
+    both estimators agree with each other to 2e-5 and differ from the stored value by 1.35e-3; and the nodes stored as
+    exactly 0 (total internal reflection in the smooth limit), where the rough surface does transmit a little (up to
+    1.6e-3): those are held to 2e-3."""
     tab = json.load(open(os.path.join(GOLDEN, "rtrans_nodes.json")))["tables"][distr]
     code = S.DISTR_BECKMANN if distr == "beckmann" else S.DISTR_GGX
-    n = 384
-    u = (np.stack(np.meshgrid(np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 2) + 0.5) / n
-    u = u.astype(np.float32)
-    worst = 0.0
-    checked = 0
-    for pt in tab["points"][:40]:
-        eta, alpha, cos_t = _node_params(tab, pt)
-        if alpha > 1.5 or cos_t < 0.05:
-            continue    # very rough / grazing nodes converge too slowly for a fast test
+    n = 512
+    u = ((np.stack(np.meshgrid(np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 2) + 0.5) / n).astype(np.float32)
+
+    def estimate(eta, alpha, cos_t, visible):
         wi = np.tile(np.array([np.sqrt(max(0, 1 - cos_t * cos_t)), 0, cos_t], np.float32), (u.shape[0], 1))
-        m, pdf = oracle_mod.microfacet_sample(code, alpha, alpha, True, wi, u)
+        m, pdf = oracle_mod.microfacet_sample(code, alpha, alpha, visible, wi, u)
         cos_i = np.einsum("ij,ij->i", wi, m).astype(np.float32)
         F, cos_tt = oracle_mod.fresnel_dielectric(cos_i, eta)
         e = np.where(cos_tt < 0, 1.0 / eta, eta).astype(np.float32)      # refract(wi, n, eta, cosThetaT), util.cpp:767-772
         wo = m * (cos_i * e + cos_tt)[:, None] - wi * e[:, None]
-        g1 = oracle_mod.microfacet_eval(code, alpha, alpha, True, 2, wo.astype(np.float32), m)
-        w = (1 - F) * g1
+        w = (1 - F) * oracle_mod.microfacet_eval(code, alpha, alpha, True, 2, wo.astype(np.float32), m)
+        if not visible:
+            w = w * oracle_mod.microfacet_eval(code, alpha, alpha, True, 2, wi, m) * np.abs(cos_i) / np.maximum(wi[:, 2] * m[:, 2], 1e-20)
         w = np.where((cos_tt == 0) | (wo[:, 2] * wi[:, 2] >= 0) | (pdf == 0), 0, w)
-        est = float(np.mean(w.astype(np.float64)))
-        worst = max(worst, abs(est - pt["T"]))
-        checked += 1
-    assert checked >= 15
-    assert worst < 2e-3, worst
+        return float(np.mean(w.astype(np.float64)))
+
+    points = tab["points"][:40]
+    assert len(points) == 40
+    outside = []
+    for pt in points:
+        eta, alpha, cos_t = _node_params(tab, pt)
+        err = abs(estimate(eta, alpha, cos_t, distr == "ggx") - pt["T"])
+        if pt["T"] == 0.0:
+            assert err < 2e-3, (eta, alpha, cos_t, err)
+        elif err >= 1e-3:
+            outside.append((round(eta, 3), round(alpha, 3), round(cos_t, 4), err))
+    # the Beckmann node named above, and it is within 2e-3
+    assert [o[:3] for o in outside] == ([(0.948, 0.111, 0.3294)] if distr == "beckmann" else []), outside
+    assert all(o[3] < 2e-3 for o in outside), outside
+    if distr == "beckmann":     # the two estimators at that node: same integral, same value, not the file's
+        eta, alpha, cos_t = _node_params(tab, next(p for p in points if abs(_node_params(tab, p)[2] - 0.3294) < 1e-4))
+        assert abs(estimate(eta, alpha, cos_t, True) - estimate(eta, alpha, cos_t, False)) < 1e-4
 
 
 def test_rtrans_reduction_matches_packaged_slices(oracle_mod):
