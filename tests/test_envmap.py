@@ -187,11 +187,15 @@ def test_background_of_the_reference_held_renders(oracle_mod):
     (testScene/testScenes/*_sphere.xml) show a sphere with one of the fork's BRDFs in front of envmap.exr, and the renders
     are kept beside them. The BRDFs are outside this library; the BACKGROUND is the environment emitter seen through the
     perspective camera, the same in all four files. Rendered here from the scene files' camera and emitter parameters, it
-    agrees with every one of them in every 32 x 32-pixel cell that the object does not touch (50 of 256): within 4 %
-    (observed: 1.0 to 2.9 % darker, median 1.8 %, varying smoothly over the frame; the cause of that residue was not found -
-    a spectral build of the reference, which converts the map's RGB to spectra and back, would leave one of this size). A flipped or
-    rotated map, a wrong scale or field of view, or a wrong decode of the PIZ-compressed map would be off by tens of
-    per cent. The files are read where they lie (nothing of them is kept in this repository), so the test runs only where
+    agrees with every one of them in every 32 x 32-pixel cell that the object does not touch (50 of 256). What is left
+    between the two has a shape: reference / ours = 1.002 + 0.19 tan^2(angle to the optical axis) - 0.02 tan(vertical angle),
+    the same in all three channels, with 0.1 % of scatter around that surface. So on the optical axis the two agree to 0.2 %
+    (map decode, scale, orientation, the emitter's lookup: all pinned there), and the reference's frames brighten towards
+    the corners by up to 2.9 % in a purely radial pattern. The scene files say what made them: `bdpt` (100 samples,
+    independent sampler), not `path` -- the background of those frames went through the bidirectional connection and
+    light-image machinery (src/integrators/bdpt), which is outside this library; a constant environment rendered here
+    is flat to 1e-6, so the radial term is not in this camera, film or emitter. A flipped or rotated map, a wrong scale
+    or field of view, or a wrong decode of the PIZ-compressed map would be off by tens of per cent. The files are read where they lie (nothing of them is kept in this repository), so the test runs only where
     the reference is present; it pins the oracle's environment map and the library's OpenEXR reader, the GPU path is
     held to the oracle by tests/test_gpu_parity.py."""
     from mitsuba_amd import capi
@@ -223,8 +227,26 @@ def test_background_of_the_reference_held_renders(oracle_mod):
     film, _ = o.render(4, seed=1, n_threads=os.cpu_count() or 1)
     ours = cells(o.develop(film)[..., :3])
     ratio = ours[None, background] / ref_cells[:, background]
-    assert np.all(np.abs(ratio - 0.98) < 0.02), (ratio.min(), ratio.max())
+    assert np.all(np.abs(ratio - 0.98) < 0.012), (ratio.min(), ratio.max())
     assert 0.975 < np.median(ratio) < 0.99
+    # the residue as a surface over the frame: flat term (the optical axis), radial term, vertical term
+    lum = lambda a: a @ np.float64([0.2126, 0.7152, 0.0722])
+    cy, cx = np.mgrid[0:16, 0:16]
+    t = np.tan(np.radians(28.8415 / 2))
+    tx, ty = (cx * 32 + 16 - 256) / 256 * t, (cy * 32 + 16 - 256) / 256 * t
+    A = np.stack([np.ones(background.sum()), (tx ** 2 + ty ** 2)[background], ty[background]], 1)
+    for k in range(4):
+        r = (lum(ref_cells[k]) / lum(ours))[background]
+        coef = np.linalg.lstsq(A, r, rcond=None)[0]
+        assert abs(coef[0] - 1.0) < 0.005, coef                    # on the axis: within half a per cent
+        assert 0.15 < coef[1] < 0.24 and abs(coef[2]) < 0.03, coef
+        assert np.max(np.abs(r - A @ coef)) < 0.004, np.max(np.abs(r - A @ coef))
+    flat = S.SceneBuilder()
+    flat.add_mesh(np.float32([[100, 100, 100], [100.001, 100, 100], [100, 100.001, 100]]), np.uint32([[0, 1, 2]]), flat.add_material(S.diffuse((0.0, 0.0, 0.0))))
+    flat.add_envmap_emitter(np.ones_like(env), to_world=to_world, scale=3.0)
+    of = oracle_mod.OracleScene(flat.finish(cam, S.make_film(512, 512), dict(max_depth=2)))
+    constant = of.develop(of.render(1, seed=1, n_threads=os.cpu_count() or 1)[0])[..., :3]
+    assert np.all(np.abs(constant - 3.0) < 1e-5)
     # the orientation matters: the same map turned by a quarter about the vertical is far off
     b2 = S.SceneBuilder()
     b2.add_mesh(np.float32([[100, 100, 100], [100.001, 100, 100], [100, 100.001, 100]]), np.uint32([[0, 1, 2]]), b2.add_material(S.diffuse((0.0, 0.0, 0.0))))
