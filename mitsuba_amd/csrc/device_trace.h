@@ -211,7 +211,8 @@ MTS_DEV uint32_t visitNode(const DevScene &sc, LaneRay &r, LdsUint2 *ldsStack, u
 
     // (a copy of the top levels of the tree in LDS was measured and bought nothing: those nodes are L1 hits anyway)
     const float4 *np = sc.nodes + sc.nodeStride * (size_t) nodeIdx;
-    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+    const float4 n0 = np[0], n2 = np[2], n3 = np[3], n4 = np[4];
+    const float3 n1 = *reinterpret_cast<const float3 *>(np + 1);      // child base, triangle base, triangle bits
     const uint32_t ebits = __float_as_uint(n0.w);
     const float sx = __uint_as_float((ebits & 0xffu) << 23), sy = __uint_as_float(((ebits >> 8) & 0xffu) << 23),
                 sz = __uint_as_float(((ebits >> 16) & 0xffu) << 23);
@@ -273,7 +274,7 @@ MTS_DEV uint32_t visitNode(const DevScene &sc, LaneRay &r, LdsUint2 *ldsStack, u
 MTS_DEV bool testRecord(LaneRay &r, const float4 r0, const float4 r1, const float4 r2, bool enabled) {
     float t, u, v;
     // global triangle index in bits 0..27, BSDF type of its material in bits 28..30 (carried along for the shading kernel)
-    const uint32_t tri = __float_as_uint(r2.z) | __float_as_uint(r2.w);
+    const uint32_t tri = __float_as_uint(r2.z);
     const bool inside = triTest(r0, r1, r2, r.o, r.d, r.mint, r.maxt, t, u, v);
     // (without a hit so far hit.t is infinite and hit.tri all ones: the tie rule cannot fire)
     const bool accept = enabled & inside & !((t == r.hit.t) & ((tri & kTriIndexMask) >= (r.hit.tri & kTriIndexMask)));
@@ -285,7 +286,10 @@ MTS_DEV bool testRecord(LaneRay &r, const float4 r0, const float4 r1, const floa
 
 // (non-temporal loads of the records were measured: the closest-hit kernel half as slow again -- it lives on the caches)
 MTS_DEV void loadTriangle(const float4 *tp, float4 &r0, float4 &r1, float4 &r2) {
-    r0 = tp[0]; r1 = tp[1]; r2 = tp[2];
+    // 44 of the record's 48 bytes: the last word is not used
+    r0 = tp[0]; r1 = tp[1];
+    const float3 last = *reinterpret_cast<const float3 *>(tp + 2);
+    r2 = make_float4(last.x, last.y, last.z, 0.0f);
 }
 
 // Tests the next triangle record of the lane's triangle group. Returns true when a hit was accepted.

@@ -718,7 +718,8 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         }
     }
     if (d->n_materials >= (1u << 24)) return "too many materials";
-    for (TriRecord &r : hs.bvh.tris) r.pad = (uint32_t) std::min(hs.materials[hs.shapes[hs.triShape[r.tri]].material].type, 7) << 28;
+    // the BSDF type of a triangle's material travels in the top bits of the record's triangle word (the traversal hands it on with the hit)
+    for (TriRecord &r : hs.bvh.tris) r.tri |= (uint32_t) std::min(hs.materials[hs.shapes[hs.triShape[r.tri]].material].type, 7) << 28;
 
     // ---- scalar parameters -------------------------------------------------------------------------------------
     DevScene &p = hs.params;

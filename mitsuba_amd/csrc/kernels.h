@@ -958,15 +958,15 @@ __global__ void __launch_bounds__(256) k_film_tiled(DevScene sc, PassParams pp, 
 }
 
 // After a device-side BVH build: every triangle record learns the BSDF type of its triangle's material (bits 28..30 of
-// the spare word), which the traversal hands on with the hit. The host-built path does the same on the host.
+// its triangle word), which the traversal hands on with the hit. The host-built path does the same on the host.
 __global__ void k_tag_triangle_records(float4 *tris, uint32_t triStride, uint32_t n, const float4 *shadeTris, const DevMaterial *materials) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float4 *rec = tris + (size_t) triStride * i;
-    const uint32_t tri = __float_as_uint(rec[2].z);
+    const uint32_t tri = __float_as_uint(rec[2].z) & kTriIndexMask;
     const uint32_t mat = __float_as_uint(shadeTris[kShadeTriStride * (size_t) tri].w) & 0xffffffu;
     const int type = materials[mat].type;
-    rec[2].w = __uint_as_float((uint32_t) (type < 7 ? type : 7) << 28);      // mixtures share the last sorting key
+    rec[2].z = __uint_as_float(tri | ((uint32_t) (type < 7 ? type : 7) << 28));      // mixtures share the last sorting key
 }
 
 // ---- batch kernels behind the parity entry points -------------------------------------------------------------------------
