@@ -11,10 +11,10 @@ if [ "${2:-}" = "tests" ]; then
   tail -1 gpurun_out/${tag}_tests.log
 fi
 rm -rf gpurun_out/${tag}_stats
-timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_stats --output-format csv -- python3 bench.py --no-cpu-baseline > gpurun_out/${tag}_stats.log 2>&1 || { tail -5 gpurun_out/${tag}_stats.log; exit 1; }
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-extra-workloads > gpurun_out/${tag}_stats.log 2>&1 || { tail -5 gpurun_out/${tag}_stats.log; exit 1; }
 cp $(find gpurun_out/${tag}_stats -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_kernel_stats.csv
 rm -rf gpurun_out/${tag}_stats
-BENCH="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline"
+BENCH="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-extra-workloads"
 groups=(
   "FETCH_SIZE"
   "WRITE_SIZE"
