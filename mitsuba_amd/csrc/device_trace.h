@@ -58,6 +58,19 @@ MTS_DEV bool rayInterval(const DevScene &sc, V3 o, V3 d, float rayMint, float ra
     return maxt > mint;
 }
 
+// Three-input bit operations (full rate, where compares and conditional moves run at half rate): (a & m) | (b & ~m),
+// and a | b | c. Written out because the compiler turns the first back into a conditional move and the second into v_or3_b32.
+MTS_DEV uint32_t bitSelect(uint32_t m, uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xca" : "=v"(d) : "v"(m), "v"(a), "v"(b));
+    return d;
+}
+MTS_DEV uint32_t bitOr3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xfe" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // The reference's projection test on a precomputed triangle record, same operation order, no contraction. Written
 // without early exits so that the three loads of the record are issued together and the wave takes no branches;
 // a degenerate record (k == 3) computes garbage that the final predicate rejects.
@@ -68,12 +81,12 @@ MTS_DEV bool triTest(const float4 r0, const float4 r1, const float4 r2, V3 o, V3
     const float n_u = r0.y, n_v = r0.z, n_d = r0.w;
     const float a_u = r1.x, a_v = r1.y, b_nu = r1.z, b_nv = r1.w;
     const float c_nu = r2.x, c_nv = r2.y;
-    const float o_u = k == 0 ? o.y : (k == 1 ? o.z : o.x);
-    const float o_v = k == 0 ? o.z : (k == 1 ? o.x : o.y);
-    const float o_k = k == 0 ? o.x : (k == 1 ? o.y : o.z);
-    const float d_u = k == 0 ? d.y : (k == 1 ? d.z : d.x);
-    const float d_v = k == 0 ? d.z : (k == 1 ? d.x : d.y);
-    const float d_k = k == 0 ? d.x : (k == 1 ? d.y : d.z);
+    // the ray's components in the record's (u, v, k) order, picked with bit masks (all ones for k == 0, for k == 1)
+    const uint32_t m0 = (uint32_t) ((int) (k - 1u) >> 31), m1 = (uint32_t) ((int) ((k ^ 1u) - 1u) >> 31);
+#define MTS_PICK3(a0, a1, a2) __uint_as_float(bitSelect(m0, __float_as_uint(a0), bitSelect(m1, __float_as_uint(a1), __float_as_uint(a2))))
+    const float o_u = MTS_PICK3(o.y, o.z, o.x), o_v = MTS_PICK3(o.z, o.x, o.y), o_k = MTS_PICK3(o.x, o.y, o.z);
+    const float d_u = MTS_PICK3(d.y, d.z, d.x), d_v = MTS_PICK3(d.z, d.x, d.y), d_k = MTS_PICK3(d.x, d.y, d.z);
+#undef MTS_PICK3
     t = (n_d - o_u * n_u - o_v * n_v - o_k) / (d_u * n_u + d_v * n_v + d_k);
     const float hu = o_u + t * d_u - a_u;
     const float hv = o_v + t * d_v - a_v;
@@ -189,6 +202,9 @@ MTS_DEV const float4 *triRecord(const DevScene &sc, const LaneRay &r, uint32_t b
 }
 
 // mask = 2 * mask + (a <= b): the comparison's lane mask goes straight into the carry input of an add
+#ifndef MTS_VISIT_SIGNS
+#define MTS_VISIT_SIGNS 1
+#endif
 #ifndef MTS_VISIT_ADDC
 #define MTS_VISIT_ADDC 1
 #endif
@@ -225,20 +241,25 @@ MTS_DEV uint32_t visitNode(const DevScene &sc, LaneRay &r, LdsUint2 *ldsStack, u
     const float fpx = apx * kFar, fpy = apy * kFar, fpz = apz * kFar;
     const float fsx = asx * kFar, fsy = asy * kFar, fsz = asz * kFar;
     const float maxtPad = r.maxt * kFar;
-    const bool nx = r.idx < 0, ny = r.idy < 0, nz = r.idz < 0;
+    // all ones where the direction component is negative: there the high plane is the near one
+    const uint32_t nx = (uint32_t) ((int) __float_as_uint(r.idx) >> 31), ny = (uint32_t) ((int) __float_as_uint(r.idy) >> 31),
+                   nz = (uint32_t) ((int) __float_as_uint(r.idz) >> 31);
+#define MTS_PICK(m, a, b) bitSelect(m, a, b)
     // near/far plane bytes per axis, two dwords (children 0-3, 4-7) each
     const uint32_t lox0 = __float_as_uint(n2.x), lox1 = __float_as_uint(n2.y), loy0 = __float_as_uint(n2.z), loy1 = __float_as_uint(n2.w);
     const uint32_t loz0 = __float_as_uint(n3.x), loz1 = __float_as_uint(n3.y), hix0 = __float_as_uint(n3.z), hix1 = __float_as_uint(n3.w);
     const uint32_t hiy0 = __float_as_uint(n4.x), hiy1 = __float_as_uint(n4.y), hiz0 = __float_as_uint(n4.z), hiz1 = __float_as_uint(n4.w);
-    const uint32_t nearx[2] = { nx ? hix0 : lox0, nx ? hix1 : lox1 }, farx[2] = { nx ? lox0 : hix0, nx ? lox1 : hix1 };
-    const uint32_t neary[2] = { ny ? hiy0 : loy0, ny ? hiy1 : loy1 }, fary[2] = { ny ? loy0 : hiy0, ny ? loy1 : hiy1 };
-    const uint32_t nearz[2] = { nz ? hiz0 : loz0, nz ? hiz1 : loz1 }, farz[2] = { nz ? loz0 : hiz0, nz ? loz1 : hiz1 };
+    const uint32_t nearx[2] = { MTS_PICK(nx, hix0, lox0), MTS_PICK(nx, hix1, lox1) }, farx[2] = { MTS_PICK(nx, lox0, hix0), MTS_PICK(nx, lox1, hix1) };
+    const uint32_t neary[2] = { MTS_PICK(ny, hiy0, loy0), MTS_PICK(ny, hiy1, loy1) }, fary[2] = { MTS_PICK(ny, loy0, hiy0), MTS_PICK(ny, loy1, hiy1) };
+    const uint32_t nearz[2] = { MTS_PICK(nz, hiz0, loz0), MTS_PICK(nz, hiz1, loz1) }, farz[2] = { MTS_PICK(nz, loz0, hiz0), MTS_PICK(nz, loz1, hiz1) };
+#undef MTS_PICK
 
     const Float2 asx2 = { asx, asx }, apx2 = { apx, apx }, fsx2 = { fsx, fsx }, fpx2 = { fpx, fpx };
     const Float2 asy2 = { asy, asy }, apy2 = { apy, apy }, fsy2 = { fsy, fsy }, fpy2 = { fpy, fpy };
     const Float2 asz2 = { asz, asz }, apz2 = { apz, apz }, fsz2 = { fsz, fsz }, fpz2 = { fpz, fpz };
     // (gathering the bits in two or four independent compare chains instead of one was measured: no faster)
     uint32_t hitSlots = 0;      // bit s: the box in slot s is entered within [mint, maxt]
+    uint32_t missSlots = 0;     // (MTS_VISIT_SIGNS: the complement is gathered)
 #pragma unroll
     for (int h = 1; h >= 0; --h) {
 #pragma unroll
@@ -249,13 +270,26 @@ MTS_DEV uint32_t visitNode(const DevScene &sc, LaneRay &r, LdsUint2 *ldsStack, u
             const Float2 tx0 = __builtin_elementwise_fma(qx0, asx2, apx2), tx1 = __builtin_elementwise_fma(qx1, fsx2, fpx2);
             const Float2 ty0 = __builtin_elementwise_fma(qy0, asy2, apy2), ty1 = __builtin_elementwise_fma(qy1, fsy2, fpy2);
             const Float2 tz0 = __builtin_elementwise_fma(qz0, asz2, apz2), tz1 = __builtin_elementwise_fma(qz1, fsz2, fpz2);
+#if MTS_VISIT_SIGNS
+            // entered within [mint, maxt]  <=>  none of (far - near), (maxt - near), (far - mint) is negative: the sign
+            // bits of the three differences (a difference of two floats is negative exactly when the second is larger),
+            // ORed, go into the mask as a "missed" bit -- subtractions and bit operations run at twice the rate of compares
+            const float tnB = fmaxf(fmaxf(tx0.y, ty0.y), tz0.y), tfB = fminf(fminf(tx1.y, ty1.y), tz1.y);
+            const float tnA = fmaxf(fmaxf(tx0.x, ty0.x), tz0.x), tfA = fminf(fminf(tx1.x, ty1.x), tz1.x);
+            const uint32_t sB = bitOr3(__float_as_uint(tfB - tnB), __float_as_uint(maxtPad - tnB), __float_as_uint(tfB - r.mint));
+            const uint32_t sA = bitOr3(__float_as_uint(tfA - tnA), __float_as_uint(maxtPad - tnA), __float_as_uint(tfA - r.mint));
+            missSlots = __builtin_amdgcn_alignbit(missSlots, sB, 31);
+            missSlots = __builtin_amdgcn_alignbit(missSlots, sA, 31);
+#else
             const float tnB = fmaxf(fmaxf(tx0.y, ty0.y), fmaxf(tz0.y, r.mint)), tfB = fminf(fminf(tx1.y, ty1.y), fminf(tz1.y, maxtPad));
             const float tnA = fmaxf(fmaxf(tx0.x, ty0.x), fmaxf(tz0.x, r.mint)), tfA = fminf(fminf(tx1.x, ty1.x), fminf(tz1.x, maxtPad));
             shiftInLessEqual(hitSlots, tnB, tfB);
             shiftInLessEqual(hitSlots, tnA, tfA);
+#endif
         }
     }
 
+    if (MTS_VISIT_SIGNS) hitSlots = ~missSlots & 0xffu;
     const uint32_t leafTris = __float_as_uint(n1.z);        // bit 3s + j: slot s is a leaf with more than j triangles
     const uint32_t triMask = tripleBits8(hitSlots) & leafTris;
     const uint32_t childPending = xorPermute8(hitSlots & imask, r.oct);
