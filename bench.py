@@ -325,7 +325,7 @@ def main():
         records_per_s = (nodes_per_ray + tris_per_ray) * wave_rays / launches / (avg_ms * 1e-3)
         micro = RECORD_GATHER_GRS["l2"] if structure <= (4 << 20) else RECORD_GATHER_GRS["8MB"] if structure <= (16 << 20) else RECORD_GATHER_GRS["58MB"]
         out["roofline"] = {"kernel": "k_trace<TRACE_CLOSEST> (extend)",
-                           "bound": "cache hierarchy (vector-memory pipeline of the CUs: texture addresser 80 % busy, L1 99 % active; not HBM, not MFMA)",
+                           "bound": "latency of dependent 16-byte fetches through L1 / L2 with the vector ALUs nearly full (not HBM, not MFMA): +13 % vector instructions cost 5 %, a fifth fewer node loads or a sixth wavefront per SIMD change nothing, one wavefront fewer costs 5 %",
                            "record_rate": {"achieved_Grecords_s": records_per_s / 1e9,
                                            "uniform_random_80B_records_Grecords_s": RECORD_GATHER_GRS,
                                            "frac_of_uniform_random_at_this_structure_size": records_per_s / 1e9 / micro,
