@@ -103,8 +103,12 @@ typedef struct {
     /* Textured roughness of roughconductor and roughdielectric (a <texture> child named alpha, or alphaU / alphaV): 1-based
        texture indices, 0 = the constants alpha_u / alpha_v. The BSDF takes `m_alphaU->eval(bRec.its).average()` at every
        query (src/bsdfs/roughconductor.cpp:257-270, src/bsdfs/roughdielectric.cpp:296-316), with the texture's own
-       colours and scale (no energy-conservation factor). roughplastic is not taken with a textured roughness: it would
-       need the whole three-dimensional transmittance table instead of its slice at one roughness. */
+       colours and scale (no energy-conservation factor). roughplastic (one texture: alpha_u_texture == alpha_v_texture,
+       roughplastic.cpp:336-341) then needs `rtrans` to be the block of mtsamd_rtrans_reduce_eta instead of the
+       one-dimensional table: transmittances are looked up at the textured roughness (rtrans.h:195-205, 254-259);
+       rtrans_diffuse_ext / rtrans_diffuse_int are not used. The texture's values must lie inside the table's roughness
+       range (RoughTransmittance::checkAlpha, rtrans.h:400-407): checked for procedural textures at scene creation,
+       not for bitmaps (a value outside gives a transmittance of 0, as the reference's lookup does). */
     int32_t alpha_u_texture, alpha_v_texture;
 } mtsamd_material;
 enum { MTSAMD_FRAME_NONE = 0, MTSAMD_FRAME_BUMPMAP = 1, MTSAMD_FRAME_NORMALMAP = 2 };
@@ -416,6 +420,14 @@ int mtsamd_rng_stream(uint32_t seed, uint64_t key, uint32_t n, float *out);
    *theta_samples floats (capacity out_cap). */
 int mtsamd_rtrans_reduce(const void *dat, uint64_t size, float eta, float alpha, float *out_T, uint32_t out_cap,
                          uint32_t *theta_samples, float *diffuse_ext, float *diffuse_int);
+/* The same file reduced only to the material's relative index of refraction (setEta, rtrans.h:292-345), for a
+   roughplastic whose roughness is a texture (RoughPlastic::configure with a non-constant alpha, roughplastic.cpp:281-299:
+   the exterior copy stays two-dimensional, and both copies answer evalDiffuse(alpha) from a table over alpha). out
+   receives *n floats (capacity out_cap; *n is set even when the capacity is too small):
+   thetaSamples, alphaSamples, alphaMin, alphaMax, then T[alpha][theta] of the exterior copy, then the diffuse
+   transmittance over alpha of the exterior and of the interior (1 / eta) copy. This block is what
+   mtsamd_material.rtrans points to for such a material. */
+int mtsamd_rtrans_reduce_eta(const void *dat, uint64_t size, float eta, float *out, uint32_t out_cap, uint32_t *n);
 
 /* A measured spectrum (n wavelength [nm] / value pairs, wavelengths increasing) to linear Rec. 709 RGB, as the
    three-sample build of the reference converts the data/ior/<material>.{eta,k}.spd presets: product with the CIE 1931

@@ -110,7 +110,7 @@ EXPORTS = ["mtsamd_last_error", "mtsamd_init", "mtsamd_scene_create", "mtsamd_sc
            "mtsamd_render", "mtsamd_render_device", "mtsamd_cancel", "mtsamd_scene_set_counting", "mtsamd_film_develop", "mtsamd_trace", "mtsamd_trace_device", "mtsamd_occluded_device",
            "mtsamd_occluded", "mtsamd_intersect", "mtsamd_bsdf_eval", "mtsamd_bsdf_pdf", "mtsamd_bsdf_sample",
            "mtsamd_sample_emitter_direct", "mtsamd_camera_rays", "mtsamd_li", "mtsamd_film_put", "mtsamd_film_develop_ldr", "mtsamd_abi_version", "mtsamd_sizeof", "mtsamd_filter_table", "mtsamd_rng_stream",
-           "mtsamd_rtrans_reduce", "mtsamd_filter_gaussian", "mtsamd_filter_box", "mtsamd_bvh_host_info", "mtsamd_bvh_max_depth",
+           "mtsamd_rtrans_reduce", "mtsamd_rtrans_reduce_eta", "mtsamd_filter_gaussian", "mtsamd_filter_box", "mtsamd_bvh_host_info", "mtsamd_bvh_max_depth",
            "mtsamd_trace_device_static", "mtsamd_trace_device_static_max", "mtsamd_render_multi", "mtsamd_spd_to_rgb",
            "mtsamd_spd_file_to_rgb", "mtsamd_bsdf_query_uv", "mtsamd_texture_eval", "mtsamd_image_load", "mtsamd_image_free", "mtsamd_env_eval",
            "mtsamd_spectrum_value_to_rgb", "mtsamd_spectrum_file_to_rgb", "mtsamd_blackbody_to_rgb"]
@@ -531,6 +531,15 @@ def rtrans_reduce(dat: bytes, eta, alpha):
     _check(lib().mtsamd_rtrans_reduce(dat, C.c_uint64(len(dat)), C.c_float(eta), C.c_float(alpha), _fp(out), 256,
                                       C.byref(n), C.byref(de), C.byref(di)))
     return out[:n.value].copy(), de.value, di.value
+
+
+def rtrans_reduce_eta(dat: bytes, eta):
+    """The table a roughplastic with a TEXTURED roughness needs (mtsamd_rtrans_reduce_eta): one float32 block
+    [thetaSamples, alphaSamples, alphaMin, alphaMax, T[alpha][theta], diffuse exterior [alpha], diffuse interior [alpha]]."""
+    n = C.c_uint32()
+    out = np.zeros(1 << 16, np.float32)
+    _check(lib().mtsamd_rtrans_reduce_eta(dat, C.c_uint64(len(dat)), C.c_float(eta), _fp(out), C.c_uint32(out.size), C.byref(n)))
+    return out[:n.value].copy()
 
 
 def filter_gaussian(stddev=0.5):

@@ -71,6 +71,17 @@ static void describe(const LoadedScene &s) {
         printf("%s[%d, %d, %d]", i ? ", " : "", s.materials[i].diffuse_texture, s.materials[i].specular_texture, s.materials[i].transmittance_texture);
     printf("], \"alpha_textures\": [");
     for (size_t i = 0; i < s.materials.size(); ++i) printf("%s[%d, %d]", i ? ", " : "", s.materials[i].alpha_u_texture, s.materials[i].alpha_v_texture);
+    printf("], \"rtrans_tables\": [");       // per material: entries of its rough-transmittance table and their sum
+    for (size_t i = 0, table = 0; i < s.materials.size(); ++i) {       // (tables belong to the roughplastic records, in their order)
+        double sum = 0;
+        uint32_t n = 0;
+        if (s.materials[i].type == MTSAMD_BSDF_ROUGHPLASTIC && table < s.rtransTables.size()) {
+            n = s.materials[i].rtrans_n;
+            for (uint32_t k = 0; k < n && k < s.rtransTables[table].size(); ++k) sum += s.rtransTables[table][k];
+            ++table;
+        }
+        printf("%s[%u, %.9g]", i ? ", " : "", n, sum);
+    }
     printf("], \"envmaps\": [");
     bool firstEnv = true;
     for (size_t i = 0; i < s.emitters.size(); ++i) {

@@ -396,11 +396,13 @@ void attachTextures(const Element &node, LoadedScene &out, mtsamd_material &m) {
         const bool usesDiffuse = m.type == MTSAMD_BSDF_DIFFUSE || m.type == MTSAMD_BSDF_ROUGHPLASTIC || m.type == MTSAMD_BSDF_PLASTIC || m.type == MTSAMD_BSDF_WARD;
         const bool usesTransmittance = m.type == MTSAMD_BSDF_DIELECTRIC || m.type == MTSAMD_BSDF_ROUGHDIELECTRIC;
         const bool usesRoughnessTexture = m.type == MTSAMD_BSDF_ROUGHCONDUCTOR || m.type == MTSAMD_BSDF_ROUGHDIELECTRIC;
+        // roughplastic.cpp:218: one isotropic roughness; its transmittance table was kept two-dimensional by makeBsdf
+        const bool plasticRoughness = m.type == MTSAMD_BSDF_ROUGHPLASTIC && name == "alpha";
         if (diffuseName && usesDiffuse) m.diffuse_texture = (int32_t) index;
         else if (name == "specularReflectance" && m.type != MTSAMD_BSDF_DIFFUSE) m.specular_texture = (int32_t) index;
         else if (name == "specularTransmittance" && usesTransmittance) m.transmittance_texture = (int32_t) index;
         // roughconductor.cpp:207-221, roughdielectric.cpp:224-243: alpha sets both directions
-        else if (name == "alpha" && usesRoughnessTexture) m.alpha_u_texture = m.alpha_v_texture = (int32_t) index;
+        else if (name == "alpha" && (usesRoughnessTexture || plasticRoughness)) m.alpha_u_texture = m.alpha_v_texture = (int32_t) index;
         else if (name == "alphaU" && usesRoughnessTexture) m.alpha_u_texture = (int32_t) index;
         else if (name == "alphaV" && usesRoughnessTexture) m.alpha_v_texture = (int32_t) index;
         else throw Fail("a texture for the parameter '" + name + "' of <bsdf type=\"" + node.get("type") + "\"> is not supported");
@@ -583,11 +585,22 @@ mtsamd_material makeBsdf(const Element &node, const LoadOptions &opts, LoadedSce
         std::vector<uint8_t> dat;
         const std::string path = opts.dataDir + "/microfacet/" + distr + ".dat";
         if (!readFile(path, dat)) throw Fail("cannot read " + path);
-        out.rtransTables.emplace_back(512);
+        bool texturedAlpha = false;     // <texture name="alpha"> or <ref name="alpha">: the roughness is looked up per intersection
+        for (const auto &c : node.children) texturedAlpha |= (c->tag == "texture" || c->tag == "ref") && c->get("name") == "alpha";
         uint32_t n = 0;
-        if (mtsamd_rtrans_reduce(dat.data(), dat.size(), m.int_ior / m.ext_ior, m.alpha_u, out.rtransTables.back().data(), 512, &n,
-                                 &m.rtrans_diffuse_ext, &m.rtrans_diffuse_int) != MTSAMD_OK)
-            throw Fail(mtsamd_last_error());
+        if (texturedAlpha) {
+            // the table stays a function of the roughness (RoughPlastic::configure without setAlpha, roughplastic.cpp:281-299)
+            out.rtransTables.emplace_back(1);
+            (void) mtsamd_rtrans_reduce_eta(dat.data(), dat.size(), m.int_ior / m.ext_ior, out.rtransTables.back().data(), 0, &n);    // asks for the size
+            out.rtransTables.back().assign(std::max<uint32_t>(n, 1), 0.0f);
+            if (n == 0 || mtsamd_rtrans_reduce_eta(dat.data(), dat.size(), m.int_ior / m.ext_ior, out.rtransTables.back().data(), n, &n) != MTSAMD_OK)
+                throw Fail("cannot reduce " + path + " to the material's index of refraction");
+        } else {
+            out.rtransTables.emplace_back(512);
+            if (mtsamd_rtrans_reduce(dat.data(), dat.size(), m.int_ior / m.ext_ior, m.alpha_u, out.rtransTables.back().data(), 512, &n,
+                                     &m.rtrans_diffuse_ext, &m.rtrans_diffuse_int) != MTSAMD_OK)
+                throw Fail(mtsamd_last_error());
+        }
         m.rtrans_n = n;     // the pointer is set in desc(), once the table storage no longer moves
     } else if (type == "roughdielectric") {     // src/bsdfs/roughdielectric.cpp:183-211
         m.type = MTSAMD_BSDF_ROUGHDIELECTRIC;

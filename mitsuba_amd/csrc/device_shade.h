@@ -174,11 +174,60 @@ MTS_DEV float evalCubicInterp1D01(float x, const float *values, uint32_t size) {
     return (2 * t3 - 3 * t2 + 1) * f0 + (-2 * t3 + 3 * t2) * f1 + (t3 - 2 * t2 + t) * d0 + (t3 - t2) * d1;
 }
 
-// RoughTransmittance::eval in its fully reduced state (src/bsdfs/rtrans.h:183-194,233)
+// One dimension of evalCubicInterp2D on [0,1] (src/libcore/spline.cpp:242-287): the knot and the four node weights
+// around it, derivative stencils folded in. False outside [0,1].
+MTS_DEV bool cubicWeights01(float p, uint32_t size, float (&w)[4], uint32_t &knot) {
+    if (!(p >= 0.0f && p <= 1.0f)) return false;
+    float t = ((p - 0.0f) * (float) (size - 1)) / (1.0f - 0.0f);
+    knot = (uint32_t) t;
+    if (knot > size - 2) knot = size - 2;
+    t = t - (float) knot;
+    const float t2 = t * t, t3 = t2 * t;
+    w[0] = 0.0f; w[1] = 2 * t3 - 3 * t2 + 1; w[2] = -2 * t3 + 3 * t2; w[3] = 0.0f;
+    const float d0 = t3 - 2 * t2 + t, d1 = t3 - t2;
+    if (knot > 0) { w[2] += 0.5f * d0; w[0] -= 0.5f * d0; } else { w[2] += d0; w[1] -= d0; }
+    if (knot + 2 < size) { w[3] += 0.5f * d1; w[1] -= 0.5f * d1; } else { w[2] += d1; w[1] -= d1; }
+    return true;
+}
+// evalCubicInterp2D on [0,1]^2 (spline.cpp:236-304); values[y * sx + x]
+MTS_DEV float evalCubicInterp2D01(float px, float py, const float *values, uint32_t sx, uint32_t sy) {
+    float wx[4], wy[4];
+    uint32_t kx, ky;
+    if (!cubicWeights01(px, sx, wx, kx)) return 0.0f;
+    if (!cubicWeights01(py, sy, wy, ky)) return 0.0f;
+    float result = 0.0f;
+    for (int y = -1; y <= 2; ++y)
+        for (int x = -1; x <= 2; ++x) {
+            const float wxy = wx[x + 1] * wy[y + 1];
+            if (wxy == 0) continue;     // (the nodes beyond the table's edge carry zero weight)
+            result += values[(size_t) ((int) ky + y) * sx + (size_t) ((int) kx + x)] * wxy;
+        }
+    return result;
+}
+
+// A roughplastic whose roughness is a texture keeps the transmittance table two-dimensional (variant bit 1): the block
+// thetaSamples, alphaSamples, alphaMin, alphaMax, T[alpha][theta], diffuse exterior [alpha], diffuse interior [alpha]
+MTS_DEV bool rtransTextured(const DevMaterial &m) { return (m.variant & 2) != 0; }
+// (the roughness as the microfacet distribution keeps it: distr.getAlpha(), clamped from below, microfacet.h:67-74)
+MTS_DEV float rtransWarpedAlpha(const float *block, float alpha) { return powM((fmaxf(alpha, 1e-4f) - block[2]) / (block[3] - block[2]), 0.25f); }
+
+// RoughTransmittance::eval with the index of refraction fixed: fully reduced (src/bsdfs/rtrans.h:183-194,233) or, for
+// a textured roughness, still a function of alpha (rtrans.h:195-205); m.alphaU is the roughness at this intersection
 MTS_DEV float rtransEval(const DevScene &sc, const DevMaterial &m, float cosTheta) {
     const float warped = powM(fabsf(cosTheta), 0.25f);
     if (!(cosTheta >= 0)) return 0.f;
-    const float result = evalCubicInterp1D01(warped, sc.rtrans + m.rtransOffset, m.rtransN);
+    const float *table = sc.rtrans + m.rtransOffset;
+    float result;
+    if (rtransTextured(m)) result = evalCubicInterp2D01(warped, rtransWarpedAlpha(table, m.alphaU), table + 4, (uint32_t) table[0], (uint32_t) table[1]);
+    else result = evalCubicInterp1D01(warped, table, m.rtransN);
+    return fminf(1.0f, fmaxf(0.0f, result));
+}
+// m_internalRoughTransmittance->evalDiffuse(alpha) (rtrans.h:249-259)
+MTS_DEV float rtransDiffuseInterior(const DevScene &sc, const DevMaterial &m) {
+    if (!rtransTextured(m)) return m.fdrInt;
+    const float *table = sc.rtrans + m.rtransOffset;
+    const uint32_t nTheta = (uint32_t) table[0], nAlpha = (uint32_t) table[1];
+    const float result = evalCubicInterp1D01(rtransWarpedAlpha(table, m.alphaU), table + 4 + nTheta * nAlpha + nAlpha, nAlpha);
     return fminf(1.0f, fmaxf(0.0f, result));
 }
 
@@ -407,8 +456,8 @@ MTS_DEV V3 bsdfEval(const DevScene &sc, const DevMaterial &m, V3 wi, V3 wo) {
                 V3 d = diff;
                 const float T12 = rtransEval(sc, m, wi.z);
                 const float T21 = rtransEval(sc, m, wo.z);
-                const float Fdr = 1 - m.fdrInt;
-                if (m.variant) d = d / (mk(1.0f) - d * Fdr);
+                const float Fdr = 1 - rtransDiffuseInterior(sc, m);
+                if (m.variant & 1) d = d / (mk(1.0f) - d * Fdr);
                 else d = d / (1 - Fdr);
                 result = result + d * (kInvPi * wo.z * T12 * T21 * m.invEta2);
             }

@@ -249,8 +249,10 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
         // roughness textures (roughconductor.cpp:228-250, roughdielectric.cpp:245-274): evaluated per query; they count
         // for the anisotropy flag and for usesRayDifferentials like the colours
         if (m.alpha_u_texture || m.alpha_v_texture) {
-            if (m.type != MTSAMD_BSDF_ROUGHCONDUCTOR && m.type != MTSAMD_BSDF_ROUGHDIELECTRIC)
-                return "a textured roughness is supported for roughconductor and roughdielectric only (roughplastic would need the whole transmittance table)";
+            if (m.type != MTSAMD_BSDF_ROUGHCONDUCTOR && m.type != MTSAMD_BSDF_ROUGHDIELECTRIC && m.type != MTSAMD_BSDF_ROUGHPLASTIC)
+                return "a textured roughness is supported for roughconductor, roughdielectric and roughplastic only";
+            if (m.type == MTSAMD_BSDF_ROUGHPLASTIC && m.alpha_u_texture != m.alpha_v_texture)
+                return "The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!";
             for (int32_t t : { m.alpha_u_texture, m.alpha_v_texture }) {
                 if (t < 0 || (uint32_t) t > d->n_textures || (t && !d->textures)) return "roughness texture index out of range";
                 if (t && d->textures[t - 1].type == MTSAMD_TEX_BITMAP) wantsPartials[i] = 1;       // bitmap.cpp:541-543
@@ -287,6 +289,22 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
                 if (m.alpha_u != m.alpha_v)
                     return "The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!";
                 if (!m.rtrans || m.rtrans_n < 2) return "roughplastic needs the reduced rough transmittance table";
+                if (m.alpha_u_texture) {
+                    // textured roughness: the table stays two-dimensional (the block of mtsamd_rtrans_reduce_eta)
+                    if (m.rtrans_n < 4) return "roughplastic with a textured roughness needs the transmittance table reduced to its index of refraction only";
+                    const float nTheta = m.rtrans[0], nAlpha = m.rtrans[1], aMin = m.rtrans[2], aMax = m.rtrans[3];
+                    if (!(nTheta >= 2 && nAlpha >= 2 && nTheta <= 4096 && nAlpha <= 4096 && aMax > aMin) ||
+                        (uint64_t) m.rtrans_n != 4 + (uint64_t) nTheta * (uint64_t) nAlpha + 2 * (uint64_t) nAlpha)
+                        return "roughplastic with a textured roughness: malformed two-dimensional transmittance table";
+                    // RoughTransmittance::checkAlpha on the texture's extremes (roughplastic.cpp:287-288, rtrans.h:400-407)
+                    const mtsamd_texture &tx = d->textures[m.alpha_u_texture - 1];
+                    if (tx.type != MTSAMD_TEX_BITMAP) {
+                        for (const float *c : { tx.color0, tx.color1 }) {
+                            const float avg = ((c[0] + c[1]) + c[2]) * (1.0f / 3.0f) * tx.scale;
+                            if (avg < aMin || avg > aMax) return "roughplastic: the roughness texture leaves the range of the transmittance table";
+                        }
+                    }
+                }
                 ensureEnergy(ee, spec);
                 ensureEnergy(ee, diff);
                 dm.eta = m.int_ior / m.ext_ior;
@@ -294,6 +312,7 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
                 float dAvg = averageLuminance(diff), sAvg = averageLuminance(spec);
                 dm.specSamplingWeight = sAvg / (dAvg + sAvg);
                 dm.fdrInt = m.rtrans_diffuse_int;
+                dm.variant = (m.variant ? 1 : 0) | (m.alpha_u_texture ? 2 : 0);     // nonlinear; two-dimensional table
                 dm.rtransOffset = (uint32_t) hs.rtrans.size();
                 dm.rtransN = m.rtrans_n;
                 hs.rtrans.insert(hs.rtrans.end(), m.rtrans, m.rtrans + m.rtrans_n);

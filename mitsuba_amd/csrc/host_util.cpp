@@ -75,33 +75,28 @@ float cubic3D(float px, float py, float pz, const float *v, size_t sx, size_t sy
 
 inline float clamp01(float v) { return std::min(1.0f, std::max(0.0f, v)); }
 
-}  // namespace
+// The image of a data/microfacet/<distribution>.dat file (src/bsdfs/rtrans.h:100-148): magic, 3 x uint64 sample counts,
+// 4 x float ranges, then for each of the 2*etaSamples blocks and each alpha: thetaSamples transmittances followed by
+// one diffuse transmittance
+struct TransmittanceFile {
+    size_t nEta = 0, nAlpha = 0, nTheta = 0;
+    float etaMin = 0, etaMax = 0, alphaMin = 0, alphaMax = 0;
+    std::vector<float> trans, diff;
 
-extern "C" int mtsamd_rtrans_reduce(const void *dat, uint64_t size, float eta, float alpha, float *out_T, uint32_t out_cap,
-                                    uint32_t *theta_samples, float *diffuse_ext, float *diffuse_int) {
-    if (!dat || !out_T || !theta_samples || !diffuse_ext || !diffuse_int) return MTSAMD_EINVAL;
-    // file layout (src/bsdfs/rtrans.h:100-148): magic, 3 x uint64 sample counts, 4 x float ranges, then for each
-    // of the 2*etaSamples blocks and each alpha: thetaSamples transmittances followed by one diffuse transmittance
-    static const char magic[] = "MTS_TRANSMITTANCE";
-    const size_t ml = sizeof(magic) - 1;
-    const uint8_t *p = (const uint8_t *) dat;
-    if (size < ml + 40 || memcmp(p, magic, ml) != 0) return MTSAMD_EINVAL;
-    uint64_t cnt[3];
-    float range[4];
-    memcpy(cnt, p + ml, 24);
-    memcpy(range, p + ml + 24, 16);
-    const size_t nEta = cnt[0], nAlpha = cnt[1], nTheta = cnt[2];
-    const float etaMin = range[0], etaMax = range[1], alphaMin = range[2], alphaMax = range[3];
-    const size_t nT = 2 * nEta * nAlpha * nTheta, nD = 2 * nEta * nAlpha;
-    if (nEta < 2 || nAlpha < 2 || nTheta < 2 || size != ml + 40 + (nT + nD) * 4) return MTSAMD_EINVAL;
-    if (out_cap < nTheta) return MTSAMD_EINVAL;
-    // RoughTransmittance::checkEta / checkAlpha (rtrans.h:390-407)
-    {
-        float e = eta < 1 ? 1 / eta : eta;
-        if (e < etaMin || e > etaMax || alpha < alphaMin || alpha > alphaMax) return MTSAMD_EUNSUPPORTED;
-    }
-    std::vector<float> trans(nT), diff(nD);
-    {
+    int load(const void *dat, uint64_t size) {
+        static const char magic[] = "MTS_TRANSMITTANCE";
+        const size_t ml = sizeof(magic) - 1;
+        const uint8_t *p = (const uint8_t *) dat;
+        if (size < ml + 40 || memcmp(p, magic, ml) != 0) return MTSAMD_EINVAL;
+        uint64_t cnt[3];
+        float range[4];
+        memcpy(cnt, p + ml, 24);
+        memcpy(range, p + ml + 24, 16);
+        nEta = cnt[0]; nAlpha = cnt[1]; nTheta = cnt[2];
+        etaMin = range[0]; etaMax = range[1]; alphaMin = range[2]; alphaMax = range[3];
+        const size_t nT = 2 * nEta * nAlpha * nTheta, nD = 2 * nEta * nAlpha;
+        if (nEta < 2 || nAlpha < 2 || nTheta < 2 || size != ml + 40 + (nT + nD) * 4) return MTSAMD_EINVAL;
+        trans.resize(nT); diff.resize(nD);
         const float *src = (const float *) (p + ml + 40);
         size_t q = 0, a = 0, b = 0;
         std::vector<float> tmp(nT + nD);
@@ -111,9 +106,12 @@ extern "C" int mtsamd_rtrans_reduce(const void *dat, uint64_t size, float eta, f
                 for (size_t k = 0; k < nTheta; ++k) trans[a++] = tmp[q++];
                 diff[b++] = tmp[q++];
             }
+        return MTSAMD_OK;
     }
-    // setEta (rtrans.h:292-345) for the exterior (eta) and interior (1/eta) copies
-    auto sliceEta = [&](float e, std::vector<float> &t2, std::vector<float> &d2) {
+    // RoughTransmittance::checkEta (rtrans.h:390-398)
+    bool etaInRange(float eta) const { const float e = eta < 1 ? 1 / eta : eta; return e >= etaMin && e <= etaMax; }
+    // setEta (rtrans.h:292-345): the slice at one relative index of refraction, [alpha][theta] and [alpha]
+    void sliceEta(float e, std::vector<float> &t2, std::vector<float> &d2) const {
         const float *tr = trans.data(), *dt = diff.data();
         if (e < 1) { tr += nEta * nAlpha * nTheta; dt += nEta * nAlpha; e = 1.0f / e; }
         if (e < etaMin) e = etaMin;
@@ -125,17 +123,50 @@ extern "C" int mtsamd_rtrans_reduce(const void *dat, uint64_t size, float eta, f
                 t2[i * nTheta + j] = cubic3D((float) j * dTheta, (float) i * dAlpha, warpedEta, tr, nTheta, nAlpha, nEta);
             d2[i] = cubic2D((float) i * dAlpha, warpedEta, dt, nAlpha, nEta);
         }
-    };
+    }
+};
+
+}  // namespace
+
+extern "C" int mtsamd_rtrans_reduce(const void *dat, uint64_t size, float eta, float alpha, float *out_T, uint32_t out_cap,
+                                    uint32_t *theta_samples, float *diffuse_ext, float *diffuse_int) {
+    if (!dat || !out_T || !theta_samples || !diffuse_ext || !diffuse_int) return MTSAMD_EINVAL;
+    TransmittanceFile f;
+    const int rc = f.load(dat, size);
+    if (rc != MTSAMD_OK) return rc;
+    if (out_cap < f.nTheta) return MTSAMD_EINVAL;
+    // RoughTransmittance::checkEta / checkAlpha (rtrans.h:390-407)
+    if (!f.etaInRange(eta) || alpha < f.alphaMin || alpha > f.alphaMax) return MTSAMD_EUNSUPPORTED;
+    // setEta for the exterior (eta) and interior (1/eta) copies
     std::vector<float> extT, extD, intT, intD;
-    sliceEta(eta, extT, extD);
-    sliceEta(1 / eta, intT, intD);
+    f.sliceEta(eta, extT, extD);
+    f.sliceEta(1 / eta, intT, intD);
     // setAlpha on the exterior copy (rtrans.h:353-388); evalDiffuse(alpha) on both (rtrans.h:249-259)
-    const float warpedAlpha = std::pow((alpha - alphaMin) / (alphaMax - alphaMin), 0.25f);
-    const float dTheta = 1.0f / (float) (nTheta - 1);
-    for (size_t i = 0; i < nTheta; ++i) out_T[i] = cubic2D((float) i * dTheta, warpedAlpha, extT.data(), nTheta, nAlpha);
-    *theta_samples = (uint32_t) nTheta;
-    *diffuse_ext = clamp01(cubic1D(warpedAlpha, extD.data(), nAlpha));
-    *diffuse_int = clamp01(cubic1D(warpedAlpha, intD.data(), nAlpha));
+    const float warpedAlpha = std::pow((alpha - f.alphaMin) / (f.alphaMax - f.alphaMin), 0.25f);
+    const float dTheta = 1.0f / (float) (f.nTheta - 1);
+    for (size_t i = 0; i < f.nTheta; ++i) out_T[i] = cubic2D((float) i * dTheta, warpedAlpha, extT.data(), f.nTheta, f.nAlpha);
+    *theta_samples = (uint32_t) f.nTheta;
+    *diffuse_ext = clamp01(cubic1D(warpedAlpha, extD.data(), f.nAlpha));
+    *diffuse_int = clamp01(cubic1D(warpedAlpha, intD.data(), f.nAlpha));
+    return MTSAMD_OK;
+}
+
+extern "C" int mtsamd_rtrans_reduce_eta(const void *dat, uint64_t size, float eta, float *out, uint32_t out_cap, uint32_t *n_out) {
+    if (!dat || !out || !n_out) return MTSAMD_EINVAL;
+    TransmittanceFile f;
+    const int rc = f.load(dat, size);
+    if (rc != MTSAMD_OK) return rc;
+    if (!f.etaInRange(eta)) return MTSAMD_EUNSUPPORTED;
+    const size_t n = 4 + f.nAlpha * f.nTheta + 2 * f.nAlpha;
+    *n_out = (uint32_t) n;
+    if (out_cap < n) return MTSAMD_EINVAL;
+    std::vector<float> extT, extD, intT, intD;
+    f.sliceEta(eta, extT, extD);
+    f.sliceEta(1 / eta, intT, intD);
+    out[0] = (float) f.nTheta; out[1] = (float) f.nAlpha; out[2] = f.alphaMin; out[3] = f.alphaMax;
+    memcpy(out + 4, extT.data(), extT.size() * 4);
+    memcpy(out + 4 + extT.size(), extD.data(), f.nAlpha * 4);
+    memcpy(out + 4 + extT.size() + f.nAlpha, intD.data(), f.nAlpha * 4);
     return MTSAMD_OK;
 }
 

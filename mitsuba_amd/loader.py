@@ -398,6 +398,17 @@ def _attach_textures(node, m: Dict, ctx) -> None:
             m["specular_texture"] = index
         elif name == "specularTransmittance" and ty in (S.BSDF_DIELECTRIC, S.BSDF_ROUGHDIELECTRIC):
             m["transmittance_texture"] = index
+        elif name == "alpha" and ty == S.BSDF_ROUGHPLASTIC:
+            # roughplastic.cpp:218,281-299: one isotropic roughness; the transmittance table stays a function of it
+            m["alpha_u_texture"] = m["alpha_v_texture"] = index
+            eta = m["int_ior"] / m["ext_ior"]
+            distr = "ggx" if m["distribution"] == S.DISTR_GGX else "beckmann"
+            if ctx.get("data_dir") is not None:
+                from . import capi
+                dat = open(os.path.join(ctx["data_dir"], "microfacet", distr + ".dat"), "rb").read()
+                m["rtrans"] = capi.rtrans_reduce_eta(dat, eta)
+            else:
+                m["rtrans"] = np.asarray(S.load_rtrans_eta_block(distr, eta), np.float32)
         elif name in ("alpha", "alphaU", "alphaV") and ty in (S.BSDF_ROUGHCONDUCTOR, S.BSDF_ROUGHDIELECTRIC):
             # roughconductor.cpp:207-221, roughdielectric.cpp:224-243: alpha sets both directions
             if name != "alphaV":
@@ -570,7 +581,7 @@ def load_xml(path: str, width: Optional[int] = None, height: Optional[int] = Non
 
     named_records: Dict[str, Dict] = {}
 
-    ctx = dict(base=base, textures=b.textures, named_textures={})
+    ctx = dict(base=base, textures=b.textures, named_textures={}, data_dir=data_dir)
     for el in root:         # textures first: BSDFs refer to them by id
         if el.tag == "texture":
             idx = _make_texture(el, ctx)

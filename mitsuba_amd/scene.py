@@ -267,18 +267,22 @@ def ward(alpha=0.1, diffuse_reflectance=(0.5, 0.5, 0.5), specular_reflectance=(0
 
 def roughplastic(alpha=0.1, distribution="beckmann", int_ior=IOR["polypropylene"], ext_ior=IOR["air"],
                  diffuse_reflectance=(0.5, 0.5, 0.5), specular_reflectance=(1, 1, 1), nonlinear=False,
-                 sample_visible=True, rtrans=None) -> Dict:
+                 sample_visible=True, rtrans=None, alpha_texture=0) -> Dict:
     """src/bsdfs/roughplastic.cpp:197-228. The reduced rough-transmittance table (what
     RoughPlastic::configure derives from data/microfacet/<distr>.dat, roughplastic.cpp:281-299) is
-    looked up in the packaged slices unless given."""
+    looked up in the packaged slices unless given. With `alpha_texture` (what SceneBuilder.add_texture returned) the
+    roughness is that texture's average at every intersection and the table is the two-dimensional block of
+    capi.rtrans_reduce_eta (given as `rtrans`, or looked up in the packaged ones)."""
+    common = dict(type=BSDF_ROUGHPLASTIC, distribution=_distr(distribution), alpha_u=alpha, alpha_v=alpha,
+                  int_ior=int_ior, ext_ior=ext_ior, diffuse_reflectance=tuple(diffuse_reflectance),
+                  specular_reflectance=tuple(specular_reflectance), variant=int(nonlinear), sample_visible=int(sample_visible))
+    if alpha_texture:
+        block = load_rtrans_eta_block(distribution, int_ior / ext_ior) if rtrans is None else rtrans
+        return _mat(rtrans=np.asarray(block, np.float32), alpha_u_texture=int(alpha_texture), alpha_v_texture=int(alpha_texture), **common)
     if rtrans is None:
         rtrans = load_rtrans_slice(distribution, int_ior / ext_ior, alpha)
     T, d_ext, d_int = rtrans
-    return _mat(type=BSDF_ROUGHPLASTIC, distribution=_distr(distribution), alpha_u=alpha, alpha_v=alpha,
-                int_ior=int_ior, ext_ior=ext_ior, diffuse_reflectance=tuple(diffuse_reflectance),
-                specular_reflectance=tuple(specular_reflectance), variant=int(nonlinear),
-                sample_visible=int(sample_visible), rtrans=np.asarray(T, np.float32),
-                rtrans_diffuse_ext=float(d_ext), rtrans_diffuse_int=float(d_int))
+    return _mat(rtrans=np.asarray(T, np.float32), rtrans_diffuse_ext=float(d_ext), rtrans_diffuse_int=float(d_int), **common)
 
 
 def conductor(eta, k, specular_reflectance=(1, 1, 1), ext_eta=IOR["air"]) -> Dict:
@@ -349,6 +353,22 @@ def load_rtrans_slice(distribution, eta, alpha):
                        "with mitsuba_amd.capi.rtrans_reduce()" % key)
     e = _slices[key]
     return np.asarray(e["T"], np.float32), e["diffuse_ext"], e["diffuse_int"]
+
+
+_eta_blocks = None
+
+
+def load_rtrans_eta_block(distribution, eta):
+    """Rough-transmittance tables reduced to an index of refraction only (capi.rtrans_reduce_eta), for the
+    (distribution, eta) combinations the bundled scenes use with a textured roughness (tools/make_golden.py)."""
+    global _eta_blocks
+    if _eta_blocks is None:
+        _eta_blocks = np.load(os.path.join(_DATA_DIR, "rtrans_eta_blocks.npz"))
+    key = "%s_%.6f" % (distribution, eta)
+    if key not in _eta_blocks.files:
+        raise KeyError("no packaged two-dimensional rough-transmittance table for %s; reduce it from the Mitsuba data file "
+                       "with mitsuba_amd.capi.rtrans_reduce_eta()" % key)
+    return _eta_blocks[key]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -754,8 +774,8 @@ def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_
     environment emitter of that radiance next to the two area lights; `lamps` adds a point, a spot and a directional light;
     `blend` makes the ground and two of the blobs mixtures of the other materials; `textured` puts checkerboard and grid
     textures on colours of most materials (meshes with and without texture coordinates, colours above one, a scale
-    texture, two textures in one energy check); `rough_maps` textures the roughness of the rough conductors and of a rough
-    dielectric."""
+    texture, two textures in one energy check); `rough_maps` textures the roughness of the rough conductors, the rough plastics
+    and a rough dielectric."""
     rng = np.random.default_rng(7)
     b = SceneBuilder()
     mats = [b.add_material(diffuse((0.6, 0.5, 0.4))),
@@ -824,6 +844,11 @@ def small_test_scene(width=64, height=48, subdiv=2, max_depth=-1, sky=None, sky_
         M[mats[1]].update(alpha_u_texture=t_check, alpha_v_texture=t_check)
         M[mats[5]].update(alpha_u_texture=t_image)
         mats[3] = b.add_material(dict(roughdielectric(alpha=0.2, distribution="ggx", int_ior=1.5, ext_ior=1.0), alpha_u_texture=t_image, alpha_v_texture=t_image))
+        # the two rough plastics: their transmittance tables stay functions of the roughness (roughplastic.cpp:281-299)
+        M[mats[2]].update(alpha_u_texture=t_image, alpha_v_texture=t_image,
+                          rtrans=np.asarray(load_rtrans_eta_block("ggx", M[mats[2]]["int_ior"] / M[mats[2]]["ext_ior"]), np.float32))
+        M[mats[6]].update(alpha_u_texture=t_check, alpha_v_texture=t_check, variant=1,
+                          rtrans=np.asarray(load_rtrans_eta_block("beckmann", M[mats[6]]["int_ior"] / M[mats[6]]["ext_ior"]), np.float32))
     if blend:
         m_ground = b.add_material(twosided(mixture([m_ground, mats[1]], [0.75, 0.25])))
         mats[0] = b.add_material(mixture([mats[0], mats[2], mats[4]], [0.6, 0.5, 0.4]))      # weights above one: rescaled

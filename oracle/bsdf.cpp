@@ -510,8 +510,10 @@ void Material::configure(const std::vector<Texture> &textures) {
         if (err) throw std::runtime_error(err);
     alphaUTextured = m.alpha_u_texture != 0; alphaVTextured = m.alpha_v_texture != 0;
     if (alphaUTextured || alphaVTextured) {
-        if (m.type != ORC_BSDF_ROUGHCONDUCTOR && m.type != ORC_BSDF_ROUGHDIELECTRIC)
-            throw std::runtime_error("a textured roughness is supported for roughconductor and roughdielectric only");
+        if (m.type != ORC_BSDF_ROUGHCONDUCTOR && m.type != ORC_BSDF_ROUGHDIELECTRIC && m.type != ORC_BSDF_ROUGHPLASTIC)
+            throw std::runtime_error("a textured roughness is supported for roughconductor, roughdielectric and roughplastic only");
+        if (m.type == ORC_BSDF_ROUGHPLASTIC && m.alpha_u_texture != m.alpha_v_texture)
+            throw std::runtime_error("The 'roughplastic' plugin currently does not support anisotropic microfacet distributions!");
         for (int32_t t : { m.alpha_u_texture, m.alpha_v_texture })
             if (t < 0 || (size_t) t > textures.size()) throw std::runtime_error("roughness texture index out of range");
         if (alphaUTextured) alphaUTex = textures[m.alpha_u_texture - 1];
@@ -556,6 +558,13 @@ void Material::configure(const std::vector<Texture> &textures) {
             float dAvg = luminance(diffuse.getAverage()), sAvg = luminance(specular.getAverage());
             specularSamplingWeight = sAvg / (dAvg + sAvg);
             if (m.rtrans && m.rtrans_n) rtrans.assign(m.rtrans, m.rtrans + m.rtrans_n);
+            if (alphaUTextured) {
+                // roughplastic.cpp:281-299 with a non-constant alpha: the exterior table stays two-dimensional; the block is
+                // thetaSamples, alphaSamples, alphaMin, alphaMax, T[alpha][theta], diffuse exterior [alpha], diffuse interior [alpha]
+                if (rtrans.size() < 4 || !(rtrans[0] >= 2 && rtrans[1] >= 2 && rtrans[3] > rtrans[2]) ||
+                    rtrans.size() != 4 + (size_t) rtrans[0] * (size_t) rtrans[1] + 2 * (size_t) rtrans[1])
+                    throw std::runtime_error("roughplastic with a textured roughness: malformed two-dimensional transmittance table");
+            }
             type_flags = EGlossyReflection | EDiffuseReflection | EFrontSide;
             break;
         }
@@ -662,11 +671,26 @@ const char *linkTwoSided(std::vector<Material> &materials) {
     return nullptr;
 }
 
-// ---- RoughTransmittance::eval in the fully reduced (1-D) state (src/bsdfs/rtrans.h:183-194,233) ---
-static float rtransEval(const Material &mat, float cosTheta) {
+// ---- RoughTransmittance::eval with the index of refraction fixed: fully reduced (src/bsdfs/rtrans.h:183-194,233) or,
+//      for a textured roughness, still a function of alpha (rtrans.h:195-205) -----------------------------------------
+static float rtransWarpedAlpha(const Material &mat, float alpha) {
+    return std::pow((alpha - mat.rtrans[2]) / (mat.rtrans[3] - mat.rtrans[2]), 0.25f);
+}
+static float rtransEval(const Material &mat, float cosTheta, float alpha) {
     float warpedCosTheta = std::pow(std::abs(cosTheta), 0.25f);
     if (!(cosTheta >= 0)) return 0.f;
-    float result = evalCubicInterp1D(warpedCosTheta, mat.rtrans.data(), mat.rtrans.size(), 0.0f, 1.0f);
+    float result;
+    if (mat.alphaUTextured)
+        result = evalCubicInterp2D(warpedCosTheta, rtransWarpedAlpha(mat, alpha), mat.rtrans.data() + 4, (size_t) mat.rtrans[0], (size_t) mat.rtrans[1]);
+    else
+        result = evalCubicInterp1D(warpedCosTheta, mat.rtrans.data(), mat.rtrans.size(), 0.0f, 1.0f);
+    return std::min(1.0f, std::max(0.0f, result));
+}
+// m_internalRoughTransmittance->evalDiffuse(alpha) (rtrans.h:249-259)
+static float rtransDiffuseInterior(const Material &mat, float alpha) {
+    if (!mat.alphaUTextured) return mat.m.rtrans_diffuse_int;
+    const size_t nTheta = (size_t) mat.rtrans[0], nAlpha = (size_t) mat.rtrans[1];
+    float result = evalCubicInterp1D(rtransWarpedAlpha(mat, alpha), mat.rtrans.data() + 4 + nTheta * nAlpha + nAlpha, nAlpha, 0.0f, 1.0f);
     return std::min(1.0f, std::max(0.0f, result));
 }
 
@@ -702,7 +726,7 @@ static Spectrum evalOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo
         }
         case ORC_BSDF_ROUGHPLASTIC: {   // roughplastic.cpp:326-382
             if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0) return Spectrum(0.0f);
-            MicrofacetDistribution distr(m.distribution, m.alpha_u, m.alpha_u, m.sample_visible != 0);
+            MicrofacetDistribution distr(m.distribution, mat.AU(), mat.AU(), m.sample_visible != 0);
             Spectrum result(0.0f);
             {
                 const Vec3 H = normalize(wo + wi);
@@ -714,9 +738,9 @@ static Spectrum evalOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo
             }
             {
                 Spectrum diff = mat.D();
-                float T12 = rtransEval(mat, Frame::cosTheta(wi));
-                float T21 = rtransEval(mat, Frame::cosTheta(wo));
-                float Fdr = 1 - m.rtrans_diffuse_int;
+                float T12 = rtransEval(mat, Frame::cosTheta(wi), distr.getAlpha());
+                float T21 = rtransEval(mat, Frame::cosTheta(wo), distr.getAlpha());
+                float Fdr = 1 - rtransDiffuseInterior(mat, distr.getAlpha());
                 if (m.variant) diff = diff / (Spectrum(1.0f) - diff * Fdr);
                 else diff /= 1 - Fdr;
                 result += diff * (INV_PI_F * Frame::cosTheta(wo) * T12 * T21 * mat.invEta2);
@@ -805,9 +829,9 @@ static float pdfOneSided(const Material &mat, const Vec3 &wi, const Vec3 &wo) {
         }
         case ORC_BSDF_ROUGHPLASTIC: {   // roughplastic.cpp:384-437
             if (Frame::cosTheta(wi) <= 0 || Frame::cosTheta(wo) <= 0) return 0.0f;
-            MicrofacetDistribution distr(m.distribution, m.alpha_u, m.alpha_u, m.sample_visible != 0);
+            MicrofacetDistribution distr(m.distribution, mat.AU(), mat.AU(), m.sample_visible != 0);
             const Vec3 H = normalize(wo + wi);
-            float probSpecular = 1 - rtransEval(mat, Frame::cosTheta(wi));
+            float probSpecular = 1 - rtransEval(mat, Frame::cosTheta(wi), distr.getAlpha());
             probSpecular = (probSpecular * mat.specularSamplingWeight) /
                 (probSpecular * mat.specularSamplingWeight + (1 - probSpecular) * (1 - mat.specularSamplingWeight));
             float probDiffuse = 1 - probSpecular;
@@ -899,8 +923,8 @@ static Spectrum sampleOneSided(const Material &mat, const Vec3 &wi, const Vec2 &
             if (Frame::cosTheta(wi) <= 0) return Spectrum(0.0f);
             bool choseSpecular = true;
             Vec2 sample = _sample;
-            MicrofacetDistribution distr(m.distribution, m.alpha_u, m.alpha_u, m.sample_visible != 0);
-            float probSpecular = 1 - rtransEval(mat, Frame::cosTheta(wi));
+            MicrofacetDistribution distr(m.distribution, mat.AU(), mat.AU(), m.sample_visible != 0);
+            float probSpecular = 1 - rtransEval(mat, Frame::cosTheta(wi), distr.getAlpha());
             probSpecular = (probSpecular * mat.specularSamplingWeight) /
                 (probSpecular * mat.specularSamplingWeight + (1 - probSpecular) * (1 - mat.specularSamplingWeight));
             if (sample.y < probSpecular) {

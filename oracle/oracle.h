@@ -53,7 +53,7 @@ typedef struct {
     /* the record is the BSDF nested in a bumpmap (1, src/bsdfs/bumpmap.cpp) or normalmap (2, src/bsdfs/normalmap.cpp)
        adapter with that displacement / normal texture (1-based) */
     int32_t frame_kind, frame_texture;
-    int32_t alpha_u_texture, alpha_v_texture;   /* textured roughness (roughconductor, roughdielectric), 1-based, 0 = constant */
+    int32_t alpha_u_texture, alpha_v_texture;   /* textured roughness (roughconductor, roughdielectric; roughplastic with the table of orc_rtrans_reduce_eta), 1-based, 0 = constant */
 } orc_material;
 
 /* type 1: checkerboard (src/textures/checkerboard.cpp), 2: gridtexture (src/textures/gridtexture.cpp), 3: bitmap
@@ -207,6 +207,7 @@ int orc_clipped_aabb(const float *v, const float *box, float *out);
 int orc_rtrans_reduce(const void *dat, uint64_t size, float eta, float alpha, float *out_T,
                       uint32_t out_cap, uint32_t *theta_samples, float *diffuse_ext, float *diffuse_int);
 /* Full 3-D lookup RoughTransmittance::eval(cosTheta, alpha, eta) on the raw table */
+int orc_rtrans_reduce_eta(const void *dat, uint64_t size, float eta, float *out, uint32_t out_cap, uint32_t *n);
 int orc_rtrans_eval3d(const void *dat, uint64_t size, uint64_t n, const float *cos_theta,
                       const float *alpha, const float *eta, float *out);
 

@@ -417,6 +417,16 @@ def rtrans_reduce(dat: bytes, eta, alpha):
     return out[:n.value].copy(), de.value, di.value
 
 
+def rtrans_reduce_eta(dat: bytes, eta):
+    """orc_rtrans_reduce_eta: the two-dimensional table of a roughplastic with a textured roughness, one float32 block."""
+    n = C.c_uint32()
+    out = np.zeros(1 << 16, np.float32)
+    r = lib().orc_rtrans_reduce_eta(dat, C.c_uint64(len(dat)), C.c_float(eta), _fp(out), C.c_uint32(out.size), C.byref(n))
+    if r != 0:
+        raise RuntimeError("orc_rtrans_reduce_eta failed: %d" % r)
+    return out[:n.value].copy()
+
+
 def rtrans_eval3d(dat: bytes, cos_theta, alpha, eta):
     ct, al, et = (np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float32), np.shape(cos_theta)), np.float32)
                   for a in (cos_theta, alpha, eta))

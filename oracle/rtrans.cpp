@@ -138,6 +138,25 @@ extern "C" int orc_rtrans_reduce(const void *dat, uint64_t size, float eta, floa
     return 0;
 }
 
+extern "C" int orc_rtrans_reduce_eta(const void *dat, uint64_t size, float eta, float *out, uint32_t out_cap, uint32_t *n_out) {
+    // RoughPlastic::configure with a textured roughness (roughplastic.cpp:281-299): both copies only get setEta. The block:
+    // thetaSamples, alphaSamples, alphaMin, alphaMax, T[alpha][theta] exterior, diffuse exterior [alpha], diffuse interior [alpha]
+    RoughTransmittance ext;
+    if (!ext.load(dat, size)) return -1;
+    RoughTransmittance in = ext;
+    ext.setEta(eta);
+    in.setEta(1 / eta);
+    const size_t n = 4 + ext.trans.size() + 2 * ext.alphaSamples;
+    *n_out = (uint32_t) n;
+    if (out_cap < n) return -2;
+    out[0] = (float) ext.thetaSamples; out[1] = (float) ext.alphaSamples; out[2] = ext.alphaMin; out[3] = ext.alphaMax;
+    size_t k = 4;
+    for (float v : ext.trans) out[k++] = v;
+    for (float v : ext.diffTrans) out[k++] = v;
+    for (float v : in.diffTrans) out[k++] = v;
+    return 0;
+}
+
 extern "C" int orc_rtrans_eval3d(const void *dat, uint64_t size, uint64_t n, const float *cos_theta,
                                  const float *alpha, const float *eta, float *out) {
     RoughTransmittance rt;

@@ -1008,6 +1008,42 @@ def test_cli_textured_roughness(scene_dir, tmp_path):
         loader.load_xml(str(g))
 
 
+def test_cli_textured_roughness_on_roughplastic(scene_dir, tmp_path):
+    """A <texture> / <ref> named alpha under roughplastic (roughplastic.cpp:218, 281-299): both loaders keep the
+    transmittance table a function of the roughness (mtsamd_rtrans_reduce_eta on <data dir>/microfacet/<distribution>.dat)
+    and fill both roughness slots; without the texture the table is the one-dimensional slice."""
+    import struct
+    (tmp_path / "meshes.serialized").write_bytes((scene_dir / "meshes.serialized").read_bytes())
+    n_eta, n_alpha, n_theta = 4, 5, 6
+    tab = np.zeros((2, n_eta, n_alpha, n_theta + 1), np.float32)
+    tab[...] = 0.3 + 0.5 * (np.arange(n_theta + 1) / n_theta) ** 0.5
+    tab *= (1 - 0.1 * np.arange(n_alpha) / n_alpha)[None, None, :, None]
+    data = tmp_path / "data"
+    (data / "microfacet").mkdir(parents=True)
+    (data / "microfacet" / "ggx.dat").write_bytes(b"MTS_TRANSMITTANCE" + struct.pack("<3Q4f", n_eta, n_alpha, n_theta, 1.0, 3.0, 0.0, 2.0) + tab.tobytes())
+    body = ('<texture type="checkerboard" id="rough"><rgb name="color0" value="0.05"/><rgb name="color1" value="0.4"/></texture>'
+            '<bsdf type="roughplastic"><string name="distribution" value="ggx"/><ref name="alpha" id="rough"/><float name="intIOR" value="1.5"/><float name="extIOR" value="1.0"/></bsdf>'
+            '<bsdf type="roughplastic"><string name="distribution" value="ggx"/><float name="alpha" value="0.2"/><float name="intIOR" value="1.5"/><float name="extIOR" value="1.0"/></bsdf>')
+    f = tmp_path / "plastic.xml"
+    f.write_text(SCENE % body)
+    d = _describe(f, "--data-dir", str(data))
+    sd, _ = loader.load_xml(str(f), data_dir=str(data))
+    assert d["alpha_textures"] == [[m["alpha_u_texture"], m["alpha_v_texture"]] for m in sd.materials]
+    assert d["alpha_textures"][2:4] == [[1, 1], [0, 0]]
+    block = 4 + n_alpha * n_theta + 2 * n_alpha
+    assert [t[0] for t in d["rtrans_tables"][2:4]] == [block, n_theta]
+    for t, m in zip(d["rtrans_tables"][2:4], sd.materials[2:4]):
+        assert np.asarray(m["rtrans"]).size == t[0] and abs(float(np.asarray(m["rtrans"], np.float64).sum()) - t[1]) < 1e-4 * abs(t[1])
+    assert tuple(np.asarray(sd.materials[2]["rtrans"])[:4]) == (n_theta, n_alpha, 0.0, 2.0)
+    # alphaU / alphaV are not parameters of this model
+    g = tmp_path / "bad.xml"
+    g.write_text(SCENE % '<bsdf type="roughplastic"><string name="distribution" value="ggx"/><texture type="checkerboard" name="alphaU"/></bsdf>')
+    out = subprocess.run([CLI, str(g), "--describe", "--data-dir", str(data)], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "parameter 'alphaU'" in out.stderr
+    with pytest.raises(loader.SceneFormatError, match="parameter 'alphaU'"):
+        loader.load_xml(str(g), data_dir=str(data))
+
+
 def test_cli_rectangle_shape(scene_dir, tmp_path):
     """<shape type="rectangle"> (src/shapes/rectangle.cpp:80-110,150-165): two triangles over [-1, 1]^2 with uv
     (x + 1) / 2, (y + 1) / 2 under toWorld; it may carry an area emitter; other analytic shapes are still refused."""

@@ -362,14 +362,15 @@ def test_bump_and_normal_mapped_bsdf_parity(pairs):
 
 
 def test_textured_roughness_bsdf_parity(pairs):
-    """Rough conductors and a rough dielectric whose roughness is a texture (roughconductor.cpp:264-268,
-    roughdielectric.cpp:303-308): eval, pdf and sample at several uv, directly and as nested records of mixtures."""
+    """Rough conductors, rough plastics and a rough dielectric whose roughness is a texture (roughconductor.cpp:264-268,
+    roughplastic.cpp:336-341 with the transmittance table still a function of the roughness, roughdielectric.cpp:303-308):
+    eval, pdf and sample at several uv, directly and as nested records of mixtures."""
     sd, g, o = pairs["rough_blend"]
     rng = np.random.default_rng(14)
     n = 20000
     direct = [i for i, m in enumerate(sd.materials) if m.get("alpha_u_texture") or m.get("alpha_v_texture")]
     nested = [i for i, m in enumerate(sd.materials) if any(c in direct for c, _ in m.get("mix", ()))]
-    assert len(direct) == 3 and len(nested) >= 2 and any(sd.materials[i]["alpha_u_texture"] != sd.materials[i]["alpha_v_texture"] for i in direct)
+    assert len(direct) == 5 and len(nested) >= 2 and sum(sd.materials[i]["type"] == S.BSDF_ROUGHPLASTIC for i in direct) == 2 and any(sd.materials[i]["alpha_u_texture"] != sd.materials[i]["alpha_v_texture"] for i in direct)
 
     def dirs():
         d = rng.normal(size=(n, 3))

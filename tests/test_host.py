@@ -67,6 +67,45 @@ def test_rtrans_reduce_product_vs_oracle_and_packaged(oracle_mod):
         capi.rtrans_reduce(dat[:100], 1.5, 0.1)
     with pytest.raises(capi.MtsamdError):
         capi.rtrans_reduce(dat, 9.0, 0.1)       # checkEta (rtrans.h:399-407)
+    # reduced to the index of refraction only (a roughplastic with a textured roughness): product, oracle, packaged
+    eta = 1.49 / 1.000277
+    blk = capi.rtrans_reduce_eta(dat, eta)
+    assert np.array_equal(blk, oracle_mod.rtrans_reduce_eta(dat, eta)) and np.array_equal(blk, S.load_rtrans_eta_block("beckmann", eta))
+    with pytest.raises(capi.MtsamdError):
+        capi.rtrans_reduce_eta(dat, 9.0)
+
+
+def test_rtrans_reduce_eta_on_a_synthetic_table(oracle_mod):
+    """mtsamd_rtrans_reduce_eta against the oracle's setEta (rtrans.h:292-345) on a file of the reference's layout
+    (rtrans.h:100-148) filled with a smooth function: bit-equal blocks; at an index of refraction that is a node of the
+    table the slice reproduces the table's own entries; the reduction to one roughness agrees with interpolating
+    the block."""
+    import struct
+    n_eta, n_alpha, n_theta = 5, 6, 7
+    eta_min, eta_max, a_min, a_max = 1.0, 3.0, 0.0, 2.0
+    rng = np.random.default_rng(1)
+    body = []
+    tables = np.zeros((2, n_eta, n_alpha, n_theta + 1), np.float32)
+    for half in range(2):
+        for i in range(n_eta):
+            for j in range(n_alpha):
+                row = 0.2 + 0.6 * (np.arange(n_theta + 1) / n_theta) ** 0.5 * (1 - 0.1 * j / n_alpha) * (1 - 0.05 * i / n_eta) * (0.9 if half else 1.0)
+                tables[half, i, j] = row + rng.uniform(-0.01, 0.01, n_theta + 1)
+    dat = b"MTS_TRANSMITTANCE" + struct.pack("<3Q4f", n_eta, n_alpha, n_theta, eta_min, eta_max, a_min, a_max) + tables.tobytes()
+    for eta in (1.5, 1.0 / 1.5, eta_min + (eta_max - eta_min) * 0.5 ** 4):
+        blk = capi.rtrans_reduce_eta(dat, eta)
+        assert np.array_equal(blk, oracle_mod.rtrans_reduce_eta(dat, eta))
+        assert blk.size == 4 + n_alpha * n_theta + 2 * n_alpha and tuple(blk[:4]) == (n_theta, n_alpha, a_min, a_max)
+    # warped eta = 0.5 is the middle node of the five: the exterior slice is that node's rows
+    assert np.allclose(blk[4:4 + n_alpha * n_theta].reshape(n_alpha, n_theta), tables[0, 2, :, :n_theta], atol=1e-6)
+    assert np.allclose(blk[4 + n_alpha * n_theta:4 + n_alpha * n_theta + n_alpha], tables[0, 2, :, n_theta], atol=1e-6)
+    # the one-dimensional reduction at a roughness that is a node of the table: a row of the block
+    eta = 1.5
+    blk = capi.rtrans_reduce_eta(dat, eta)
+    alpha = a_min + (a_max - a_min) * (2 / (n_alpha - 1)) ** 4
+    T, d_ext, d_int = capi.rtrans_reduce(dat, eta, alpha)
+    T2 = blk[4:4 + n_alpha * n_theta].reshape(n_alpha, n_theta)
+    assert np.allclose(T, T2[2], atol=2e-6) and abs(d_ext - blk[4 + n_alpha * n_theta + 2]) < 2e-6 and abs(d_int - blk[4 + n_alpha * n_theta + n_alpha + 2]) < 2e-6
 
 
 def test_scene_builders_are_well_formed():

@@ -567,10 +567,88 @@ def test_textured_roughness(oracle_mod):
     same("big_tex", "big", (0.5, 0.5))
     o.bsdf_query_uv(0.0, 0.0)
     assert np.abs(o.bsdf_eval(rec["lo"], wi, wo) - o.bsdf_eval(rec["hi"], wi, wo)).max() > 0.1
-    for bad in (S.roughplastic(alpha=0.1, distribution="ggx", int_ior=1.49), S.diffuse()):
+    # a record that cannot take one says so; a rough plastic needs its transmittance table as a function of the roughness
+    for bad, message in ((S.diffuse(), "roughconductor, roughdielectric and roughplastic only"),
+                         (S.roughplastic(alpha=0.1, distribution="ggx", int_ior=1.49), "two-dimensional transmittance table")):
         b2 = S.SceneBuilder()
         t = b2.add_texture(S.checkerboard())
         m = b2.add_material(dict(bad, alpha_u_texture=t, alpha_v_texture=t))
         b2.add_quad([-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0], m, radiance=(1, 1, 1))
-        with pytest.raises(RuntimeError, match="roughconductor and roughdielectric only"):
+        with pytest.raises(RuntimeError, match=message):
             oracle_mod.OracleScene(b2.finish(S.make_camera([0, -3, 2], [0, 0, 0], [0, 0, 1], 40), S.make_film(8, 8)))
+
+
+def test_textured_roughness_on_roughplastic(oracle_mod):
+    """RoughPlastic with a non-constant alpha (roughplastic.cpp:281-299, 336-341, 361-363): the microfacet lobe uses the
+    roughness found at the intersection, and the transmittances T12, T21 and the interior diffuse transmittance are
+    looked up at that roughness in the table reduced to the index of refraction only (rtrans.h:195-205, 254-259).
+    Where the texture is flat the record must give what the record with that constant roughness gives -- exactly in the
+    microfacet lobe, and in the diffuse lobe up to the difference between interpolating the two-dimensional table and
+    interpolating its slice (setAlpha samples the same interpolant at the table's own angles, rtrans.h:353-388)."""
+    b = S.SceneBuilder()
+    t_flat = b.add_texture(S.bitmap(np.full((4, 4), 0.2, np.float32), "bilinear"))
+    t_check = b.add_texture(S.checkerboard((0.1, 0.1, 0.1), (0.5, 0.5, 0.5), uscale=2.0, vscale=2.0))
+    rec = {}
+    for distr in ("ggx", "beckmann"):
+        kw = dict(distribution=distr, int_ior=1.49, diffuse_reflectance=(0.5, 0.3, 0.2))
+        rec[distr, "flat"] = b.add_material(S.roughplastic(alpha=0.7, alpha_texture=t_flat, **kw))
+        rec[distr, 0.2] = b.add_material(S.roughplastic(alpha=0.2, **kw))
+        rec[distr, "check"] = b.add_material(S.roughplastic(alpha=0.7, alpha_texture=t_check, nonlinear=True, **kw))
+        rec[distr, 0.1] = b.add_material(S.roughplastic(alpha=0.1, nonlinear=True, **kw))
+        rec[distr, 0.5] = b.add_material(S.roughplastic(alpha=0.5, nonlinear=True, **kw))
+    b.add_quad([-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0], rec["ggx", "flat"], radiance=(1, 1, 1))
+    sd = b.finish(S.make_camera([0, -3, 2], [0, 0, 0], [0, 0, 1], 40), S.make_film(8, 8))
+    o = oracle_mod.OracleScene(sd)
+    rng = np.random.default_rng(5)
+    n = 4000
+    d = rng.normal(size=(2, n, 3))
+    d[:, :, 2] = np.abs(d[:, :, 2])
+    d /= np.linalg.norm(d, axis=2, keepdims=True)
+    wi, wo = d[0].astype(np.float32), d[1].astype(np.float32)
+    for distr in ("ggx", "beckmann"):
+        for a, c, uv in (("flat", 0.2, (0.4, 0.6)), ("check", 0.1, (0.1, 0.1)), ("check", 0.5, (0.1, 0.35))):
+            o.bsdf_query_uv(*uv)
+            ea, ec = o.bsdf_eval(rec[distr, a], wi, wo), o.bsdf_eval(rec[distr, c], wi, wo)
+            assert np.allclose(ea, ec, rtol=3e-3, atol=1e-6), (distr, a, c, np.abs(ea - ec).max())
+            assert np.allclose(o.bsdf_pdf(rec[distr, a], wi, wo), o.bsdf_pdf(rec[distr, c], wi, wo), rtol=3e-3, atol=1e-6), (distr, a, c)
+        # the two colours of the checkerboard are two different materials
+        o.bsdf_query_uv(0.1, 0.1)
+        lo = o.bsdf_eval(rec[distr, "check"], wi, wo)
+        o.bsdf_query_uv(0.1, 0.35)
+        assert np.abs(lo - o.bsdf_eval(rec[distr, "check"], wi, wo)).max() > 0.05
+    o.bsdf_query_uv(0.0, 0.0)
+    # the roughness texture must stay inside the table's range (RoughTransmittance::checkAlpha, rtrans.h:400-407)
+    # and a rough plastic takes one isotropic roughness
+    b3 = S.SceneBuilder()
+    t1, t2 = b3.add_texture(S.checkerboard()), b3.add_texture(S.checkerboard((0.2, 0.2, 0.2), (0.3, 0.3, 0.3)))
+    m = b3.add_material(dict(S.roughplastic(alpha_texture=t1, distribution="ggx", int_ior=1.49), alpha_v_texture=t2))
+    b3.add_quad([-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0], m, radiance=(1, 1, 1))
+    with pytest.raises(RuntimeError, match="anisotropic"):
+        oracle_mod.OracleScene(b3.finish(S.make_camera([0, -3, 2], [0, 0, 0], [0, 0, 1], 40), S.make_film(8, 8)))
+
+
+def test_rtrans_eta_block_contains_the_reduced_slices(oracle_mod):
+    """The packaged two-dimensional tables against the packaged one-dimensional ones (both made from the reference's
+    data/microfacet/*.dat): setAlpha evaluates the two-dimensional interpolant at the table's own angles
+    (rtrans.h:371-377), so looking the block up there must reproduce the slice; the diffuse transmittances likewise."""
+    for distr in ("ggx", "beckmann"):
+        eta = 1.49 / 1.000277
+        blk = np.asarray(S.load_rtrans_eta_block(distr, eta), np.float32)
+        n_theta, n_alpha, a_min, a_max = int(blk[0]), int(blk[1]), blk[2], blk[3]
+        assert blk.size == 4 + n_theta * n_alpha + 2 * n_alpha and a_max > a_min
+        T2 = blk[4:4 + n_theta * n_alpha].reshape(n_alpha, n_theta)
+        assert ((T2 >= -1e-3) & (T2 <= 1 + 1e-3)).all()
+        for alpha in (0.1, 0.3):
+            T1, d_ext, d_int = S.load_rtrans_slice(distr, eta, alpha)
+            b = S.SceneBuilder()
+            t = b.add_texture(S.bitmap(np.full((2, 2), alpha, np.float32), "nearest"))
+            mt = b.add_material(S.roughplastic(alpha_texture=t, distribution=distr, int_ior=1.49, diffuse_reflectance=(0.5, 0.5, 0.5), specular_reflectance=(0, 0, 0)))
+            mc = b.add_material(S.roughplastic(alpha=alpha, distribution=distr, int_ior=1.49, diffuse_reflectance=(0.5, 0.5, 0.5), specular_reflectance=(0, 0, 0)))
+            b.add_quad([-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0], mt, radiance=(1, 1, 1))
+            o = oracle_mod.OracleScene(b.finish(S.make_camera([0, -3, 2], [0, 0, 0], [0, 0, 1], 40), S.make_film(8, 8)))
+            # directions whose cosines are the table's angles: cos = (j / (n - 1))^4
+            cos = (np.arange(1, n_theta, dtype=np.float64) / (n_theta - 1)) ** 4
+            cos = cos[cos > 1e-3]
+            w = np.stack([np.sqrt(1 - cos * cos), np.zeros_like(cos), cos], 1).astype(np.float32)
+            et, ec = o.bsdf_eval(mt, w, w[::-1].copy()), o.bsdf_eval(mc, w, w[::-1].copy())
+            assert np.allclose(et, ec, rtol=2e-4, atol=1e-7), (distr, alpha, np.abs(et / np.maximum(ec, 1e-9) - 1).max())

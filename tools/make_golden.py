@@ -16,6 +16,7 @@ checkout (no reference source is copied): run in the build container where /root
                                        src/libcore/spectrum.cpp:743-1141
   tests/golden/ior_spd/                three of the measured spectra under data/ior/ (Cu, Au, a-C), unchanged
   mitsuba_amd/data/rtrans_slices.json  reduced rough-transmittance tables for the bundled scenes (mtsamd_rtrans_reduce)
+  mitsuba_amd/data/rtrans_eta_blocks.npz  the same tables reduced to an index of refraction only (mtsamd_rtrans_reduce_eta)
 """
 import json
 import os
@@ -83,6 +84,14 @@ def rtrans_slices():
                 Tt, de, di = capi.rtrans_reduce(dat, eta, alpha)
                 out[S.rtrans_key(distr, eta, alpha)] = dict(T=[float(x) for x in Tt], diffuse_ext=de, diffuse_int=di)
     json.dump(out, open(os.path.join(ROOT, "mitsuba_amd", "data", "rtrans_slices.json"), "w"))
+    # the same files reduced to an index of refraction only (roughplastic with a textured roughness)
+    blocks = {}
+    for distr in ("beckmann", "ggx"):
+        dat = open(os.path.join(R, "data", "microfacet", distr + ".dat"), "rb").read()
+        for int_ior, ext_ior in ((1.49, 1.000277), (1.5, 1.0)):
+            eta = int_ior / ext_ior
+            blocks["%s_%.6f" % (distr, eta)] = capi.rtrans_reduce_eta(dat, eta)
+    np.savez_compressed(os.path.join(ROOT, "mitsuba_amd", "data", "rtrans_eta_blocks.npz"), **blocks)
 
 
 def veach():
