@@ -9,14 +9,9 @@
 
 namespace mtsamd {
 
-// float4s from one triangle's shading record to the next. The record itself is six; eight puts every record in a
-// 128-byte line of its own, so that a gathered record costs one line from the fabric instead of 1.75 on average
-// (the shading kernel 2 % faster for a third more memory: 128 MB per million triangles).
-#ifndef MTS_SHADE_TRI_STRIDE
-#define MTS_SHADE_TRI_STRIDE 8
-#endif
-constexpr int kShadeTriStride = MTS_SHADE_TRI_STRIDE;
-static_assert(kShadeTriStride >= 6, "a shading record is six float4");
+// float4s from one triangle's shading record to the next: eight, i.e. every record in a 128-byte line of its own
+// (positions + words, normals, texture coordinates), so that a gathered record costs one line from the fabric.
+constexpr int kShadeTriStride = 8;
 
 
 // 80-byte node. Child boxes are stored on an 8-bit grid local to the node:

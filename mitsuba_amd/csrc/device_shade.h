@@ -2,6 +2,7 @@
 // emitter sampling. Each function names the reference code it reproduces.
 #pragma once
 #include "device_math.h"
+#include "uv_tangents.h"
 
 namespace mtsamd {
 
@@ -34,11 +35,14 @@ MTS_DEV void fillIntersection(const DevScene &sc, uint32_t tri, float u, float v
     V3 dpdu = side1;
     its.dpdv = side2;
     its.uvx = by; its.uvy = bz;
-    if (its.flags & 2u) {       // TriMesh::computeUVTangents result (trimesh.cpp:683-735) and interpolated texture coordinates
-        const float4 *q = sc.shadeUV + 3 * (size_t) tri;
-        const float4 q0 = q[0], q1 = q[1], q2 = q[2];
-        dpdu = mk(q1.z, q1.w, q2.x);
-        its.dpdv = mk(q2.y, q2.z, q2.w);
+    if (its.flags & 2u) {       // TriMesh::computeUVTangents (trimesh.cpp:683-735) and interpolated texture coordinates
+        const float4 q0 = g[6], q1 = g[7];      // uv0, uv1 | uv2: the tail of the record's own line
+        const float v0[3] = { p0.x, p0.y, p0.z }, v1[3] = { p1.x, p1.y, p1.z }, v2[3] = { p2.x, p2.y, p2.z };
+        const float t0[2] = { q0.x, q0.y }, t1[2] = { q0.z, q0.w }, t2[2] = { q1.x, q1.y };
+        float du[3], dv[3];
+        uvTangents(v0, v1, v2, t0, t1, t2, du, dv);
+        dpdu = mk(du[0], du[1], du[2]);
+        its.dpdv = mk(dv[0], dv[1], dv[2]);
         its.uvx = q0.x * bx + q0.z * by + q1.x * bz;
         its.uvy = q0.y * bx + q0.w * by + q1.y * bz;
     }

@@ -96,11 +96,10 @@ struct DevScene {
     const float4 *nodes;        // 5 x float4 per wide node, nodeStride float4 apart
     const float4 *tris;         // 3 x float4 per triangle record (BVH order), triStride float4 apart
     uint32_t nodeStride, triStride;
-    // Shading record of a triangle, global order, 6 x float4 (kShadeTriStride float4 apart): three vertex positions whose w components carry
-    // material | flags << 24, emitter (int, -1 = none) and shape; then three vertex normals (zero without normals).
+    // Shading record of a triangle, global order, 8 x float4 (one 128-byte line): three vertex positions whose w components carry
+    // material | flags << 24, emitter (int, -1 = none) and shape; three vertex normals (zero without normals); the three
+    // texture coordinates (uv0, uv1 | uv2, 0, 0; zero for meshes without).
     const float4 *shadeTris;
-    // Only when some mesh has texture coordinates, 3 x float4 per triangle: (uv0, uv1), (uv2, dpdu.xy), (dpdu.z, 0, 0, 0)
-    const float4 *shadeUV;
     const DevShape *shapes;
     const DevMaterial *materials;
     const DevEmitter *emitters;

@@ -490,45 +490,6 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
     for (uint32_t t = 0; t < d->n_triangles; ++t)
         if (hs.triShape[t] == 0xFFFFFFFFu) return "triangle not owned by any shape";
 
-    // per-triangle UV tangents (TriMesh::computeUVTangents, src/librender/trimesh.cpp:683-735)
-    if (anyUV) {
-        hs.uvDpdu.assign((size_t) d->n_triangles * 6, 0.0f);      // dpdu, dpdv
-        for (uint32_t s = 0; s < d->n_shapes; ++s) {
-            const DevShape &sh = hs.shapes[s];
-            if (!(sh.flags & MTSAMD_SHAPE_HAS_TEXCOORDS)) continue;
-            for (uint32_t j = 0; j < sh.nTris; ++j) {
-                const uint32_t t = sh.firstTri + j;
-                const uint32_t i0 = hs.indices[3 * (size_t) t], i1 = hs.indices[3 * (size_t) t + 1], i2 = hs.indices[3 * (size_t) t + 2];
-                const float *v0 = &hs.positions[3 * (size_t) i0], *v1 = &hs.positions[3 * (size_t) i1], *v2 = &hs.positions[3 * (size_t) i2];
-                const float *uv0 = &hs.texcoords[2 * (size_t) i0], *uv1 = &hs.texcoords[2 * (size_t) i1], *uv2 = &hs.texcoords[2 * (size_t) i2];
-                float dP1[3] = { v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2] }, dP2[3] = { v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2] };
-                float dUV1[2] = { uv1[0] - uv0[0], uv1[1] - uv0[1] }, dUV2[2] = { uv2[0] - uv0[0], uv2[1] - uv0[1] };
-                float n[3] = { dP1[1] * dP2[2] - dP1[2] * dP2[1], dP1[2] * dP2[0] - dP1[0] * dP2[2], dP1[0] * dP2[1] - dP1[1] * dP2[0] };
-                float length = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-                if (length == 0) continue;
-                float determinant = dUV1[0] * dUV2[1] - dUV1[1] * dUV2[0];
-                float *out = &hs.uvDpdu[6 * (size_t) t];
-                if (determinant == 0) {
-                    // coordinateSystem(n/length, dpdu, dpdv) (src/libcore/util.cpp:592-601): dpdu = cross(c, a)
-                    float r = 1.0f / length;
-                    float a[3] = { n[0] * r, n[1] * r, n[2] * r }, c[3];
-                    if (std::fabs(a[0]) > std::fabs(a[1])) {
-                        float invLen = 1.0f / std::sqrt(a[0] * a[0] + a[2] * a[2]);
-                        c[0] = a[2] * invLen; c[1] = 0.0f; c[2] = -a[0] * invLen;
-                    } else {
-                        float invLen = 1.0f / std::sqrt(a[1] * a[1] + a[2] * a[2]);
-                        c[0] = 0.0f; c[1] = a[2] * invLen; c[2] = -a[1] * invLen;
-                    }
-                    out[0] = c[1] * a[2] - c[2] * a[1]; out[1] = c[2] * a[0] - c[0] * a[2]; out[2] = c[0] * a[1] - c[1] * a[0];
-                    out[3] = c[0]; out[4] = c[1]; out[5] = c[2];
-                } else {
-                    float invDet = 1.0f / determinant;
-                    for (int k = 0; k < 3; ++k) out[k] = (dUV2[1] * dP1[k] - dUV1[1] * dP2[k]) * invDet;
-                    for (int k = 0; k < 3; ++k) out[3 + k] = (-dUV2[0] * dP1[k] + dUV1[0] * dP2[k]) * invDet;
-                }
-            }
-        }
-    }
 
     if (d->integrator.type == MTSAMD_INTEGRATOR_DIRECT) {   // direct.cpp:96-107
         if (d->integrator.emitter_samples < 0 || d->integrator.bsdf_samples < 0 || d->integrator.emitter_samples + d->integrator.bsdf_samples <= 0)
@@ -719,7 +680,6 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
     //      that a hit carries it (bits 28..30 of the triangle word of a hit) -----------------------------------------
     if (d->n_triangles >= (1u << 27)) return "too many triangles";
     hs.shadeTris.assign((size_t) d->n_triangles * 4 * kShadeTriStride, 0.0f);
-    if (anyUV) hs.shadeUV.assign((size_t) d->n_triangles * 12, 0.0f);
     for (uint32_t t = 0; t < d->n_triangles; ++t) {
         const DevShape &sh = hs.shapes[hs.triShape[t]];
         float *g = &hs.shadeTris[(size_t) t * 4 * kShadeTriStride];
@@ -730,11 +690,10 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
             memcpy(g + 4 * k + 3, &w[k], 4);
             if (sh.flags & MTSAMD_SHAPE_HAS_NORMALS) memcpy(g + 12 + 4 * k, &hs.normals[3 * (size_t) vi], 12);
         }
-        if (sh.flags & MTSAMD_SHAPE_HAS_TEXCOORDS) {
-            float *u = &hs.shadeUV[(size_t) t * 12];
-            for (int k = 0; k < 3; ++k) memcpy(u + 2 * k, &hs.texcoords[2 * (size_t) hs.indices[3 * (size_t) t + k]], 8);
-            memcpy(u + 6, &hs.uvDpdu[6 * (size_t) t], 24);     // dpdu, dpdv
-        }
+        // the three texture coordinates ride in the record's own 128-byte line (the position partials of
+        // TriMesh::computeUVTangents are worked out from them at the hit, uv_tangents.h)
+        if (sh.flags & MTSAMD_SHAPE_HAS_TEXCOORDS)
+            for (int k = 0; k < 3; ++k) memcpy(g + 24 + 2 * k, &hs.texcoords[2 * (size_t) hs.indices[3 * (size_t) t + k]], 8);
     }
     if (d->n_materials >= (1u << 24)) return "too many materials";
     // the BSDF type of a triangle's material travels in the top bits of the record's triangle word (the traversal hands it on with the hit)

@@ -10,9 +10,9 @@
 namespace mtsamd {
 
 struct HostScene {
-    std::vector<float> positions, normals, texcoords, uvDpdu;
+    std::vector<float> positions, normals, texcoords;
     std::vector<uint32_t> indices, triShape;
-    std::vector<float> shadeTris, shadeUV;      // packed per-triangle shading records (see DevScene)
+    std::vector<float> shadeTris;               // packed per-triangle shading records (see DevScene)
     std::vector<DevShape> shapes;
     std::vector<DevMaterial> materials;
     std::vector<DevEmitter> emitters;

@@ -111,7 +111,7 @@ struct mtsamd_scene {
     HostScene host;
     DevScene dev;
     int device = 0;
-    DeviceBuffer nodes, tris, shadeTris, shadeUV, shapes, materials, emitters, deltaEmitters,
+    DeviceBuffer nodes, tris, shadeTris, shapes, materials, emitters, deltaEmitters,
         emitterCdf, areaCdf, rtrans, textures, materialTextures, materialAlphaTextures, plainTextures, mipLevels, texels, ewaLut, envCdfRows, envCdfCols, envRowWeights, devSelf;
     // work buffers of the wavefront loop
     DeviceBuffer fetchHeads, qbuf[2][6], hits, sbuf[3], sampleL, samplePos, shadowFlags, counters, scratch[8];
@@ -243,7 +243,6 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
             if (rc2 != MTSAMD_OK) return rc2;
         }
         HIP_TRY(upload(s->shadeTris, h.shadeTris));
-        if (!h.shadeUV.empty()) HIP_TRY(upload(s->shadeUV, h.shadeUV));
         HIP_TRY(upload(s->shapes, h.shapes));
         HIP_TRY(upload(s->materials, h.materials));
         HIP_TRY(upload(s->emitters, h.emitters));
@@ -302,7 +301,6 @@ extern "C" int mtsamd_scene_create(const mtsamd_scene_desc *desc, mtsamd_scene *
     d.nodes = s->nodes.as<float4>(); d.tris = s->tris.as<float4>();
     d.nodeStride = s->nodeStride; d.triStride = s->triStride;
     d.shadeTris = s->shadeTris.as<float4>();
-    d.shadeUV = h.shadeUV.empty() ? nullptr : s->shadeUV.as<float4>();
     d.shapes = s->shapes.as<DevShape>(); d.materials = s->materials.as<DevMaterial>(); d.emitters = s->emitters.as<DevEmitter>();
     d.deltaEmitters = s->deltaEmitters.as<DevDeltaEmitter>();
     d.emitterCdf = s->emitterCdf.as<float>(); d.areaCdf = s->areaCdf.as<float>(); d.rtrans = s->rtrans.as<float>();
