@@ -3,8 +3,8 @@
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-for w in config3 config3tex:bilinear; do
-  tag=$(echo $w | tr ':' '_')
+for w in ${WORKLOADS:-config3 config3tex:bilinear}; do
+  tag=${TAGPREFIX:-}$(echo $w | tr ":" "_")
   dirs=""
   i=0
   for g in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
@@ -17,5 +17,4 @@ for w in config3 config3tex:bilinear; do
   python3 tools/pmc_summary.py $dirs > gpurun_out/tex_${tag}_pmc.txt
   rm -rf $dirs
 done
-grep -A12 "^k_shade" gpurun_out/tex_config3_pmc.txt | head -16
-grep -A12 "^k_shade" gpurun_out/tex_config3tex_bilinear_pmc.txt | head -16
+for f in gpurun_out/tex_${TAGPREFIX:-}*_pmc.txt; do echo $f; grep -A12 "^k_shade" $f | head -14; done
