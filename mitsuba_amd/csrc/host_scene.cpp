@@ -469,7 +469,6 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
     // ---- shapes ----------------------------------------------------------------------------------------
     hs.shapes.resize(d->n_shapes);
     hs.triShape.assign(d->n_triangles, 0xFFFFFFFFu);
-    bool anyUV = false;
     for (uint32_t s = 0; s < d->n_shapes; ++s) {
         const mtsamd_shape &sh = d->shapes[s];
         if ((uint64_t) sh.first_triangle + sh.n_triangles > d->n_triangles) return "shape triangle range out of bounds";
@@ -485,7 +484,6 @@ std::string prepareScene(const mtsamd_scene_desc *d, HostScene &hs) {
             if (hs.triShape[sh.first_triangle + j] != 0xFFFFFFFFu) return "triangle owned by two shapes";
             hs.triShape[sh.first_triangle + j] = s;
         }
-        if (sh.flags & MTSAMD_SHAPE_HAS_TEXCOORDS) anyUV = true;
     }
     for (uint32_t t = 0; t < d->n_triangles; ++t)
         if (hs.triShape[t] == 0xFFFFFFFFu) return "triangle not owned by any shape";
