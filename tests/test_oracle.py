@@ -715,11 +715,40 @@ def test_measured_spectra_to_rgb():
         capi.spd_to_rgb([500.0, 400.0], [1.0, 1.0])
 
 
+def test_reference_spectrum_known_answers():
+    """The known answers of the reference's own spectrum test (src/tests/test_spectrum.cpp:73-92 InterpolatedSpectrum
+    eval / average / zeroExtend, :94-108 a flat spectrum has X = Y = Z = 1 to 1e-3, :131-141 a 5000 K black body against
+    tabulated radiances) on the restatement the library's conversions are checked against bit for bit."""
+    from mitsuba_amd import capi
+    from oracle import spd
+    s = spd.Spd([500.0, 700.0, 800.0], [1.0, 2.0, 3.0])
+    for lam, want in ((499, 0.0), (500, 1.0), (600, 1.5), (700, 2.0), (750, 2.5), (800, 3.0), (801, 0.0)):
+        assert float(s.eval(np.float32(lam))) == want, lam
+    assert abs(float(s.average(np.float32(0), np.float32(1000))) - 550.0 / 1000.0) < 1e-6
+    assert abs(float(s.average(np.float32(550), np.float32(551))) - 1.2525) < 1e-6
+    z = s.zero_extended()
+    assert float(z.eval(np.float32(500.0 - 150.0))) == 0.0 and float(z.eval(np.float32(500.0 - 75.0))) == 0.5
+    # fromContinuousSpectrum of a spectrum that is 1 on [0, 1000] nm, then toXYZ: (1, 1, 1) within 1e-3
+    rgb = np.asarray(capi.spd_to_rgb([0.0, 1000.0], [1.0, 1.0]), np.float64)
+    to_xyz = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]])
+    assert np.allclose(to_xyz @ rgb, 1.0, atol=1e-3)
+    # the adaptive Gauss-Lobatto rule on the reference's own quadrature test (src/tests/test_quad.cpp:62-70): the integral
+    # of sin over [0, 10] is 2 sin^2(5); the reference asks for 1e-5 at tolerances of 1e-5, the restatement runs the
+    # 1e-4 tolerances the spectrum code uses (spectrum.cpp:547)
+    q = spd._Lobatto(lambda t: np.float32(np.sin(np.float32(t))))
+    assert abs(float(q.integrate(np.float32(0), np.float32(10))) - 2 * np.sin(5.0) ** 2) < 1e-5 and q.evals < 1024
+    # Planck's law, W m^-2 sr^-1 nm^-1: the reference's spot checks are in units ten times larger
+    b = spd.BlackBody(5000.0)
+    for lam, want in ((400, 874.0), (500, 1211.0), (600, 1276.0), (2000, 115.8)):
+        assert abs(float(b.eval(np.float32(lam))) / 10 - want) < 0.5, lam
+
+
 def test_scene_file_spectra_to_rgb():
     """<spectrum value="l:v, ..."> / <spectrum filename=> / <blackbody> as SceneHandler converts them
     (scenehandler.cpp:534-620): the library against the single-precision restatement (bit for bit) and a dense Riemann sum
-    in double precision; closed forms for what zeroExtend adds and for the blackbody's chromaticity. Parity unpinned
-    beyond that: the reference holds no expected RGB value for any spectrum."""
+    in double precision; closed forms for what zeroExtend adds and for the blackbody's chromaticity. The pieces (interpolation, averaging,
+    the quadrature rule, Planck's law, a flat spectrum's tristimulus values) are pinned on the reference's own test values in
+    test_reference_spectrum_known_answers; the reference holds no expected RGB value for a measured spectrum."""
     from mitsuba_amd import capi
     from oracle import spd
     # zeroExtend: a 2-entry spectrum 500:1, 600:1 gains 400:0 and 700:0, so the value ramps linearly outside 500-600 nm
