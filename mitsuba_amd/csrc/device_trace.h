@@ -201,13 +201,16 @@ MTS_DEV const float4 *triRecord(const DevScene &sc, const LaneRay &r, uint32_t b
     return sc.tris + sc.triStride * (size_t) (r.tg.x + __popc(r.tv & ((1u << b) - 1u)));
 }
 
-// mask = 2 * mask + (a <= b): the comparison's lane mask goes straight into the carry input of an add
+// How a node visit turns its eight slab tests into a bit mask: MTS_VISIT_SIGNS (the shipped form) ORs the sign bits of
+// three differences per slot and shifts them in with v_alignbit_b32; without it, max / min / compare, and
+// MTS_VISIT_ADDC feeds the comparison's lane mask straight into the carry input of an add.
 #ifndef MTS_VISIT_SIGNS
 #define MTS_VISIT_SIGNS 1
 #endif
 #ifndef MTS_VISIT_ADDC
 #define MTS_VISIT_ADDC 1
 #endif
+// mask = 2 * mask + (a <= b)
 MTS_DEV void shiftInLessEqual(uint32_t &mask, float a, float b) {
     if (!MTS_VISIT_ADDC) { mask = (mask << 1) | (a <= b ? 1u : 0u); return; }
     asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(a), "v"(b) : "vcc");
